@@ -1,0 +1,115 @@
+/* synthanatomy_hip.h -- C ABI of libsynthanatomy_hip.so (MI355X / gfx950).
+ *
+ * The reference (AmigoLab/SynthAnatomy) is pure Python: its hot paths call torch's cuDNN / cuBLAS / NCCL back-end
+ * from src/networks/{vqvae,transformers,discriminator}.  This library is what the MI355X build puts *under* that
+ * unchanged plugin surface.  Each entry point names the reference call site(s) it replaces (paths relative to the
+ * reference root).  Conventions:
+ *   - raw device pointers + explicit sizes; no torch types; activations are channels-last [N, D, H, W, C]
+ *   - no allocation, no synchronisation, no global state; `stream` is a hipStream_t passed as void*
+ *   - return 0 on success, a negative SA_E* code or a positive hipError_t otherwise; never throws
+ *   - dtype: SA_F32 (exact-f32 MFMA 16x16x4) or SA_BF16 (MFMA 16x16x32, fp32 accumulate)
+ */
+#ifndef SYNTHANATOMY_HIP_H
+#define SYNTHANATOMY_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SA_ABI_VERSION 1
+enum { SA_F32 = 0, SA_BF16 = 1 };
+enum { SA_ACT_NONE = 0, SA_ACT_RELU = 1, SA_ACT_LRELU = 2, SA_ACT_GELU = 3 };
+enum { SA_MASK_NONE = 0, SA_MASK_POS = 1 /* out *= (mask > 0) */, SA_MASK_LRELU = 2 /* out *= mask>0 ? 1 : slope */,
+       SA_MASK_GELU = 3 /* out *= gelu'(mask) */ };
+enum { SA_EINVAL = -1, SA_EUNSUPPORTED = -2, SA_ENOGPU = -3 };
+#define SA_MAX_TAPS 64
+
+/* Geometry of one implicit-GEMM convolution-like gather.  The GEMM M index enumerates a logical grid
+ * (N, Dm, Hm, Wm); for tap t = (td, th, tw) the input voxel is  i_x = m_x * in_mult[x] + t_x * tap_step[x] + in_off[x]
+ * (zero outside [0, I_x)), and the output voxel is o_x = m_x * out_mult[x] + out_off[x].  This one form covers
+ *   nn.Conv3d k4 s2 p1 / k3 s1 p1 / k1        (baseline.py:218-227, :153, :156, :242-244, :258)
+ *   nn.ConvTranspose3d k4 s2 p1, as 8 output-parity classes of 2x2x2 taps   (baseline.py:283-293)
+ *   their data gradients (conv <-> transposed conv with the channel roles swapped) and nn.Linear (1 tap). */
+typedef struct sa_conv_geom {
+    int32_t N, Dm, Hm, Wm;          /* logical grid, M = N*Dm*Hm*Wm */
+    int32_t Di, Hi, Wi, Cin;        /* input tensor [N,Di,Hi,Wi,Cin]; Cin = channel stride (multiple of 16 bytes) */
+    int32_t Do, Ho, Wo, Cout;       /* output tensor [N,Do,Ho,Wo,Cout]; Cout = channel stride */
+    int32_t cin_valid, cout_valid;  /* real channel counts (<= strides) */
+    int32_t KT[3];                  /* taps per axis (d,h,w) */
+    int32_t in_mult[3], tap_step[3], in_off[3];
+    int32_t out_mult[3], out_off[3];
+    int32_t Kpad;                   /* packed-weight row length in elements: roundup(KT0*KT1*KT2*Cin, 128 bytes) */
+    int32_t CoutPad;                /* packed-weight rows: roundup(cout_valid, 128) */
+} sa_conv_geom;
+
+/* Fused epilogue of sa_conv_fprop:  v = acc (+bias[co]);  if add_before_act v += addend;  v = act(v);
+ * if alpha v *= *alpha;  if !add_before_act v += addend;  v = mask-op(v, mask);  store as out_dtype. */
+typedef struct sa_epilogue {
+    const float *bias;    /* [CoutPad] or NULL */
+    const void *addend;   /* same layout as out, dtype add_dtype, or NULL */
+    const void *mask;     /* same layout as out, dtype mask_dtype, or NULL */
+    const float *alpha;   /* device scalar or NULL (ReZero gate) */
+    int32_t act;          /* SA_ACT_* */
+    int32_t mask_mode;    /* SA_MASK_* */
+    int32_t add_before_act;
+    int32_t out_dtype, add_dtype, mask_dtype;
+    float slope;          /* LeakyReLU slope */
+} sa_epilogue;
+
+int sa_abi_version(void);
+/* last hipError_t seen by this thread's launches, as text */
+const char *sa_last_error(void);
+
+/* ---- weights: reference layout (fp32 nn.Parameter) -> packed [CoutPad][Kpad] GEMM operand ------------------------
+ * element (row r, reduce channel c, tap t) is read at  w[r*s_row + c*s_red + tap_lut[t]]  (tap_lut NULL = identity).
+ * Conv3d weight [Co,Ci,k,k,k] (baseline.py:218): s_row=Ci*T, s_red=T.  ConvTranspose3d weight [Ci,Co,k,k,k]
+ * (baseline.py:283): s_row=T, s_red=Co*T.  Swapping the two gives the data-gradient operand. */
+int sa_pack_weights(const float *w, void *wpk, int dtype, int rows, int red, int ntaps, const int32_t *tap_lut_host,
+                    int64_t s_row, int64_t s_red, int rows_pad, int red_stride, int Kpad, void *stream);
+
+/* ---- convolution forward / data gradient (implicit GEMM on MFMA) -- replaces cuDNN behind nn.Conv3d /
+ * nn.ConvTranspose3d / nn.Linear at baseline.py:153-160,218-244,258-293; discriminator/baseline.py:41-80;
+ * performer_pytorch to_q/to_k/to_v/to_out/FeedForward (performer.py:194-219) and performer.py:221 to_out. */
+int sa_conv_fprop(const sa_conv_geom *g, int dtype, const void *in, const void *wpk, void *out, const sa_epilogue *ep,
+                  void *stream);
+
+/* ---- weight gradient: dw[r*s_row + c*s_red + tap_lut[t]] += sum_m in[gather(m,t)][c] * gout[out(m)][r]  (fp32 atomics;
+ * caller zeroes dw).  Replaces cuDNN wgrad behind the same modules' autograd. */
+int sa_conv_wgrad(const sa_conv_geom *g, int dtype, const void *in, const void *gout, float *dw, const int32_t *tap_lut_host,
+                  int64_t s_row, int64_t s_red, void *stream);
+
+/* db[c] += sum_m g[m][c]   (bias gradient), g is [M][cstride] of dtype */
+int sa_colsum(const void *g, int dtype, int64_t M, int C, int cstride, float *db, void *stream);
+
+/* ---- EMA vector quantizer -- replaces Quantizer_impl.forward (baseline.py:38-87) ---------------------------------
+ * rows [M,D] fp32 (already channels-last = the reference's flat_inputs), codebook [K,D] fp32 (pre-update).
+ * Writes idx[M] (int64, first-minimum tie-break), zq_st[M,D] = (W[idx]-x)+x, optional zq_lp (bf16 copy),
+ * and accumulates counts[K], dw[K,D], sqerr[1] = sum (W[idx]-x)^2 (fp32 atomics; caller zeroes them).
+ * wnorm[K] is scratch for |W_k|^2. */
+int sa_vq_assign(const float *rows, const float *codebook, int64_t M, int K, int D, int64_t *idx, float *zq_st, void *zq_lp,
+                 float *counts, float *dw, float *sqerr, float *wnorm, void *stream);
+/* baseline.py:75-80: N <- g N + (1-g) counts; embed_avg <- g embed_avg + (1-g) dw; codebook <- embed_avg / smoothed N */
+int sa_vq_ema_update(float *N, float *embed_avg, float *codebook, const float *counts, const float *dw, int K, int D,
+                     float decay, float eps, void *stream);
+/* baseline.py:110-120: perplexity = exp(-sum p log(p+1e-10)), p = counts / M */
+int sa_vq_perplexity(const float *counts, int K, int64_t M, float *out, void *stream);
+/* gradient of (zq_st, loss) wrt the encoder output: dz = g_zq + g_loss * beta * 2 (x - W[idx]) / (M D)   (baseline.py:82-85) */
+int sa_vq_backward(const float *rows, const float *codebook, const int64_t *idx, const void *g_zq, int g_dtype,
+                   const float *g_loss, float beta, int64_t M, int D, void *dz, int dz_dtype, void *stream);
+/* codebook lookup  out[m] = W[idx[m]]  (Quantizer_impl.embed, baseline.py:89-91) */
+int sa_vq_embed(const float *codebook, const int64_t *idx, int64_t M, int K, int D, void *out, int out_dtype, void *stream);
+
+/* ---- small fused elementwise / reduction kernels ---------------------------------------------------------------- */
+/* dst[i*dst_stride + c] = (c < src_c) ? src[i*src_c + c] : 0,  i < rows  (dtype conversion + channel padding) */
+int sa_cast_pad(const void *src, int src_dtype, int src_c, void *dst, int dst_dtype, int dst_stride, int64_t rows, void *stream);
+/* MSELoss (losses/vqvae/vqvae.py:14-71): loss_sum[0] += sum (a-b)^2 ; grad = (a-b) * (2*gscale/n) if grad != NULL */
+int sa_mse(const float *a, const float *b, int64_t n, float *loss_sum, float *grad, float gscale, void *stream);
+/* Adam (torch.optim.Adam semantics, run_vqvae.py:82-86) over a flat fp32 parameter buffer; step >= 1 */
+int sa_adam(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps,
+            float weight_decay, int step, float grad_scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,118 @@
+"""ctypes binding of libsynthanatomy_hip.so (include/synthanatomy_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a launch fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsynthanatomy_hip.so")
+
+SA_F32, SA_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU = 0, 1, 2, 3
+MASK_NONE, MASK_POS, MASK_LRELU, MASK_GELU = 0, 1, 2, 3
+MAX_TAPS = 64
+
+
+class ConvGeom(Structure):
+    _fields_ = [
+        ("N", c_int32), ("Dm", c_int32), ("Hm", c_int32), ("Wm", c_int32),
+        ("Di", c_int32), ("Hi", c_int32), ("Wi", c_int32), ("Cin", c_int32),
+        ("Do", c_int32), ("Ho", c_int32), ("Wo", c_int32), ("Cout", c_int32),
+        ("cin_valid", c_int32), ("cout_valid", c_int32),
+        ("KT", c_int32 * 3),
+        ("in_mult", c_int32 * 3), ("tap_step", c_int32 * 3), ("in_off", c_int32 * 3),
+        ("out_mult", c_int32 * 3), ("out_off", c_int32 * 3),
+        ("Kpad", c_int32), ("CoutPad", c_int32),
+    ]
+
+
+class Epilogue(Structure):
+    _fields_ = [
+        ("bias", c_void_p), ("addend", c_void_p), ("mask", c_void_p), ("alpha", c_void_p),
+        ("act", c_int32), ("mask_mode", c_int32), ("add_before_act", c_int32),
+        ("out_dtype", c_int32), ("add_dtype", c_int32), ("mask_dtype", c_int32),
+        ("slope", c_float),
+    ]
+
+
+_SIGS = {
+    "sa_abi_version": (c_int, []),
+    "sa_last_error": (c_char_p, []),
+    "sa_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int32), c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "sa_conv_fprop": (c_int, [POINTER(ConvGeom), c_int, c_void_p, c_void_p, c_void_p, POINTER(Epilogue), c_void_p]),
+    "sa_conv_wgrad": (c_int, [POINTER(ConvGeom), c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int32), c_int64, c_int64, c_void_p]),
+    "sa_colsum": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "sa_vq_assign": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sa_vq_ema_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p]),
+    "sa_vq_perplexity": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "sa_vq_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_int64, c_int, c_void_p, c_int, c_void_p]),
+    "sa_vq_embed": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "sa_cast_pad": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "sa_mse": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p]),
+    "sa_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load the library (once).  Raises HipLibraryError when it is absent -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} not found: build it with `python -m synthanatomy_amd.build` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback for the product path.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        if l.sa_abi_version() != 1:
+            raise HipLibraryError("ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        err = lib().sa_last_error()
+        raise RuntimeError(f"synthanatomy_hip: {what} failed with code {rc} ({err.decode() if err else ''})")
+
+
+def dtype_id(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return SA_F32
+    if dt == torch.bfloat16:
+        return SA_BF16
+    raise TypeError(f"unsupported dtype {dt}")
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "synthanatomy_hip kernels need device tensors (no CPU fallback)"
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise HipLibraryError("no HIP device visible: the synthanatomy_amd product path only runs on MI355X (no CPU fallback)")

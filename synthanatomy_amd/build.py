@@ -1,0 +1,70 @@
+"""Builds libsynthanatomy_hip.so (the C-ABI of include/synthanatomy_hip.h) for gfx950 with hipcc, in-tree.
+
+    python -m synthanatomy_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the repo snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsynthanatomy_hip.so")
+OBJ = os.path.join(HERE, "_obj")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off", "-Wno-unused-value"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest(path):
+    h = hashlib.sha1()
+    for dep in [path, os.path.join(CSRC, "sa_common.h"), os.path.join(HERE, "..", "include", "synthanatomy_hip.h")]:
+        with open(dep, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src):
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    stamp = obj + ".sha1"
+    dg = _digest(path)
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dg:
+        return obj, False
+    cmd = [HIPCC, *FLAGS, "-c", path, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    with open(stamp, "w") as f:
+        f.write(dg)
+    return obj, True
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        res = list(ex.map(_compile, _sources()))
+    objs = [o for o, _ in res]
+    if any(c for _, c in res) or not os.path.exists(LIB):
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[synthanatomy_amd.build] linked {LIB} ({len(objs)} objects, {sum(c for _, c in res)} recompiled)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,293 @@
+// Implicit-GEMM convolution forward / data-gradient on MFMA (gfx950).
+//
+//   out[o(m)][co] = epilogue( sum_{tap, ci} in[g(m, tap)][ci] * Wpk[co][tap*Cin + ci] )
+//
+// One kernel covers Conv3d (k4 s2, k3 s1, k1), ConvTranspose3d k4 s2 (as 8 output-parity classes of 2x2x2 taps),
+// their data gradients and nn.Linear: only the gather geometry (sa_conv_geom) differs.  Activations are channels-last so
+// a tap contributes one contiguous Cin-vector per voxel.
+//
+// Tiling: 256 threads = 4 waves.  Block tile BM=128 voxels x BN in {128,64,32,16} channels, K-slab = 128 BYTES per row
+// (64 bf16 / 32 f32), double-buffered in LDS with a 16-byte XOR swizzle (conflict-free ds_read_b128 / ds_write_b128).
+// The MFMA "A" operand is the WEIGHT tile and "B" the activation tile, so each lane ends up holding 4 consecutive output
+// channels of one voxel -> 8/16-byte channels-last stores.
+//   bf16: __builtin_amdgcn_mfma_f32_16x16x32_bf16   (one per 64 bytes of K)
+//   f32 : __builtin_amdgcn_mfma_f32_16x16x4f32 x4   (exact fp32 fma chain; parity mode)
+#include "sa_common.h"
+
+namespace sa {
+
+struct FpropArgs {
+    const void* in;
+    const void* wpk;
+    void* out;
+    sa_epilogue ep;
+    sa_conv_geom g;
+    FastDiv dW, dH, dD;   // decode m -> (n, dm, hm, wm)
+    FastDiv dTw, dThw;    // decode tap -> (td, th, tw)
+    FastDiv dCv;          // k-vector -> (tap, channel-vector): divisor Cin/VEC
+    uint32_t M;
+    uint32_t ntaps;
+    uint32_t nk;          // K-slabs
+    uint32_t nblk_m;
+};
+
+template <typename T>
+__device__ __forceinline__ void mma_slab(float4_t& acc, const u32x4& wa, const u32x4& xb);
+
+template <>
+__device__ __forceinline__ void mma_slab<bf16_t>(float4_t& acc, const u32x4& wa, const u32x4& xb) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const short8_t*)&wa, *(const short8_t*)&xb, acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_slab<float>(float4_t& acc, const u32x4& wa, const u32x4& xb) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.x), __uint_as_float(xb.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.y), __uint_as_float(xb.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.z), __uint_as_float(xb.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.w), __uint_as_float(xb.w), acc, 0, 0, 0);
+}
+
+// byte offset of 16-byte vector `vec` (0..7) of row `row` inside a [rows][128 B] swizzled tile
+__device__ __forceinline__ uint32_t tile_off(uint32_t row, uint32_t vec) { return row * 128u + ((vec ^ (row & 7u)) << 4); }
+
+template <typename T, int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(256) void conv_fprop_kernel(const FpropArgs a) {
+    constexpr int BM = WM * MI * 16;
+    constexpr int BN = WN * NI * 16;
+    static_assert(BM == 128, "A loader assumes 128 rows");
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int VEC = DT<T>::VEC;
+    constexpr int B_IT = (BN + 31) / 32;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;                      // 2 x BM x 128
+    unsigned char* sB = smem + 2 * BM * 128;       // 2 x BN x 128
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wm = wave / WN, wn = wave % WN;
+
+    const uint32_t nblk = gridDim.x;
+    const uint32_t bid = xcd_remap(blockIdx.x, nblk);
+    const uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
+    const uint32_t m_base = bm * BM, n_base = bn * BN;
+
+    const sa_conv_geom& g = a.g;
+    const T* __restrict__ in = (const T*)a.in;
+    const T* __restrict__ wpk = (const T*)a.wpk;
+
+    // ---- loader state: this thread owns k-vector column `lv` of 4 activation rows and B_IT weight rows
+    const uint32_t lv = tid & 7u;
+    const uint32_t lr = tid >> 3;  // 0..31
+    int32_t id0[4], ih0[4], iw0[4];
+    int64_t rowbase[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t m = m_base + lr + 32u * j;
+        if (m < a.M) {
+            uint32_t q = fdiv(m, a.dW);
+            const uint32_t wmx = m - q * g.Wm;
+            uint32_t q2 = fdiv(q, a.dH);
+            const uint32_t hmx = q - q2 * g.Hm;
+            const uint32_t n = fdiv(q2, a.dD);
+            const uint32_t dmx = q2 - n * g.Dm;
+            id0[j] = (int32_t)dmx * g.in_mult[0] + g.in_off[0];
+            ih0[j] = (int32_t)hmx * g.in_mult[1] + g.in_off[1];
+            iw0[j] = (int32_t)wmx * g.in_mult[2] + g.in_off[2];
+            rowbase[j] = (((int64_t)n * g.Di + id0[j]) * g.Hi + ih0[j]) * g.Wi + iw0[j];
+        } else {
+            id0[j] = ih0[j] = iw0[j] = -(1 << 28);  // always out of range -> zero rows
+            rowbase[j] = 0;
+        }
+    }
+    const T* wrow[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) wrow[j] = wpk + (int64_t)(n_base + lr + 32u * j) * g.Kpad + lv * VEC;
+
+    u32x4 ra[4], rb[B_IT];
+    auto gload = [&](uint32_t s) __attribute__((always_inline)) {
+        const uint32_t kv = s * 8u + lv;               // k index in 16-byte vectors
+        const uint32_t tap = fdiv(kv, a.dCv);
+        const uint32_t cv = kv - tap * a.dCv.d;
+        const uint32_t td = fdiv(tap, a.dThw);
+        const uint32_t t2 = tap - td * a.dThw.d;
+        const uint32_t th = fdiv(t2, a.dTw);
+        const uint32_t tw = t2 - th * a.dTw.d;
+        const int32_t od = (int32_t)td * g.tap_step[0], oh = (int32_t)th * g.tap_step[1], ow = (int32_t)tw * g.tap_step[2];
+        const int64_t tapoff = ((int64_t)od * g.Hi + oh) * g.Wi + ow;
+        const bool tap_ok = tap < a.ntaps;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = tap_ok && (uint32_t)(id0[j] + od) < (uint32_t)g.Di && (uint32_t)(ih0[j] + oh) < (uint32_t)g.Hi &&
+                            (uint32_t)(iw0[j] + ow) < (uint32_t)g.Wi;
+            if (ok) ra[j] = *(const u32x4*)(in + (rowbase[j] + tapoff) * g.Cin + cv * VEC);
+            else ra[j] = (u32x4){0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            if (BN >= 32 || lr < (uint32_t)BN) rb[j] = *(const u32x4*)(wrow[j] + (int64_t)s * (8 * VEC));
+        }
+    };
+    auto lstore = [&](uint32_t buf) __attribute__((always_inline)) {
+        unsigned char* pa = sA + buf * (BM * 128);
+        unsigned char* pb = sB + buf * (BN * 128);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(u32x4*)(pa + tile_off(lr + 32u * j, lv)) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            if (BN >= 32 || lr < (uint32_t)BN) *(u32x4*)(pb + tile_off(lr + 32u * j, lv)) = rb[j];
+        }
+    };
+
+    float4_t acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    const uint32_t frow = lane & 15u, fq = lane >> 4;
+    for (uint32_t s = 0; s < a.nk; ++s) {
+        const uint32_t buf = s & 1u;
+        // prefetch the next K-slab unconditionally (clamped: the last iteration re-reads its own slab) so that the
+        // staging registers stay in VGPRs instead of a scratch alloca
+        gload((s + 1) < a.nk ? s + 1 : s);
+        const unsigned char* pa = sA + buf * (BM * 128);
+        const unsigned char* pb = sB + buf * (BN * 128);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 xf[MI], wf[NI];
+#pragma unroll
+            for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(pa + tile_off(wm * (MI * 16) + j * 16 + frow, ks * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + tile_off(wn * (NI * 16) + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
+        }
+        lstore(buf ^ 1u);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds out[m = .. + (lane&15)][co = .. + (lane>>4)*4 + r], r = 0..3
+    const sa_epilogue& ep = a.ep;
+    const float alpha = ep.alpha ? *ep.alpha : 1.f;
+    const bool vec_ok = (g.Cout & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+        const uint32_t m = m_base + wm * (MI * 16) + j * 16 + frow;
+        if (m >= a.M) continue;
+        uint32_t q = fdiv(m, a.dW);
+        const uint32_t wmx = m - q * g.Wm;
+        uint32_t q2 = fdiv(q, a.dH);
+        const uint32_t hmx = q - q2 * g.Hm;
+        const uint32_t n = fdiv(q2, a.dD);
+        const uint32_t dmx = q2 - n * g.Dm;
+        const int64_t ovox = (((int64_t)n * g.Do + (dmx * g.out_mult[0] + g.out_off[0])) * g.Ho + (hmx * g.out_mult[1] + g.out_off[1])) * g.Wo +
+                             (wmx * g.out_mult[2] + g.out_off[2]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const uint32_t co0 = n_base + wn * (NI * 16) + i * 16 + fq * 4;
+            if (co0 >= (uint32_t)g.cout_valid) continue;
+            const int64_t o = ovox * g.Cout + co0;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (co0 + r >= (uint32_t)g.cout_valid) continue;
+                float x = v[r];
+                if (ep.bias) x += ep.bias[co0 + r];
+                float ad = 0.f;
+                if (ep.addend) ad = load_as_f32(ep.addend, ep.add_dtype, o + r);
+                if (ep.add_before_act) x += ad;
+                if (ep.act == SA_ACT_RELU) x = fmaxf(x, 0.f);
+                else if (ep.act == SA_ACT_LRELU) x = x > 0.f ? x : x * ep.slope;
+                else if (ep.act == SA_ACT_GELU) x = gelu_f(x);
+                x *= alpha;
+                if (!ep.add_before_act) x += ad;
+                if (ep.mask_mode != SA_MASK_NONE) {
+                    const float mk = load_as_f32(ep.mask, ep.mask_dtype, o + r);
+                    if (ep.mask_mode == SA_MASK_POS) x = mk > 0.f ? x : 0.f;
+                    else if (ep.mask_mode == SA_MASK_LRELU) x = mk > 0.f ? x : x * ep.slope;
+                    else x *= gelu_grad_f(mk);
+                }
+                v[r] = x;
+            }
+            if (vec_ok && co0 + 3 < (uint32_t)g.cout_valid) {
+                if (ep.out_dtype == SA_F32) {
+                    *(float4*)((float*)a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *(uint2*)((bf16_t*)a.out + o) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co0 + r < (uint32_t)g.cout_valid) store_from_f32(a.out, ep.out_dtype, o + r, v[r]);
+            }
+        }
+    }
+}
+
+template <typename T, int WM, int WN, int MI, int NI>
+static int launch_fprop(const FpropArgs& a, hipStream_t st) {
+    constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
+    const uint32_t nbn = (uint32_t)a.g.CoutPad / BN;
+    // only tiles that contain valid channels
+    const uint32_t nbn_valid = ((uint32_t)a.g.cout_valid + BN - 1) / BN;
+    (void)nbn;
+    const size_t lds = 2 * (BM + BN) * 128;
+    dim3 grid(a.nblk_m * nbn_valid);
+    hipLaunchKernelGGL((conv_fprop_kernel<T, WM, WN, MI, NI>), grid, dim3(256), lds, st, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
+static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
+    const int cv = a.g.cout_valid;
+    if (cv > 64) return launch_fprop<T, 2, 2, 4, 4>(a, st);
+    if (cv > 32) return launch_fprop<T, 4, 1, 2, 4>(a, st);
+    if (cv > 16) return launch_fprop<T, 4, 1, 2, 2>(a, st);
+    return launch_fprop<T, 4, 1, 2, 1>(a, st);
+}
+
+}  // namespace sa
+
+extern "C" int sa_conv_fprop(const sa_conv_geom* g, int dtype, const void* in, const void* wpk, void* out, const sa_epilogue* ep,
+                             void* stream) {
+    using namespace sa;
+    if (!g || !in || !wpk || !out || !ep) return SA_EINVAL;
+    const int vec = dtype == SA_F32 ? 4 : 8;
+    const int bke = dtype == SA_F32 ? 32 : 64;
+    if (dtype != SA_F32 && dtype != SA_BF16) return SA_EUNSUPPORTED;
+    const int ntaps = g->KT[0] * g->KT[1] * g->KT[2];
+    if (g->Cin % vec || g->Kpad % bke || g->Kpad < ntaps * g->Cin || g->CoutPad % 128 || g->cout_valid > g->CoutPad ||
+        g->cout_valid > g->Cout || ntaps < 1 || ntaps > SA_MAX_TAPS)
+        return SA_EINVAL;
+    const int64_t M = (int64_t)g->N * g->Dm * g->Hm * g->Wm;
+    if (M <= 0 || M >= (1ll << 31)) return SA_EINVAL;
+    FpropArgs a;
+    a.in = in;
+    a.wpk = wpk;
+    a.out = out;
+    a.ep = *ep;
+    a.g = *g;
+    a.dW = make_fastdiv(g->Wm);
+    a.dH = make_fastdiv(g->Hm);
+    a.dD = make_fastdiv(g->Dm);
+    a.dTw = make_fastdiv(g->KT[2]);
+    a.dThw = make_fastdiv(g->KT[1] * g->KT[2]);
+    a.dCv = make_fastdiv(g->Cin / vec);
+    a.M = (uint32_t)M;
+    a.ntaps = ntaps;
+    a.nk = g->Kpad / bke;
+    a.nblk_m = (uint32_t)((M + 127) / 128);
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == SA_F32 ? dispatch_fprop<float>(a, st) : dispatch_fprop<bf16_t>(a, st);
+}

@@ -1,0 +1,339 @@
+// Weight gradient of the implicit-GEMM convolution family on MFMA (gfx950).
+//
+//   dW[co][ci][tap] += sum_m in[g(m, tap)][ci] * gout[o(m)][co]
+//
+// A GEMM whose reduction runs over the voxels m.  Block tile: 128 (tap,ci) rows x 128 co columns; the voxel range is
+// split across blockIdx.z and combined with fp32 atomics (device scope, hardware global_atomic_add_f32).
+// Both operands are stored voxel-major in HBM ([m][c]) but MFMA wants the reduction index contiguous per lane:
+//   bf16: tiles are transposed on the way into LDS ([c][m], pairs of voxels packed per dword, XOR-swizzled so that the
+//         ds_write_b32 are <=2-way and the ds_read_b128 conflict-free), then fed to mfma_f32_16x16x32_bf16;
+//   f32 : tiles stay [m][c]; mfma_f32_16x16x4f32 takes one float per lane so fragments are plain ds_read_b32.
+#include "sa_common.h"
+
+namespace sa {
+
+struct WgradArgs {
+    const void* in;
+    const void* gout;
+    float* dw;
+    sa_conv_geom g;
+    FastDiv dW, dH, dD, dTw, dThw, dCin;
+    int32_t lut[SA_MAX_TAPS];
+    int64_t s_row, s_red;
+    uint32_t M, ntaps, ktot;       // ktot = ntaps * Cin
+    uint32_t chunks_per_split, nchunks;
+};
+
+template <typename T> struct WG;
+template <> struct WG<bf16_t> { static constexpr int MK = 64; };
+template <> struct WG<float> { static constexpr int MK = 16; };
+
+__device__ __forceinline__ uint32_t toff_t(uint32_t row, uint32_t vec) {  // transposed bf16 tile [128 c][64 m]
+    return row * 128u + ((vec ^ (row & 7u) ^ ((row >> 4) & 7u)) << 4);
+}
+
+struct RowPos {
+    int32_t id, ih, iw;   // input base coordinate (before tap offset)
+    int64_t ibase;        // linear input voxel (virtual when out of range)
+    int64_t ovox;         // linear output voxel
+    bool ok;
+};
+
+__device__ __forceinline__ RowPos decode_row(uint32_t m, const WgradArgs& a) {
+    RowPos r;
+    const sa_conv_geom& g = a.g;
+    r.ok = m < a.M;
+    const uint32_t mm = r.ok ? m : 0u;
+    uint32_t q = fdiv(mm, a.dW);
+    const uint32_t wmx = mm - q * g.Wm;
+    uint32_t q2 = fdiv(q, a.dH);
+    const uint32_t hmx = q - q2 * g.Hm;
+    const uint32_t n = fdiv(q2, a.dD);
+    const uint32_t dmx = q2 - n * g.Dm;
+    r.id = (int32_t)dmx * g.in_mult[0] + g.in_off[0];
+    r.ih = (int32_t)hmx * g.in_mult[1] + g.in_off[1];
+    r.iw = (int32_t)wmx * g.in_mult[2] + g.in_off[2];
+    r.ibase = (((int64_t)n * g.Di + r.id) * g.Hi + r.ih) * g.Wi + r.iw;
+    r.ovox = (((int64_t)n * g.Do + (dmx * g.out_mult[0] + g.out_off[0])) * g.Ho + (hmx * g.out_mult[1] + g.out_off[1])) * g.Wo +
+             (wmx * g.out_mult[2] + g.out_off[2]);
+    return r;
+}
+
+struct TapPos {
+    int32_t od, oh, ow;
+    int64_t off;
+    uint32_t c0;
+    bool ok;
+};
+
+__device__ __forceinline__ TapPos decode_k(uint32_t kidx0, const WgradArgs& a) {
+    TapPos t;
+    const sa_conv_geom& g = a.g;
+    const uint32_t tap = fdiv(kidx0, a.dCin);
+    t.c0 = kidx0 - tap * g.Cin;
+    t.ok = tap < a.ntaps;
+    const uint32_t td = fdiv(tap, a.dThw);
+    const uint32_t t2 = tap - td * a.dThw.d;
+    const uint32_t th = fdiv(t2, a.dTw);
+    const uint32_t tw = t2 - th * a.dTw.d;
+    t.od = (int32_t)td * g.tap_step[0];
+    t.oh = (int32_t)th * g.tap_step[1];
+    t.ow = (int32_t)tw * g.tap_step[2];
+    t.off = ((int64_t)t.od * g.Hi + t.oh) * g.Wi + t.ow;
+    return t;
+}
+
+__device__ __forceinline__ bool in_range(const RowPos& r, const TapPos& t, const sa_conv_geom& g) {
+    return r.ok && t.ok && (uint32_t)(r.id + t.od) < (uint32_t)g.Di && (uint32_t)(r.ih + t.oh) < (uint32_t)g.Hi &&
+           (uint32_t)(r.iw + t.ow) < (uint32_t)g.Wi;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int MK = WG<T>::MK;
+    constexpr bool IS_BF16 = sizeof(T) == 2;
+    constexpr int TILE_BYTES = IS_BF16 ? 128 * 128 : MK * 128 * 4;  // 16 KB / 8 KB
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem;                   // 2 x TILE
+    unsigned char* sG = smem + 2 * TILE_BYTES;  // 2 x TILE
+
+    const sa_conv_geom& g = a.g;
+    const T* __restrict__ in = (const T*)a.in;
+    const T* __restrict__ go = (const T*)a.gout;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wm = wave >> 1, wn = wave & 1u;
+    const uint32_t kt = blockIdx.x, ct = blockIdx.y;
+    const uint32_t chunk0 = blockIdx.z * a.chunks_per_split;
+    uint32_t chunk1 = chunk0 + a.chunks_per_split;
+    if (chunk1 > a.nchunks) chunk1 = a.nchunks;
+    if (chunk0 >= chunk1) return;
+
+    float4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    // ------------------------------------------------------------------ loader roles
+    // bf16: thread -> voxel pair mp = tid>>3 (0..31), 16-byte channel vectors v = (tid&7) + 8j (j=0,1) of both operands
+    // f32 : thread -> voxel rows (tid>>5) + 8j (j=0,1), 16-byte channel vector v = tid&31 of both operands
+    TapPos tp[2];
+    uint32_t gco[2];
+    if constexpr (IS_BF16) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t v = (tid & 7u) + 8u * j;
+            tp[j] = decode_k(kt * 128u + v * 8u, a);
+            if (kt * 128u + v * 8u >= a.ktot) tp[j].ok = false;
+            gco[j] = ct * 128u + v * 8u;
+        }
+    } else {
+        const uint32_t v = tid & 31u;
+        tp[0] = decode_k(kt * 128u + v * 4u, a);
+        if (kt * 128u + v * 4u >= a.ktot) tp[0].ok = false;
+        tp[1] = tp[0];
+        gco[0] = gco[1] = ct * 128u + v * 4u;
+    }
+
+    u32x4 rx[2][2], rg[2][2];  // [j][row]
+    auto gload = [&](uint32_t chunk) __attribute__((always_inline)) {
+        const uint32_t mb = chunk * MK;
+        if constexpr (IS_BF16) {
+            const uint32_t mp = tid >> 3;
+            RowPos r0 = decode_row(mb + 2 * mp, a), r1 = decode_row(mb + 2 * mp + 1, a);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                rx[j][0] = in_range(r0, tp[j], g) ? *(const u32x4*)(in + (r0.ibase + tp[j].off) * g.Cin + tp[j].c0) : (u32x4){0u, 0u, 0u, 0u};
+                rx[j][1] = in_range(r1, tp[j], g) ? *(const u32x4*)(in + (r1.ibase + tp[j].off) * g.Cin + tp[j].c0) : (u32x4){0u, 0u, 0u, 0u};
+                const bool cok = gco[j] + 8u <= (uint32_t)g.Cout;
+                rg[j][0] = (r0.ok && cok) ? *(const u32x4*)(go + r0.ovox * g.Cout + gco[j]) : (u32x4){0u, 0u, 0u, 0u};
+                rg[j][1] = (r1.ok && cok) ? *(const u32x4*)(go + r1.ovox * g.Cout + gco[j]) : (u32x4){0u, 0u, 0u, 0u};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                RowPos r = decode_row(mb + (tid >> 5) + 8u * j, a);
+                rx[j][0] = in_range(r, tp[0], g) ? *(const u32x4*)(in + (r.ibase + tp[0].off) * g.Cin + tp[0].c0) : (u32x4){0u, 0u, 0u, 0u};
+                const bool cok = gco[0] + 4u <= (uint32_t)g.Cout;
+                rg[j][0] = (r.ok && cok) ? *(const u32x4*)(go + r.ovox * g.Cout + gco[0]) : (u32x4){0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    auto lstore = [&](uint32_t buf) __attribute__((always_inline)) {
+        unsigned char* px = sX + buf * TILE_BYTES;
+        unsigned char* pg = sG + buf * TILE_BYTES;
+        if constexpr (IS_BF16) {
+            const uint32_t mp = tid >> 3;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t v = (tid & 7u) + 8u * j;
+                const uint32_t x0[4] = {rx[j][0].x, rx[j][0].y, rx[j][0].z, rx[j][0].w};
+                const uint32_t x1[4] = {rx[j][1].x, rx[j][1].y, rx[j][1].z, rx[j][1].w};
+                const uint32_t g0[4] = {rg[j][0].x, rg[j][0].y, rg[j][0].z, rg[j][0].w};
+                const uint32_t g1[4] = {rg[j][1].x, rg[j][1].y, rg[j][1].z, rg[j][1].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t row = v * 8u + e;
+                    const uint32_t sh = (e & 1) * 16;
+                    const uint32_t xd = ((x0[e >> 1] >> sh) & 0xffffu) | (((x1[e >> 1] >> sh) & 0xffffu) << 16);
+                    const uint32_t gd = ((g0[e >> 1] >> sh) & 0xffffu) | (((g1[e >> 1] >> sh) & 0xffffu) << 16);
+                    const uint32_t o = toff_t(row, mp >> 2) + (mp & 3u) * 4u;
+                    *(uint32_t*)(px + o) = xd;
+                    *(uint32_t*)(pg + o) = gd;
+                }
+            }
+        } else {
+            const uint32_t v = tid & 31u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t m = (tid >> 5) + 8u * j;
+                const uint32_t o = m * 512u + (((v * 4u) ^ ((m & 1u) << 4)) << 2);
+                *(u32x4*)(px + o) = rx[j][0];
+                *(u32x4*)(pg + o) = rg[j][0];
+            }
+        }
+    };
+
+    gload(chunk0);
+    lstore(0);
+    __syncthreads();
+    const uint32_t frow = lane & 15u, fq = lane >> 4;
+    for (uint32_t c = chunk0; c < chunk1; ++c) {
+        const uint32_t buf = (c - chunk0) & 1u;
+        gload((c + 1) < chunk1 ? c + 1 : c);  // unconditional (clamped) prefetch keeps the staging registers in VGPRs
+        const unsigned char* px = sX + buf * TILE_BYTES;
+        const unsigned char* pg = sG + buf * TILE_BYTES;
+        if constexpr (IS_BF16) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 xf[4], gf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xf[i] = *(const u32x4*)(px + toff_t(wm * 64 + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gf[j] = *(const u32x4*)(pg + toff_t(wn * 64 + j * 16 + frow, ks * 4 + fq));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const short8_t*)&xf[i], *(const short8_t*)&gf[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const uint32_t m = kk * 4u + fq;
+                const uint32_t sw = (m & 1u) << 4;
+                float xf[4], gf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xf[i] = *(const float*)(px + m * 512u + (((wm * 64 + i * 16 + frow) ^ sw) << 2));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gf[j] = *(const float*)(pg + m * 512u + (((wn * 64 + j * 16 + frow) ^ sw) << 2));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[i], gf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        lstore(buf ^ 1u);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds rows kidx = .. + fq*4 + r (4 consecutive ci of one tap), column co = .. + frow
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t k0 = kt * 128u + wm * 64u + i * 16u + fq * 4u;
+        if (k0 >= a.ktot) continue;
+        const uint32_t tap = fdiv(k0, a.dCin);
+        const uint32_t c0 = k0 - tap * g.Cin;
+        const int64_t tapo = a.lut[tap];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t co = ct * 128u + wn * 64u + j * 16u + frow;
+            if (co >= (uint32_t)g.cout_valid) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (c0 + r >= (uint32_t)g.cin_valid) continue;
+                unsafeAtomicAdd(a.dw + co * a.s_row + (int64_t)(c0 + r) * a.s_red + tapo, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+__global__ void colsum_kernel(const void* gp, int dtype, int64_t M, int C, int cstride, float* db, int64_t rows_per_block) {
+    // block (32 channel lanes x 8 row lanes); each block reduces rows_per_block rows of a 32-channel stripe
+    const int c = blockIdx.y * 32 + (threadIdx.x & 31);
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float s = 0.f;
+    if (c < C)
+        for (int64_t r = r0 + (threadIdx.x >> 5); r < r1; r += 8) s += load_as_f32(gp, dtype, r * cstride + c);
+    __shared__ float red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[threadIdx.x + 32 * k];
+        if (c < C) unsafeAtomicAdd(db + c, t);
+    }
+}
+
+}  // namespace sa
+
+extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, const void* gout, float* dw, const int32_t* tap_lut_host,
+                             int64_t s_row, int64_t s_red, void* stream) {
+    using namespace sa;
+    if (!g || !in || !gout || !dw) return SA_EINVAL;
+    if (dtype != SA_F32 && dtype != SA_BF16) return SA_EUNSUPPORTED;
+    const int vec = dtype == SA_F32 ? 4 : 8;
+    const int ntaps = g->KT[0] * g->KT[1] * g->KT[2];
+    if (g->Cin % vec || g->Cout % vec || ntaps < 1 || ntaps > SA_MAX_TAPS) return SA_EINVAL;
+    const int64_t M = (int64_t)g->N * g->Dm * g->Hm * g->Wm;
+    if (M <= 0 || M >= (1ll << 31)) return SA_EINVAL;
+    WgradArgs a;
+    a.in = in;
+    a.gout = gout;
+    a.dw = dw;
+    a.g = *g;
+    a.dW = make_fastdiv(g->Wm);
+    a.dH = make_fastdiv(g->Hm);
+    a.dD = make_fastdiv(g->Dm);
+    a.dTw = make_fastdiv(g->KT[2]);
+    a.dThw = make_fastdiv(g->KT[1] * g->KT[2]);
+    a.dCin = make_fastdiv(g->Cin);
+    for (int t = 0; t < SA_MAX_TAPS; ++t) a.lut[t] = tap_lut_host ? (t < ntaps ? tap_lut_host[t] : 0) : t;
+    a.s_row = s_row;
+    a.s_red = s_red;
+    a.M = (uint32_t)M;
+    a.ntaps = ntaps;
+    a.ktot = ntaps * g->Cin;
+    const int mk = dtype == SA_F32 ? 16 : 64;
+    a.nchunks = (uint32_t)((M + mk - 1) / mk);
+    const uint32_t nkt = (a.ktot + 127) / 128, nct = ((uint32_t)g->cout_valid + 127) / 128;
+    uint32_t splits = (2048 + nkt * nct - 1) / (nkt * nct);
+    const uint32_t min_chunks = dtype == SA_F32 ? 16 : 8;  // >= ~512 voxels per block
+    uint32_t max_splits = (a.nchunks + min_chunks - 1) / min_chunks;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    a.chunks_per_split = (a.nchunks + splits - 1) / splits;
+    splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    const size_t lds = dtype == SA_F32 ? 4 * 8192 : 4 * 16384;
+    dim3 grid(nkt, nct, splits);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SA_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_colsum(const void* gp, int dtype, int64_t M, int C, int cstride, float* db, void* stream) {
+    using namespace sa;
+    if (!gp || !db || M <= 0 || C <= 0) return SA_EINVAL;
+    int64_t rows_per_block = (M + 1023) / 1024;
+    if (rows_per_block < 64) rows_per_block = 64;
+    dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (C + 31) / 32);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, gp, dtype, M, C, cstride, db, rows_per_block);
+    SA_CHECK_LAUNCH();
+    return 0;
+}

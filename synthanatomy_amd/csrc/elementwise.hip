@@ -1,0 +1,135 @@
+// Small HBM-bound kernels: weight packing, dtype/channel-pad casts, MSE loss (+grad), Adam.
+#include "sa_common.h"
+
+namespace sa {
+
+thread_local hipError_t g_last_error = hipSuccess;
+
+struct PackArgs {
+    const float* w;
+    void* wpk;
+    int32_t lut[SA_MAX_TAPS];
+    int64_t s_row, s_red;
+    int32_t dtype, rows, red, ntaps, rows_pad, red_stride, Kpad;
+};
+
+// wpk[r][t*red_stride + c] = w[r*s_row + c*s_red + lut[t]]  (zero in every padded position)
+__global__ void pack_weights_kernel(const PackArgs a) {
+    const int64_t total = (int64_t)a.rows_pad * a.Kpad;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e / a.Kpad);
+        const int k = (int)(e - (int64_t)r * a.Kpad);
+        const int t = k / a.red_stride;
+        const int c = k - t * a.red_stride;
+        float v = 0.f;
+        if (r < a.rows && t < a.ntaps && c < a.red) v = a.w[r * a.s_row + c * a.s_red + a.lut[t]];
+        store_from_f32(a.wpk, a.dtype, e, v);
+    }
+}
+
+__global__ void cast_pad_kernel(const void* src, int src_dtype, int src_c, void* dst, int dst_dtype, int dst_stride, int64_t rows) {
+    const int64_t total = rows * dst_stride;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / dst_stride;
+        const int c = (int)(e - r * dst_stride);
+        const float v = c < src_c ? load_as_f32(src, src_dtype, r * src_c + c) : 0.f;
+        store_from_f32(dst, dst_dtype, e, v);
+    }
+}
+
+__global__ void mse_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* __restrict__ loss_sum, float* __restrict__ grad,
+                           float gcoef) {
+    float s = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const float d = a[e] - b[e];
+        s += d * d;
+        if (grad) grad[e] = d * gcoef;
+    }
+    s = wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss_sum, red[0] + red[1] + red[2] + red[3]);
+}
+
+// torch.optim.Adam (no amsgrad): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                            float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        float gr = g[e] * gscale;
+        const float pe = p[e];
+        if (wd != 0.f) gr += wd * pe;
+        const float me = b1 * m[e] + (1.f - b1) * gr;
+        const float ve = b2 * v[e] + (1.f - b2) * gr * gr;
+        m[e] = me;
+        v[e] = ve;
+        const float denom = sqrtf(ve) / bc2_sqrt + eps;
+        p[e] = pe - (lr / bc1) * (me / denom);
+    }
+}
+
+static inline unsigned grid_for(int64_t n, int block = 256, unsigned cap = 4096) {
+    int64_t b = (n + block - 1) / block;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace sa
+
+extern "C" int sa_abi_version(void) { return SA_ABI_VERSION; }
+extern "C" const char* sa_last_error(void) { return hipGetErrorString(sa::g_last_error); }
+
+extern "C" int sa_pack_weights(const float* w, void* wpk, int dtype, int rows, int red, int ntaps, const int32_t* tap_lut_host, int64_t s_row,
+                               int64_t s_red, int rows_pad, int red_stride, int Kpad, void* stream) {
+    using namespace sa;
+    if (!w || !wpk || rows <= 0 || red <= 0 || ntaps <= 0 || ntaps > SA_MAX_TAPS || rows_pad < rows || red_stride < red ||
+        Kpad < ntaps * red_stride)
+        return SA_EINVAL;
+    if (dtype != SA_F32 && dtype != SA_BF16) return SA_EUNSUPPORTED;
+    PackArgs a;
+    a.w = w;
+    a.wpk = wpk;
+    for (int t = 0; t < SA_MAX_TAPS; ++t) a.lut[t] = tap_lut_host ? (t < ntaps ? tap_lut_host[t] : 0) : t;
+    a.s_row = s_row;
+    a.s_red = s_red;
+    a.dtype = dtype;
+    a.rows = rows;
+    a.red = red;
+    a.ntaps = ntaps;
+    a.rows_pad = rows_pad;
+    a.red_stride = red_stride;
+    a.Kpad = Kpad;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for((int64_t)rows_pad * Kpad)), dim3(256), 0, (hipStream_t)stream, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_cast_pad(const void* src, int src_dtype, int src_c, void* dst, int dst_dtype, int dst_stride, int64_t rows, void* stream) {
+    using namespace sa;
+    if (!src || !dst || src_c <= 0 || dst_stride <= 0 || rows <= 0) return SA_EINVAL;
+    hipLaunchKernelGGL(cast_pad_kernel, dim3(grid_for(rows * dst_stride)), dim3(256), 0, (hipStream_t)stream, src, src_dtype, src_c, dst, dst_dtype,
+                       dst_stride, rows);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_mse(const float* a, const float* b, int64_t n, float* loss_sum, float* grad, float gscale, void* stream) {
+    using namespace sa;
+    if (!a || !b || !loss_sum || n <= 0) return SA_EINVAL;
+    hipLaunchKernelGGL(mse_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a, b, n, loss_sum, grad, 2.f * gscale / (float)n);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int step, float grad_scale, void* stream) {
+    using namespace sa;
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return SA_EINVAL;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1,
+                       sqrtf(bc2), grad_scale);
+    SA_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,96 @@
+// Shared device/host helpers for the gfx950 kernels (wave = 64 lanes, MFMA 16x16 tiles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/synthanatomy_hip.h"
+
+namespace sa {
+
+typedef unsigned short bf16_t;  // raw storage
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+extern thread_local hipError_t g_last_error;
+
+#define SA_CHECK_LAUNCH()                         \
+    do {                                          \
+        hipError_t e__ = hipGetLastError();       \
+        if (e__ != hipSuccess) {                  \
+            sa::g_last_error = e__;               \
+            return (int)e__;                      \
+        }                                         \
+    } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, NaN preserved (same as torch's float->bfloat16)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+    static constexpr int id = SA_F32;
+    static constexpr int VEC = 4;  // elements per 16 bytes
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct DT<bf16_t> {
+    static constexpr int id = SA_BF16;
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float load_as_f32(const void* base, int dtype, int64_t off) {
+    return dtype == SA_F32 ? ((const float*)base)[off] : bf16_to_f32(((const bf16_t*)base)[off]);
+}
+__device__ __forceinline__ void store_from_f32(void* base, int dtype, int64_t off, float v) {
+    if (dtype == SA_F32) ((float*)base)[off] = v;
+    else ((bf16_t*)base)[off] = f32_to_bf16(v);
+}
+
+// Division by a launch-invariant 32-bit divisor via multiply-high (valid for x < 2^31).
+struct FastDiv {
+    uint32_t mul, shr, d;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    if (d <= 1) {
+        f.mul = 0;
+        f.shr = 0;
+        return f;
+    }
+    uint32_t l = 0;
+    while ((1u << l) < d) ++l;  // ceil(log2 d)
+    uint64_t p = 31 + l;
+    f.mul = (uint32_t)(((1ull << p) + d - 1) / d);
+    f.shr = (uint32_t)(p - 32);
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t x, const FastDiv& f) { return f.d <= 1 ? x : (__umulhi(x, f.mul) >> f.shr); }
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// XCD-aware bijective remap of a linear block id: blocks that are adjacent in the remapped order (and so share
+// input halos / weight panels) land on the same XCD's L2.  Dispatch places block b on XCD b % 8 (speed only).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
+    const uint32_t q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+}  // namespace sa

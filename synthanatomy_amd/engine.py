@@ -1,0 +1,245 @@
+"""Host-side launch planning for the implicit-GEMM convolution family (csrc/conv_fprop.hip, conv_wgrad.hip).
+
+A ``ConvOp`` owns the packed GEMM operands of one reference layer (``nn.Conv3d`` / ``nn.ConvTranspose3d`` /
+``nn.Linear``; reference src/networks/vqvae/baseline.py:153-160,218-244,258-293) and turns forward, data-gradient and
+weight-gradient requests into ``sa_conv_geom`` launches.  Activations are channels-last ``[N, D, H, W, C]`` tensors of
+the compute dtype (fp32 = exact-f32 MFMA parity mode, bf16 = throughput mode).
+
+Everything here runs on the HIP device through the C ABI; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _ffi
+from ._ffi import ACT_NONE, MASK_NONE, ConvGeom, Epilogue
+
+
+def _ru(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def vec_of(dtype: torch.dtype) -> int:
+    return 4 if dtype == torch.float32 else 8
+
+
+def _i3(v):
+    return (ctypes.c_int32 * 3)(*[int(a) for a in v])
+
+
+class _Plan:
+    """One kernel launch: geometry + how to pack (or scatter, for wgrad) the weight operand."""
+
+    __slots__ = ("geom", "rows", "red", "ntaps", "lut", "s_row", "s_red", "wpk", "lut_c", "packed_ver")
+
+    def __init__(self, geom, rows, red, ntaps, lut, s_row, s_red):
+        self.geom, self.rows, self.red, self.ntaps, self.lut, self.s_row, self.s_red = geom, rows, red, ntaps, lut, s_row, s_red
+        self.wpk = None
+        self.packed_ver = None
+        self.lut_c = (ctypes.c_int32 * len(lut))(*lut) if lut is not None else None
+
+
+def make_geom(dtype, N, grid, idims, cin_s, odims, cout_s, cin_valid, cout_valid, KT, in_mult, tap_step, in_off, out_mult, out_off) -> ConvGeom:
+    g = ConvGeom()
+    g.N, (g.Dm, g.Hm, g.Wm) = N, grid
+    g.Di, g.Hi, g.Wi = idims
+    g.Cin = cin_s
+    g.Do, g.Ho, g.Wo = odims
+    g.Cout = cout_s
+    g.cin_valid, g.cout_valid = cin_valid, cout_valid
+    g.KT = _i3(KT)
+    g.in_mult, g.tap_step, g.in_off = _i3(in_mult), _i3(tap_step), _i3(in_off)
+    g.out_mult, g.out_off = _i3(out_mult), _i3(out_off)
+    bke = 32 if dtype == torch.float32 else 64
+    g.Kpad = _ru(KT[0] * KT[1] * KT[2] * cin_s, bke)
+    g.CoutPad = _ru(cout_valid, 128)
+    return g
+
+
+def _parities():
+    return [(a, b, c) for a in (0, 1) for b in (0, 1) for c in (0, 1)]
+
+
+def _parity_lut(par, k=4):
+    k0 = [(p + 1) % 2 for p in par]
+    return [((k0[0] + 2 * td) * k + (k0[1] + 2 * th)) * k + (k0[2] + 2 * tw) for td in (0, 1) for th in (0, 1) for tw in (0, 1)]
+
+
+class ConvOp:
+    """kind="conv": weight [Cout, Cin, k,k,k];  kind="convT": weight [Cin, Cout, k,k,k] (k4 s2 p1 only)."""
+
+    def __init__(self, kind: str, cin: int, cout: int, k: int, stride: int, pad: int, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                 dtype: torch.dtype):
+        assert kind in ("conv", "convT")
+        if kind == "convT" and not (k == 4 and stride == 2 and pad == 1):
+            raise NotImplementedError("ConvTranspose3d is implemented for kernel 4 / stride 2 / padding 1 / output_padding 0 (the reference's setting)")
+        self.kind, self.cin, self.cout, self.k, self.stride, self.pad = kind, cin, cout, k, stride, pad
+        self.weight, self.bias = weight, bias
+        self.dtype = dtype
+        self.vec = vec_of(dtype)
+        self.T = k ** 3
+        self._plans = {}
+        self._bias_pad = None
+        self._epoch = 0
+
+    # ------------------------------------------------------------------ shapes
+    def out_dims(self, idims):
+        if self.kind == "conv":
+            return tuple((d + 2 * self.pad - self.k) // self.stride + 1 for d in idims)
+        return tuple(2 * d for d in idims)
+
+    def cs_in(self):
+        return _ru(self.cin, self.vec)
+
+    # ------------------------------------------------------------------ plans
+    def _get_plans(self, N: int, idims: Tuple[int, int, int], cout_s: int, gout_s: int):
+        key = (N, tuple(idims), cout_s, gout_s)
+        if key in self._plans:
+            return self._plans[key]
+        dt, k, s, p, T = self.dtype, self.k, self.stride, self.pad, self.T
+        cin, cout = self.cin, self.cout
+        cin_s = self.cs_in()
+        odims = self.out_dims(idims)
+        fwd: List[_Plan] = []
+        dgr: List[_Plan] = []
+        wgr: List[_Plan] = []
+        one, zero = (1, 1, 1), (0, 0, 0)
+        if self.kind == "conv":
+            g = make_geom(dt, N, odims, idims, cin_s, odims, cout_s, cin, cout, (k,) * 3, (s,) * 3, one, (-p,) * 3, one, zero)
+            fwd.append(_Plan(g, cout, cin, T, None, cin * T, T))
+            gw = make_geom(dt, N, odims, idims, cin_s, odims, gout_s, cin, cout, (k,) * 3, (s,) * 3, one, (-p,) * 3, one, zero)
+            wgr.append(_Plan(gw, cout, cin, T, None, cin * T, T))
+            if s == 1:
+                g = make_geom(dt, N, idims, odims, gout_s, idims, cin_s, cout, cin, (k,) * 3, one, (-1,) * 3, (p,) * 3, one, zero)
+                dgr.append(_Plan(g, cin, cout, T, None, T, cin * T))
+            elif s == 2 and k == 4 and p == 1 and all(d % 2 == 0 for d in idims):
+                half = tuple(d // 2 for d in idims)
+                for par in _parities():
+                    g = make_geom(dt, N, half, odims, gout_s, idims, cin_s, cout, cin, (2, 2, 2), one, (-1,) * 3, par, (2, 2, 2), par)
+                    dgr.append(_Plan(g, cin, cout, 8, _parity_lut(par), T, cin * T))
+            else:
+                dgr = None  # data gradient not available for this geometry
+        else:  # convT k4 s2 p1
+            for par in _parities():
+                lut = _parity_lut(par)
+                g = make_geom(dt, N, idims, idims, cin_s, odims, cout_s, cin, cout, (2, 2, 2), one, (-1,) * 3, par, (2, 2, 2), par)
+                fwd.append(_Plan(g, cout, cin, 8, lut, T, cout * T))
+                gw = make_geom(dt, N, idims, idims, cin_s, odims, gout_s, cin, cout, (2, 2, 2), one, (-1,) * 3, par, (2, 2, 2), par)
+                wgr.append(_Plan(gw, cout, cin, 8, lut, T, cout * T))
+            g = make_geom(dt, N, idims, odims, gout_s, idims, cin_s, cout, cin, (4,) * 3, (2, 2, 2), one, (-1,) * 3, one, zero)
+            dgr.append(_Plan(g, cin, cout, T, None, cout * T, T))
+        plans = {"fwd": fwd, "dgrad": dgr, "wgrad": wgr, "odims": odims}
+        self._plans[key] = plans
+        return plans
+
+    # ------------------------------------------------------------------ weight packing
+    def _pack(self, plan: _Plan, ver):
+        g = plan.geom
+        if plan.wpk is None:
+            plan.wpk = torch.empty(g.CoutPad * g.Kpad, dtype=self.dtype, device=self.weight.device)
+        elif plan.packed_ver == ver:
+            return
+        _ffi.check(_ffi.lib().sa_pack_weights(_ffi.ptr(self.weight), _ffi.ptr(plan.wpk), _ffi.dtype_id(self.dtype), plan.rows, plan.red,
+                                              plan.ntaps, plan.lut_c, plan.s_row, plan.s_red, g.CoutPad, g.Cin, g.Kpad, _ffi.stream()),
+                   "sa_pack_weights")
+        plan.packed_ver = ver
+
+    def invalidate(self):
+        """Call after the weights changed through a raw pointer (our Adam kernel): packed operands are rebuilt lazily."""
+        self._epoch += 1
+
+    def _ensure_packed(self, plans: Sequence[_Plan]):
+        ver = (self.weight._version, self.weight.data_ptr(), self._epoch)
+        for pl in plans:
+            self._pack(pl, ver)
+
+    def _bias_padded(self):
+        if self.bias is None:
+            return None
+        ver = (self.bias._version, self.bias.data_ptr(), self._epoch)
+        if self._bias_pad is None or self._bias_pad[0] != ver:
+            bp = torch.zeros(_ru(self.cout, 128), dtype=torch.float32, device=self.bias.device)
+            bp[: self.cout] = self.bias.detach()
+            self._bias_pad = (ver, bp)
+        return self._bias_pad[1]
+
+    # ------------------------------------------------------------------ launches
+    @staticmethod
+    def _epilogue(bias, addend, mask, alpha, act, mask_mode, add_before_act, out_dtype, slope) -> Epilogue:
+        ep = Epilogue()
+        ep.bias = bias.data_ptr() if bias is not None else None
+        ep.addend = addend.data_ptr() if addend is not None else None
+        ep.mask = mask.data_ptr() if mask is not None else None
+        ep.alpha = alpha.data_ptr() if alpha is not None else None
+        ep.act, ep.mask_mode, ep.add_before_act = act, (mask_mode if mask is not None else MASK_NONE), int(add_before_act)
+        ep.out_dtype = _ffi.dtype_id(out_dtype)
+        ep.add_dtype = _ffi.dtype_id(addend.dtype) if addend is not None else 0
+        ep.mask_dtype = _ffi.dtype_id(mask.dtype) if mask is not None else 0
+        ep.slope = slope
+        return ep
+
+    def fprop(self, x: torch.Tensor, *, act=ACT_NONE, addend=None, add_before_act=False, mask=None, mask_mode=MASK_NONE, alpha=None,
+              out_dtype=None, out_channels_stride=None, slope=0.2, use_bias=True) -> torch.Tensor:
+        N, D, H, W, C = x.shape
+        assert x.dtype == self.dtype and x.is_contiguous() and C == self.cs_in(), (x.dtype, x.shape, self.cs_in())
+        out_dtype = out_dtype or self.dtype
+        cout_s = out_channels_stride or self.cout
+        plans = self._get_plans(N, (D, H, W), cout_s, _ru(self.cout, self.vec))
+        self._ensure_packed(plans["fwd"])
+        od = plans["odims"]
+        out = torch.empty((N, *od, cout_s), dtype=out_dtype, device=x.device)
+        if cout_s != self.cout:
+            out.zero_()
+        ep = self._epilogue(self._bias_padded() if use_bias else None, addend, mask, alpha, act, mask_mode, add_before_act, out_dtype, slope)
+        lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
+        for pl in plans["fwd"]:
+            _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(x), _ffi.ptr(pl.wpk), _ffi.ptr(out), ctypes.byref(ep), st), "sa_conv_fprop")
+        return out
+
+    def dgrad(self, g: torch.Tensor, idims: Tuple[int, int, int], *, addend=None, mask=None, mask_mode=MASK_NONE, out_dtype=None, slope=0.2,
+              fwd_out_stride=None) -> torch.Tensor:
+        """dx [N, *idims, cs_in] from g [N, *odims, gout_s] (gradient wrt this layer's pre-activation output)."""
+        N = g.shape[0]
+        gout_s = g.shape[-1]
+        assert g.dtype == self.dtype and g.is_contiguous() and gout_s == _ru(self.cout, self.vec)
+        plans = self._get_plans(N, tuple(idims), fwd_out_stride or self.cout, gout_s)
+        if plans["dgrad"] is None:
+            raise NotImplementedError("data gradient for this conv geometry")
+        self._ensure_packed(plans["dgrad"])
+        out_dtype = out_dtype or self.dtype
+        cin_s = self.cs_in()
+        dx = torch.empty((N, *idims, cin_s), dtype=out_dtype, device=g.device)
+        if cin_s != self.cin:
+            dx.zero_()
+        ep = self._epilogue(None, addend, mask, None, ACT_NONE, mask_mode, False, out_dtype, slope)
+        lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
+        for pl in plans["dgrad"]:
+            _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(g), _ffi.ptr(pl.wpk), _ffi.ptr(dx), ctypes.byref(ep), st), "sa_conv_fprop(dgrad)")
+        return dx
+
+    def wgrad(self, x: torch.Tensor, g: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor] = None, fwd_out_stride=None):
+        """dw (fp32, reference weight layout, pre-zeroed or accumulating) += x (*) g ; db += colsum(g)."""
+        N, D, H, W, C = x.shape
+        assert x.dtype == self.dtype and g.dtype == self.dtype and x.is_contiguous() and g.is_contiguous()
+        assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.shape == self.weight.shape
+        plans = self._get_plans(N, (D, H, W), fwd_out_stride or self.cout, g.shape[-1])
+        lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
+        for pl in plans["wgrad"]:
+            _ffi.check(lib.sa_conv_wgrad(ctypes.byref(pl.geom), did, _ffi.ptr(x), _ffi.ptr(g), _ffi.ptr(dw), pl.lut_c, pl.s_row, pl.s_red, st), "sa_conv_wgrad")
+        if db is not None:
+            M = g.numel() // g.shape[-1]
+            _ffi.check(lib.sa_colsum(_ffi.ptr(g), did, M, self.cout, g.shape[-1], _ffi.ptr(db), st), "sa_colsum")
+
+
+def cast_pad(src: torch.Tensor, dst_dtype: torch.dtype, dst_stride: int) -> torch.Tensor:
+    """[..., C] -> [..., dst_stride] of dst_dtype (zero channel padding) via the HIP cast kernel."""
+    src = src.contiguous()
+    C = src.shape[-1]
+    rows = src.numel() // C
+    dst = torch.empty((*src.shape[:-1], dst_stride), dtype=dst_dtype, device=src.device)
+    _ffi.check(_ffi.lib().sa_cast_pad(_ffi.ptr(src), _ffi.dtype_id(src.dtype), C, _ffi.ptr(dst), _ffi.dtype_id(dst_dtype), dst_stride, rows, _ffi.stream()),
+               "sa_cast_pad")
+    return dst

@@ -1,0 +1,484 @@
+"""``baseline_vqvae`` on MI355X: the reference's plugin surface over hand-written HIP kernels.
+
+Mirrors reference ``src/networks/vqvae/baseline.py`` -- ``Quantizer_impl`` (:24-91), ``Quantizer`` (:94-147),
+``ResidualLayer`` (:150-160), ``BaselineVQVAE`` (:163-362): same constructor arguments, methods, return types (dicts of
+1-element lists) and ``state_dict`` keys (``encoder.0.{0,2,3,..}``, ``quantizer.0.impl.{weight,N,embed_avg,
+embedding.weight}``, ``decoder.0.{0,1,2,4,..}``), so checkpoints and callers are interchangeable.
+
+What differs is everything underneath: the ``nn.Conv3d``/``nn.ConvTranspose3d`` objects are only parameter holders; the
+arithmetic is a chain of implicit-GEMM MFMA launches (``synthanatomy_amd.engine``) over channels-last activations in
+``compute_dtype`` (``torch.bfloat16`` = throughput mode, ``torch.float32`` = exact-f32 MFMA parity mode), and the
+quantizer is one fused HIP kernel + one RCCL all-reduce of the packed EMA statistics on a side stream.  Autograd sees
+three nodes (encoder, quantizer, decoder) whose backward passes are hand-scheduled dgrad/wgrad launches with the ReLU
+masks and residual adds fused into the GEMM epilogues.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple, Union
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from ... import _ffi
+from ..._ffi import ACT_NONE, ACT_RELU, MASK_POS
+from ...engine import ConvOp, cast_pad, vec_of
+from .vqvae import VQVAEBase
+
+
+# ------------------------------------------------------------------------------------------------ quantizer
+class Quantizer_impl(nn.Module):
+    def __init__(self, n_embed: int, embed_dim: int, eps: float):
+        super().__init__()
+        self.embed_dim, self.n_embed, self.eps = embed_dim, n_embed, eps
+        self.embedding = nn.Embedding(n_embed, embed_dim)
+        self.embedding.weight.requires_grad = False
+        self.weight = self.embedding.weight  # same Parameter under a second name, as the reference (baseline.py:33)
+        self.register_buffer("N", torch.zeros(n_embed))
+        self.register_buffer("embed_avg", self.weight.data.clone())
+        self._stats = None      # packed [K + K*D] fp32: counts | dw  (one all-reduce instead of the reference's two)
+        self._scratch = None    # wnorm[K] | sqerr[1] | perplexity[1]
+        self._side = None
+        self._ema_done = None
+        self.process_group = None
+
+    # ---- device buffers -------------------------------------------------------------------------------------
+    def _buffers(self, dev):
+        K, D = self.n_embed, self.embed_dim
+        if self._stats is None or self._stats.device != dev:
+            self._stats = torch.zeros(K + K * D, dtype=torch.float32, device=dev)
+            self._scratch = torch.zeros(K + 2, dtype=torch.float32, device=dev)
+        return self._stats, self._scratch
+
+    def wait_ema(self):
+        """Make the current stream wait for an EMA update still running on the side stream."""
+        if self._ema_done is not None:
+            torch.cuda.current_stream().wait_event(self._ema_done)
+            self._ema_done = None
+
+    # ---- forward (Quantizer_impl.forward, baseline.py:38-87) --------------------------------------------------
+    def forward(self, x: torch.Tensor, decay: float, commitment_cost: float):
+        zq, loss, idx, _ = _VQFn.apply(x, self, float(decay), float(commitment_cost), self.training)
+        return zq, loss, idx
+
+    def embed(self, embedding_indices: torch.Tensor) -> torch.Tensor:
+        """indices [B,h,w,d] -> codes [B,D,h,w,d] (baseline.py:89-91)."""
+        _ffi.require_gpu()
+        self.wait_ema()
+        idx = embedding_indices.to(device=self.weight.device, dtype=torch.int64).contiguous()
+        out = torch.empty((*idx.shape, self.embed_dim), dtype=torch.float32, device=idx.device)
+        _ffi.check(_ffi.lib().sa_vq_embed(_ffi.ptr(self.weight), _ffi.ptr(idx), idx.numel(), self.n_embed, self.embed_dim, _ffi.ptr(out),
+                                          _ffi.SA_F32, _ffi.stream()), "sa_vq_embed")
+        return out.permute(0, 4, 1, 2, 3)
+
+
+class _VQFn(torch.autograd.Function):
+    """x [B,D,h,w,d] (any strides) -> (zq_st [B,D,h,w,d], loss, idx [B,h,w,d], perplexity)."""
+
+    @staticmethod
+    def forward(ctx, x, q: Quantizer_impl, decay, beta, training):
+        _ffi.require_gpu()
+        lib, st = _ffi.lib(), _ffi.stream()
+        K, D = q.n_embed, q.embed_dim
+        b = x.shape[0]
+        sp = tuple(x.shape[2:])
+        rows = x.float().permute(0, 2, 3, 4, 1).contiguous()  # no copy when x is the encoder's channels-last output
+        M = rows.numel() // D
+        dev = rows.device
+        q.wait_ema()
+        stats, scratch = q._buffers(dev)
+        stats.zero_()
+        scratch.zero_()
+        counts, dw = stats[:K], stats[K:]
+        wnorm, sqerr, ppl = scratch[:K], scratch[K:K + 1], scratch[K + 1:K + 2]
+        idx = torch.empty((b, *sp), dtype=torch.int64, device=dev)
+        zq = torch.empty_like(rows)
+        cb = q.weight.detach()
+        cb_used = cb.clone() if training else cb  # backward needs the pre-update codebook (baseline.py:63)
+        _ffi.check(lib.sa_vq_assign(_ffi.ptr(rows), _ffi.ptr(cb), M, K, D, _ffi.ptr(idx), _ffi.ptr(zq), None, _ffi.ptr(counts), _ffi.ptr(dw),
+                                    _ffi.ptr(sqerr), _ffi.ptr(wnorm), st), "sa_vq_assign")
+        _ffi.check(lib.sa_vq_perplexity(_ffi.ptr(counts), K, M, _ffi.ptr(ppl), st), "sa_vq_perplexity")
+        loss = (sqerr * (beta / float(M * D))).reshape(())
+        perplexity = ppl.clone().reshape(())
+        if training:
+            # EMA update (baseline.py:66-80).  The statistics are SUMMED over ranks; the all-reduce and the update run on a
+            # side stream because nothing downstream in this step reads the new codebook.
+            use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(q.process_group) > 1
+            if q._side is None:
+                q._side = torch.cuda.Stream(device=dev)
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(q._side):
+                q._side.wait_event(ready)
+                if use_dist:
+                    dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=q.process_group)
+                _ffi.check(lib.sa_vq_ema_update(_ffi.ptr(q.N), _ffi.ptr(q.embed_avg), _ffi.ptr(cb), _ffi.ptr(counts), _ffi.ptr(dw), K, D, decay, q.eps,
+                                                _ffi.stream()), "sa_vq_ema_update")
+                done = torch.cuda.Event()
+                done.record()
+            q._ema_done = done
+        ctx.save_for_backward(rows, cb_used, idx)
+        ctx.beta = beta
+        ctx.mark_non_differentiable(idx, perplexity)
+        return zq.permute(0, 4, 1, 2, 3), loss, idx, perplexity
+
+    @staticmethod
+    def backward(ctx, g_zq, g_loss, _gi, _gp):
+        rows, cb, idx = ctx.saved_tensors
+        D = rows.shape[-1]
+        M = rows.numel() // D
+        gz = None
+        if g_zq is not None:
+            gz = g_zq.permute(0, 2, 3, 4, 1).contiguous()
+            if gz.dtype not in (torch.float32, torch.bfloat16):
+                gz = gz.float()
+        gl = g_loss.float().reshape(1).contiguous() if g_loss is not None else None
+        dz = torch.empty_like(rows)
+        _ffi.check(_ffi.lib().sa_vq_backward(_ffi.ptr(rows), _ffi.ptr(cb), _ffi.ptr(idx), _ffi.ptr(gz), _ffi.dtype_id(gz.dtype) if gz is not None else 0,
+                                             _ffi.ptr(gl), ctx.beta, M, D, _ffi.ptr(dz), _ffi.SA_F32, _ffi.stream()), "sa_vq_backward")
+        return dz.permute(0, 4, 1, 2, 3), None, None, None, None
+
+
+class Quantizer(nn.Module):
+    def __init__(self, n_embed, embed_dim, commitment_cost=0.25, decay=0.99, eps=1e-5):
+        super().__init__()
+        self.impl = Quantizer_impl(n_embed, embed_dim, eps)
+        self.n_embed = n_embed
+        self.commitment_cost = commitment_cost
+        self.decay = decay
+        self.perplexity_code: torch.Tensor = torch.rand(1)
+
+    def forward(self, x):
+        zq, loss, idx, ppl = _VQFn.apply(x, self.impl, float(self.decay), float(self.commitment_cost), self.impl.training)
+        self.perplexity_code = ppl
+        return zq, loss
+
+    def get_ema_decay(self) -> float:
+        return self.decay
+
+    def set_ema_decay(self, decay: float) -> float:
+        self.decay = decay
+        return self.get_ema_decay()
+
+    def get_commitment_cost(self) -> float:
+        return self.commitment_cost
+
+    def set_commitment_cost(self, commitment_cost) -> float:
+        self.commitment_cost = commitment_cost
+        return self.get_commitment_cost()
+
+    def get_perplexity(self) -> torch.Tensor:
+        return self.perplexity_code
+
+    def embed(self, embedding_indices: torch.Tensor) -> torch.Tensor:
+        return self.impl.embed(embedding_indices=embedding_indices)
+
+    def quantize(self, encodings: torch.Tensor):
+        return self.impl(encodings, self.decay, self.commitment_cost)
+
+
+# ------------------------------------------------------------------------------------------------ parameter holders
+class ResidualLayer(nn.Sequential):
+    """relu(x + conv1x1(dropout(relu(conv3x3(x)))))  (baseline.py:150-160).  Holder of the two convs' parameters; the
+    arithmetic runs in ``_ResStage``.  Dropout3d is kept for key numbering; only p == 0 is implemented."""
+
+    def __init__(self, n_channels, n_res_channels, p_dropout):
+        super().__init__(nn.Conv3d(n_channels, n_res_channels, kernel_size=3, padding=1), nn.ReLU(True), nn.Dropout3d(p_dropout),
+                         nn.Conv3d(n_res_channels, n_channels, kernel_size=1))
+        if p_dropout != 0.0:
+            raise NotImplementedError("baseline_vqvae on MI355X implements dropout=0.0 (the reference's configuration, README.md:93)")
+
+
+# ------------------------------------------------------------------------------------------------ chain stages
+class _ConvStage:
+    """conv / convT (+ReLU).  ``in_act``: the stage's input is a post-ReLU tensor, so the data gradient it hands back is
+    masked with (x > 0) in the dgrad epilogue."""
+
+    def __init__(self, mod: nn.Module, kind, act, in_act, dtype, out_f32=False, need_dx=True):
+        k, s, p = mod.kernel_size[0], mod.stride[0], mod.padding[0]
+        self.mod, self.act, self.in_act, self.out_f32, self.need_dx = mod, act, in_act, out_f32, need_dx
+        self.op = ConvOp(kind, mod.in_channels, mod.out_channels, k, s, p, mod.weight, mod.bias, dtype)
+        self.dtype = dtype
+
+    def params(self):
+        return [self.mod.weight, self.mod.bias]
+
+    def _sync(self):
+        self.op.weight, self.op.bias = self.mod.weight, self.mod.bias
+
+    def fwd(self, x, tape):
+        self._sync()
+        cout = self.op.cout
+        y = self.op.fprop(x, act=self.act, out_dtype=torch.float32 if self.out_f32 else self.dtype, out_channels_stride=cout)
+        if tape is not None:
+            tape.append((x,))
+        return y
+
+    def bwd(self, G, saved, grads):
+        (x,) = saved
+        self._sync()
+        vec = vec_of(self.dtype)
+        if G.shape[-1] % vec or G.dtype != self.dtype:
+            G = cast_pad(G, self.dtype, (G.shape[-1] + vec - 1) // vec * vec)
+        dw = torch.zeros_like(self.mod.weight)
+        db = torch.zeros_like(self.mod.bias)
+        self.op.wgrad(x, G, dw, db)
+        grads[self.mod.weight], grads[self.mod.bias] = dw, db
+        if not self.need_dx:
+            return None
+        return self.op.dgrad(G, tuple(x.shape[1:4]), mask=x if self.in_act else None, mask_mode=MASK_POS)
+
+
+class _ResStage:
+    def __init__(self, mod: ResidualLayer, in_act, dtype):
+        c3, c1 = mod[0], mod[3]
+        self.c3m, self.c1m, self.in_act, self.dtype = c3, c1, in_act, dtype
+        self.c3 = ConvOp("conv", c3.in_channels, c3.out_channels, 3, 1, 1, c3.weight, c3.bias, dtype)
+        self.c1 = ConvOp("conv", c1.in_channels, c1.out_channels, 1, 1, 0, c1.weight, c1.bias, dtype)
+
+    def params(self):
+        return [self.c3m.weight, self.c3m.bias, self.c1m.weight, self.c1m.bias]
+
+    def _sync(self):
+        self.c3.weight, self.c3.bias = self.c3m.weight, self.c3m.bias
+        self.c1.weight, self.c1.bias = self.c1m.weight, self.c1m.bias
+
+    def fwd(self, x, tape):
+        self._sync()
+        h = self.c3.fprop(x, act=ACT_RELU)
+        y = self.c1.fprop(h, act=ACT_RELU, addend=x, add_before_act=True)
+        if tape is not None:
+            tape.append((x, h))
+        return y
+
+    def bwd(self, G, saved, grads):
+        x, h = saved
+        self._sync()
+        dims = tuple(x.shape[1:4])
+        dw2, db2 = torch.zeros_like(self.c1m.weight), torch.zeros_like(self.c1m.bias)
+        self.c1.wgrad(h, G, dw2, db2)
+        dp = self.c1.dgrad(G, dims, mask=h, mask_mode=MASK_POS)
+        dw1, db1 = torch.zeros_like(self.c3m.weight), torch.zeros_like(self.c3m.bias)
+        self.c3.wgrad(x, dp, dw1, db1)
+        grads[self.c3m.weight], grads[self.c3m.bias], grads[self.c1m.weight], grads[self.c1m.bias] = dw1, db1, dw2, db2
+        return self.c3.dgrad(dp, dims, addend=G, mask=x if self.in_act else None, mask_mode=MASK_POS)
+
+
+class _Chain:
+    def __init__(self, stages, dtype, in_channels):
+        self.stages, self.dtype, self.in_channels = stages, dtype, in_channels
+
+    def params(self) -> List[nn.Parameter]:
+        return [p for s in self.stages for p in s.params()]
+
+    def invalidate(self):
+        for s in self.stages:
+            for op in (getattr(s, "op", None), getattr(s, "c3", None), getattr(s, "c1", None)):
+                if op is not None:
+                    op.invalidate()
+
+    def forward(self, x_ncdhw: torch.Tensor, record: bool):
+        """x [B,C,D,H,W] fp32 (any strides) -> y channels-last [B,D,H,W,C'] (+ tape)."""
+        _ffi.require_gpu()
+        vec = vec_of(self.dtype)
+        x = x_ncdhw.float().permute(0, 2, 3, 4, 1).contiguous()
+        x = cast_pad(x, self.dtype, (self.in_channels + vec - 1) // vec * vec)
+        tape = [] if record else None
+        for s in self.stages:
+            x = s.fwd(x, tape)
+        return x, tape
+
+    def backward(self, G: torch.Tensor, tape):
+        grads = {}
+        for s, saved in zip(reversed(self.stages), reversed(tape)):
+            G = s.bwd(G, saved, grads)
+        return G, grads
+
+
+class _ChainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, chain: _Chain, record: bool, x, *params):
+        y, tape = chain.forward(x, record=record)
+        ctx.chain, ctx.tape, ctx.nparams = chain, tape, len(params)
+        ctx.x_needs = x.requires_grad
+        return y.permute(0, 4, 1, 2, 3)
+
+    @staticmethod
+    def backward(ctx, gy):
+        chain: _Chain = ctx.chain
+        G = gy.permute(0, 2, 3, 4, 1).contiguous()
+        Gin, grads = chain.backward(G, ctx.tape)
+        ctx.tape = None
+        gx = None
+        if ctx.x_needs and Gin is not None:
+            gx = Gin[..., : chain.in_channels].float().permute(0, 4, 1, 2, 3)
+        return (None, None, gx, *[grads.get(p) for p in chain.params()])
+
+
+# ------------------------------------------------------------------------------------------------ the network
+class BaselineVQVAE(VQVAEBase, nn.Module):
+    def __init__(
+        self,
+        n_levels: int = 3,
+        downsample_parameters: Tuple[Tuple[int, int, int, int], ...] = ((4, 2, 1, 1), (4, 2, 1, 1), (4, 2, 1, 1)),
+        upsample_parameters: Tuple[Tuple[int, int, int, int, int], ...] = ((4, 2, 1, 0, 1), (4, 2, 1, 0, 1), (4, 2, 1, 0, 1)),
+        n_embed: int = 256,
+        embed_dim: int = 256,
+        n_channels: int = 144,
+        n_res_channels: int = 144,
+        n_res_layers: int = 3,
+        p_dropout: float = 0.0,
+        commitment_cost: float = 0.25,
+        vq_decay: float = 0.5,
+        use_subpixel_conv: bool = False,
+        compute_dtype: torch.dtype = torch.bfloat16,
+    ):
+        super().__init__()
+        assert n_levels == len(downsample_parameters) and n_levels == len(upsample_parameters), (
+            f"downsample_parameters, upsample_parameters must have the same number of elements as n_levels. "
+            f"But got {len(downsample_parameters)} and {len(upsample_parameters)}, instead of {n_levels}."
+        )
+        if use_subpixel_conv:
+            raise NotImplementedError("use_subpixel_conv=True needs MONAI's SubpixelUpsample; the MI355X build implements the README setting (False)")
+        for dp in downsample_parameters:
+            if dp[3] != 1:
+                raise NotImplementedError("dilation != 1")
+        for up in upsample_parameters:
+            if tuple(up) != (4, 2, 1, 0, 1):
+                raise NotImplementedError("upsample_parameters other than (4, 2, 1, 0, 1)")
+        if n_res_channels != n_channels:
+            raise NotImplementedError("n_res_channels != n_channels (configure.py:27-28 always passes them equal)")
+        self.n_levels, self.downsample_parameters, self.upsample_parameters = n_levels, downsample_parameters, upsample_parameters
+        self.n_embed, self.embed_dim, self.use_subpixel_conv = n_embed, embed_dim, use_subpixel_conv
+        self.n_channels, self.n_res_channels, self.n_res_layers, self.p_dropout = n_channels, n_res_channels, n_res_layers, p_dropout
+        self.commitment_cost, self.vq_decay = commitment_cost, vq_decay
+        self.compute_dtype = compute_dtype
+        if (n_channels // 2) % 8 or embed_dim % 8:
+            raise NotImplementedError("channel counts must be multiples of 8 (16-byte channels-last vectors): n_channels//2 and embed_dim")
+
+        self.encoder = self.construct_encoder()
+        self.quantizer = self.construct_quantizer()
+        self.decoder = self.construct_decoder()
+        self._enc_chain = self._build_encoder_chain()
+        self._dec_chain = self._build_decoder_chain()
+
+    # ---------------------------------------------------------------- parameter trees (same numbering as the reference)
+    def _level_width(self, level: int, decoder: bool) -> int:
+        full = (level == 0) if decoder else (level == self.n_levels - 1)
+        return self.n_channels if full else self.n_channels // 2
+
+    def _res_stack(self, width: int) -> nn.Sequential:
+        return nn.Sequential(*[ResidualLayer(width, width, self.p_dropout) for _ in range(self.n_res_layers)])
+
+    def construct_encoder(self) -> nn.ModuleList:
+        seq: List[nn.Module] = []
+        cin = 1
+        for lvl, (k, s, p, dil) in enumerate(self.downsample_parameters):
+            width = self._level_width(lvl, decoder=False)
+            seq += [nn.Conv3d(cin, width, kernel_size=k, stride=s, padding=p, dilation=dil), nn.ReLU(), self._res_stack(width)]
+            cin = width
+        seq.append(nn.Conv3d(self.n_channels, self.embed_dim, 3, stride=1, padding=1))
+        return nn.ModuleList([nn.Sequential(*seq)])
+
+    def construct_quantizer(self) -> nn.ModuleList:
+        return nn.ModuleList([Quantizer(self.n_embed, self.embed_dim, commitment_cost=self.commitment_cost, decay=self.vq_decay)])
+
+    def construct_decoder(self) -> nn.ModuleList:
+        seq: List[nn.Module] = [nn.Conv3d(self.embed_dim, self.n_channels, 3, stride=1, padding=1)]
+        for lvl, (k, s, p, op, dil) in enumerate(self.upsample_parameters):
+            width = self._level_width(lvl, decoder=True)
+            last = lvl == self.n_levels - 1
+            seq.append(self._res_stack(width))
+            seq.append(nn.ConvTranspose3d(width, 1 if last else self.n_channels // 2, kernel_size=k, stride=s, padding=p, output_padding=op, dilation=dil))
+            if not last:
+                seq.append(nn.ReLU())
+        return nn.ModuleList([nn.Sequential(*seq)])
+
+    # ---------------------------------------------------------------- launch chains over those parameters
+    def _build_encoder_chain(self) -> _Chain:
+        dt = self.compute_dtype
+        mods = list(self.encoder[0])
+        stages = []
+        for lvl in range(self.n_levels):
+            conv, res = mods[3 * lvl], mods[3 * lvl + 2]
+            stages.append(_ConvStage(conv, "conv", ACT_RELU, in_act=lvl > 0, dtype=dt, need_dx=lvl > 0))
+            stages += [_ResStage(r, in_act=True, dtype=dt) for r in res]
+        stages.append(_ConvStage(mods[3 * self.n_levels], "conv", ACT_NONE, in_act=True, dtype=dt, out_f32=True))
+        return _Chain(stages, dt, in_channels=1)
+
+    def _build_decoder_chain(self) -> _Chain:
+        dt = self.compute_dtype
+        mods = list(self.decoder[0])
+        stages = [_ConvStage(mods[0], "conv", ACT_NONE, in_act=False, dtype=dt)]
+        i = 1
+        for lvl in range(self.n_levels):
+            last = lvl == self.n_levels - 1
+            res, up = mods[i], mods[i + 1]
+            for j, r in enumerate(res):
+                stages.append(_ResStage(r, in_act=not (lvl == 0 and j == 0), dtype=dt))
+            stages.append(_ConvStage(up, "convT", ACT_NONE if last else ACT_RELU, in_act=True, dtype=dt, out_f32=last))
+            i += 2 if last else 3
+        return _Chain(stages, dt, in_channels=self.embed_dim)
+
+    def invalidate_packed_weights(self):
+        """Tell the launch chains that parameters were modified through raw pointers (fused Adam kernel)."""
+        self._enc_chain.invalidate()
+        self._dec_chain.invalidate()
+
+    # ---------------------------------------------------------------- accessors (baseline.py:301-327)
+    def get_ema_decay(self) -> Sequence[float]:
+        return [self.quantizer[0].get_ema_decay()]
+
+    def set_ema_decay(self, decay: Union[Sequence[float], float]) -> Sequence[float]:
+        self.quantizer[0].set_ema_decay(decay[0] if isinstance(decay, list) else decay)
+        return self.get_ema_decay()
+
+    def get_commitment_cost(self) -> Sequence[float]:
+        return [self.quantizer[0].get_commitment_cost()]
+
+    def set_commitment_cost(self, commitment_factor: Union[Sequence[float], float]) -> Sequence[float]:
+        self.quantizer[0].set_commitment_cost(commitment_factor[0] if isinstance(commitment_factor, list) else commitment_factor)
+        return self.get_commitment_cost()
+
+    def get_perplexity(self) -> Sequence[float]:
+        return [self.quantizer[0].get_perplexity()]
+
+    def get_last_layer(self) -> nn.parameter.Parameter:
+        return list(self.decoder.modules())[-1].weight
+
+    # ---------------------------------------------------------------- hot path (baseline.py:329-362)
+    @staticmethod
+    def _run(chain: _Chain, x: torch.Tensor) -> torch.Tensor:
+        params = chain.params()
+        record = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        return _ChainFn.apply(chain, record, x, *params)
+
+    def encode(self, images: torch.Tensor) -> List[torch.Tensor]:
+        return [self._run(self._enc_chain, images)]
+
+    def quantize(self, encodings: List[torch.Tensor]) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+        x, x_loss = self.quantizer[0](encodings[0])
+        return [x], [x_loss]
+
+    def decode(self, quantizations: List[torch.Tensor]) -> torch.Tensor:
+        return self._run(self._dec_chain, quantizations[0])
+
+    def index_quantize(self, images: torch.Tensor) -> List[torch.Tensor]:
+        encodings = self.encode(images)
+        _, _, encoding_indices = self.quantizer[0].quantize(encodings[0])
+        return [encoding_indices]
+
+    def decode_samples(self, embedding_indices: List[torch.Tensor]) -> torch.Tensor:
+        samples_codes = self.quantizer[0].embed(embedding_indices[0])
+        return self.decode([samples_codes])
+
+    def forward(self, images: torch.Tensor) -> Dict[str, List[torch.Tensor]]:
+        encodings = self.encode(images)
+        quantizations, quantization_losses = self.quantize(encodings)
+        reconstruction = self.decode(quantizations)
+        return {"reconstruction": [reconstruction], "quantization_losses": quantization_losses}
+
+    def state_dict(self, *args, **kwargs):
+        if torch.cuda.is_available():
+            self.quantizer[0].impl.wait_ema()
+        return super().state_dict(*args, **kwargs)

@@ -1,0 +1,265 @@
+"""GPU: each HIP kernel through the C ABI against a plain PyTorch fp32 CPU reference of the same op."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden  # noqa: E402
+
+
+def _ops():
+    from synthanatomy_amd import _ffi, engine
+    return _ffi, engine
+
+
+def _tol(dtype):
+    # bf16 operands are rounded once (inputs AND weights are pre-rounded in the reference), so only the output rounding
+    # and fp32 summation order differ
+    return (2e-5, 2e-5) if dtype == torch.float32 else (1.2e-2, 1e-2)
+
+
+def _close(got, ref, dtype, what=""):
+    rtol, atol = _tol(dtype)
+    scale = ref.abs().max().item() + 1e-12
+    err = (got.double() - ref.double()).abs().max().item()
+    assert err <= atol * scale + rtol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def _cl(x):  # NCDHW -> channels-last
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _rt(x, dtype):  # round-trip through the compute dtype (what the kernel sees)
+    return x.to(dtype).float()
+
+
+CASES = [
+    # kind, cin, cout, k, s, p, dims
+    ("conv", 16, 24, 3, 1, 1, (6, 7, 9)),
+    ("conv", 8, 136, 3, 1, 1, (5, 6, 7)),
+    ("conv", 32, 40, 4, 2, 1, (8, 10, 12)),
+    ("conv", 128, 128, 1, 1, 0, (4, 5, 6)),
+    ("conv", 24, 16, 4, 1, 1, (6, 6, 7)),
+    ("conv", 1, 16, 4, 2, 1, (12, 8, 10)),
+    ("convT", 32, 24, 4, 2, 1, (4, 5, 6)),
+    ("convT", 16, 1, 4, 2, 1, (5, 4, 6)),
+    ("convT", 136, 64, 4, 2, 1, (3, 4, 3)),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-{c[1]}-{c[2]}-k{c[3]}s{c[4]}" for c in CASES])
+def test_conv_fprop_dgrad_wgrad(case, dtype):
+    _ffi, engine = _ops()
+    kind, cin, cout, k, s, p, dims = case
+    torch.manual_seed(hash(case) % 1000)
+    N = 2
+    dev = "cuda"
+    vec = engine.vec_of(dtype)
+    wshape = (cout, cin, k, k, k) if kind == "conv" else (cin, cout, k, k, k)
+    w = _rt(torch.randn(wshape) * 0.1, dtype)
+    b = torch.randn(cout) * 0.1
+    x = _rt(torch.randn(N, cin, *dims), dtype)
+    wd, bd = w.to(dev), b.to(dev)
+    op = engine.ConvOp(kind, cin, cout, k, s, p, wd, bd, dtype)
+    xin = engine.cast_pad(_cl(x).to(dev), dtype, op.cs_in())
+
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    if kind == "conv":
+        yr = F.conv3d(xr, wr, br, stride=s, padding=p)
+    else:
+        yr = F.conv_transpose3d(xr, wr, br, stride=s, padding=p)
+
+    # ---- forward, plain and with fused epilogues
+    cout_s = cout if cout % vec == 0 else cout
+    y = op.fprop(xin, out_dtype=torch.float32, out_channels_stride=cout_s)
+    torch.cuda.synchronize()
+    _close(y.cpu()[..., :cout], _cl(yr.detach()), dtype, "fprop")
+
+    y2 = op.fprop(xin, act=_ffi.ACT_RELU, out_dtype=torch.float32, out_channels_stride=cout_s)
+    _close(y2.cpu()[..., :cout], _cl(F.relu(yr.detach())), dtype, "fprop+relu")
+
+    if cout % vec == 0:
+        add = _rt(torch.randn(N, *y.shape[1:4], cout), dtype)
+        y3 = op.fprop(xin, act=_ffi.ACT_RELU, addend=add.to(dev).to(dtype), add_before_act=True)
+        assert y3.dtype == dtype
+        _close(y3.float().cpu(), F.relu(_cl(yr.detach()) + add), torch.bfloat16 if dtype == torch.bfloat16 else dtype, "fprop+add+relu")
+        mk = torch.randn_like(add)
+        y4 = op.fprop(xin, addend=add.to(dev).to(dtype), mask=mk.to(dev).to(dtype), mask_mode=_ffi.MASK_POS, out_dtype=torch.float32)
+        _close(y4.cpu(), (_cl(yr.detach()) + add) * (_rt(mk, dtype) > 0), dtype, "fprop+add+mask")
+
+    # ---- backward
+    g = _rt(torch.randn_like(yr), dtype)
+    yr.backward(g)
+    gin = engine.cast_pad(_cl(g).to(dev), dtype, (cout + vec - 1) // vec * vec)
+    dw = torch.zeros_like(wd)
+    db = torch.zeros_like(bd)
+    op.wgrad(xin, gin, dw, db)
+    torch.cuda.synchronize()
+    _close(dw.cpu(), wr.grad, dtype, "wgrad")
+    _close(db.cpu(), br.grad, dtype, "bgrad")
+    if not (kind == "conv" and s == 2 and any(d % 2 for d in dims)):
+        dx = op.dgrad(gin, dims, out_dtype=torch.float32)
+        torch.cuda.synchronize()
+        _close(dx.cpu()[..., :cin], _cl(xr.grad), dtype, "dgrad")
+
+
+def test_conv_large_m_tail():
+    """M not a multiple of 128, several N tiles, cout tail, fp32."""
+    _ffi, engine = _ops()
+    torch.manual_seed(1)
+    cin, cout, dims = 16, 264, (7, 9, 11)
+    w = torch.randn(cout, cin, 3, 3, 3) * 0.05
+    x = torch.randn(3, cin, *dims)
+    op = engine.ConvOp("conv", cin, cout, 3, 1, 1, w.cuda(), None, torch.float32)
+    y = op.fprop(_cl(x).cuda(), use_bias=False)
+    _close(y.cpu(), _cl(F.conv3d(x, w, None, padding=1)), torch.float32, "fprop tail")
+
+
+def test_linear_as_one_tap_conv():
+    _ffi, engine = _ops()
+    torch.manual_seed(2)
+    M, K, Nn = 1000, 512, 2049
+    x = torch.randn(M, K)
+    w = torch.randn(Nn, K) * 0.05
+    b = torch.randn(Nn)
+    for dtype in (torch.float32, torch.bfloat16):
+        op = engine.ConvOp("conv", K, Nn, 1, 1, 0, _rt(w, dtype).view(Nn, K, 1, 1, 1).cuda(), b.cuda(), dtype)
+        y = op.fprop(_rt(x, dtype).view(1, 1, 1, M, K).cuda().to(dtype), out_dtype=torch.float32, act=_ffi.ACT_GELU)
+        _close(y.cpu().view(M, Nn), F.gelu(_rt(x, dtype) @ _rt(w, dtype).t() + b), dtype, "linear+gelu")
+
+
+# ----------------------------------------------------------------------------------------------- quantizer
+def _vq_run(x_rows, cb, decay=None, N=None, avg=None):
+    _ffi, _ = _ops()
+    lib, st = _ffi.lib(), _ffi.stream()
+    M, D = x_rows.shape
+    K = cb.shape[0]
+    dev = "cuda"
+    rows = x_rows.to(dev).contiguous()
+    cbd = cb.to(dev).contiguous()
+    idx = torch.empty(M, dtype=torch.int64, device=dev)
+    zq = torch.empty_like(rows)
+    counts = torch.zeros(K, device=dev)
+    dw = torch.zeros(K, D, device=dev)
+    sq = torch.zeros(1, device=dev)
+    wn = torch.zeros(K, device=dev)
+    _ffi.check(lib.sa_vq_assign(_ffi.ptr(rows), _ffi.ptr(cbd), M, K, D, _ffi.ptr(idx), _ffi.ptr(zq), None, _ffi.ptr(counts), _ffi.ptr(dw), _ffi.ptr(sq),
+                                _ffi.ptr(wn), st))
+    out = dict(idx=idx, zq=zq, counts=counts, dw=dw, sq=sq)
+    if decay is not None:
+        Nd, avgd = N.to(dev), avg.to(dev)
+        _ffi.check(lib.sa_vq_ema_update(_ffi.ptr(Nd), _ffi.ptr(avgd), _ffi.ptr(cbd), _ffi.ptr(counts), _ffi.ptr(dw), K, D, decay, 1e-5, st))
+        out.update(N=Nd, avg=avgd, cb=cbd)
+    torch.cuda.synchronize()
+    return {k: v.cpu() for k, v in out.items()}
+
+
+def test_vq_against_reference_golden():
+    g = load_golden("quantizer")
+    cb = torch.from_numpy(g["W0"].copy())
+    K, D = cb.shape
+    N = torch.zeros(K)
+    avg = cb.clone()
+    x = torch.from_numpy(np.transpose(g["eval/x"], (0, 2, 3, 4, 1)).reshape(-1, D).copy())
+    r = _vq_run(x, cb)
+    assert np.array_equal(r["idx"].numpy().reshape(g["eval/idx"].shape), g["eval/idx"])  # bit-exact code indices
+    np.testing.assert_allclose(0.25 * r["sq"].item() / x.numel(), g["eval/loss"], rtol=1e-5)
+    for s in range(3):
+        x = torch.from_numpy(np.transpose(g[f"train{s}/x"], (0, 2, 3, 4, 1)).reshape(-1, D).copy())
+        r = _vq_run(x, cb, 0.5, N, avg)
+        assert np.array_equal(r["idx"].numpy().reshape(g[f"train{s}/idx"].shape), g[f"train{s}/idx"]), s
+        np.testing.assert_allclose(r["zq"].numpy(), np.transpose(g[f"train{s}/zq"], (0, 2, 3, 4, 1)).reshape(-1, D), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(r["N"].numpy(), g[f"train{s}/N"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(r["avg"].numpy(), g[f"train{s}/embed_avg"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(r["cb"].numpy(), g[f"train{s}/weight"], rtol=2e-5, atol=1e-6)
+        cb, N, avg = r["cb"], r["N"], r["avg"]
+
+
+@pytest.mark.parametrize("M,K,D", [(1, 16, 4), (17, 40, 8), (1400, 2048, 32), (333, 256, 256), (11200, 2048, 32)])
+def test_vq_against_c_oracle(M, K, D):
+    from test_oracle_vs_golden import c_vq_assign
+    torch.manual_seed(M + K)
+    x = torch.randn(M, D)
+    cb = torch.randn(K, D)
+    cb[K // 3] = cb[K // 3 + 1] if K > 4 else cb[K // 3]  # exact duplicate code: first index must win
+    r = _vq_run(x, cb)
+    idx, counts, dw, se, gap = c_vq_assign(x.numpy(), cb.numpy())
+    safe = gap > 1e-4  # rows whose top-2 margin is above fp32 rounding noise must agree exactly
+    assert np.array_equal(r["idx"].numpy()[safe], idx[safe])
+    assert (r["idx"].numpy() != idx).mean() < 1e-3
+    assert not np.any(r["idx"].numpy() == K // 3 + 1) or K <= 4
+    if np.array_equal(r["idx"].numpy(), idx):
+        np.testing.assert_allclose(r["counts"].numpy(), counts)
+        np.testing.assert_allclose(r["dw"].numpy(), dw, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(r["sq"].item(), se, rtol=1e-4)
+
+
+def test_vq_misc_kernels():
+    _ffi, _ = _ops()
+    lib, st = _ffi.lib(), _ffi.stream()
+    torch.manual_seed(0)
+    K, D, M = 64, 8, 100
+    counts = torch.randint(0, 5, (K,)).float()
+    Mtot = int(counts.sum().item())
+    out = torch.zeros(1, device="cuda")
+    _ffi.check(lib.sa_vq_perplexity(_ffi.ptr(counts.cuda()), K, Mtot, _ffi.ptr(out), st))
+    p = counts / Mtot
+    np.testing.assert_allclose(out.item(), torch.exp(-(p * torch.log(p + 1e-10)).sum()).item(), rtol=1e-5)
+    cb = torch.randn(K, D)
+    idx = torch.randint(0, K, (M,))
+    rows = torch.randn(M, D)
+    gz = torch.randn(M, D)
+    gl = torch.tensor([0.7])
+    dz = torch.empty(M, D, device="cuda")
+    _ffi.check(lib.sa_vq_backward(_ffi.ptr(rows.cuda()), _ffi.ptr(cb.cuda()), _ffi.ptr(idx.cuda()), _ffi.ptr(gz.cuda()), 0, _ffi.ptr(gl.cuda()), 0.25, M, D,
+                                  _ffi.ptr(dz), 0, st))
+    ref = gz + 0.7 * 0.25 * 2 * (rows - cb[idx]) / (M * D)
+    np.testing.assert_allclose(dz.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    e = torch.empty(M, D, device="cuda")
+    _ffi.check(lib.sa_vq_embed(_ffi.ptr(cb.cuda()), _ffi.ptr(idx.cuda()), M, K, D, _ffi.ptr(e), 0, st))
+    assert torch.equal(e.cpu(), cb[idx])
+
+
+def test_elementwise_kernels():
+    _ffi, engine = _ops()
+    lib, st = _ffi.lib(), _ffi.stream()
+    torch.manual_seed(3)
+    a, b = torch.randn(10007), torch.randn(10007)
+    ls = torch.zeros(1, device="cuda")
+    gr = torch.empty(10007, device="cuda")
+    _ffi.check(lib.sa_mse(_ffi.ptr(a.cuda()), _ffi.ptr(b.cuda()), a.numel(), _ffi.ptr(ls), _ffi.ptr(gr), 1.0, st))
+    np.testing.assert_allclose(ls.item() / a.numel(), F.mse_loss(a, b).item(), rtol=1e-5)
+    np.testing.assert_allclose(gr.cpu().numpy(), (2 * (a - b) / a.numel()).numpy(), rtol=1e-5, atol=1e-9)
+    # Adam against torch.optim.Adam, 3 steps
+    p = torch.randn(5000)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1.65e-4)
+    pd, m, v = p.cuda(), torch.zeros(5000, device="cuda"), torch.zeros(5000, device="cuda")
+    for step in range(1, 4):
+        g = torch.randn(5000)
+        pr.grad = g.clone()
+        opt.step()
+        _ffi.check(lib.sa_adam(_ffi.ptr(pd), _ffi.ptr(g.cuda()), _ffi.ptr(m), _ffi.ptr(v), 5000, 1.65e-4, 0.9, 0.999, 1e-8, 0.0, step, 1.0, st))
+    np.testing.assert_allclose(pd.cpu().numpy(), pr.detach().numpy(), rtol=1e-5, atol=1e-7)
+    # cast + channel pad
+    x = torch.randn(37, 3)
+    y = engine.cast_pad(x.cuda(), torch.bfloat16, 8)
+    assert y.shape == (37, 8) and torch.equal(y[:, :3].float().cpu(), x.bfloat16().float()) and float(y[:, 3:].abs().max()) == 0.0
+
+
+def test_abi_rejects_bad_arguments():
+    _ffi, engine = _ops()
+    lib = _ffi.lib()
+    assert lib.sa_conv_fprop(None, 0, None, None, None, None, None) == -1
+    assert lib.sa_vq_assign(None, None, 0, 0, 0, None, None, None, None, None, None, None, None) == -1
+    g = _ffi.ConvGeom()
+    ep = _ffi.Epilogue()
+    x = torch.zeros(8, device="cuda")
+    assert lib.sa_conv_fprop(ctypes.byref(g), 7, _ffi.ptr(x), _ffi.ptr(x), _ffi.ptr(x), ctypes.byref(ep), None) == -2
