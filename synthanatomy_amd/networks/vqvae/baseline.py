@@ -43,7 +43,7 @@ class Quantizer_impl(nn.Module):
         self.process_group = None
 
     # ---- device buffers -------------------------------------------------------------------------------------
-    def _buffers(self, dev):
+    def _work_buffers(self, dev):
         K, D = self.n_embed, self.embed_dim
         if self._stats is None or self._stats.device != dev:
             self._stats = torch.zeros(K + K * D, dtype=torch.float32, device=dev)
@@ -86,7 +86,7 @@ class _VQFn(torch.autograd.Function):
         M = rows.numel() // D
         dev = rows.device
         q.wait_ema()
-        stats, scratch = q._buffers(dev)
+        stats, scratch = q._work_buffers(dev)
         stats.zero_()
         scratch.zero_()
         counts, dw = stats[:K], stats[K:]

@@ -209,7 +209,8 @@ def test_vq_misc_kernels():
     counts = torch.randint(0, 5, (K,)).float()
     Mtot = int(counts.sum().item())
     out = torch.zeros(1, device="cuda")
-    _ffi.check(lib.sa_vq_perplexity(_ffi.ptr(counts.cuda()), K, Mtot, _ffi.ptr(out), st))
+    counts_d = counts.cuda()
+    _ffi.check(lib.sa_vq_perplexity(_ffi.ptr(counts_d), K, Mtot, _ffi.ptr(out), st))
     p = counts / Mtot
     np.testing.assert_allclose(out.item(), torch.exp(-(p * torch.log(p + 1e-10)).sum()).item(), rtol=1e-5)
     cb = torch.randn(K, D)
@@ -218,12 +219,13 @@ def test_vq_misc_kernels():
     gz = torch.randn(M, D)
     gl = torch.tensor([0.7])
     dz = torch.empty(M, D, device="cuda")
-    _ffi.check(lib.sa_vq_backward(_ffi.ptr(rows.cuda()), _ffi.ptr(cb.cuda()), _ffi.ptr(idx.cuda()), _ffi.ptr(gz.cuda()), 0, _ffi.ptr(gl.cuda()), 0.25, M, D,
+    rows_d, cb_d, idx_d, gz_d, gl_d = rows.cuda(), cb.cuda(), idx.cuda(), gz.cuda(), gl.cuda()  # keep device buffers alive across the launch
+    _ffi.check(lib.sa_vq_backward(_ffi.ptr(rows_d), _ffi.ptr(cb_d), _ffi.ptr(idx_d), _ffi.ptr(gz_d), 0, _ffi.ptr(gl_d), 0.25, M, D,
                                   _ffi.ptr(dz), 0, st))
     ref = gz + 0.7 * 0.25 * 2 * (rows - cb[idx]) / (M * D)
     np.testing.assert_allclose(dz.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
     e = torch.empty(M, D, device="cuda")
-    _ffi.check(lib.sa_vq_embed(_ffi.ptr(cb.cuda()), _ffi.ptr(idx.cuda()), M, K, D, _ffi.ptr(e), 0, st))
+    _ffi.check(lib.sa_vq_embed(_ffi.ptr(cb_d), _ffi.ptr(idx_d), M, K, D, _ffi.ptr(e), 0, st))
     assert torch.equal(e.cpu(), cb[idx])
 
 
@@ -234,7 +236,8 @@ def test_elementwise_kernels():
     a, b = torch.randn(10007), torch.randn(10007)
     ls = torch.zeros(1, device="cuda")
     gr = torch.empty(10007, device="cuda")
-    _ffi.check(lib.sa_mse(_ffi.ptr(a.cuda()), _ffi.ptr(b.cuda()), a.numel(), _ffi.ptr(ls), _ffi.ptr(gr), 1.0, st))
+    a_d, b_d = a.cuda(), b.cuda()
+    _ffi.check(lib.sa_mse(_ffi.ptr(a_d), _ffi.ptr(b_d), a.numel(), _ffi.ptr(ls), _ffi.ptr(gr), 1.0, st))
     np.testing.assert_allclose(ls.item() / a.numel(), F.mse_loss(a, b).item(), rtol=1e-5)
     np.testing.assert_allclose(gr.cpu().numpy(), (2 * (a - b) / a.numel()).numpy(), rtol=1e-5, atol=1e-9)
     # Adam against torch.optim.Adam, 3 steps
@@ -246,7 +249,9 @@ def test_elementwise_kernels():
         g = torch.randn(5000)
         pr.grad = g.clone()
         opt.step()
-        _ffi.check(lib.sa_adam(_ffi.ptr(pd), _ffi.ptr(g.cuda()), _ffi.ptr(m), _ffi.ptr(v), 5000, 1.65e-4, 0.9, 0.999, 1e-8, 0.0, step, 1.0, st))
+        g_d = g.cuda()
+        _ffi.check(lib.sa_adam(_ffi.ptr(pd), _ffi.ptr(g_d), _ffi.ptr(m), _ffi.ptr(v), 5000, 1.65e-4, 0.9, 0.999, 1e-8, 0.0, step, 1.0, st))
+        torch.cuda.synchronize()
     np.testing.assert_allclose(pd.cpu().numpy(), pr.detach().numpy(), rtol=1e-5, atol=1e-7)
     # cast + channel pad
     x = torch.randn(37, 3)
