@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Headline benchmark: VQ-VAE training-step throughput (volumes/s, 160x224x160) on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = forward + MSE loss + backward + EMA codebook update + Adam over one batch of synthetic volumes already resident
+in HBM (BASELINE.json configs[1]/[2]: baseline_vqvae no_levels=4 no_channels=256 embedding_dim=32 num_embeddings=2048,
+bf16 MFMA, batch 8 per GPU, batch-sharded data parallel with RCCL all-reduce of gradients and EMA statistics).  Rank 0 prints
+ONE JSON line.  The oracle / CPU restatement is touched only by the `cpu_baseline` leg.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+VOL = (160, 224, 160)
+NET = dict(n_levels=4, downsample_parameters=((4, 2, 1, 1),) * 4, upsample_parameters=((4, 2, 1, 0, 1),) * 4, n_embed=2048, embed_dim=32,
+           n_channels=256, n_res_channels=256, n_res_layers=3, p_dropout=0.0, commitment_cost=0.25, vq_decay=0.5)
+FWD_TFLOP_PER_VOLUME = 4.991      # 2 x 2495.5 GMAC
+STEP_TFLOP_PER_VOLUME = 14.97     # fwd + dgrad + wgrad
+PEAK_BF16_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense bf16 MFMA
+PEAK_F32_TFLOPS = 157.3
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """Reference-equivalent CPU path (the oracle restatement, fp32 torch-CPU) timed on this host for a bounded sample."""
+    from oracle import vqvae_ref
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(min(cores, 32))
+    cfg = vqvae_ref.VQVAEConfig(**NET)
+    st = vqvae_ref.init_state(cfg, seed=4)
+    leaf = {k: v.requires_grad_(True) for k, v in st.items() if "quantizer" not in k}
+    st.update(leaf)
+    crop = (64, 64, 64)
+    torch.manual_seed(4)
+    x = torch.rand(1, 1, *crop)
+    t0 = time.perf_counter()
+    out = vqvae_ref.forward(st, cfg, x, training=True)
+    vqvae_ref.mse_loss(out, x).backward()
+    dt = time.perf_counter() - t0
+    frac = (crop[0] * crop[1] * crop[2]) / float(VOL[0] * VOL[1] * VOL[2])
+    return {"value": frac / dt, "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": f"1 training step (fwd+MSE+bwd, fp32 torch-CPU oracle, {torch.get_num_threads()} threads) of the config-2 network on one "
+                      f"{crop[0]}x{crop[1]}x{crop[2]} crop = {frac:.5f} of a volume, {dt:.2f} s; scaled by voxel count"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="volumes per GPU per step (README.md:72: batch 8/GPU)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    from synthanatomy_amd import engine
+    from synthanatomy_amd.losses.vqvae import MSELoss
+    from synthanatomy_amd.networks.vqvae.baseline import BaselineVQVAE
+    from synthanatomy_amd.runtime.ddp import GradReducer, init_distributed
+    from synthanatomy_amd.runtime.optim import ExponentialLR, FlatParams, FusedAdam
+
+    rank, local, world = init_distributed()
+    assert world == args.gpus or (world == 1 and args.gpus == 1), f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    dev = torch.device("cuda", local)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    torch.manual_seed(4)
+    net = BaselineVQVAE(**NET, compute_dtype=dtype).to(dev).train()
+    flat = FlatParams(net.parameters())
+    opt = FusedAdam(flat, lr=1.65e-4)
+    opt.on_step.append(net.invalidate_packed_weights)
+    sched = ExponentialLR(opt, gamma=0.99999)
+    reducer = GradReducer(flat)
+    net.set_grad_sink(reducer)
+    loss_fn = MSELoss()
+    gen = torch.Generator(device=dev).manual_seed(4 + rank)
+    x = torch.rand(args.batch, 1, *VOL, generator=gen, device=dev, dtype=torch.float32)
+
+    def step():
+        flat.zero_grad()
+        out = net(x)
+        loss = loss_fn(out, x)
+        loss.backward()
+        scale = reducer.finish()
+        opt.step(grad_scale=scale)
+        sched.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    timer = None
+    if not args.no_kernel_timer:
+        timer = engine.KernelTimer()
+        engine.TIMER = timer
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    engine.TIMER = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+
+    roof = None
+    if timer is not None:
+        stats = timer.collect()
+        dom = max(stats.items(), key=lambda kv: kv[1][2])
+        name, (n, flops, ms) = dom
+        ach = flops / (ms * 1e-3) / 1e12
+        peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "kernel": name, "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
+                "kernels": {k: {"launches": v[0], "ms": round(v[2], 3), "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2) if v[2] > 0 else None}
+                            for k, v in sorted(stats.items(), key=lambda kv: -kv[1][2])}}
+
+    if rank == 0:
+        vols = args.batch * world * args.steps
+        value = vols / dt
+        line = {
+            "metric": "vqvae_train_volumes_per_sec", "value": round(value, 4), "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "baseline_vqvae no_levels=4 no_channels=256 embedding_dim=32 num_embeddings=2048, 160x224x160 fp32 volumes, "
+                                   "training step = fwd + MSE + bwd + EMA codebook update + Adam", "batch_per_gpu": args.batch,
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+            "tflops_per_gpu": round(value / world * STEP_TFLOP_PER_VOLUME, 2), "final_loss": round(final_loss, 6),
+            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+        }
+        if roof is not None:
+            line["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

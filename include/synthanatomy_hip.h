@@ -74,10 +74,13 @@ int sa_pack_weights(const float *w, void *wpk, int dtype, int rows, int red, int
 int sa_conv_fprop(const sa_conv_geom *g, int dtype, const void *in, const void *wpk, void *out, const sa_epilogue *ep,
                   void *stream);
 
-/* ---- weight gradient: dw[r*s_row + c*s_red + tap_lut[t]] += sum_m in[gather(m,t)][c] * gout[out(m)][r]  (fp32 atomics;
+/* ---- weight gradient: dw[r*s_row + c*s_red + tap_lut[t]] += sum_m in[gather(m,t)][c] * gout[out(m)][r]  (accumulates:
  * caller zeroes dw).  Replaces cuDNN wgrad behind the same modules' autograd. */
 int sa_conv_wgrad(const sa_conv_geom *g, int dtype, const void *in, const void *gout, float *dw, const int32_t *tap_lut_host,
-                  int64_t s_row, int64_t s_red, void *stream);
+                  int64_t s_row, int64_t s_red, void *workspace, int64_t workspace_bytes, void *stream);
+/* bytes of scratch sa_conv_wgrad wants for this geometry (partial tiles of the voxel splits; a second kernel reduces them
+ * without atomics).  With workspace == NULL the kernel falls back to fp32 atomics straight into dw. */
+int64_t sa_conv_wgrad_workspace_bytes(const sa_conv_geom *g, int dtype);
 
 /* db[c] += sum_m g[m][c]   (bias gradient), g is [M][cstride] of dtype */
 int sa_colsum(const void *g, int dtype, int64_t M, int C, int cstride, float *db, void *stream);

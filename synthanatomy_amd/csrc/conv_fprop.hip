@@ -173,52 +173,107 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const FpropArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds out[m = .. + (lane&15)][co = .. + (lane>>4)*4 + r], r = 0..3
+    // ---- epilogue, staged through LDS so that HBM sees full channel rows:
+    //  A) every lane parks its 4x(acc + bias) for one voxel in an fp32 tile [BM][BN+4] (stride padded: conflict-free b128)
+    //  B) the block re-reads the tile voxel-row-wise, 4 channels per thread: addend / activation / mask are applied with
+    //     8- or 16-byte coalesced loads and the result leaves as 8-byte (bf16) or 16-byte (fp32) coalesced stores.
+    constexpr int LDT = BN + 4;
+    float* sT = (float*)smem;
+    long long* sOv = (long long*)(smem + BM * LDT * 4);
     const sa_epilogue& ep = a.ep;
-    const float alpha = ep.alpha ? *ep.alpha : 1.f;
-    const bool vec_ok = (g.Cout & 3) == 0;
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
-        const uint32_t m = m_base + wm * (MI * 16) + j * 16 + frow;
-        if (m >= a.M) continue;
-        uint32_t q = fdiv(m, a.dW);
-        const uint32_t wmx = m - q * g.Wm;
-        uint32_t q2 = fdiv(q, a.dH);
-        const uint32_t hmx = q - q2 * g.Hm;
-        const uint32_t n = fdiv(q2, a.dD);
-        const uint32_t dmx = q2 - n * g.Dm;
-        const int64_t ovox = (((int64_t)n * g.Do + (dmx * g.out_mult[0] + g.out_off[0])) * g.Ho + (hmx * g.out_mult[1] + g.out_off[1])) * g.Wo +
-                             (wmx * g.out_mult[2] + g.out_off[2]);
+        const uint32_t row = wm * (MI * 16) + j * 16 + frow;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const uint32_t co0 = n_base + wn * (NI * 16) + i * 16 + fq * 4;
-            if (co0 >= (uint32_t)g.cout_valid) continue;
-            const int64_t o = ovox * g.Cout + co0;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            const uint32_t col = wn * (NI * 16) + i * 16 + fq * 4;
+            float4_t v = acc[i][j];
+            if (ep.bias) {
+                const float4_t bv = *(const float4_t*)(ep.bias + n_base + col);
+                v += bv;
+            }
+            *(float4_t*)(sT + row * LDT + col) = v;
+        }
+    }
+    if (tid < BM) {
+        const uint32_t m = m_base + tid;
+        long long ov = -1;
+        if (m < a.M) {
+            uint32_t q = fdiv(m, a.dW);
+            const uint32_t wmx = m - q * g.Wm;
+            uint32_t q2 = fdiv(q, a.dH);
+            const uint32_t hmx = q - q2 * g.Hm;
+            const uint32_t n = fdiv(q2, a.dD);
+            const uint32_t dmx = q2 - n * g.Dm;
+            ov = (((long long)n * g.Do + (dmx * g.out_mult[0] + g.out_off[0])) * g.Ho + (hmx * g.out_mult[1] + g.out_off[1])) * g.Wo +
+                 (wmx * g.out_mult[2] + g.out_off[2]);
+        }
+        sOv[tid] = ov;
+    }
+    __syncthreads();
+    const float alpha = ep.alpha ? *ep.alpha : 1.f;
+    const bool vec_ok = (g.Cout & 3) == 0;
+    constexpr int NG = BN / 4;           // 4-channel groups per voxel row
+    constexpr int RPP = 256 / NG;        // rows per pass
+    const uint32_t grp = tid % NG, r0 = tid / NG;
+    const uint32_t co0 = n_base + grp * 4;
+    if (co0 < (uint32_t)g.cout_valid) {
+#pragma unroll 4
+        for (int it = 0; it < BM / RPP; ++it) {
+            const uint32_t row = r0 + it * RPP;
+            const long long ov = sOv[row];
+            if (ov < 0) continue;
+            const int64_t o = ov * g.Cout + co0;
+            const float4_t tv = *(const float4_t*)(sT + row * LDT + grp * 4);
+            float v[4] = {tv[0], tv[1], tv[2], tv[3]};
+            const bool full = vec_ok && co0 + 3 < (uint32_t)g.cout_valid;
+            float ad[4] = {0.f, 0.f, 0.f, 0.f}, mk[4] = {1.f, 1.f, 1.f, 1.f};
+            if (full) {
+                if (ep.addend) {
+                    if (ep.add_dtype == SA_F32) {
+                        const float4_t t4 = *(const float4_t*)((const float*)ep.addend + o);
+                        ad[0] = t4[0]; ad[1] = t4[1]; ad[2] = t4[2]; ad[3] = t4[3];
+                    } else {
+                        const uint2 t2 = *(const uint2*)((const bf16_t*)ep.addend + o);
+                        ad[0] = __uint_as_float(t2.x << 16); ad[1] = __uint_as_float(t2.x & 0xffff0000u);
+                        ad[2] = __uint_as_float(t2.y << 16); ad[3] = __uint_as_float(t2.y & 0xffff0000u);
+                    }
+                }
+                if (ep.mask_mode != SA_MASK_NONE) {
+                    if (ep.mask_dtype == SA_F32) {
+                        const float4_t t4 = *(const float4_t*)((const float*)ep.mask + o);
+                        mk[0] = t4[0]; mk[1] = t4[1]; mk[2] = t4[2]; mk[3] = t4[3];
+                    } else {
+                        const uint2 t2 = *(const uint2*)((const bf16_t*)ep.mask + o);
+                        mk[0] = __uint_as_float(t2.x << 16); mk[1] = __uint_as_float(t2.x & 0xffff0000u);
+                        mk[2] = __uint_as_float(t2.y << 16); mk[3] = __uint_as_float(t2.y & 0xffff0000u);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (co0 + r >= (uint32_t)g.cout_valid) continue;
+                    if (ep.addend) ad[r] = load_as_f32(ep.addend, ep.add_dtype, o + r);
+                    if (ep.mask_mode != SA_MASK_NONE) mk[r] = load_as_f32(ep.mask, ep.mask_dtype, o + r);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (co0 + r >= (uint32_t)g.cout_valid) continue;
                 float x = v[r];
-                if (ep.bias) x += ep.bias[co0 + r];
-                float ad = 0.f;
-                if (ep.addend) ad = load_as_f32(ep.addend, ep.add_dtype, o + r);
-                if (ep.add_before_act) x += ad;
+                if (ep.add_before_act) x += ad[r];
                 if (ep.act == SA_ACT_RELU) x = fmaxf(x, 0.f);
                 else if (ep.act == SA_ACT_LRELU) x = x > 0.f ? x : x * ep.slope;
                 else if (ep.act == SA_ACT_GELU) x = gelu_f(x);
                 x *= alpha;
-                if (!ep.add_before_act) x += ad;
-                if (ep.mask_mode != SA_MASK_NONE) {
-                    const float mk = load_as_f32(ep.mask, ep.mask_dtype, o + r);
-                    if (ep.mask_mode == SA_MASK_POS) x = mk > 0.f ? x : 0.f;
-                    else if (ep.mask_mode == SA_MASK_LRELU) x = mk > 0.f ? x : x * ep.slope;
-                    else x *= gelu_grad_f(mk);
-                }
+                if (!ep.add_before_act) x += ad[r];
+                if (ep.mask_mode == SA_MASK_POS) x = mk[r] > 0.f ? x : 0.f;
+                else if (ep.mask_mode == SA_MASK_LRELU) x = mk[r] > 0.f ? x : x * ep.slope;
+                else if (ep.mask_mode == SA_MASK_GELU) x *= gelu_grad_f(mk[r]);
                 v[r] = x;
             }
-            if (vec_ok && co0 + 3 < (uint32_t)g.cout_valid) {
+            if (full) {
                 if (ep.out_dtype == SA_F32) {
-                    *(float4*)((float*)a.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4_t*)((float*)a.out + o) = (float4_t){v[0], v[1], v[2], v[3]};
                 } else {
                     uint2 pk;
                     pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
@@ -241,7 +296,8 @@ static int launch_fprop(const FpropArgs& a, hipStream_t st) {
     // only tiles that contain valid channels
     const uint32_t nbn_valid = ((uint32_t)a.g.cout_valid + BN - 1) / BN;
     (void)nbn;
-    const size_t lds = 2 * (BM + BN) * 128;
+    const size_t pipe = 2 * (BM + BN) * 128, epi = (size_t)BM * (BN + 4) * 4 + BM * 8;
+    const size_t lds = pipe > epi ? pipe : epi;
     dim3 grid(a.nblk_m * nbn_valid);
     hipLaunchKernelGGL((conv_fprop_kernel<T, WM, WN, MI, NI>), grid, dim3(256), lds, st, a);
     SA_CHECK_LAUNCH();

@@ -5,8 +5,10 @@
 // A GEMM whose reduction runs over the voxels m.  Block tile: 128 (tap,ci) rows x 128 co columns; the voxel range is
 // split across blockIdx.z and combined with fp32 atomics (device scope, hardware global_atomic_add_f32).
 // Both operands are stored voxel-major in HBM ([m][c]) but MFMA wants the reduction index contiguous per lane:
-//   bf16: tiles are transposed on the way into LDS ([c][m], pairs of voxels packed per dword, XOR-swizzled so that the
-//         ds_write_b32 are <=2-way and the ds_read_b128 conflict-free), then fed to mfma_f32_16x16x32_bf16;
+//   bf16: tiles stay voxel-major [64 m][128 c] in LDS (coalesced 16-byte loads -> ds_write_b128) and the fragments are
+//         fetched with the gfx950 hardware transpose read ds_read_b64_tr_b16: per 16-lane group it turns a [4 m][16 c] block
+//         into "lane = channel, 4 consecutive voxels"; two reads make one mfma_f32_16x16x32_bf16 operand.  32-byte chunks
+//         are XOR-swizzled with (m & 7) so the 8 rows a half-wave touches cover all 64 banks exactly once;
 //   f32 : tiles stay [m][c]; mfma_f32_16x16x4f32 takes one float per lane so fragments are plain ds_read_b32.
 #include "sa_common.h"
 
@@ -22,14 +24,20 @@ struct WgradArgs {
     int64_t s_row, s_red;
     uint32_t M, ntaps, ktot;       // ktot = ntaps * Cin
     uint32_t chunks_per_split, nchunks;
+    uint32_t nkt, ntiles;
+    float* ws;            // [split][tile][co 128][kidx 128] partial tiles, or NULL -> fp32 atomics straight into dw
 };
 
 template <typename T> struct WG;
 template <> struct WG<bf16_t> { static constexpr int MK = 64; };
 template <> struct WG<float> { static constexpr int MK = 16; };
 
-__device__ __forceinline__ uint32_t toff_t(uint32_t row, uint32_t vec) {  // transposed bf16 tile [128 c][64 m]
-    return row * 128u + ((vec ^ (row & 7u) ^ ((row >> 4) & 7u)) << 4);
+// bf16 tile [64 m][128 c], 256 B per voxel row; byte offset of channel c (multiple of 4) in row m
+__device__ __forceinline__ uint32_t roff(uint32_t m, uint32_t c) { return m * 256u + ((((c >> 4) ^ (m & 7u)) << 5) | ((c & 15u) << 1)); }
+
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4s_t lds_tr16(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(p));
 }
 
 struct RowPos {
@@ -103,8 +111,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wm = wave >> 1, wn = wave & 1u;
-    const uint32_t kt = blockIdx.x, ct = blockIdx.y;
-    const uint32_t chunk0 = blockIdx.z * a.chunks_per_split;
+    // XCD-aware order: block b runs on XCD b % 8 (observed dispatch; speed only).  All (tap, co) tiles of one voxel split are
+    // issued back-to-back on ONE XCD so that the X / G voxel rows they all re-read are served by that XCD's L2 instead
+    // of being fetched once per tap from HBM.
+    const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
+    const uint32_t tile = seq % a.ntiles, split = (seq / a.ntiles) * 8u + xcd;
+    const uint32_t kt = tile % a.nkt, ct = tile / a.nkt;
+    const uint32_t chunk0 = split * a.chunks_per_split;
     uint32_t chunk1 = chunk0 + a.chunks_per_split;
     if (chunk1 > a.nchunks) chunk1 = a.nchunks;
     if (chunk0 >= chunk1) return;
@@ -116,18 +129,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
     // ------------------------------------------------------------------ loader roles
-    // bf16: thread -> voxel pair mp = tid>>3 (0..31), 16-byte channel vectors v = (tid&7) + 8j (j=0,1) of both operands
+    // bf16: thread -> 16-byte channel vector v = tid&15 (8 channels) of voxel rows (tid>>4) + 16j (j=0..3), both operands
     // f32 : thread -> voxel rows (tid>>5) + 8j (j=0,1), 16-byte channel vector v = tid&31 of both operands
     TapPos tp[2];
     uint32_t gco[2];
     if constexpr (IS_BF16) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const uint32_t v = (tid & 7u) + 8u * j;
-            tp[j] = decode_k(kt * 128u + v * 8u, a);
-            if (kt * 128u + v * 8u >= a.ktot) tp[j].ok = false;
-            gco[j] = ct * 128u + v * 8u;
-        }
+        const uint32_t v = tid & 15u;
+        tp[0] = decode_k(kt * 128u + v * 8u, a);
+        if (kt * 128u + v * 8u >= a.ktot) tp[0].ok = false;
+        tp[1] = tp[0];
+        gco[0] = gco[1] = ct * 128u + v * 8u;
     } else {
         const uint32_t v = tid & 31u;
         tp[0] = decode_k(kt * 128u + v * 4u, a);
@@ -136,27 +147,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         gco[0] = gco[1] = ct * 128u + v * 4u;
     }
 
-    u32x4 rx[2][2], rg[2][2];  // [j][row]
+    u32x4 rx[4], rg[4];
     auto gload = [&](uint32_t chunk) __attribute__((always_inline)) {
         const uint32_t mb = chunk * MK;
         if constexpr (IS_BF16) {
-            const uint32_t mp = tid >> 3;
-            RowPos r0 = decode_row(mb + 2 * mp, a), r1 = decode_row(mb + 2 * mp + 1, a);
+            const bool cok = gco[0] + 8u <= (uint32_t)g.Cout;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                rx[j][0] = in_range(r0, tp[j], g) ? *(const u32x4*)(in + (r0.ibase + tp[j].off) * g.Cin + tp[j].c0) : (u32x4){0u, 0u, 0u, 0u};
-                rx[j][1] = in_range(r1, tp[j], g) ? *(const u32x4*)(in + (r1.ibase + tp[j].off) * g.Cin + tp[j].c0) : (u32x4){0u, 0u, 0u, 0u};
-                const bool cok = gco[j] + 8u <= (uint32_t)g.Cout;
-                rg[j][0] = (r0.ok && cok) ? *(const u32x4*)(go + r0.ovox * g.Cout + gco[j]) : (u32x4){0u, 0u, 0u, 0u};
-                rg[j][1] = (r1.ok && cok) ? *(const u32x4*)(go + r1.ovox * g.Cout + gco[j]) : (u32x4){0u, 0u, 0u, 0u};
+            for (int j = 0; j < 4; ++j) {
+                RowPos r = decode_row(mb + (tid >> 4) + 16u * j, a);
+                rx[j] = in_range(r, tp[0], g) ? *(const u32x4*)(in + (r.ibase + tp[0].off) * g.Cin + tp[0].c0) : (u32x4){0u, 0u, 0u, 0u};
+                rg[j] = (r.ok && cok) ? *(const u32x4*)(go + r.ovox * g.Cout + gco[0]) : (u32x4){0u, 0u, 0u, 0u};
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 RowPos r = decode_row(mb + (tid >> 5) + 8u * j, a);
-                rx[j][0] = in_range(r, tp[0], g) ? *(const u32x4*)(in + (r.ibase + tp[0].off) * g.Cin + tp[0].c0) : (u32x4){0u, 0u, 0u, 0u};
+                rx[j] = in_range(r, tp[0], g) ? *(const u32x4*)(in + (r.ibase + tp[0].off) * g.Cin + tp[0].c0) : (u32x4){0u, 0u, 0u, 0u};
                 const bool cok = gco[0] + 4u <= (uint32_t)g.Cout;
-                rg[j][0] = (r.ok && cok) ? *(const u32x4*)(go + r.ovox * g.Cout + gco[0]) : (u32x4){0u, 0u, 0u, 0u};
+                rg[j] = (r.ok && cok) ? *(const u32x4*)(go + r.ovox * g.Cout + gco[0]) : (u32x4){0u, 0u, 0u, 0u};
             }
         }
     };
@@ -164,24 +172,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         unsigned char* px = sX + buf * TILE_BYTES;
         unsigned char* pg = sG + buf * TILE_BYTES;
         if constexpr (IS_BF16) {
-            const uint32_t mp = tid >> 3;
+            const uint32_t v = tid & 15u;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const uint32_t v = (tid & 7u) + 8u * j;
-                const uint32_t x0[4] = {rx[j][0].x, rx[j][0].y, rx[j][0].z, rx[j][0].w};
-                const uint32_t x1[4] = {rx[j][1].x, rx[j][1].y, rx[j][1].z, rx[j][1].w};
-                const uint32_t g0[4] = {rg[j][0].x, rg[j][0].y, rg[j][0].z, rg[j][0].w};
-                const uint32_t g1[4] = {rg[j][1].x, rg[j][1].y, rg[j][1].z, rg[j][1].w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const uint32_t row = v * 8u + e;
-                    const uint32_t sh = (e & 1) * 16;
-                    const uint32_t xd = ((x0[e >> 1] >> sh) & 0xffffu) | (((x1[e >> 1] >> sh) & 0xffffu) << 16);
-                    const uint32_t gd = ((g0[e >> 1] >> sh) & 0xffffu) | (((g1[e >> 1] >> sh) & 0xffffu) << 16);
-                    const uint32_t o = toff_t(row, mp >> 2) + (mp & 3u) * 4u;
-                    *(uint32_t*)(px + o) = xd;
-                    *(uint32_t*)(pg + o) = gd;
-                }
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t o = roff((tid >> 4) + 16u * j, v * 8u);
+                *(u32x4*)(px + o) = rx[j];
+                *(u32x4*)(pg + o) = rg[j];
             }
         } else {
             const uint32_t v = tid & 31u;
@@ -189,8 +185,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             for (int j = 0; j < 2; ++j) {
                 const uint32_t m = (tid >> 5) + 8u * j;
                 const uint32_t o = m * 512u + (((v * 4u) ^ ((m & 1u) << 4)) << 2);
-                *(u32x4*)(px + o) = rx[j][0];
-                *(u32x4*)(pg + o) = rg[j][0];
+                *(u32x4*)(px + o) = rx[j];
+                *(u32x4*)(pg + o) = rg[j];
             }
         }
     };
@@ -205,18 +201,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         const unsigned char* px = sX + buf * TILE_BYTES;
         const unsigned char* pg = sG + buf * TILE_BYTES;
         if constexpr (IS_BF16) {
+            // lane (group gq = lane>>4, s = lane&15) addresses voxel row 4*gq + (s>>2) and channels 4*(s&3)..+3 of each 16x(4 m) block
+            const uint32_t trow = fq * 4u + (frow >> 2), tcol = (frow & 3u) * 4u;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                u32x4 xf[4], gf[4];
+                short8_t xf[4], gf[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xf[i] = *(const u32x4*)(px + toff_t(wm * 64 + i * 16 + frow, ks * 4 + fq));
+                for (int i = 0; i < 4; ++i) {
+                    const v4s_t lo = lds_tr16(px + roff(ks * 32 + trow, wm * 64 + i * 16 + tcol));
+                    const v4s_t hi = lds_tr16(px + roff(ks * 32 + 16 + trow, wm * 64 + i * 16 + tcol));
+                    xf[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) gf[j] = *(const u32x4*)(pg + toff_t(wn * 64 + j * 16 + frow, ks * 4 + fq));
+                for (int j = 0; j < 4; ++j) {
+                    const v4s_t lo = lds_tr16(pg + roff(ks * 32 + trow, wn * 64 + j * 16 + tcol));
+                    const v4s_t hi = lds_tr16(pg + roff(ks * 32 + 16 + trow, wn * 64 + j * 16 + tcol));
+                    gf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const short8_t*)&xf[i], *(const short8_t*)&gf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], gf[j], acc[i][j], 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -239,6 +244,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     }
 
     // ---- epilogue: lane holds rows kidx = .. + fq*4 + r (4 consecutive ci of one tap), column co = .. + frow
+    if (a.ws) {
+        // partial tile to the workspace (plain 16-byte stores); wgrad_reduce_kernel sums the splits and scatters into dw
+        float* wt = a.ws + ((size_t)split * a.ntiles + tile) * (128 * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(float4_t*)(wt + (wn * 64 + j * 16 + frow) * 128 + wm * 64 + i * 16 + fq * 4) = acc[i][j];
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t k0 = kt * 128u + wm * 64u + i * 16u + fq * 4u;
@@ -257,6 +272,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             }
         }
     }
+}
+
+// dw[co][ci][tap] += sum_split ws[split][tile][co][kidx]   (one thread per output element; no atomics)
+__global__ void wgrad_reduce_kernel(const WgradArgs a, uint32_t splits) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;  // tile*16384 + co_l*128 + k_l
+    if (e >= a.ntiles * 16384u) return;
+    const uint32_t tile = e >> 14, co_l = (e >> 7) & 127u, k_l = e & 127u;
+    const uint32_t kt = tile % a.nkt, ct = tile / a.nkt;
+    const uint32_t kidx = kt * 128u + k_l, co = ct * 128u + co_l;
+    if (kidx >= a.ktot || co >= (uint32_t)a.g.cout_valid) return;
+    const uint32_t tap = fdiv(kidx, a.dCin);
+    const uint32_t c = kidx - tap * a.g.Cin;
+    if (c >= (uint32_t)a.g.cin_valid) return;
+    float s = 0.f;
+    const float* p = a.ws + e;
+    const size_t stride = (size_t)a.ntiles * 16384u;
+    for (uint32_t sp = 0; sp < splits; ++sp) s += p[sp * stride];
+    float* d = a.dw + co * a.s_row + (int64_t)c * a.s_red + a.lut[tap];
+    *d += s;
 }
 
 __global__ void colsum_kernel(const void* gp, int dtype, int64_t M, int C, int cstride, float* db, int64_t rows_per_block) {
@@ -281,20 +315,16 @@ __global__ void colsum_kernel(const void* gp, int dtype, int64_t M, int C, int c
 
 }  // namespace sa
 
-extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, const void* gout, float* dw, const int32_t* tap_lut_host,
-                             int64_t s_row, int64_t s_red, void* stream) {
-    using namespace sa;
-    if (!g || !in || !gout || !dw) return SA_EINVAL;
+namespace sa {
+// Shared launch plan: how the voxel range is split.  ~1024 blocks (two waves of the 512 resident block slots) keeps the chip
+// full while bounding the partial-tile traffic.
+static int plan_wgrad(const sa_conv_geom* g, int dtype, WgradArgs& a, uint32_t& splits) {
     if (dtype != SA_F32 && dtype != SA_BF16) return SA_EUNSUPPORTED;
     const int vec = dtype == SA_F32 ? 4 : 8;
     const int ntaps = g->KT[0] * g->KT[1] * g->KT[2];
     if (g->Cin % vec || g->Cout % vec || ntaps < 1 || ntaps > SA_MAX_TAPS) return SA_EINVAL;
     const int64_t M = (int64_t)g->N * g->Dm * g->Hm * g->Wm;
     if (M <= 0 || M >= (1ll << 31)) return SA_EINVAL;
-    WgradArgs a;
-    a.in = in;
-    a.gout = gout;
-    a.dw = dw;
     a.g = *g;
     a.dW = make_fastdiv(g->Wm);
     a.dH = make_fastdiv(g->Hm);
@@ -302,28 +332,64 @@ extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, c
     a.dTw = make_fastdiv(g->KT[2]);
     a.dThw = make_fastdiv(g->KT[1] * g->KT[2]);
     a.dCin = make_fastdiv(g->Cin);
-    for (int t = 0; t < SA_MAX_TAPS; ++t) a.lut[t] = tap_lut_host ? (t < ntaps ? tap_lut_host[t] : 0) : t;
-    a.s_row = s_row;
-    a.s_red = s_red;
     a.M = (uint32_t)M;
     a.ntaps = ntaps;
     a.ktot = ntaps * g->Cin;
     const int mk = dtype == SA_F32 ? 16 : 64;
     a.nchunks = (uint32_t)((M + mk - 1) / mk);
-    const uint32_t nkt = (a.ktot + 127) / 128, nct = ((uint32_t)g->cout_valid + 127) / 128;
-    uint32_t splits = (2048 + nkt * nct - 1) / (nkt * nct);
-    const uint32_t min_chunks = dtype == SA_F32 ? 16 : 8;  // >= ~512 voxels per block
+    a.nkt = (a.ktot + 127) / 128;
+    const uint32_t nct = ((uint32_t)g->cout_valid + 127) / 128;
+    a.ntiles = a.nkt * nct;
+    splits = (1024 + a.ntiles - 1) / a.ntiles;
+    const uint32_t min_chunks = dtype == SA_F32 ? 16 : 4;
     uint32_t max_splits = (a.nchunks + min_chunks - 1) / min_chunks;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     a.chunks_per_split = (a.nchunks + splits - 1) / splits;
     splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    return 0;
+}
+}  // namespace sa
+
+extern "C" int64_t sa_conv_wgrad_workspace_bytes(const sa_conv_geom* g, int dtype) {
+    using namespace sa;
+    if (!g) return SA_EINVAL;
+    WgradArgs a;
+    uint32_t splits;
+    const int rc = plan_wgrad(g, dtype, a, splits);
+    if (rc) return rc;
+    return (int64_t)splits * a.ntiles * 128 * 128 * 4;
+}
+
+extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, const void* gout, float* dw, const int32_t* tap_lut_host,
+                             int64_t s_row, int64_t s_red, void* workspace, int64_t workspace_bytes, void* stream) {
+    using namespace sa;
+    if (!g || !in || !gout || !dw) return SA_EINVAL;
+    WgradArgs a;
+    uint32_t splits;
+    const int rc = plan_wgrad(g, dtype, a, splits);
+    if (rc) return rc;
+    a.in = in;
+    a.gout = gout;
+    a.dw = dw;
+    const int ntaps = a.ntaps;
+    for (int t = 0; t < SA_MAX_TAPS; ++t) a.lut[t] = tap_lut_host ? (t < ntaps ? tap_lut_host[t] : 0) : t;
+    a.s_row = s_row;
+    a.s_red = s_red;
+    const int64_t need = (int64_t)splits * a.ntiles * 128 * 128 * 4;
+    a.ws = (workspace && workspace_bytes >= need) ? (float*)workspace : nullptr;
+    if (workspace && !a.ws) return SA_EINVAL;  // a workspace was given but is too small
     const size_t lds = dtype == SA_F32 ? 4 * 8192 : 4 * 16384;
-    dim3 grid(nkt, nct, splits);
+    const uint32_t splits8 = (splits + 7u) & ~7u;  // blocks of the padded splits exit immediately
+    dim3 grid(a.ntiles * splits8);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SA_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, a);
     SA_CHECK_LAUNCH();
+    if (a.ws) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((a.ntiles * 16384u + 255) / 256), dim3(256), 0, st, a, splits);
+        SA_CHECK_LAUNCH();
+    }
     return 0;
 }
 

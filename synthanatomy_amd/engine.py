@@ -18,6 +18,55 @@ from . import _ffi
 from ._ffi import ACT_NONE, MASK_NONE, ConvGeom, Epilogue
 
 
+class KernelTimer:
+    """Optional live per-kernel timing with HIP events on the launch stream (used by bench.py's roofline leg).
+
+    Keyed by the kernel INSTANCE (same granularity as rocprofv3's kernel names), accumulating launches, algorithmic
+    FLOPs and -- after ``collect()`` -- device time."""
+
+    def __init__(self):
+        self.pending = []   # (key, flops, ev0, ev1)
+        self.stats = {}     # key -> [launches, flops, ms]
+
+    def wrap(self, key, flops, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.pending.append((key, flops, e0, e1))
+
+    def collect(self):
+        torch.cuda.synchronize()
+        for key, flops, e0, e1 in self.pending:
+            st = self.stats.setdefault(key, [0, 0.0, 0.0])
+            st[0] += 1
+            st[1] += flops
+            st[2] += e0.elapsed_time(e1)
+        self.pending = []
+        return self.stats
+
+
+TIMER: Optional[KernelTimer] = None  # set by bench.py around the timed region
+
+
+def _fprop_instance(dtype, cout_valid):
+    t = "f32" if dtype == torch.float32 else "bf16"
+    tile = "2,2,4,4" if cout_valid > 64 else ("4,1,2,4" if cout_valid > 32 else ("4,1,2,2" if cout_valid > 16 else "4,1,2,1"))
+    return f"conv_fprop_kernel<{t},{tile}>"
+
+
+def _geom_flops(g) -> float:
+    m = g.N * g.Dm * g.Hm * g.Wm
+    return 2.0 * m * (g.KT[0] * g.KT[1] * g.KT[2]) * g.cin_valid * g.cout_valid
+
+
+def _launch(key, flops, fn):
+    if TIMER is not None:
+        TIMER.wrap(key, flops, fn)
+    else:
+        fn()
+
+
 def _ru(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -196,7 +245,9 @@ class ConvOp:
         ep = self._epilogue(self._bias_padded() if use_bias else None, addend, mask, alpha, act, mask_mode, add_before_act, out_dtype, slope)
         lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
         for pl in plans["fwd"]:
-            _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(x), _ffi.ptr(pl.wpk), _ffi.ptr(out), ctypes.byref(ep), st), "sa_conv_fprop")
+            _launch(_fprop_instance(self.dtype, pl.geom.cout_valid), _geom_flops(pl.geom),
+                    lambda pl=pl: _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(x), _ffi.ptr(pl.wpk), _ffi.ptr(out), ctypes.byref(ep), st),
+                                             "sa_conv_fprop"))
         return out
 
     def dgrad(self, g: torch.Tensor, idims: Tuple[int, int, int], *, addend=None, mask=None, mask_mode=MASK_NONE, out_dtype=None, slope=0.2,
@@ -217,7 +268,9 @@ class ConvOp:
         ep = self._epilogue(None, addend, mask, None, ACT_NONE, mask_mode, False, out_dtype, slope)
         lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
         for pl in plans["dgrad"]:
-            _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(g), _ffi.ptr(pl.wpk), _ffi.ptr(dx), ctypes.byref(ep), st), "sa_conv_fprop(dgrad)")
+            _launch(_fprop_instance(self.dtype, pl.geom.cout_valid), _geom_flops(pl.geom),
+                    lambda pl=pl: _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(g), _ffi.ptr(pl.wpk), _ffi.ptr(dx), ctypes.byref(ep), st),
+                                             "sa_conv_fprop(dgrad)"))
         return dx
 
     def wgrad(self, x: torch.Tensor, g: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor] = None, fwd_out_stride=None):
@@ -227,8 +280,16 @@ class ConvOp:
         assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.shape == self.weight.shape
         plans = self._get_plans(N, (D, H, W), fwd_out_stride or self.cout, g.shape[-1])
         lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
+        wname = "conv_wgrad_kernel<%s>" % ("f32" if self.dtype == torch.float32 else "bf16")
         for pl in plans["wgrad"]:
-            _ffi.check(lib.sa_conv_wgrad(ctypes.byref(pl.geom), did, _ffi.ptr(x), _ffi.ptr(g), _ffi.ptr(dw), pl.lut_c, pl.s_row, pl.s_red, st), "sa_conv_wgrad")
+            nbytes = lib.sa_conv_wgrad_workspace_bytes(ctypes.byref(pl.geom), did)
+            if nbytes < 0:
+                _ffi.check(int(nbytes), "sa_conv_wgrad_workspace_bytes")
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)  # caching allocator: stream-ordered scratch
+            _launch(wname, _geom_flops(pl.geom),
+                    lambda pl=pl, ws=ws, nbytes=nbytes: _ffi.check(
+                        lib.sa_conv_wgrad(ctypes.byref(pl.geom), did, _ffi.ptr(x), _ffi.ptr(g), _ffi.ptr(dw), pl.lut_c, pl.s_row, pl.s_red, _ffi.ptr(ws), nbytes, st),
+                        "sa_conv_wgrad"))
         if db is not None:
             M = g.numel() // g.shape[-1]
             _ffi.check(lib.sa_colsum(_ffi.ptr(g), did, M, self.cout, g.shape[-1], _ffi.ptr(db), st), "sa_colsum")

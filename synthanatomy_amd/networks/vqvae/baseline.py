@@ -220,10 +220,9 @@ class _ConvStage:
         vec = vec_of(self.dtype)
         if G.shape[-1] % vec or G.dtype != self.dtype:
             G = cast_pad(G, self.dtype, (G.shape[-1] + vec - 1) // vec * vec)
-        dw = torch.zeros_like(self.mod.weight)
-        db = torch.zeros_like(self.mod.bias)
+        dw, db = grads.buf(self.mod.weight), grads.buf(self.mod.bias)
         self.op.wgrad(x, G, dw, db)
-        grads[self.mod.weight], grads[self.mod.bias] = dw, db
+        grads.done(self.mod.weight, self.mod.bias)
         if not self.need_dx:
             return None
         return self.op.dgrad(G, tuple(x.shape[1:4]), mask=x if self.in_act else None, mask_mode=MASK_POS)
@@ -255,18 +254,41 @@ class _ResStage:
         x, h = saved
         self._sync()
         dims = tuple(x.shape[1:4])
-        dw2, db2 = torch.zeros_like(self.c1m.weight), torch.zeros_like(self.c1m.bias)
-        self.c1.wgrad(h, G, dw2, db2)
+        self.c1.wgrad(h, G, grads.buf(self.c1m.weight), grads.buf(self.c1m.bias))
+        grads.done(self.c1m.weight, self.c1m.bias)
         dp = self.c1.dgrad(G, dims, mask=h, mask_mode=MASK_POS)
-        dw1, db1 = torch.zeros_like(self.c3m.weight), torch.zeros_like(self.c3m.bias)
-        self.c3.wgrad(x, dp, dw1, db1)
-        grads[self.c3m.weight], grads[self.c3m.bias], grads[self.c1m.weight], grads[self.c1m.bias] = dw1, db1, dw2, db2
+        self.c3.wgrad(x, dp, grads.buf(self.c3m.weight), grads.buf(self.c3m.bias))
+        grads.done(self.c3m.weight, self.c3m.bias)
         return self.c3.dgrad(dp, dims, addend=G, mask=x if self.in_act else None, mask_mode=MASK_POS)
+
+
+class _GradCtx:
+    """Where the weight-gradient kernels accumulate.  Without a sink: fresh zeroed tensors handed back to autograd.  With a
+    sink (runtime.ddp.GradReducer): views of the flat gradient buffer, and the sink is told as soon as a parameter's
+    gradient kernels are queued so that its bucket's all-reduce can start while backward continues."""
+
+    def __init__(self, sink=None):
+        self.sink, self.grads = sink, {}
+
+    def buf(self, p):
+        if self.sink is not None:
+            b = self.sink.buffer(p)
+            if b is not None:
+                return b
+        t = torch.zeros_like(p)
+        self.grads[p] = t
+        return t
+
+    def done(self, *params):
+        if self.sink is not None:
+            for p in params:
+                self.sink.ready(p)
 
 
 class _Chain:
     def __init__(self, stages, dtype, in_channels):
         self.stages, self.dtype, self.in_channels = stages, dtype, in_channels
+        self.grad_sink = None
 
     def params(self) -> List[nn.Parameter]:
         return [p for s in self.stages for p in s.params()]
@@ -289,10 +311,10 @@ class _Chain:
         return x, tape
 
     def backward(self, G: torch.Tensor, tape):
-        grads = {}
+        gc = _GradCtx(self.grad_sink)
         for s, saved in zip(reversed(self.stages), reversed(tape)):
-            G = s.bwd(G, saved, grads)
-        return G, grads
+            G = s.bwd(G, saved, gc)
+        return G, gc.grads
 
 
 class _ChainFn(torch.autograd.Function):
@@ -419,6 +441,11 @@ class BaselineVQVAE(VQVAEBase, nn.Module):
             stages.append(_ConvStage(up, "convT", ACT_NONE if last else ACT_RELU, in_act=True, dtype=dt, out_f32=last))
             i += 2 if last else 3
         return _Chain(stages, dt, in_channels=self.embed_dim)
+
+    def set_grad_sink(self, sink):
+        """Route weight gradients into a ``runtime.ddp.GradReducer`` (flat buffer + overlapped RCCL all-reduce)."""
+        self._enc_chain.grad_sink = sink
+        self._dec_chain.grad_sink = sink
 
     def invalidate_packed_weights(self):
         """Tell the launch chains that parameters were modified through raw pointers (fused Adam kernel)."""
