@@ -1,0 +1,272 @@
+"""ORACLE (test infrastructure only) -- CPU restatement of the Performer hot path (path B).
+
+PARITY UNPINNED.  The arithmetic of this path does not live in the reference tree: ``src/networks/transformers/
+performer.py:8-16,194-219`` delegates to the third-party ``performer-pytorch==1.0.11`` (docker/requirements.txt:10),
+which uses the un-pinned ``local-attention`` package and, on CUDA, ``fast_transformers.causal_product`` (docker/Dockerfile:32).
+None of them is installed or vendored here and the reference has no tests or golden vectors for this path, so this file
+restates the PUBLISHED algorithms as best known and is the build's frozen spec ("spec by restatement"):
+
+* wrapper        reference performer.py:70-288 (token / absolute-spatial / absolute positional embeddings, LayerNorm, to_out)
+* layer stack    performer_pytorch.Performer with use_rezero=True: x += g_a * Attn(x); x += g_f * FF(x)  (no LayerNorm inside)
+* SelfAttention  to_q/to_k/to_v (no bias) -> heads; first (heads - local_heads) heads FAVOR+, the rest local; to_out (no bias)
+* FAVOR+         softmax_kernel: ratio * (exp(c x P^T - |x|^2 c^2 / 2 - stab) + 1e-4), c = d^-1/4, ratio = m^-1/2;
+                 stab = per-row max for queries, GLOBAL max over the whole key tensor for keys (1.0.11 `torch.max(data_dash)`);
+                 causal: out_i = (q'_i . sum_{j<=i} k'_j (x) v_j) / (q'_i . (sum_{j<=i} k'_j + 1e-6))
+* local attention  local-attention >= 1.2 semantics: rotary (sinusoidal) embedding on q,k of the local heads, autopad to a
+                 multiple of the window, look_backward=1, look_forward=0, causal mask q_pos < k_pos, softmax over <= 2*window keys
+* FeedForward    Linear(dim, 4 dim) -> GELU(erf) -> Linear(4 dim, dim)
+* projection     gaussian_orthogonal_random_matrix(nb_rows = int(d ln d), d, scaling=0)
+
+Known ambiguities: the key-stabiliser scope and the local-attention relative-position variant.
+What IS pinned: ordering / batch preparation / sampling post-processing (tests/golden/{ordering,sample}.npz) and the
+closed-form identities in tests/test_performer_oracle.py (chunk-free quadratic forms).
+
+Only tests / smoke / bench's cpu_baseline may import this module.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class PerformerConfig:
+    num_tokens: int = 2049
+    max_seq_len: int = 1400
+    dim: int = 512
+    depth: int = 24
+    heads: int = 16
+    dim_head: int = 64
+    local_attn_heads: int = 8
+    local_window_size: int = 420
+    ff_mult: int = 4
+    nb_features: Optional[int] = None
+    spatial_shape: tuple = (10, 14, 10)
+
+    @property
+    def m(self):
+        return self.nb_features or int(self.dim_head * math.log(self.dim_head))
+
+    @property
+    def inner(self):
+        return self.heads * self.dim_head
+
+
+def orthogonal_matrix_chunk(cols, gen):
+    block = torch.randn((cols, cols), generator=gen)
+    q, _ = torch.linalg.qr(block)
+    return q.t()
+
+
+def gaussian_orthogonal_random_matrix(nb_rows, nb_cols, gen):
+    blocks = []
+    full = nb_rows // nb_cols
+    for _ in range(full):
+        blocks.append(orthogonal_matrix_chunk(nb_cols, gen))
+    rem = nb_rows - full * nb_cols
+    if rem > 0:
+        blocks.append(orthogonal_matrix_chunk(nb_cols, gen)[:rem])
+    final = torch.cat(blocks)
+    mult = torch.randn((nb_rows, nb_cols), generator=gen).norm(dim=1)
+    return torch.diag(mult) @ final
+
+
+def init_state(cfg: PerformerConfig, seed: int = 0, spatial_index_len: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    """Parameter dict with performer_pytorch's / the wrapper's state_dict names."""
+    g = torch.Generator().manual_seed(seed)
+    st: Dict[str, torch.Tensor] = {}
+
+    def lin(prefix, out_f, in_f, bias=True):
+        b = 1.0 / math.sqrt(in_f)
+        st[prefix + ".weight"] = (torch.rand(out_f, in_f, generator=g) * 2 - 1) * b
+        if bias:
+            st[prefix + ".bias"] = (torch.rand(out_f, generator=g) * 2 - 1) * b
+
+    n = cfg.max_seq_len
+    st["token_emb.weight"] = torch.randn(cfg.num_tokens, cfg.dim, generator=g)
+    st["pos_emb.emb.weight"] = torch.randn(n, cfg.dim, generator=g)
+    for a in range(len(cfg.spatial_shape)):
+        st[f"spatial_position_emb.{a}.emb.weight"] = torch.randn(spatial_index_len or (n - 1), cfg.dim, generator=g)
+    for i in range(cfg.depth):
+        p = f"performer.net.layers.{i}"
+        st[p + ".0.g"] = torch.tensor(1e-3)
+        lin(p + ".0.fn.to_q", cfg.inner, cfg.dim, bias=False)
+        lin(p + ".0.fn.to_k", cfg.inner, cfg.dim, bias=False)
+        lin(p + ".0.fn.to_v", cfg.inner, cfg.dim, bias=False)
+        lin(p + ".0.fn.to_out", cfg.dim, cfg.inner, bias=False)
+        st[p + ".0.fn.fast_attention.projection_matrix"] = gaussian_orthogonal_random_matrix(cfg.m, cfg.dim_head, g)
+        st[p + ".1.g"] = torch.tensor(1e-3)
+        lin(p + ".1.fn.fn.w1", cfg.dim * cfg.ff_mult, cfg.dim)
+        lin(p + ".1.fn.fn.w2", cfg.dim, cfg.dim * cfg.ff_mult)
+    st["norm.weight"] = torch.ones(cfg.dim)
+    st["norm.bias"] = torch.zeros(cfg.dim)
+    lin("to_out", cfg.num_tokens, cfg.dim)
+    return st
+
+
+# ------------------------------------------------------------------------------------------------ FAVOR+
+def softmax_kernel(data, proj, is_query, eps=1e-4):
+    d = data.shape[-1]
+    c = d ** -0.25
+    ratio = proj.shape[0] ** -0.5
+    dash = torch.einsum("...id,jd->...ij", c * data, proj)
+    diag = (data ** 2).sum(dim=-1, keepdim=True) / 2.0 * (c ** 2)
+    if is_query:
+        stab = dash.max(dim=-1, keepdim=True).values
+    else:
+        stab = dash.max()
+    return ratio * (torch.exp(dash - diag - stab) + eps)
+
+
+def causal_linear_attention(qp, kp, v, eps=1e-6):
+    """Quadratic (chunk-free) statement: out_i = sum_{j<=i} (q'_i.k'_j) v_j / (q'_i . (sum_{j<=i} k'_j + eps))."""
+    n = qp.shape[-2]
+    a = torch.einsum("...im,...jm->...ij", qp, kp)
+    a = a * torch.tril(torch.ones(n, n, dtype=a.dtype))
+    num = a @ v
+    kc = kp.cumsum(dim=-2) + eps
+    den = (qp * kc).sum(dim=-1, keepdim=True)
+    return num / den
+
+
+def causal_linear_attention_scan(qp, kp, v, eps=1e-6):
+    """Same quantity by the running-state recurrence (what fast_transformers' CausalDotProduct computes)."""
+    out = torch.empty(*qp.shape[:-1], v.shape[-1], dtype=qp.dtype)
+    S = torch.zeros(*qp.shape[:-2], qp.shape[-1], v.shape[-1], dtype=qp.dtype)
+    z = torch.zeros(*qp.shape[:-2], qp.shape[-1], dtype=qp.dtype)
+    for i in range(qp.shape[-2]):
+        S = S + kp[..., i, :, None] * v[..., i, None, :]
+        z = z + kp[..., i, :]
+        num = torch.einsum("...m,...md->...d", qp[..., i, :], S)
+        den = (qp[..., i, :] * (z + eps)).sum(-1, keepdim=True)
+        out[..., i, :] = num / den
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ local attention
+def rotary_tables(n, dim):
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim))
+    t = torch.arange(n).float()
+    freqs = torch.einsum("i,j->ij", t, inv_freq)
+    freqs = torch.cat((freqs, freqs), dim=-1)
+    return freqs.cos(), freqs.sin()
+
+
+def apply_rotary(x, cos, sin):
+    half = x.shape[-1] // 2
+    x1, x2 = x[..., :half], x[..., half:]
+    rot = torch.cat((-x2, x1), dim=-1)
+    return x * cos + rot * sin
+
+
+def local_attention(q, k, v, window, rotary=True):
+    """q,k,v [..., n, e] -> [..., n, e]; dense statement with the band mask (identical to the bucketed form)."""
+    n, e = q.shape[-2], q.shape[-1]
+    if rotary:
+        cos, sin = rotary_tables(n, e)
+        q, k = apply_rotary(q, cos, sin), apply_rotary(k, cos, sin)
+    dots = torch.einsum("...ie,...je->...ij", q, k) * (e ** -0.5)
+    i = torch.arange(n)[:, None]
+    j = torch.arange(n)[None, :]
+    lo = (i // window - 1).clamp(min=0) * window
+    allowed = (j <= i) & (j >= lo)
+    dots = dots.masked_fill(~allowed, -torch.finfo(dots.dtype).max)
+    return dots.softmax(dim=-1) @ v
+
+
+def local_attention_bucketed(q, k, v, window, rotary=True):
+    """The bucketed form of the package (pad to a multiple of the window, look back one window)."""
+    shape = q.shape
+    n, e = shape[-2], shape[-1]
+    q, k, v = (t.reshape(-1, n, e) for t in (q, k, v))
+    if rotary:
+        cos, sin = rotary_tables(n, e)
+        q, k = apply_rotary(q, cos, sin), apply_rotary(k, cos, sin)
+    pad = (-n) % window
+    if pad:
+        q, k, v = (F.pad(t, (0, 0, 0, pad)) for t in (q, k, v))
+    t = n + pad
+    w = t // window
+    b = q.shape[0]
+    ticker = torch.arange(t, dtype=q.dtype)[None, :].reshape(1, w, window)
+
+    def look(x, padv):
+        prev = F.pad(x, (0, 0) * (x.dim() - 2) + (1, 0), value=padv)[:, :-1] if x.dim() == 3 else F.pad(x, (0, 0, 0, 0, 1, 0), value=padv)[:, :-1]
+        return torch.cat((prev, x), dim=2)
+
+    bq, bk, bv = (x.reshape(b, w, window, e) for x in (q, k, v))
+    bk, bv = look(bk, 0.0), look(bv, 0.0)
+    tq = ticker
+    tk = torch.cat((F.pad(ticker, (0, 0, 1, 0), value=-1)[:, :-1], ticker), dim=2)
+    dots = torch.einsum("bhie,bhje->bhij", bq, bk) * (e ** -0.5)
+    neg = -torch.finfo(dots.dtype).max
+    dots = dots.masked_fill(tq[:, :, :, None] < tk[:, :, None, :], neg)
+    dots = dots.masked_fill(tk[:, :, None, :] == -1, neg)
+    out = torch.einsum("bhij,bhje->bhie", dots.softmax(dim=-1), bv).reshape(-1, t, e)[:, :n]
+    return out.reshape(shape)
+
+
+# ------------------------------------------------------------------------------------------------ network
+def self_attention(st, p, cfg: PerformerConfig, x):
+    b, n, _ = x.shape
+    h, gh = cfg.heads, cfg.heads - cfg.local_attn_heads
+    q = F.linear(x, st[p + ".to_q.weight"], st.get(p + ".to_q.bias"))
+    k = F.linear(x, st[p + ".to_k.weight"], st.get(p + ".to_k.bias"))
+    v = F.linear(x, st[p + ".to_v.weight"], st.get(p + ".to_v.bias"))
+    q, k, v = (t.reshape(b, n, h, cfg.dim_head).permute(0, 2, 1, 3) for t in (q, k, v))
+    outs = []
+    if gh > 0:
+        proj = st[p + ".fast_attention.projection_matrix"]
+        qp = softmax_kernel(q[:, :gh], proj, True)
+        kp = softmax_kernel(k[:, :gh], proj, False)
+        outs.append(causal_linear_attention(qp, kp, v[:, :gh]))
+    if gh < h:
+        outs.append(local_attention(q[:, gh:], k[:, gh:], v[:, gh:], cfg.local_window_size))
+    out = torch.cat(outs, dim=1).permute(0, 2, 1, 3).reshape(b, n, h * cfg.dim_head)
+    return F.linear(out, st[p + ".to_out.weight"], st.get(p + ".to_out.bias"))
+
+
+def feed_forward(st, p, x):
+    return F.linear(F.gelu(F.linear(x, st[p + ".w1.weight"], st[p + ".w1.bias"])), st[p + ".w2.weight"], st[p + ".w2.bias"])
+
+
+def layer_stack(st, cfg: PerformerConfig, x):
+    for i in range(cfg.depth):
+        p = f"performer.net.layers.{i}"
+        x = x + self_attention(st, p + ".0.fn", cfg, x) * st[p + ".0.g"]
+        x = x + feed_forward(st, p + ".1.fn.fn", x) * st[p + ".1.g"]
+    return x
+
+
+def embed(st, cfg: PerformerConfig, tokens, spatial_index_sequences):
+    """performer.py:241-266: token emb + zero-front-padded absolute-spatial embeddings + absolute positional embedding."""
+    b, n = tokens.shape
+    x = F.embedding(tokens, st["token_emb.weight"])
+    for a, seq in enumerate(spatial_index_sequences):
+        sc = F.embedding(seq[:-1], st[f"spatial_position_emb.{a}.emb.weight"])[None, : n - 1]
+        x = x + F.pad(sc, (0, 0, 1, 0, 0, 0))
+    x = x + st["pos_emb.emb.weight"][:n][None]
+    return x
+
+
+def forward(st, cfg: PerformerConfig, tokens, spatial_index_sequences):
+    x = embed(st, cfg, tokens, spatial_index_sequences)
+    x = layer_stack(st, cfg, x)
+    x = F.layer_norm(x, (cfg.dim,), st["norm.weight"], st["norm.bias"])
+    return F.linear(x, st["to_out.weight"], st["to_out.bias"])
+
+
+def ce_loss(logits, target):
+    """losses/transformer/transformer.py:24-33 with the inferer's transpose (inferer/transformer.py:28-29)."""
+    return F.cross_entropy(logits.transpose(1, 2).float(), target.long(), reduction="mean")
+
+
+def spatial_index_sequences(spatial_shape, ordering):
+    """performer.py:159-171: per-axis ij-meshgrid coordinate, flattened and re-ordered."""
+    import numpy as np
+    coords = np.array(np.meshgrid(*[np.arange(s) for s in spatial_shape], indexing="ij"))
+    return [torch.from_numpy(coords[a].flatten()[ordering]).long() for a in range(len(spatial_shape))]
