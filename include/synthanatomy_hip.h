@@ -112,6 +112,61 @@ int sa_mse(const float *a, const float *b, int64_t n, float *loss_sum, float *gr
 int sa_adam(float *p, const float *g, float *m, float *v, int64_t n, float lr, float beta1, float beta2, float eps,
             float weight_decay, int step, float grad_scale, void *stream);
 
+/* ==== Performer path (reference src/networks/transformers/performer.py:194-221,229-288 -> third-party performer-pytorch
+ * 1.0.11 / local-attention / fast_transformers CausalDotProduct; torch embedding, LayerNorm, cross_entropy).  All fp32.
+ * The dense projections (to_q/to_k/to_v/to_out, FeedForward w1/w2, final to_out) are 1-tap sa_conv_fprop / sa_conv_wgrad. */
+
+/* out[r,:] = sum_t table_t[idx_t[per_position_t ? r % N : r], :]  (idx < 0 skips) -- token + spatial + positional embeddings
+ * (performer.py:241-266); sa_embed_scatter is its gradient wrt one table (fp32 atomics). */
+int sa_embed_sum(int ntab, const float *const *tables, const int64_t *const *idx, const int32_t *per_position, int dim, int N,
+                 int64_t R, float *out, void *stream);
+int sa_embed_scatter(const float *dy, float *dtable, const int64_t *idx, int per_position, int dim, int N, int64_t R, void *stream);
+/* nn.LayerNorm (performer.py:220,273); stats[2r] = mean, stats[2r+1] = rstd; y_lp optional copy in lp_dtype */
+int sa_layernorm_fwd(const float *x, const float *w, const float *b, float *y, void *y_lp, int lp_dtype, float *stats, int64_t R, int C,
+                     float eps, void *stream);
+int sa_layernorm_bwd(const float *dy, const float *x, const float *w, const float *stats, float *dx, float *dw, float *db, int64_t R,
+                     int C, void *stream);
+/* FeedForward activation (exact erf GELU) */
+int sa_gelu(const void *u, int u_dtype, void *h, int h_dtype, int64_t n, void *stream);
+/* ReZero residual: y = x + g*F ; backward dF = g*dy, dg += sum dy*F */
+int sa_rezero_fwd(const float *x, const void *F, int f_dtype, const float *g, float *y, void *y_lp, int lp_dtype, int64_t n, void *stream);
+int sa_rezero_bwd(const float *dy, const void *F, int f_dtype, const float *g, void *dF, int df_dtype, float *dg, int64_t n, void *stream);
+int sa_axpy(float *y, const float *x, float alpha, int64_t n, void *stream);
+/* FAVOR+ softmax_kernel feature map on top of the projection GEMM output dd [rows, LDF] (rows = B*N*G):
+ * feat = m^-1/2 (exp(dd - |x|^2 d^-1/2 / 2 - stab) + 1e-4), stab = row max (is_query) or the GLOBAL max (keys; gmax_ws = 8 bytes). */
+int sa_favor_features_fwd(const float *dd, const float *src, int src_stride, int h0, int G, int dh, int is_query, float *feat, void *gmax_ws,
+                          int64_t rows, int m, int LDF, void *stream);
+int sa_favor_features_bwd(const float *dfeat, const float *feat, const float *dd, const float *src, int src_stride, int h0, int G, int dh,
+                          int is_query, float *ddd, float *dsrc, const void *gmax_ws, float *tsum_ws, int64_t rows, int m, int LDF,
+                          void *stream);
+/* FastAttention.redraw_projection_matrix: out[m,d] = rowwise-orthonormalised Gaussian blocks [nblk,d,d] scaled by |rows[r]| */
+int sa_favor_projection(const float *blocks, const float *rows, float *out, int nblk, int m, int d, void *stream);
+/* causal running-state scans replacing fast_transformers' CausalDotProduct (forward and both backward directions):
+ *   scan_a: T[m][d] += a_i[m] b_i[d] ; y_i[d] = (sum_m c_i[m] T[m][d]) * y_scale_i        (a, c: [B,N,G,LDF]; b, y: strided head blocks)
+ *   scan_b: T[m][d] += a_i[m] b_i[d] ; y_i[m] = sum_d T[m][d] c_i[d] + ex_scale_i (ex_vec_i[m] + ex_const)   (y: [B,N,G,LDF]) */
+int sa_favor_scan_a(const float *a, const float *c, const float *b, int b_stride, int b_off, const float *b_scale, float *y, int y_stride,
+                    int y_off, const float *y_scale, int B, int N, int G, int LDF, int dv, int reverse, int accumulate, void *stream);
+int sa_favor_scan_b(const float *a, const float *b, int b_stride, int b_off, const float *b_scale, const float *c, int c_stride, int c_off,
+                    const float *c_scale, float *y, const float *ex_scale, const float *ex_vec, float ex_const, int B, int N, int G,
+                    int LDF, int dv, int reverse, void *stream);
+int sa_cumsum_rows(const float *x, const float *scale, float *out, int B, int N, int G, int LDF, int reverse, void *stream);
+int sa_favor_den(const float *q, const float *z, float eps, float *inv, int64_t rows, int m, int LDF, void *stream);
+int sa_favor_dden(const float *dout, const float *out, int stride, int off, int G, int dv, const float *inv, float *dden, int64_t rows,
+                  void *stream);
+/* rotary embedding of the local heads (local-attention >= 1.2); transpose=1 applies the adjoint (backward) */
+int sa_rotary(const float *x, int stride, int off, int L, int dh, const float *cosb, const float *sinb, float *y, int y_stride, int y_off,
+              int N, int64_t R, int transpose, int accumulate, void *stream);
+/* causal local-window attention (window W, look back one window): per query softmax over keys [max(0,(n/W-1)W), n] */
+int sa_local_attn_fwd(const float *q, int q_stride, int q_off, const float *k, int k_stride, int k_off, const float *v, int v_stride, int v_off,
+                      float *o, int o_stride, int o_off, float *lse, int B, int N, int L, int W, int dh, void *stream);
+/* dq/dk/dv use the strides and offsets of q/k/v */
+int sa_local_attn_bwd(const float *q, int q_stride, int q_off, const float *k, int k_stride, int k_off, const float *v, int v_stride, int v_off,
+                      const float *out, const float *dout, int o_stride, int o_off, const float *lse, float *dq, float *dk, float *dv,
+                      float *Dbuf, int B, int N, int L, int W, int dh, void *stream);
+/* CELoss (losses/transformer/transformer.py:24-33): loss_sum += sum_r (lse_r - logit[r,target_r]); dlogits = (softmax - onehot) * gscale */
+int sa_cross_entropy(const float *logits, const int64_t *target, int64_t R, int V, float *loss_sum, void *dlogits, int d_dtype, float gscale,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,7 @@ class PerformerConfig:
     ff_mult: int = 4
     nb_features: Optional[int] = None
     spatial_shape: tuple = (10, 14, 10)
+    use_rezero: bool = True
 
     @property
     def m(self):
@@ -93,13 +94,18 @@ def init_state(cfg: PerformerConfig, seed: int = 0, spatial_index_len: Optional[
         st[f"spatial_position_emb.{a}.emb.weight"] = torch.randn(spatial_index_len or (n - 1), cfg.dim, generator=g)
     for i in range(cfg.depth):
         p = f"performer.net.layers.{i}"
-        st[p + ".0.g"] = torch.tensor(1e-3)
+        if cfg.use_rezero:
+            st[p + ".0.g"] = torch.tensor(1e-3)
+            st[p + ".1.g"] = torch.tensor(1e-3)
+        else:
+            for j in (0, 1):
+                st[p + f".{j}.norm.weight"] = torch.ones(cfg.dim) + 0.1 * torch.randn(cfg.dim, generator=g)
+                st[p + f".{j}.norm.bias"] = 0.1 * torch.randn(cfg.dim, generator=g)
         lin(p + ".0.fn.to_q", cfg.inner, cfg.dim, bias=False)
         lin(p + ".0.fn.to_k", cfg.inner, cfg.dim, bias=False)
         lin(p + ".0.fn.to_v", cfg.inner, cfg.dim, bias=False)
         lin(p + ".0.fn.to_out", cfg.dim, cfg.inner, bias=False)
         st[p + ".0.fn.fast_attention.projection_matrix"] = gaussian_orthogonal_random_matrix(cfg.m, cfg.dim_head, g)
-        st[p + ".1.g"] = torch.tensor(1e-3)
         lin(p + ".1.fn.fn.w1", cfg.dim * cfg.ff_mult, cfg.dim)
         lin(p + ".1.fn.fn.w2", cfg.dim, cfg.dim * cfg.ff_mult)
     st["norm.weight"] = torch.ones(cfg.dim)
@@ -237,8 +243,12 @@ def feed_forward(st, p, x):
 def layer_stack(st, cfg: PerformerConfig, x):
     for i in range(cfg.depth):
         p = f"performer.net.layers.{i}"
-        x = x + self_attention(st, p + ".0.fn", cfg, x) * st[p + ".0.g"]
-        x = x + feed_forward(st, p + ".1.fn.fn", x) * st[p + ".1.g"]
+        if cfg.use_rezero:  # performer_pytorch.ReZero: fn(x) * g
+            x = x + self_attention(st, p + ".0.fn", cfg, x) * st[p + ".0.g"]
+            x = x + feed_forward(st, p + ".1.fn.fn", x) * st[p + ".1.g"]
+        else:  # performer_pytorch.PreLayerNorm: fn(norm(x))
+            x = x + self_attention(st, p + ".0.fn", cfg, F.layer_norm(x, (cfg.dim,), st[p + ".0.norm.weight"], st[p + ".0.norm.bias"]))
+            x = x + feed_forward(st, p + ".1.fn.fn", F.layer_norm(x, (cfg.dim,), st[p + ".1.norm.weight"], st[p + ".1.norm.bias"]))
     return x
 
 

@@ -57,6 +57,31 @@ _SIGS = {
     "sa_cast_pad": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "sa_mse": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p]),
     "sa_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
+    "sa_embed_sum": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), c_int, c_int, c_int64, c_void_p, c_void_p]),
+    "sa_embed_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
+    "sa_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "sa_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "sa_gelu": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "sa_rezero_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "sa_rezero_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    "sa_axpy": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_void_p]),
+    "sa_favor_features_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "sa_favor_features_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_int64, c_int, c_int, c_void_p]),
+    "sa_favor_projection": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sa_favor_scan_a": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                c_int, c_int, c_void_p]),
+    "sa_favor_scan_b": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                                c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "sa_cumsum_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "sa_favor_den": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "sa_favor_dden": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sa_rotary": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
+    "sa_local_attn_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                  c_int, c_int, c_void_p]),
+    "sa_local_attn_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "sa_cross_entropy": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p]),
 }
 
 _lib = None

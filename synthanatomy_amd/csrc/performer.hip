@@ -1,0 +1,877 @@
+// Performer hot-path kernels other than the dense projections (those are 1-tap launches of conv_fprop / conv_wgrad).
+//
+// Replaces, behind reference src/networks/transformers/performer.py:194-221,229-288, the third-party arithmetic of
+// performer-pytorch 1.0.11 (softmax_kernel, causal_linear_attention -> fast_transformers CausalDotProduct CUDA kernel,
+// ReZero, FeedForward's GELU), local-attention (rotary + banded causal softmax attention) and torch's embedding /
+// LayerNorm / cross_entropy kernels.  Everything here is fp32 (the reference runs this path with amp=False and forces
+// fp32 around the FAVOR+ kernel).
+//
+// FAVOR+ causal attention is split into separable running-state scans so that every kernel has >= 192 independent
+// blocks (the per-(batch, head) state S = sum k' (x) v is 266 x 64 fp32):
+//   scan A  "reduce over features":  T[m][d] += a_i[m] b_i[d];  y_i[d] = sum_m c_i[m] T[m][d]     (block = 16 columns d)
+//   scan B  "reduce over columns" :  T[m][d] += a_i[m] b_i[d];  y_i[m] = sum_d T[m][d] c_i[d]     (block = 64 features m)
+// forward numerator = A(k', v, q'); dv = A(q', dnum, k') reversed; dq' = B(k', v, dnum); dk' = B(q', dnum, v) reversed.
+#include "sa_common.h"
+
+namespace sa {
+
+static inline unsigned grid1d(int64_t n, int block = 256, unsigned cap = 8192) {
+    int64_t b = (n + block - 1) / block;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// ------------------------------------------------------------------------------------------------ embeddings
+struct EmbedArgs {
+    const float* table[6];
+    const int64_t* idx[6];
+    int32_t per_position[6];  // 1: index by position n = r % N (shared across the batch); 0: index by row r
+    int32_t ntab, dim, N;
+    int64_t R;
+};
+
+__global__ void embed_sum_kernel(const EmbedArgs a, float* __restrict__ out) {
+    const int64_t total = a.R * a.dim;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / a.dim;
+        const int c = (int)(e - r * a.dim);
+        float s = 0.f;
+        for (int t = 0; t < a.ntab; ++t) {
+            const int64_t ix = a.idx[t][a.per_position[t] ? (r % a.N) : r];
+            if (ix >= 0) s += a.table[t][ix * a.dim + c];
+        }
+        out[e] = s;
+    }
+}
+
+__global__ void embed_scatter_kernel(const float* __restrict__ dy, float* __restrict__ dtable, const int64_t* __restrict__ idx, int per_position, int dim,
+                                     int N, int64_t R) {
+    const int64_t total = R * dim;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / dim;
+        const int c = (int)(e - r * dim);
+        const int64_t ix = idx[per_position ? (r % N) : r];
+        if (ix >= 0) unsafeAtomicAdd(dtable + ix * dim + c, dy[e]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm (one wave per row)
+__global__ void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
+                                     void* y_lp, int lp_dtype, float* __restrict__ stats, int64_t R, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* xr = x + r * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = xr[c] - mean;
+        v += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(v) / C + eps);
+    for (int c = lane; c < C; c += 64) {
+        const float o = (xr[c] - mean) * rstd * w[c] + b[c];
+        y[r * C + c] = o;
+        if (y_lp) store_from_f32(y_lp, lp_dtype, r * C + c, o);
+    }
+    if (lane == 0) {
+        stats[2 * r] = mean;
+        stats[2 * r + 1] = rstd;
+    }
+}
+
+__global__ void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w,
+                                     const float* __restrict__ stats, float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int64_t R,
+                                     int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (x[r * C + c] - mean) * rstd;
+        const float g = dy[r * C + c] * w[c];
+        s1 += g;
+        s2 += g * xh;
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (x[r * C + c] - mean) * rstd;
+        const float d = dy[r * C + c];
+        dx[r * C + c] = (d * w[c] - s1 - xh * s2) * rstd;
+        unsafeAtomicAdd(dw + c, d * xh);
+        unsafeAtomicAdd(db + c, d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GELU / ReZero
+__global__ void gelu_kernel(const void* u, int u_dtype, void* h, int h_dtype, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        store_from_f32(h, h_dtype, e, gelu_f(load_as_f32(u, u_dtype, e)));
+}
+
+// y = x + g * F   (ReZero, performer_pytorch.ReZero);  optional low-precision copy of y for the next GEMM
+__global__ void rezero_fwd_kernel(const float* __restrict__ x, const void* F, int f_dtype, const float* __restrict__ g, float* __restrict__ y, void* y_lp,
+                                  int lp_dtype, int64_t n) {
+    const float gv = g[0];
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const float o = x[e] + gv * load_as_f32(F, f_dtype, e);
+        y[e] = o;
+        if (y_lp) store_from_f32(y_lp, lp_dtype, e, o);
+    }
+}
+
+// dF = g * dy ; dg += sum dy * F
+__global__ void rezero_bwd_kernel(const float* __restrict__ dy, const void* F, int f_dtype, const float* __restrict__ g, void* dF, int df_dtype,
+                                  float* __restrict__ dg, int64_t n) {
+    const float gv = g[0];
+    float s = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const float d = dy[e];
+        s += d * load_as_f32(F, f_dtype, e);
+        store_from_f32(dF, df_dtype, e, gv * d);
+    }
+    s = wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(dg, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) y[e] += alpha * x[e];
+}
+
+// ------------------------------------------------------------------------------------------------ FAVOR+ feature map
+// rows r' = r*G + h (r = b*N + n).  dd [R*G, LDF] = x . (c P)^T from the projection GEMM; x = src[r, (h0+h)*dh .. +dh].
+__device__ __forceinline__ unsigned long long pack_max(float v, uint32_t idx) {
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // order-preserving map float -> uint
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - idx);  // ties: lowest index wins
+}
+__device__ __forceinline__ float unpack_max(unsigned long long p) {
+    uint32_t u = (uint32_t)(p >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+
+__global__ void favor_global_max_kernel(const float* __restrict__ dd, int64_t rows, int m, int LDF, unsigned long long* __restrict__ out) {
+    unsigned long long best = 0ull;
+    const int64_t total = rows * m;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / m;
+        const int c = (int)(e - r * m);
+        const unsigned long long p = pack_max(dd[r * LDF + c], (uint32_t)(r * LDF + c));
+        best = p > best ? p : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ot = __shfl_xor(best, o, 64);
+        best = ot > best ? ot : best;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, best);
+}
+
+// one wave per row: feat = ratio * (exp(dd - |x|^2 c^2/2 - stab) + eps); stab = row max (query) or *gmax (key)
+__global__ void favor_feat_fwd_kernel(const float* __restrict__ dd, const float* __restrict__ src, int src_stride, int h0, int G, int dh,
+                                      const unsigned long long* __restrict__ gmax, float* __restrict__ feat, int64_t rows, int m, int LDF, float c2half,
+                                      float ratio, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rp = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (rp >= rows) return;
+    const int64_t r = rp / G;
+    const int h = (int)(rp - r * G);
+    const float* x = src + r * src_stride + (h0 + h) * dh;
+    float s = 0.f;
+    for (int d = lane; d < dh; d += 64) s += x[d] * x[d];
+    const float diag = wave_sum(s) * c2half;
+    const float* dr = dd + rp * LDF;
+    float stab;
+    if (gmax) {
+        stab = unpack_max(*gmax);
+    } else {
+        float mx = -INFINITY;
+        for (int c = lane; c < m; c += 64) mx = fmaxf(mx, dr[c]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        stab = mx;
+    }
+    for (int c = lane; c < LDF; c += 64) feat[rp * LDF + c] = c < m ? ratio * (expf(dr[c] - diag - stab) + eps) : 0.f;
+}
+
+// backward of the feature map: ddd = e*g (minus the stabiliser path), dsrc[head slice] += -(sum e*g) * c^2 * x
+__global__ void favor_feat_bwd_kernel(const float* __restrict__ dfeat, const float* __restrict__ feat, const float* __restrict__ dd,
+                                      const float* __restrict__ src, int src_stride, int h0, int G, int dh, int is_query, float* __restrict__ ddd,
+                                      float* __restrict__ dsrc, float* __restrict__ tsum, int64_t rows, int m, int LDF, float c2, float ratio_eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rp = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (rp >= rows) return;
+    const int64_t r = rp / G;
+    const int h = (int)(rp - r * G);
+    float t = 0.f, mx = -INFINITY;
+    int am = 0;
+    for (int c = lane; c < LDF; c += 64) {
+        float v = 0.f;
+        if (c < m) {
+            const float e = feat[rp * LDF + c] - ratio_eps;
+            v = e * dfeat[rp * LDF + c];
+            const float dv = dd[rp * LDF + c];
+            if (dv > mx) {
+                mx = dv;
+                am = c;
+            }
+        }
+        ddd[rp * LDF + c] = v;
+        t += v;
+    }
+    t = wave_sum(t);
+    if (is_query) {
+        // stab = dd[argmax]: d feat / d stab = -e  ->  ddd[argmax] -= t   (first maximum, like torch.max)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float om = __shfl_xor(mx, o, 64);
+            const int oa = __shfl_xor(am, o, 64);
+            if (om > mx || (om == mx && oa < am)) {
+                mx = om;
+                am = oa;
+            }
+        }
+        if (lane == 0) ddd[rp * LDF + am] -= t;
+    } else if (lane == 0) {
+        unsafeAtomicAdd(tsum, t);  // the global-max element receives -sum over the whole tensor (favor_key_stab_kernel)
+    }
+    const float* x = src + r * src_stride + (h0 + h) * dh;
+    float* dx = dsrc + r * src_stride + (h0 + h) * dh;
+    for (int d = lane; d < dh; d += 64) dx[d] += -t * c2 * x[d];
+}
+
+__global__ void favor_key_stab_kernel(float* __restrict__ ddd, const unsigned long long* __restrict__ gmax, const float* __restrict__ tsum) {
+    const uint32_t idx = 0xffffffffu - (uint32_t)(*gmax & 0xffffffffull);
+    ddd[idx] -= tsum[0];
+}
+
+
+// ------------------------------------------------------------------------------------------------ FAVOR+ projection redraw
+// gaussian_orthogonal_random_matrix(m, d, scaling=0): each d x d Gaussian block is orthonormalised row by row (modified
+// Gram-Schmidt = the Q of a QR up to signs) and row r is rescaled by the norm of an independent Gaussian row.  One wave per block.
+__global__ __launch_bounds__(64) void favor_projection_kernel(const float* __restrict__ blocks, const float* __restrict__ rows, float* __restrict__ out,
+                                                               int m, int d) {
+    __shared__ float Q[64][65];
+    const int t = threadIdx.x, blk = blockIdx.x;
+    const float* A = blocks + (size_t)blk * d * d;
+    for (int j = 0; j < d; ++j) {
+        float v = t < d ? A[j * d + t] : 0.f;
+        for (int i = 0; i < j; ++i) {
+            const float qi = Q[i][t];
+            const float dot = wave_sum(qi * v);
+            v -= dot * qi;
+        }
+        const float nrm = sqrtf(wave_sum(v * v));
+        Q[j][t] = t < d ? v / nrm : 0.f;
+        __syncthreads();
+    }
+    for (int j = 0; j < d; ++j) {
+        const int r = blk * d + j;
+        if (r >= m) break;
+        const float g = t < d ? rows[(size_t)r * d + t] : 0.f;
+        const float mult = sqrtf(wave_sum(g * g));
+        if (t < d) out[(size_t)r * d + t] = mult * Q[j][t];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ FAVOR+ scans
+struct ScanArgs {
+    const float* a;       // [B,N,G,LDF]
+    const float* c_feat;  // scan A: c [B,N,G,LDF]
+    const float* b;       // [B*N, b_stride] column block at b_off + g*dv
+    const float* c_col;   // scan B: c [B*N, c_stride] column block at c_off + g*dv
+    const float* b_scale; // optional [B,N,G] multiplies b_i
+    const float* c_scale; // optional [B,N,G] multiplies c_i (scan B)
+    float* y;             // scan A: [B*N, y_stride] at y_off + g*dv ; scan B: [B,N,G,LDF]
+    const float* y_scale; // scan A optional [B,N,G] multiplies y_i
+    const float* ex_scale;  // scan B optional: y_i[m] += ex_scale_i * (ex_vec_i[m] + ex_const)   (ex_scale NULL -> 1)
+    const float* ex_vec;    // scan B optional [B,N,G,LDF]
+    float ex_const;
+    int32_t B, N, G, LDF, dv, b_stride, b_off, c_stride, c_off, y_stride, y_off, reverse, accumulate;
+};
+
+constexpr int SCAN_TB = 8;  // positions staged per barrier
+
+// scan A: block = (b, g, 16-column slice); thread = (column dl = t&15, feature group mg = t>>4), features mg + 16 r
+__global__ __launch_bounds__(256) void favor_scan_a_kernel(const ScanArgs s) {
+    constexpr int NR = 17;  // LDF <= 272
+    __shared__ float sa_[SCAN_TB][272], sc_[SCAN_TB][272], sb_[SCAN_TB][16], sp_[SCAN_TB][16][17];
+    const int nsl = s.dv / 16;
+    const int sl = blockIdx.x % nsl, g = (blockIdx.x / nsl) % s.G, b = blockIdx.x / (nsl * s.G);
+    const int t = threadIdx.x, dl = t & 15, mg = t >> 4;
+    float T[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) T[r] = 0.f;
+    for (int i0 = 0; i0 < s.N; i0 += SCAN_TB) {
+        const int nb = min(SCAN_TB, s.N - i0);
+        for (int e = t; e < nb * s.LDF; e += 256) {
+            const int k = e / s.LDF, c = e - k * s.LDF;
+            const int i = s.reverse ? s.N - 1 - (i0 + k) : i0 + k;
+            const int64_t row = ((int64_t)b * s.N + i) * s.G + g;
+            sa_[k][c] = s.a[row * s.LDF + c];
+            sc_[k][c] = s.c_feat[row * s.LDF + c];
+        }
+        if (t < nb * 16) {
+            const int k = t >> 4, d = t & 15;
+            const int i = s.reverse ? s.N - 1 - (i0 + k) : i0 + k;
+            const int64_t r = (int64_t)b * s.N + i;
+            float v = s.b[r * s.b_stride + s.b_off + g * s.dv + sl * 16 + d];
+            if (s.b_scale) v *= s.b_scale[r * s.G + g];
+            sb_[k][d] = v;
+        }
+        __syncthreads();
+        for (int k = 0; k < nb; ++k) {
+            const float bv = sb_[k][dl];
+            float p = 0.f;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int mrow = mg + 16 * r;
+                if (mrow < s.LDF) {
+                    T[r] = fmaf(sa_[k][mrow], bv, T[r]);
+                    p = fmaf(sc_[k][mrow], T[r], p);
+                }
+            }
+            sp_[k][mg][dl] = p;
+        }
+        __syncthreads();
+        if (t < nb * 16) {
+            const int k = t >> 4, d = t & 15;
+            float y = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) y += sp_[k][q][d];
+            const int i = s.reverse ? s.N - 1 - (i0 + k) : i0 + k;
+            const int64_t r = (int64_t)b * s.N + i;
+            if (s.y_scale) y *= s.y_scale[r * s.G + g];
+            float* yp = s.y + r * s.y_stride + s.y_off + g * s.dv + sl * 16 + d;
+            if (s.accumulate) *yp += y;
+            else *yp = y;
+        }
+        __syncthreads();
+    }
+}
+
+// scan B: block = (b, g, 64-feature slice); thread = (feature ml = t>>2, column quarter dq = t&3)
+__global__ __launch_bounds__(256) void favor_scan_b_kernel(const ScanArgs s) {
+    __shared__ float sa_[SCAN_TB][64], sb_[SCAN_TB][64], sc_[SCAN_TB][64];
+    const int nsl = (s.LDF + 63) / 64;
+    const int sl = blockIdx.x % nsl, g = (blockIdx.x / nsl) % s.G, b = blockIdx.x / (nsl * s.G);
+    const int t = threadIdx.x, ml = t >> 2, dq = t & 3;
+    const int mrow = sl * 64 + ml;
+    float T[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) T[j] = 0.f;
+    for (int i0 = 0; i0 < s.N; i0 += SCAN_TB) {
+        const int nb = min(SCAN_TB, s.N - i0);
+        for (int e = t; e < nb * 64; e += 256) {
+            const int k = e >> 6, c = e & 63;
+            const int i = s.reverse ? s.N - 1 - (i0 + k) : i0 + k;
+            const int64_t r = (int64_t)b * s.N + i;
+            const int64_t row = r * s.G + g;
+            sa_[k][c] = (sl * 64 + c < s.LDF) ? s.a[row * s.LDF + sl * 64 + c] : 0.f;
+            float bv = s.b[r * s.b_stride + s.b_off + g * s.dv + c];
+            if (s.b_scale) bv *= s.b_scale[row];
+            sb_[k][c] = bv;
+            float cv = s.c_col[r * s.c_stride + s.c_off + g * s.dv + c];
+            if (s.c_scale) cv *= s.c_scale[row];
+            sc_[k][c] = cv;
+        }
+        __syncthreads();
+        for (int k = 0; k < nb; ++k) {
+            const float av = sa_[k][ml];
+            float p = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                T[j] = fmaf(av, sb_[k][dq * 16 + j], T[j]);
+                p = fmaf(T[j], sc_[k][dq * 16 + j], p);
+            }
+            p += __shfl_xor(p, 1, 64);
+            p += __shfl_xor(p, 2, 64);
+            if (dq == 0 && mrow < s.LDF) {
+                const int i = s.reverse ? s.N - 1 - (i0 + k) : i0 + k;
+                const int64_t row = ((int64_t)b * s.N + i) * s.G + g;
+                if (s.ex_vec) p += (s.ex_scale ? s.ex_scale[row] : 1.f) * (s.ex_vec[row * s.LDF + mrow] + s.ex_const);
+                s.y[row * s.LDF + mrow] = p;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// running (or reverse-running) sum along N of x[b,n,g,:] * scale[b,n,g]
+__global__ void cumsum_rows_kernel(const float* __restrict__ x, const float* __restrict__ scale, float* __restrict__ out, int B, int N, int G, int LDF,
+                                   int reverse) {
+    const int64_t tix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tix >= (int64_t)B * G * LDF) return;
+    const int c = (int)(tix % LDF);
+    const int g = (int)((tix / LDF) % G);
+    const int b = (int)(tix / ((int64_t)LDF * G));
+    float acc = 0.f;
+    for (int k = 0; k < N; ++k) {
+        const int i = reverse ? N - 1 - k : k;
+        const int64_t row = ((int64_t)b * N + i) * G + g;
+        float v = x[row * LDF + c];
+        if (scale) v *= scale[row];
+        acc += v;
+        out[row * LDF + c] = acc;
+    }
+}
+
+// den[row] = sum_{c<m} q[row][c] * (z[row][c] + eps) ; inv[row] = 1/den    (one wave per row)
+__global__ void favor_den_kernel(const float* __restrict__ q, const float* __restrict__ z, float eps, float* __restrict__ inv, int64_t rows, int m,
+                                 int LDF) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rp = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (rp >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < m; c += 64) s += q[rp * LDF + c] * (z[rp * LDF + c] + eps);
+    s = wave_sum(s);
+    if (lane == 0) inv[rp] = 1.f / s;
+}
+
+// dden[row] = -(dout . out) * invden  over the head's dv columns (one wave per (row, head))
+__global__ void favor_dden_kernel(const float* __restrict__ dout, const float* __restrict__ out, int stride, int off, int G, int dv,
+                                  const float* __restrict__ inv, float* __restrict__ dden, int64_t rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rp = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (rp >= rows) return;
+    const int64_t r = rp / G;
+    const int g = (int)(rp - r * G);
+    float s = 0.f;
+    for (int d = lane; d < dv; d += 64) s += dout[r * stride + off + g * dv + d] * out[r * stride + off + g * dv + d];
+    s = wave_sum(s);
+    if (lane == 0) dden[rp] = -s * inv[rp];
+}
+
+// ------------------------------------------------------------------------------------------------ rotary (local heads)
+// x [R, stride] head block at off + h*dh; table [N, dh] (cos | sin).  mode 0: y = x cos + rot(x) sin ; mode 1: transpose
+__global__ void rotary_kernel(const float* __restrict__ x, int stride, int off, int L, int dh, const float* __restrict__ cosb,
+                              const float* __restrict__ sinb, float* __restrict__ y, int y_stride, int y_off, int N, int64_t R, int mode,
+                              int accumulate) {
+    const int half = dh / 2;
+    const int64_t total = R * L * dh;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(e % dh);
+        const int h = (int)((e / dh) % L);
+        const int64_t r = e / ((int64_t)dh * L);
+        const int n = (int)(r % N);
+        const float* xr = x + r * stride + off + h * dh;
+        const float cs = cosb[n * dh + d];
+        float o;
+        if (mode == 0) {
+            const float rot = d < half ? -xr[d + half] : xr[d - half];
+            o = xr[d] * cs + rot * sinb[n * dh + d];
+        } else {
+            // y_d = g_d cos_d + (rot^T (g sin))_d ;  rot^T(u)_d = u_{d+half} for d < half, -u_{d-half} otherwise
+            const float rt = d < half ? xr[d + half] * sinb[n * dh + d + half] : -xr[d - half] * sinb[n * dh + d - half];
+            o = xr[d] * cs + rt;
+        }
+        float* yp = y + r * y_stride + y_off + h * dh + d;
+        if (accumulate) *yp += o;
+        else *yp = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ local window attention
+// q,k,v rows: [B*N, stride] with the local head hl at column off + hl*64 (dh == 64).  One wave per (b, n, hl).
+struct LocalArgs {
+    const float *q, *k, *v, *dout, *out, *lse;
+    float *o, *lse_out, *dq, *dk, *dv, *Dbuf;
+    int32_t q_stride, q_off, k_stride, k_off, v_stride, v_off, o_stride, o_off;
+    int32_t B, N, L, W;
+    float scale;
+};
+
+constexpr int LOC_MAXK = 1024;  // >= 2 * window
+
+__global__ __launch_bounds__(256) void local_attn_fwd_kernel(const LocalArgs a) {
+    __shared__ float sp[4][LOC_MAXK];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + w;
+    if (wid >= (int64_t)a.B * a.N * a.L) return;
+    const int hl = (int)(wid % a.L);
+    const int n = (int)((wid / a.L) % a.N);
+    const int b = (int)(wid / ((int64_t)a.L * a.N));
+    const int lo = max(0, (n / a.W - 1) * a.W);
+    const int nk = n - lo + 1;
+    const int64_t rq = (int64_t)b * a.N + n;
+    const float* qp = a.q + rq * a.q_stride + a.q_off + hl * 64;
+    float qv[64];
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) {
+        const float4 t4 = *(const float4*)(qp + d);
+        qv[d] = t4.x; qv[d + 1] = t4.y; qv[d + 2] = t4.z; qv[d + 3] = t4.w;
+    }
+    float mx = -INFINITY;
+    for (int j0 = 0; j0 < nk; j0 += 64) {
+        const int j = j0 + lane;
+        float s = -INFINITY;
+        if (j < nk) {
+            const float* kp = a.k + ((int64_t)b * a.N + lo + j) * a.k_stride + a.k_off + hl * 64;
+            float acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; d += 4) {
+                const float4 t4 = *(const float4*)(kp + d);
+                acc = fmaf(qv[d], t4.x, acc); acc = fmaf(qv[d + 1], t4.y, acc); acc = fmaf(qv[d + 2], t4.z, acc); acc = fmaf(qv[d + 3], t4.w, acc);
+            }
+            s = acc * a.scale;
+            sp[w][j] = s;
+        }
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int j = lane; j < nk; j += 64) {
+        const float p = __expf(sp[w][j] - mx);
+        sp[w][j] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    float acc = 0.f;  // lane = output column
+    for (int j = 0; j < nk; ++j) acc = fmaf(sp[w][j], a.v[((int64_t)b * a.N + lo + j) * a.v_stride + a.v_off + hl * 64 + lane], acc);
+    a.o[rq * a.o_stride + a.o_off + hl * 64 + lane] = acc / sum;
+    if (lane == 0) a.lse_out[rq * a.L + hl] = mx + __logf(sum);
+}
+
+// dq_i = scale * sum_j dS_ij k_j,  dS_ij = p_ij (dO_i.v_j - D_i),  D_i = dO_i.O_i  (also written to Dbuf for the kv pass)
+__global__ __launch_bounds__(256) void local_attn_bwd_q_kernel(const LocalArgs a) {
+    __shared__ float sp[4][LOC_MAXK];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + w;
+    if (wid >= (int64_t)a.B * a.N * a.L) return;
+    const int hl = (int)(wid % a.L);
+    const int n = (int)((wid / a.L) % a.N);
+    const int b = (int)(wid / ((int64_t)a.L * a.N));
+    const int lo = max(0, (n / a.W - 1) * a.W);
+    const int nk = n - lo + 1;
+    const int64_t rq = (int64_t)b * a.N + n;
+    const float* qp = a.q + rq * a.q_stride + a.q_off + hl * 64;
+    const float* dop = a.dout + rq * a.o_stride + a.o_off + hl * 64;
+    const float* op = a.out + rq * a.o_stride + a.o_off + hl * 64;
+    float qv[64], dov[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) {
+        qv[d] = qp[d];
+        dov[d] = dop[d];
+    }
+    const float D = wave_sum(dop[lane] * op[lane]);
+    const float lse = a.lse[rq * a.L + hl];
+    if (lane == 0) a.Dbuf[rq * a.L + hl] = D;
+    for (int j0 = 0; j0 < nk; j0 += 64) {
+        const int j = j0 + lane;
+        if (j < nk) {
+            const int64_t rk = (int64_t)b * a.N + lo + j;
+            const float* kp = a.k + rk * a.k_stride + a.k_off + hl * 64;
+            const float* vp = a.v + rk * a.v_stride + a.v_off + hl * 64;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) {
+                s = fmaf(qv[d], kp[d], s);
+                dp = fmaf(dov[d], vp[d], dp);
+            }
+            const float p = __expf(s * a.scale - lse);
+            sp[w][j] = p * (dp - D);
+        }
+    }
+    float acc = 0.f;
+    for (int j = 0; j < nk; ++j) acc = fmaf(sp[w][j], a.k[((int64_t)b * a.N + lo + j) * a.k_stride + a.k_off + hl * 64 + lane], acc);
+    a.dq[rq * a.q_stride + a.q_off + hl * 64 + lane] = acc * a.scale;
+}
+
+// one wave per key j: queries i in [j, min(N-1, (j/W + 2) W - 1)];  dv_j = sum_i p_ij dO_i ; dk_j = scale * sum_i dS_ij q_i
+__global__ __launch_bounds__(256) void local_attn_bwd_kv_kernel(const LocalArgs a) {
+    __shared__ float sp[4][LOC_MAXK], sd[4][LOC_MAXK];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + w;
+    if (wid >= (int64_t)a.B * a.N * a.L) return;
+    const int hl = (int)(wid % a.L);
+    const int j = (int)((wid / a.L) % a.N);
+    const int b = (int)(wid / ((int64_t)a.L * a.N));
+    const int hi = min(a.N - 1, (j / a.W + 2) * a.W - 1);
+    const int nq = hi - j + 1;
+    const int64_t rk = (int64_t)b * a.N + j;
+    const float* kp = a.k + rk * a.k_stride + a.k_off + hl * 64;
+    const float* vp = a.v + rk * a.v_stride + a.v_off + hl * 64;
+    float kv_[64], vv[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) {
+        kv_[d] = kp[d];
+        vv[d] = vp[d];
+    }
+    for (int i0 = 0; i0 < nq; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < nq) {
+            const int64_t rq = (int64_t)b * a.N + j + i;
+            const float* qp = a.q + rq * a.q_stride + a.q_off + hl * 64;
+            const float* dop = a.dout + rq * a.o_stride + a.o_off + hl * 64;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) {
+                s = fmaf(qp[d], kv_[d], s);
+                dp = fmaf(dop[d], vv[d], dp);
+            }
+            const float p = __expf(s * a.scale - a.lse[rq * a.L + hl]);
+            sp[w][i] = p;
+            sd[w][i] = p * (dp - a.Dbuf[rq * a.L + hl]);
+        }
+    }
+    float accv = 0.f, acck = 0.f;
+    for (int i = 0; i < nq; ++i) {
+        const int64_t rq = (int64_t)b * a.N + j + i;
+        accv = fmaf(sp[w][i], a.dout[rq * a.o_stride + a.o_off + hl * 64 + lane], accv);
+        acck = fmaf(sd[w][i], a.q[rq * a.q_stride + a.q_off + hl * 64 + lane], acck);
+    }
+    a.dv[rk * a.v_stride + a.v_off + hl * 64 + lane] = accv;
+    a.dk[rk * a.k_stride + a.k_off + hl * 64 + lane] = acck * a.scale;
+}
+
+// ------------------------------------------------------------------------------------------------ cross entropy (one wave per row)
+__global__ void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, int64_t R, int V, float* __restrict__ loss_sum,
+                          void* dlogits, int d_dtype, float gscale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* lr = logits + r * V;
+    float mx = -INFINITY;
+    for (int c = lane; c < V; c += 64) mx = fmaxf(mx, lr[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float s = 0.f;
+    for (int c = lane; c < V; c += 64) s += expf(lr[c] - mx);
+    s = wave_sum(s);
+    const float lse = mx + logf(s);
+    const int64_t tg = target[r];
+    if (lane == 0) unsafeAtomicAdd(loss_sum, lse - lr[tg]);
+    if (dlogits) {
+        for (int c = lane; c < V; c += 64) {
+            const float p = expf(lr[c] - lse);
+            store_from_f32(dlogits, d_dtype, r * V + c, (p - (c == tg ? 1.f : 0.f)) * gscale);
+        }
+    }
+}
+
+}  // namespace sa
+
+using namespace sa;
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" int sa_embed_sum(int ntab, const float* const* tables, const int64_t* const* idx, const int32_t* per_position, int dim, int N, int64_t R,
+                            float* out, void* stream) {
+    if (ntab < 1 || ntab > 6 || !tables || !idx || !per_position || !out || dim <= 0 || R <= 0) return SA_EINVAL;
+    EmbedArgs a;
+    for (int t = 0; t < ntab; ++t) {
+        a.table[t] = tables[t];
+        a.idx[t] = idx[t];
+        a.per_position[t] = per_position[t];
+    }
+    a.ntab = ntab;
+    a.dim = dim;
+    a.N = N;
+    a.R = R;
+    hipLaunchKernelGGL(embed_sum_kernel, dim3(grid1d(R * dim)), dim3(256), 0, ST(stream), a, out);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_embed_scatter(const float* dy, float* dtable, const int64_t* idx, int per_position, int dim, int N, int64_t R, void* stream) {
+    if (!dy || !dtable || !idx || dim <= 0 || R <= 0) return SA_EINVAL;
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(grid1d(R * dim)), dim3(256), 0, ST(stream), dy, dtable, idx, per_position, dim, N, R);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_layernorm_fwd(const float* x, const float* w, const float* b, float* y, void* y_lp, int lp_dtype, float* stats, int64_t R, int C,
+                                float eps, void* stream) {
+    if (!x || !w || !b || !y || !stats || R <= 0 || C <= 0) return SA_EINVAL;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, ST(stream), x, w, b, y, y_lp, lp_dtype, stats, R, C, eps);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_layernorm_bwd(const float* dy, const float* x, const float* w, const float* stats, float* dx, float* dw, float* db, int64_t R, int C,
+                                void* stream) {
+    if (!dy || !x || !w || !stats || !dx || !dw || !db || R <= 0 || C <= 0) return SA_EINVAL;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, ST(stream), dy, x, w, stats, dx, dw, db, R, C);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_gelu(const void* u, int u_dtype, void* h, int h_dtype, int64_t n, void* stream) {
+    if (!u || !h || n <= 0) return SA_EINVAL;
+    hipLaunchKernelGGL(gelu_kernel, dim3(grid1d(n)), dim3(256), 0, ST(stream), u, u_dtype, h, h_dtype, n);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_rezero_fwd(const float* x, const void* F, int f_dtype, const float* g, float* y, void* y_lp, int lp_dtype, int64_t n, void* stream) {
+    if (!x || !F || !g || !y || n <= 0) return SA_EINVAL;
+    hipLaunchKernelGGL(rezero_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, ST(stream), x, F, f_dtype, g, y, y_lp, lp_dtype, n);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_rezero_bwd(const float* dy, const void* F, int f_dtype, const float* g, void* dF, int df_dtype, float* dg, int64_t n, void* stream) {
+    if (!dy || !F || !g || !dF || !dg || n <= 0) return SA_EINVAL;
+    hipLaunchKernelGGL(rezero_bwd_kernel, dim3(grid1d(n, 256, 1024)), dim3(256), 0, ST(stream), dy, F, f_dtype, g, dF, df_dtype, dg, n);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_axpy(float* y, const float* x, float alpha, int64_t n, void* stream) {
+    if (!y || !x || n <= 0) return SA_EINVAL;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid1d(n)), dim3(256), 0, ST(stream), y, x, alpha, n);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_favor_features_fwd(const float* dd, const float* src, int src_stride, int h0, int G, int dh, int is_query, float* feat, void* gmax_ws,
+                                     int64_t rows, int m, int LDF, void* stream) {
+    if (!dd || !src || !feat || rows <= 0 || m <= 0 || LDF < m || (!is_query && !gmax_ws)) return SA_EINVAL;
+    const float c = powf((float)dh, -0.25f), ratio = 1.f / sqrtf((float)m);
+    unsigned long long* gm = nullptr;
+    if (!is_query) {
+        gm = (unsigned long long*)gmax_ws;
+        hipMemsetAsync(gm, 0, 8, ST(stream));
+        hipLaunchKernelGGL(favor_global_max_kernel, dim3(grid1d(rows * m, 256, 2048)), dim3(256), 0, ST(stream), dd, rows, m, LDF, gm);
+        SA_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(favor_feat_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), dd, src, src_stride, h0, G, dh, gm, feat, rows, m,
+                       LDF, 0.5f * c * c, ratio, 1e-4f);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_favor_features_bwd(const float* dfeat, const float* feat, const float* dd, const float* src, int src_stride, int h0, int G, int dh,
+                                     int is_query, float* ddd, float* dsrc, const void* gmax_ws, float* tsum_ws, int64_t rows, int m, int LDF,
+                                     void* stream) {
+    if (!dfeat || !feat || !dd || !src || !ddd || !dsrc || rows <= 0 || (!is_query && (!gmax_ws || !tsum_ws))) return SA_EINVAL;
+    const float c = powf((float)dh, -0.25f), ratio = 1.f / sqrtf((float)m);
+    if (!is_query) hipMemsetAsync(tsum_ws, 0, 4, ST(stream));
+    hipLaunchKernelGGL(favor_feat_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), dfeat, feat, dd, src, src_stride, h0, G, dh,
+                       is_query, ddd, dsrc, tsum_ws, rows, m, LDF, c * c, ratio * 1e-4f);
+    SA_CHECK_LAUNCH();
+    if (!is_query) {
+        hipLaunchKernelGGL(favor_key_stab_kernel, dim3(1), dim3(1), 0, ST(stream), ddd, (const unsigned long long*)gmax_ws, tsum_ws);
+        SA_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int sa_favor_projection(const float* blocks, const float* rows, float* out, int nblk, int m, int d, void* stream) {
+    if (!blocks || !rows || !out || nblk <= 0 || m <= 0 || d <= 0 || d > 64 || nblk * d < m) return SA_EINVAL;
+    hipLaunchKernelGGL(favor_projection_kernel, dim3(nblk), dim3(64), 0, ST(stream), blocks, rows, out, m, d);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+static int check_scan(int B, int N, int G, int LDF, int dv) { return (B > 0 && N > 0 && G > 0 && LDF > 0 && LDF <= 272 && dv == 64) ? 0 : SA_EUNSUPPORTED; }
+
+extern "C" int sa_favor_scan_a(const float* a, const float* c, const float* b, int b_stride, int b_off, const float* b_scale, float* y, int y_stride,
+                               int y_off, const float* y_scale, int B, int N, int G, int LDF, int dv, int reverse, int accumulate, void* stream) {
+    if (!a || !c || !b || !y) return SA_EINVAL;
+    if (check_scan(B, N, G, LDF, dv)) return SA_EUNSUPPORTED;
+    ScanArgs s = {};
+    s.a = a; s.c_feat = c; s.b = b; s.b_scale = b_scale; s.y = y; s.y_scale = y_scale;
+    s.B = B; s.N = N; s.G = G; s.LDF = LDF; s.dv = dv; s.b_stride = b_stride; s.b_off = b_off; s.y_stride = y_stride; s.y_off = y_off;
+    s.reverse = reverse; s.accumulate = accumulate;
+    hipLaunchKernelGGL(favor_scan_a_kernel, dim3(B * G * (dv / 16)), dim3(256), 0, ST(stream), s);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_favor_scan_b(const float* a, const float* b, int b_stride, int b_off, const float* b_scale, const float* c, int c_stride, int c_off,
+                               const float* c_scale, float* y, const float* ex_scale, const float* ex_vec, float ex_const, int B, int N, int G,
+                               int LDF, int dv, int reverse, void* stream) {
+    if (!a || !c || !b || !y) return SA_EINVAL;
+    if (check_scan(B, N, G, LDF, dv)) return SA_EUNSUPPORTED;
+    ScanArgs s = {};
+    s.a = a; s.b = b; s.c_col = c; s.b_scale = b_scale; s.c_scale = c_scale; s.y = y; s.ex_scale = ex_scale; s.ex_vec = ex_vec; s.ex_const = ex_const;
+    s.B = B; s.N = N; s.G = G; s.LDF = LDF; s.dv = dv; s.b_stride = b_stride; s.b_off = b_off; s.c_stride = c_stride; s.c_off = c_off; s.reverse = reverse;
+    hipLaunchKernelGGL(favor_scan_b_kernel, dim3(B * G * ((LDF + 63) / 64)), dim3(256), 0, ST(stream), s);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_cumsum_rows(const float* x, const float* scale, float* out, int B, int N, int G, int LDF, int reverse, void* stream) {
+    if (!x || !out || B <= 0 || N <= 0 || G <= 0 || LDF <= 0) return SA_EINVAL;
+    hipLaunchKernelGGL(cumsum_rows_kernel, dim3((unsigned)(((int64_t)B * G * LDF + 63) / 64)), dim3(64), 0, ST(stream), x, scale, out, B, N, G, LDF, reverse);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_favor_den(const float* q, const float* z, float eps, float* inv, int64_t rows, int m, int LDF, void* stream) {
+    if (!q || !z || !inv || rows <= 0) return SA_EINVAL;
+    hipLaunchKernelGGL(favor_den_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), q, z, eps, inv, rows, m, LDF);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_favor_dden(const float* dout, const float* out, int stride, int off, int G, int dv, const float* inv, float* dden, int64_t rows,
+                             void* stream) {
+    if (!dout || !out || !inv || !dden || rows <= 0) return SA_EINVAL;
+    hipLaunchKernelGGL(favor_dden_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), dout, out, stride, off, G, dv, inv, dden, rows);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_rotary(const float* x, int stride, int off, int L, int dh, const float* cosb, const float* sinb, float* y, int y_stride, int y_off,
+                         int N, int64_t R, int transpose, int accumulate, void* stream) {
+    if (!x || !cosb || !sinb || !y || L <= 0 || dh <= 0 || (dh & 1) || R <= 0) return SA_EINVAL;
+    hipLaunchKernelGGL(rotary_kernel, dim3(grid1d(R * L * dh)), dim3(256), 0, ST(stream), x, stride, off, L, dh, cosb, sinb, y, y_stride, y_off, N, R,
+                       transpose, accumulate);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+static int fill_local(LocalArgs& a, int q_stride, int q_off, int k_stride, int k_off, int v_stride, int v_off, int o_stride, int o_off, int B, int N, int L, int W,
+                      int dh) {
+    if (dh != 64 || 2 * W > LOC_MAXK || B <= 0 || N <= 0 || L <= 0 || W <= 0) return SA_EUNSUPPORTED;
+    a.q_stride = q_stride; a.q_off = q_off; a.k_stride = k_stride; a.k_off = k_off; a.v_stride = v_stride; a.v_off = v_off; a.o_stride = o_stride; a.o_off = o_off;
+    a.B = B; a.N = N; a.L = L; a.W = W;
+    a.scale = 1.f / sqrtf((float)dh);
+    return 0;
+}
+
+extern "C" int sa_local_attn_fwd(const float* q, int q_stride, int q_off, const float* k, int k_stride, int k_off, const float* v, int v_stride, int v_off,
+                                 float* o, int o_stride, int o_off, float* lse, int B, int N, int L, int W, int dh, void* stream) {
+    if (!q || !k || !v || !o || !lse) return SA_EINVAL;
+    LocalArgs a = {};
+    if (fill_local(a, q_stride, q_off, k_stride, k_off, v_stride, v_off, o_stride, o_off, B, N, L, W, dh)) return SA_EUNSUPPORTED;
+    a.q = q; a.k = k; a.v = v; a.o = o; a.lse_out = lse;
+    const int64_t waves = (int64_t)B * N * L;
+    hipLaunchKernelGGL(local_attn_fwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ST(stream), a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_local_attn_bwd(const float* q, int q_stride, int q_off, const float* k, int k_stride, int k_off, const float* v, int v_stride, int v_off,
+                                 const float* out, const float* dout, int o_stride, int o_off, const float* lse, float* dq, float* dk, float* dv,
+                                 float* Dbuf, int B, int N, int L, int W, int dh, void* stream) {
+    if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !Dbuf) return SA_EINVAL;
+    LocalArgs a = {};
+    if (fill_local(a, q_stride, q_off, k_stride, k_off, v_stride, v_off, o_stride, o_off, B, N, L, W, dh)) return SA_EUNSUPPORTED;
+    a.q = q; a.k = k; a.v = v; a.out = out; a.dout = dout; a.lse = lse; a.dq = dq; a.dk = dk; a.dv = dv; a.Dbuf = Dbuf;
+    const int64_t waves = (int64_t)B * N * L;
+    hipLaunchKernelGGL(local_attn_bwd_q_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ST(stream), a);
+    SA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(local_attn_bwd_kv_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ST(stream), a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_cross_entropy(const float* logits, const int64_t* target, int64_t R, int V, float* loss_sum, void* dlogits, int d_dtype, float gscale,
+                                void* stream) {
+    if (!logits || !target || !loss_sum || R <= 0 || V <= 0) return SA_EINVAL;
+    hipLaunchKernelGGL(ce_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, ST(stream), logits, target, R, V, loss_sum, dlogits, d_dtype, gscale);
+    SA_CHECK_LAUNCH();
+    return 0;
+}

@@ -131,6 +131,7 @@ class ConvOp:
         self.vec = vec_of(dtype)
         self.T = k ** 3
         self._plans = {}
+        self._packs = {}
         self._bias_pad = None
         self._epoch = 0
 
@@ -181,20 +182,28 @@ class ConvOp:
             g = make_geom(dt, N, idims, odims, gout_s, idims, cin_s, cout, cin, (4,) * 3, (2, 2, 2), one, (-1,) * 3, one, zero)
             dgr.append(_Plan(g, cin, cout, T, None, cout * T, T))
         plans = {"fwd": fwd, "dgrad": dgr, "wgrad": wgr, "odims": odims}
+        if len(self._plans) > 64:  # autoregressive sampling visits every prefix length once: keep the cache bounded
+            self._plans.pop(next(iter(self._plans)))
         self._plans[key] = plans
         return plans
 
     # ------------------------------------------------------------------ weight packing
     def _pack(self, plan: _Plan, ver):
+        # packed operands are shared by every launch geometry that needs the same layout (e.g. a Linear applied to
+        # sequences of different lengths), keyed by the pack description
         g = plan.geom
-        if plan.wpk is None:
-            plan.wpk = torch.empty(g.CoutPad * g.Kpad, dtype=self.dtype, device=self.weight.device)
-        elif plan.packed_ver == ver:
+        key = (plan.rows, plan.red, plan.ntaps, tuple(plan.lut) if plan.lut is not None else None, plan.s_row, plan.s_red, g.CoutPad, g.Cin, g.Kpad)
+        ent = self._packs.get(key)
+        if ent is None or ent[0].device != self.weight.device:
+            ent = [torch.empty(g.CoutPad * g.Kpad, dtype=self.dtype, device=self.weight.device), None]
+            self._packs[key] = ent
+        plan.wpk = ent[0]
+        if ent[1] == ver:
             return
         _ffi.check(_ffi.lib().sa_pack_weights(_ffi.ptr(self.weight), _ffi.ptr(plan.wpk), _ffi.dtype_id(self.dtype), plan.rows, plan.red,
                                               plan.ntaps, plan.lut_c, plan.s_row, plan.s_red, g.CoutPad, g.Cin, g.Kpad, _ffi.stream()),
                    "sa_pack_weights")
-        plan.packed_ver = ver
+        ent[1] = ver
 
     def invalidate(self):
         """Call after the weights changed through a raw pointer (our Adam kernel): packed operands are rebuilt lazily."""
@@ -255,7 +264,7 @@ class ConvOp:
         """dx [N, *idims, cs_in] from g [N, *odims, gout_s] (gradient wrt this layer's pre-activation output)."""
         N = g.shape[0]
         gout_s = g.shape[-1]
-        assert g.dtype == self.dtype and g.is_contiguous() and gout_s == _ru(self.cout, self.vec)
+        assert g.dtype == self.dtype and g.is_contiguous() and gout_s >= self.cout and gout_s % self.vec == 0
         plans = self._get_plans(N, tuple(idims), fwd_out_stride or self.cout, gout_s)
         if plans["dgrad"] is None:
             raise NotImplementedError("data gradient for this conv geometry")

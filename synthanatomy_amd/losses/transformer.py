@@ -1,0 +1,51 @@
+"""``CELoss`` -- mirror of reference src/losses/transformer/transformer.py:10-36: cross entropy over logits ``[B, V, N]``
+(the training inferer transposes the network output, src/inferer/transformer.py:28-29), reduction "mean" or "sum", with the
+``summaries`` side channel.  log-softmax, NLL and the gradient are one fused HIP kernel (csrc/performer.hip: ce_kernel)."""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from .. import _ffi
+
+
+class _CEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits_bvn, target, mean):
+        _ffi.require_gpu()
+        rows = logits_bvn.float().transpose(1, 2).contiguous()  # [B,N,V]; free when it is our own transposed output
+        B, N, V = rows.shape
+        R = B * N
+        tgt = target.to(rows.device).long().contiguous().view(-1)
+        acc = torch.zeros(1, dtype=torch.float32, device=rows.device)
+        d = torch.empty_like(rows) if logits_bvn.requires_grad else None
+        scale = (1.0 / R) if mean else 1.0
+        _ffi.check(_ffi.lib().sa_cross_entropy(_ffi.ptr(rows), _ffi.ptr(tgt), R, V, _ffi.ptr(acc), _ffi.ptr(d), _ffi.SA_F32, scale, _ffi.stream()), "sa_cross_entropy")
+        ctx.d = d
+        return (acc * scale).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        d = ctx.d
+        ctx.d = None
+        return (d.mul_(g).transpose(1, 2) if d is not None else None), None, None
+
+
+class CELoss(torch.nn.Module):
+    def __init__(self, weight=None, size_average: bool = None, reduce: bool = None, reduction: str = "mean"):
+        super().__init__()
+        if reduction not in ["sum", "mean"]:
+            raise ValueError("Reduction must be either 'sum' or 'mean'")
+        if weight is not None:
+            raise NotImplementedError("class weights")
+        self.reduction = reduction
+        self.summaries: Dict = {"scalar": {}}
+
+    def forward(self, y_pred: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        loss = _CEFn.apply(y_pred, y, self.reduction == "mean")
+        self.summaries["scalar"]["Loss-CE-Prediction"] = loss.detach()
+        return loss
+
+    def get_summaries(self):
+        return self.summaries

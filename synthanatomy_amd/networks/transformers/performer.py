@@ -1,0 +1,747 @@
+"""``performer`` on MI355X: the reference's ``Performer`` plugin surface over hand-written HIP kernels.
+
+Mirrors reference ``src/networks/transformers/performer.py`` (``AbsoluteSpatialPositionalEmbedding`` :23-40, ``Performer``
+:70-288): same keyword-only constructor, ``forward(x, conditionings=None, return_encodings=False)``,
+``check_redraw_projections`` / ``fix_projection_matrices_``, ``.ordering`` and ``TransformerBase.sample``.  The layer
+stack the reference delegates to ``performer_pytorch.Performer`` (1.0.11, third-party) is rebuilt here with the same
+module / parameter names (``performer.net.layers.{i}.0.fn.to_q.weight`` ...), so state_dicts are interchangeable.
+
+Underneath, autograd sees FOUR nodes -- embeddings, the whole ReZero / pre-LayerNorm layer stack, the final LayerNorm and
+the vocabulary projection -- each a hand-scheduled sequence of HIP launches: 1-tap implicit-GEMM MFMA launches for
+every Linear (``compute_dtype`` fp32 = exact-f32 MFMA as the reference's amp=False, or bf16), fp32 FAVOR+ feature maps
+and running-state scans, fp32 rotary + banded local attention.  See oracle/performer_ref.py for the restated spec.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from enum import Enum
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import _ffi
+from ..._ffi import MASK_GELU
+from ...engine import ConvOp
+from .img2seq_ordering import Ordering
+from .transformer import TransformerBase
+
+
+class TransformerConditioningType(Enum):  # src/utils/transformer.py:21-24
+    NONE = "none"
+    BOSREPLACEMENT = "bos_replacement"
+    PREPENDING = "prepending"
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+def _ck(rc, what):
+    _ffi.check(rc, what)
+
+
+# ------------------------------------------------------------------------------------------------ parameter holders
+class AbsolutePositionalEmbedding(nn.Module):  # performer_pytorch.AbsolutePositionalEmbedding
+    def __init__(self, dim, max_seq_len):
+        super().__init__()
+        self.emb = nn.Embedding(max_seq_len, dim)
+
+
+class AbsoluteSpatialPositionalEmbedding(nn.Module):  # performer.py:23-40
+    def __init__(self, dim: int, spatial_indices_sequence: torch.Tensor):
+        super().__init__()
+        self.register_buffer("spatial_indices_sequence", spatial_indices_sequence)
+        self.spatial_indices_sequence = self.spatial_indices_sequence[:-1]  # the last element is the predicted one
+        self.emb = nn.Embedding(len(self.spatial_indices_sequence), dim)
+
+
+class _SinusoidalEmbeddings(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.register_buffer("inv_freq", 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim)))
+
+
+class LocalAttention(nn.Module):
+    def __init__(self, window_size, dim_head):
+        super().__init__()
+        self.window_size = window_size
+        self.rel_pos = _SinusoidalEmbeddings(dim_head)
+
+
+class FastAttention(nn.Module):
+    def __init__(self, dim_heads, nb_features=None):
+        super().__init__()
+        self.dim_heads = dim_heads
+        self.nb_features = nb_features if nb_features is not None else int(dim_heads * math.log(dim_heads))
+        self.register_buffer("projection_matrix", torch.zeros(self.nb_features, dim_heads))
+        self.redraw_projection_matrix(None, None)  # global RNG at construction, like performer_pytorch
+
+    @torch.no_grad()
+    def redraw_projection_matrix(self, device, generator):
+        """gaussian_orthogonal_random_matrix(nb_rows, nb_cols, scaling=0): orthonormalised Gaussian blocks with rows
+        rescaled by chi-distributed norms.  On a HIP device the Gram-Schmidt runs in csrc (sa_favor_projection); every
+        rank passes the same generator seed, so the matrices agree without the reference's DDP buffer broadcast."""
+        m, d = self.nb_features, self.dim_heads
+        nblk = (m + d - 1) // d
+        pm = self.projection_matrix
+        if pm.is_cuda:
+            blocks = torch.randn(nblk, d, d, generator=generator, device=pm.device)
+            rows = torch.randn(m, d, generator=generator, device=pm.device)
+            _ck(_ffi.lib().sa_favor_projection(_ffi.ptr(blocks), _ffi.ptr(rows), _ffi.ptr(pm), nblk, m, d, _ffi.stream()), "sa_favor_projection")
+        else:  # construction time on the host (before .to(device)); plain torch, not a compute fallback of the hot path
+            blocks = torch.randn(nblk, d, d, generator=generator)
+            q = torch.linalg.qr(blocks.transpose(1, 2))[0].transpose(1, 2).reshape(nblk * d, d)[:m]
+            pm.copy_(torch.randn(m, d, generator=generator).norm(dim=1)[:, None] * q)
+        pm._sa_epoch = getattr(pm, "_sa_epoch", 0) + 1
+
+
+class SelfAttention(nn.Module):
+    def __init__(self, dim, heads, dim_head, local_heads, local_window_size, nb_features, qkv_bias, attn_out_bias):
+        super().__init__()
+        inner = dim_head * heads
+        self.heads, self.global_heads, self.dim_head = heads, heads - local_heads, dim_head
+        self.fast_attention = FastAttention(dim_head, nb_features)
+        self.local_attn = LocalAttention(local_window_size, dim_head) if local_heads > 0 else None
+        self.to_q = nn.Linear(dim, inner, bias=qkv_bias)
+        self.to_k = nn.Linear(dim, inner, bias=qkv_bias)
+        self.to_v = nn.Linear(dim, inner, bias=qkv_bias)
+        self.to_out = nn.Linear(inner, dim, bias=attn_out_bias)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.w1 = nn.Linear(dim, dim * mult)
+        self.w2 = nn.Linear(dim * mult, dim)
+
+
+class Chunk(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+
+class ReZero(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.g = nn.Parameter(torch.tensor(1e-3))
+        self.fn = fn
+
+
+class PreLayerNorm(nn.Module):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = fn
+
+
+class SequentialSequence(nn.Module):
+    def __init__(self, layers):
+        super().__init__()
+        self.layers = layers
+
+
+class ProjectionUpdater(nn.Module):
+    def __init__(self, instance, feature_redraw_interval):
+        super().__init__()
+        self.instance = [instance]  # not registered (avoids a parameter cycle)
+        self.feature_redraw_interval = feature_redraw_interval
+        self.register_buffer("calls_since_last_redraw", torch.tensor(0))
+        self._calls = 0
+        self._redraws = 0
+        self.base_seed = torch.initial_seed() % (2 ** 31)
+
+    def fix_projections_(self):
+        self.feature_redraw_interval = None
+
+    def redraw_projections(self):
+        if not self.training:
+            return
+        if self.feature_redraw_interval is not None and self._calls >= self.feature_redraw_interval:
+            self._redraws += 1
+            for li, mod in enumerate(m for m in self.instance[0].modules() if isinstance(m, FastAttention)):
+                dev = mod.projection_matrix.device
+                gen = torch.Generator(device=dev).manual_seed((self.base_seed + 7919 * self._redraws + li) % (2 ** 31))
+                mod.redraw_projection_matrix(dev, gen)
+            self._calls = 0
+            self.calls_since_last_redraw.zero_()
+            return
+        self._calls += 1
+        self.calls_since_last_redraw += 1
+
+
+class BasePerformer(nn.Module):
+    """Parameter tree of performer_pytorch.Performer (the argument order of performer.py:194-219)."""
+
+    def __init__(self, dim, depth, heads, dim_head, local_attn_heads, local_window_size, causal, ff_mult, nb_features, feature_redraw_interval,
+                 reversible, ff_chunks, generalized_attention, kernel_fn, use_scalenorm, use_rezero, ff_glu, ff_dropout, attn_dropout, cross_attend,
+                 no_projection, auto_check_redraw, qkv_bias, attn_out_bias):
+        super().__init__()
+        unsupported = dict(reversible=reversible, generalized_attention=generalized_attention, use_scalenorm=use_scalenorm, ff_glu=ff_glu,
+                           cross_attend=cross_attend, no_projection=no_projection)
+        bad = [k for k, v in unsupported.items() if v]
+        if bad or not causal or ff_dropout or attn_dropout or ff_chunks != 1:
+            raise NotImplementedError(f"performer on MI355X implements the causal ReZero / pre-LayerNorm FAVOR+ configuration; unsupported: {bad}")
+        if isinstance(local_attn_heads, int):
+            local_attn_heads = (local_attn_heads,)
+        local_attn_heads = tuple(local_attn_heads) * depth if len(local_attn_heads) == 1 else tuple(local_attn_heads)
+        assert len(local_attn_heads) == depth and all(0 <= n <= heads for n in local_attn_heads)
+        wrap = (lambda fn: ReZero(fn)) if use_rezero else (lambda fn: PreLayerNorm(dim, fn))
+        layers = nn.ModuleList([])
+        for lh in local_attn_heads:
+            layers.append(nn.ModuleList([
+                wrap(SelfAttention(dim, heads, dim_head, lh, local_window_size, nb_features, qkv_bias, attn_out_bias)),
+                wrap(Chunk(FeedForward(dim, ff_mult))),
+            ]))
+        self.net = SequentialSequence(layers)
+        self.auto_check_redraw = auto_check_redraw
+        self.use_rezero = use_rezero
+        self.proj_updater = ProjectionUpdater(self.net, feature_redraw_interval)
+
+    def fix_projection_matrices_(self):
+        self.proj_updater.fix_projections_()
+
+    def check_redraw_projections(self):
+        self.proj_updater.redraw_projections()
+
+
+# ------------------------------------------------------------------------------------------------ launch helpers
+def _lin(mod: nn.Linear, dtype) -> ConvOp:
+    return ConvOp("conv", mod.in_features, mod.out_features, 1, 1, 0, mod.weight, mod.bias, dtype)
+
+
+def _as5(t):  # [R, C] -> [1,1,1,R,C]
+    return t.view(1, 1, 1, *t.shape)
+
+
+def _cast(t, dtype):
+    if t.dtype == dtype:
+        return t
+    from ...engine import cast_pad
+    return cast_pad(t, dtype, t.shape[-1])
+
+
+class _GradCtx:
+    def __init__(self, sink=None):
+        self.sink, self.grads = sink, {}
+
+    def buf(self, p):
+        if p is None:
+            return None
+        if self.sink is not None:
+            b = self.sink.buffer(p)
+            if b is not None:
+                return b
+        t = self.grads.get(p)
+        if t is None:
+            t = torch.zeros_like(p)
+            self.grads[p] = t
+        return t
+
+    def done(self, *params):
+        if self.sink is not None:
+            for p in params:
+                if p is not None:
+                    self.sink.ready(p)
+
+
+class _LayerEngine:
+    """Hand-scheduled forward / backward of ONE (attention, feed-forward) block."""
+
+    def __init__(self, attn_wrap, ff_wrap, dim, dtype, use_rezero):
+        self.aw, self.fw, self.dim, self.dtype, self.rezero = attn_wrap, ff_wrap, dim, dtype, use_rezero
+        sa: SelfAttention = attn_wrap.fn
+        ff: FeedForward = ff_wrap.fn.fn
+        self.sa, self.ff = sa, ff
+        self.H, self.G, self.dh = sa.heads, sa.global_heads, sa.dim_head
+        self.L = self.H - self.G
+        self.m = sa.fast_attention.nb_features
+        self.LDF = _ru(self.m, 16)
+        if self.G > 0 and (self.LDF > 272 or self.dh != 64):
+            raise NotImplementedError("FAVOR+ kernels are built for dim_head 64 (nb_features <= 272)")
+        self.W = sa.local_attn.window_size if sa.local_attn is not None else 0
+        self.ops = {n: _lin(getattr(sa, n), dtype) for n in ("to_q", "to_k", "to_v", "to_out")}
+        self.ops["w1"], self.ops["w2"] = _lin(ff.w1, dtype), _lin(ff.w2, dtype)
+        self._pscaled = None
+        self._pop = None
+        self._rot = None
+        self._one = None
+
+    def invalidate(self):
+        for op in self.ops.values():
+            op.invalidate()
+
+    def _sync(self):
+        sa, ff = self.sa, self.ff
+        for n in ("to_q", "to_k", "to_v", "to_out"):
+            self.ops[n].weight, self.ops[n].bias = getattr(sa, n).weight, getattr(sa, n).bias
+        self.ops["w1"].weight, self.ops["w1"].bias = ff.w1.weight, ff.w1.bias
+        self.ops["w2"].weight, self.ops["w2"].bias = ff.w2.weight, ff.w2.bias
+
+    def _proj_op(self):
+        pm = self.sa.fast_attention.projection_matrix
+        ver = (pm.data_ptr(), pm._version, getattr(pm, "_sa_epoch", 0))
+        if self._pop is None or self._pop[0] != ver:
+            c = self.dh ** -0.25
+            ps = (pm.detach() * c).contiguous()  # data_normalizer folded into the operand
+            op = ConvOp("conv", self.dh, self.m, 1, 1, 0, ps, None, torch.float32)
+            self._pop = (ver, op, ps)
+        return self._pop[1]
+
+    def _rot_tables(self, N, dev):
+        if self._rot is None or self._rot[0] != (N, dev):
+            inv = self.sa.local_attn.rel_pos.inv_freq.to(dev)
+            fr = torch.einsum("i,j->ij", torch.arange(N, device=dev, dtype=torch.float32), inv)
+            fr = torch.cat((fr, fr), dim=-1)
+            self._rot = ((N, dev), fr.cos().contiguous(), fr.sin().contiguous())
+        return self._rot[1], self._rot[2]
+
+    def _gate(self, wrap, dev):
+        if self.rezero:
+            return wrap.g
+        if self._one is None or self._one.device != dev:
+            self._one = torch.ones((), device=dev)
+        return self._one
+
+    def _pre(self, wrap, x, R):
+        """input of the wrapped fn: x itself (ReZero) or LayerNorm(x) (PreLayerNorm); returns (xin fp32, stats)"""
+        if self.rezero:
+            return x, None
+        lib, st = _ffi.lib(), _ffi.stream()
+        y = torch.empty_like(x)
+        stats = torch.empty(2 * R, dtype=torch.float32, device=x.device)
+        _ck(lib.sa_layernorm_fwd(_ffi.ptr(x), _ffi.ptr(wrap.norm.weight), _ffi.ptr(wrap.norm.bias), _ffi.ptr(y), None, 0, _ffi.ptr(stats), R, self.dim,
+                                 wrap.norm.eps, st), "sa_layernorm_fwd")
+        return y, stats
+
+    # ---------------------------------------------------------------------------------------------- forward
+    def fwd(self, x, B, N, tape):
+        self._sync()
+        lib, st, dev, T = _ffi.lib(), _ffi.stream(), x.device, self.dtype
+        R, H, G, L, dh, m, LDF = B * N, self.H, self.G, self.L, self.dh, self.m, self.LDF
+        inner = H * dh
+        f32 = torch.float32
+        xa, st_a = self._pre(self.aw, x, R)
+        xaT = _cast(xa, T)
+        q = self.ops["to_q"].fprop(_as5(xaT), out_dtype=f32).view(R, inner)
+        k = self.ops["to_k"].fprop(_as5(xaT), out_dtype=f32).view(R, inner)
+        v = self.ops["to_v"].fprop(_as5(xaT), out_dtype=f32).view(R, inner)
+        attn = torch.empty(R, inner, dtype=f32, device=dev)
+        sv = dict(x=x, xa=xa, xaT=xaT, st_a=st_a, q=q, k=k, v=v, attn=attn)
+        if G > 0:
+            pop = self._proj_op()
+            qg = q[:, : G * dh].contiguous()
+            kg = k[:, : G * dh].contiguous()
+            ddq = pop.fprop(qg.view(1, 1, 1, R * G, dh), out_channels_stride=LDF, use_bias=False).view(R * G, LDF)
+            ddk = pop.fprop(kg.view(1, 1, 1, R * G, dh), out_channels_stride=LDF, use_bias=False).view(R * G, LDF)
+            qf, kf = torch.empty_like(ddq), torch.empty_like(ddk)
+            gws = torch.zeros(2, dtype=torch.int64, device=dev)
+            _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddq), _ffi.ptr(qg), G * dh, 0, G, dh, 1, _ffi.ptr(qf), None, R * G, m, LDF, st), "favor_features(q)")
+            _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddk), _ffi.ptr(kg), G * dh, 0, G, dh, 0, _ffi.ptr(kf), _ffi.ptr(gws), R * G, m, LDF, st), "favor_features(k)")
+            Z = torch.empty_like(kf)
+            _ck(lib.sa_cumsum_rows(_ffi.ptr(kf), None, _ffi.ptr(Z), B, N, G, LDF, 0, st), "sa_cumsum_rows")
+            inv = torch.empty(R * G, dtype=f32, device=dev)
+            _ck(lib.sa_favor_den(_ffi.ptr(qf), _ffi.ptr(Z), 1e-6, _ffi.ptr(inv), R * G, m, LDF, st), "sa_favor_den")
+            _ck(lib.sa_favor_scan_a(_ffi.ptr(kf), _ffi.ptr(qf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(attn), inner, 0, _ffi.ptr(inv), B, N, G, LDF, dh, 0, 0, st),
+                "sa_favor_scan_a")
+            sv.update(qg=qg, kg=kg, ddq=ddq, ddk=ddk, qf=qf, kf=kf, gws=gws, Z=Z, inv=inv)
+        if L > 0:
+            cosb, sinb = self._rot_tables(N, dev)
+            qr = torch.empty(R, L * dh, dtype=f32, device=dev)
+            kr = torch.empty(R, L * dh, dtype=f32, device=dev)
+            _ck(lib.sa_rotary(_ffi.ptr(q), inner, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(qr), L * dh, 0, N, R, 0, 0, st), "sa_rotary(q)")
+            _ck(lib.sa_rotary(_ffi.ptr(k), inner, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(kr), L * dh, 0, N, R, 0, 0, st), "sa_rotary(k)")
+            lse = torch.empty(R * L, dtype=f32, device=dev)
+            _ck(lib.sa_local_attn_fwd(_ffi.ptr(qr), L * dh, 0, _ffi.ptr(kr), L * dh, 0, _ffi.ptr(v), inner, G * dh, _ffi.ptr(attn), inner, G * dh, _ffi.ptr(lse),
+                                      B, N, L, self.W, dh, st), "sa_local_attn_fwd")
+            sv.update(qr=qr, kr=kr, lse=lse)
+        attnT = _cast(attn, T)
+        Fa = self.ops["to_out"].fprop(_as5(attnT)).view(R, self.dim)
+        x1 = torch.empty_like(x)
+        ga = self._gate(self.aw, dev)
+        _ck(lib.sa_rezero_fwd(_ffi.ptr(x), _ffi.ptr(Fa), _ffi.dtype_id(Fa.dtype), _ffi.ptr(ga), _ffi.ptr(x1), None, 0, x.numel(), st), "sa_rezero_fwd")
+        xf, st_f = self._pre(self.fw, x1, R)
+        xfT = _cast(xf, T)
+        u = self.ops["w1"].fprop(_as5(xfT)).view(R, -1)
+        h = torch.empty_like(u)
+        _ck(lib.sa_gelu(_ffi.ptr(u), _ffi.dtype_id(u.dtype), _ffi.ptr(h), _ffi.dtype_id(h.dtype), u.numel(), st), "sa_gelu")
+        Ff = self.ops["w2"].fprop(_as5(h)).view(R, self.dim)
+        x2 = torch.empty_like(x)
+        gf = self._gate(self.fw, dev)
+        _ck(lib.sa_rezero_fwd(_ffi.ptr(x1), _ffi.ptr(Ff), _ffi.dtype_id(Ff.dtype), _ffi.ptr(gf), _ffi.ptr(x2), None, 0, x.numel(), st), "sa_rezero_fwd")
+        if tape is not None:
+            sv.update(attnT=attnT, Fa=Fa, x1=x1, xf=xf, xfT=xfT, st_f=st_f, u=u, h=h, Ff=Ff)
+            tape.append(sv)
+        return x2
+
+    # ---------------------------------------------------------------------------------------------- backward
+    def _post_bwd(self, wrap, dy, Fout, gc, dev):
+        """through y = x + g * F: returns dF (compute dtype) and accumulates dg"""
+        lib, st = _ffi.lib(), _ffi.stream()
+        dF = torch.empty(dy.shape, dtype=self.dtype, device=dev)
+        g = self._gate(wrap, dev)
+        dg = gc.buf(wrap.g) if self.rezero else torch.zeros((), device=dev)
+        _ck(lib.sa_rezero_bwd(_ffi.ptr(dy), _ffi.ptr(Fout), _ffi.dtype_id(Fout.dtype), _ffi.ptr(g), _ffi.ptr(dF), _ffi.dtype_id(dF.dtype), _ffi.ptr(dg),
+                              dy.numel(), st), "sa_rezero_bwd")
+        if self.rezero:
+            gc.done(wrap.g)
+        return dF
+
+    def _pre_bwd(self, wrap, dxin, dres, xres, stats, R, gc):
+        """gradient wrt the block input: residual path dres + path through the (identity | LayerNorm) pre-op"""
+        if self.rezero:
+            return dxin  # the dgrad epilogues already added dres
+        lib, st = _ffi.lib(), _ffi.stream()
+        dx = torch.empty_like(dres)
+        _ck(lib.sa_layernorm_bwd(_ffi.ptr(dxin), _ffi.ptr(xres), _ffi.ptr(wrap.norm.weight), _ffi.ptr(stats), _ffi.ptr(dx), _ffi.ptr(gc.buf(wrap.norm.weight)),
+                                 _ffi.ptr(gc.buf(wrap.norm.bias)), R, self.dim, st), "sa_layernorm_bwd")
+        gc.done(wrap.norm.weight, wrap.norm.bias)
+        _ck(lib.sa_axpy(_ffi.ptr(dx), _ffi.ptr(dres), 1.0, dx.numel(), st), "sa_axpy")
+        return dx
+
+    def bwd(self, dx2, sv, B, N, gc: _GradCtx):
+        self._sync()
+        lib, st, dev, T = _ffi.lib(), _ffi.stream(), dx2.device, self.dtype
+        R, H, G, L, dh, m, LDF = B * N, self.H, self.G, self.L, self.dh, self.m, self.LDF
+        inner = H * dh
+        f32 = torch.float32
+        ops, sa, ff = self.ops, self.sa, self.ff
+        r5 = (1, 1, R)
+        # ---- feed-forward block
+        dFf = self._post_bwd(self.fw, dx2, sv["Ff"], gc, dev)
+        ops["w2"].wgrad(_as5(sv["h"]), _as5(dFf), gc.buf(ff.w2.weight), gc.buf(ff.w2.bias))
+        gc.done(ff.w2.weight, ff.w2.bias)
+        du = ops["w2"].dgrad(_as5(dFf), r5, mask=_as5(sv["u"]), mask_mode=MASK_GELU)
+        ops["w1"].wgrad(_as5(sv["xfT"]), du, gc.buf(ff.w1.weight), gc.buf(ff.w1.bias))
+        gc.done(ff.w1.weight, ff.w1.bias)
+        if self.rezero:
+            dx1 = ops["w1"].dgrad(du, r5, addend=_as5(dx2), out_dtype=f32).view(R, self.dim)
+        else:
+            dxf = ops["w1"].dgrad(du, r5, out_dtype=f32).view(R, self.dim)
+            dx1 = self._pre_bwd(self.fw, dxf, dx2, sv["x1"], sv["st_f"], R, gc)
+        # ---- attention block
+        dFa = self._post_bwd(self.aw, dx1, sv["Fa"], gc, dev)
+        ops["to_out"].wgrad(_as5(sv["attnT"]), _as5(dFa), gc.buf(sa.to_out.weight), gc.buf(sa.to_out.bias))
+        gc.done(sa.to_out.weight, sa.to_out.bias)
+        dattn = ops["to_out"].dgrad(_as5(dFa), r5, out_dtype=f32).view(R, inner)
+        q, k, v, attn = sv["q"], sv["k"], sv["v"], sv["attn"]
+        dq = torch.empty(R, inner, dtype=f32, device=dev)
+        dk = torch.empty(R, inner, dtype=f32, device=dev)
+        dv = torch.empty(R, inner, dtype=f32, device=dev)
+        if G > 0:
+            qf, kf, Z, inv = sv["qf"], sv["kf"], sv["Z"], sv["inv"]
+            dden = torch.empty(R * G, dtype=f32, device=dev)
+            _ck(lib.sa_favor_dden(_ffi.ptr(dattn), _ffi.ptr(attn), inner, 0, G, dh, _ffi.ptr(inv), _ffi.ptr(dden), R * G, st), "sa_favor_dden")
+            dqf = torch.empty_like(qf)
+            _ck(lib.sa_favor_scan_b(_ffi.ptr(kf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dqf), _ffi.ptr(dden), _ffi.ptr(Z),
+                                    1e-6, B, N, G, LDF, dh, 0, st), "sa_favor_scan_b(dq')")
+            rr = torch.empty_like(qf)
+            _ck(lib.sa_cumsum_rows(_ffi.ptr(qf), _ffi.ptr(dden), _ffi.ptr(rr), B, N, G, LDF, 1, st), "sa_cumsum_rows(rev)")
+            dkf = torch.empty_like(kf)
+            _ck(lib.sa_favor_scan_b(_ffi.ptr(qf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dkf), None, _ffi.ptr(rr), 0.0,
+                                    B, N, G, LDF, dh, 1, st), "sa_favor_scan_b(dk')")
+            _ck(lib.sa_favor_scan_a(_ffi.ptr(qf), _ffi.ptr(kf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dv), inner, 0, None, B, N, G, LDF, dh, 1, 0, st),
+                "sa_favor_scan_a(dv)")
+            pop = self._proj_op()
+            dqg = torch.zeros(R, G * dh, dtype=f32, device=dev)
+            dkg = torch.zeros(R, G * dh, dtype=f32, device=dev)
+            dddq, dddk = torch.empty_like(qf), torch.empty_like(kf)
+            tsum = torch.zeros(1, dtype=f32, device=dev)
+            _ck(lib.sa_favor_features_bwd(_ffi.ptr(dqf), _ffi.ptr(qf), _ffi.ptr(sv["ddq"]), _ffi.ptr(sv["qg"]), G * dh, 0, G, dh, 1, _ffi.ptr(dddq), _ffi.ptr(dqg),
+                                          None, None, R * G, m, LDF, st), "favor_features_bwd(q)")
+            _ck(lib.sa_favor_features_bwd(_ffi.ptr(dkf), _ffi.ptr(kf), _ffi.ptr(sv["ddk"]), _ffi.ptr(sv["kg"]), G * dh, 0, G, dh, 0, _ffi.ptr(dddk), _ffi.ptr(dkg),
+                                          _ffi.ptr(sv["gws"]), _ffi.ptr(tsum), R * G, m, LDF, st), "favor_features_bwd(k)")
+            rg = (1, 1, R * G)
+            dqg = pop.dgrad(dddq.view(1, 1, 1, R * G, LDF), rg, addend=dqg.view(1, 1, 1, R * G, dh), fwd_out_stride=LDF).view(R, G * dh)
+            dkg = pop.dgrad(dddk.view(1, 1, 1, R * G, LDF), rg, addend=dkg.view(1, 1, 1, R * G, dh), fwd_out_stride=LDF).view(R, G * dh)
+            dq[:, : G * dh] = dqg
+            dk[:, : G * dh] = dkg
+        if L > 0:
+            cosb, sinb = self._rot_tables(N, dev)
+            dqr = torch.empty(R, L * dh, dtype=f32, device=dev)
+            dkr = torch.empty(R, L * dh, dtype=f32, device=dev)
+            Db = torch.empty(R * L, dtype=f32, device=dev)
+            _ck(lib.sa_local_attn_bwd(_ffi.ptr(sv["qr"]), L * dh, 0, _ffi.ptr(sv["kr"]), L * dh, 0, _ffi.ptr(v), inner, G * dh, _ffi.ptr(attn), _ffi.ptr(dattn),
+                                      inner, G * dh, _ffi.ptr(sv["lse"]), _ffi.ptr(dqr), _ffi.ptr(dkr), _ffi.ptr(dv), _ffi.ptr(Db), B, N, L, self.W, dh, st),
+                "sa_local_attn_bwd")
+            _ck(lib.sa_rotary(_ffi.ptr(dqr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dq), inner, G * dh, N, R, 1, 0, st), "sa_rotary^T(q)")
+            _ck(lib.sa_rotary(_ffi.ptr(dkr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dk), inner, G * dh, N, R, 1, 0, st), "sa_rotary^T(k)")
+        xaT = _as5(sv["xaT"])
+        dqT, dkT, dvT = (_as5(_cast(t, T)) for t in (dq, dk, dv))
+        for nm, g_ in (("to_q", dqT), ("to_k", dkT), ("to_v", dvT)):
+            mod = getattr(sa, nm)
+            ops[nm].wgrad(xaT, g_, gc.buf(mod.weight), gc.buf(mod.bias))
+            gc.done(mod.weight, mod.bias)
+        base = _as5(dx1) if self.rezero else None
+        dxa = ops["to_q"].dgrad(dqT, r5, addend=base, out_dtype=f32)
+        dxa = ops["to_k"].dgrad(dkT, r5, addend=dxa, out_dtype=f32)
+        dxa = ops["to_v"].dgrad(dvT, r5, addend=dxa, out_dtype=f32).view(R, self.dim)
+        return self._pre_bwd(self.aw, dxa, dx1, sv["x"], sv["st_a"], R, gc)
+
+
+class _StackChain:
+    def __init__(self, base: BasePerformer, dim, dtype):
+        self.base, self.dtype = base, dtype
+        self.layers = [_LayerEngine(l[0], l[1], dim, dtype, base.use_rezero) for l in base.net.layers]
+        self.grad_sink = None
+
+    def params(self):
+        return [p for p in self.base.parameters()]
+
+    def invalidate(self):
+        for l in self.layers:
+            l.invalidate()
+
+    def forward(self, x, record):
+        B, N, D = x.shape
+        x = x.reshape(B * N, D).float().contiguous()
+        tape = [] if record else None
+        for l in self.layers:
+            x = l.fwd(x, B, N, tape)
+        return x.view(B, N, D), tape
+
+    def backward(self, dy, tape):
+        B, N, D = dy.shape
+        gc = _GradCtx(self.grad_sink)
+        g = dy.reshape(B * N, D).float().contiguous()
+        for l, sv in zip(reversed(self.layers), reversed(tape)):
+            g = l.bwd(g, sv, B, N, gc)
+        return g.view(B, N, D), gc.grads
+
+
+class _StackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, chain: _StackChain, record, x, *params):
+        _ffi.require_gpu()
+        y, tape = chain.forward(x, record)
+        ctx.chain, ctx.tape = chain, tape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        dx, grads = ctx.chain.backward(gy, ctx.tape)
+        ctx.tape = None
+        return (None, None, dx, *[grads.get(p) for p in ctx.chain.params()])
+
+
+class _EmbedFn(torch.autograd.Function):
+    """x[b,n,:] = sum of embedding rows (token, spatial x3 with a zero at position 0, absolute position) -- performer.py:241-266"""
+
+    @staticmethod
+    def forward(ctx, tables: Sequence[torch.Tensor], idx: Sequence[torch.Tensor], per_pos: Sequence[int], B, N, *params):
+        _ffi.require_gpu()
+        dim = tables[0].shape[1]
+        out = torch.empty(B, N, dim, dtype=torch.float32, device=tables[0].device)
+        n = len(tables)
+        tp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tables])
+        ip = (ctypes.c_void_p * n)(*[i.data_ptr() for i in idx])
+        pp = (ctypes.c_int32 * n)(*per_pos)
+        _ck(_ffi.lib().sa_embed_sum(n, tp, ip, pp, dim, N, B * N, _ffi.ptr(out), _ffi.stream()), "sa_embed_sum")
+        ctx.idx, ctx.per_pos, ctx.shapes, ctx.BN = list(idx), list(per_pos), [t.shape for t in tables], (B, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N = ctx.BN
+        dy = dy.contiguous()
+        grads = []
+        for ix, pp, shp in zip(ctx.idx, ctx.per_pos, ctx.shapes):
+            g = torch.zeros(shp, dtype=torch.float32, device=dy.device)
+            _ck(_ffi.lib().sa_embed_scatter(_ffi.ptr(dy), _ffi.ptr(g), _ffi.ptr(ix), pp, shp[1], N, B * N, _ffi.stream()), "sa_embed_scatter")
+            grads.append(g)
+        return (None, None, None, None, None, *grads)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        _ffi.require_gpu()
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).float().contiguous()
+        R, C = x2.shape
+        y = torch.empty_like(x2)
+        stats = torch.empty(2 * R, dtype=torch.float32, device=x.device)
+        _ck(_ffi.lib().sa_layernorm_fwd(_ffi.ptr(x2), _ffi.ptr(w), _ffi.ptr(b), _ffi.ptr(y), None, 0, _ffi.ptr(stats), R, C, eps, _ffi.stream()), "sa_layernorm_fwd")
+        ctx.save_for_backward(x2, w, stats)
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, stats = ctx.saved_tensors
+        R, C = x2.shape
+        d = dy.reshape(R, C).float().contiguous()
+        dx, dw, db = torch.empty_like(x2), torch.zeros_like(w), torch.zeros_like(w)
+        _ck(_ffi.lib().sa_layernorm_bwd(_ffi.ptr(d), _ffi.ptr(x2), _ffi.ptr(w), _ffi.ptr(stats), _ffi.ptr(dx), _ffi.ptr(dw), _ffi.ptr(db), R, C, _ffi.stream()),
+            "sa_layernorm_bwd")
+        return dx.view(dy.shape), dw, db, None
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b through the 1-tap implicit-GEMM kernels (fp32 in / fp32 out; GEMM in the op's compute dtype)."""
+
+    @staticmethod
+    def forward(ctx, op: ConvOp, x, w, b):
+        _ffi.require_gpu()
+        op.weight, op.bias = w, b
+        shp = x.shape
+        x2 = _cast(x.reshape(-1, shp[-1]).float().contiguous(), op.dtype)
+        y = op.fprop(_as5(x2), out_dtype=torch.float32).view(*shp[:-1], w.shape[0])
+        ctx.op, ctx.x2, ctx.has_b = op, x2, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        op, x2 = ctx.op, ctx.x2
+        R = x2.shape[0]
+        from ...engine import cast_pad, vec_of
+        d2 = dy.reshape(R, -1).float().contiguous()
+        g = _as5(cast_pad(d2, op.dtype, _ru(d2.shape[1], vec_of(op.dtype))))  # channel stride padded to a 16-byte multiple
+        dw = torch.zeros_like(op.weight)
+        db = torch.zeros_like(op.bias) if ctx.has_b else None
+        op.wgrad(_as5(x2), g, dw, db)
+        dx = op.dgrad(g, (1, 1, R), out_dtype=torch.float32).view(*dy.shape[:-1], x2.shape[1])
+        return None, dx, dw, db
+
+
+# ------------------------------------------------------------------------------------------------ the plugin class
+class Performer(TransformerBase):
+    """NOTE: all tensor logic assumes the ordering [Batch, Length, Channel] (as the reference)."""
+
+    def __init__(
+        self,
+        *,
+        num_tokens: int,
+        max_seq_len: int,
+        dim: int,
+        depth: int,
+        heads: int,
+        ordering: Ordering,
+        dim_head: int = 64,
+        local_attn_heads: int = 0,
+        local_window_size: int = 256,
+        causal: bool = True,
+        ff_mult: int = 4,
+        nb_features: Optional[int] = None,
+        feature_redraw_interval: int = 1000,
+        reversible: bool = False,
+        ff_chunks: int = 1,
+        ff_glu: bool = False,
+        emb_dropout: float = 0.0,
+        ff_dropout: float = 0.0,
+        attn_dropout: float = 0.0,
+        generalized_attention: bool = False,
+        kernel_fn: torch.nn.Module = nn.ReLU(),
+        use_scalenorm: bool = False,
+        use_rezero: bool = False,
+        cross_attend: bool = False,
+        no_projection: bool = False,
+        tie_embed: bool = False,
+        rotary_position_emb: bool = False,
+        fixed_position_emb: bool = False,
+        axial_position_emb: bool = False,
+        axial_position_shape: Tuple[int, int] = None,
+        auto_check_redraw: bool = True,
+        qkv_bias: bool = False,
+        attn_out_bias: bool = False,
+        spatial_position_emb: str = None,
+        spatial_shape: Union[Tuple[int, int], Tuple[int, int, int]] = None,
+        conditioning_num_tokens: Optional[Tuple[int, ...]] = None,
+        conditioning_type: str = TransformerConditioningType.NONE.value,
+        compute_dtype: torch.dtype = torch.float32,
+    ):
+        super().__init__()
+        assert 0 <= sum([rotary_position_emb, fixed_position_emb, axial_position_emb]) <= 1, (
+            f"rotary_position_emb, fixed_position_emb and axial_position_emb are exclusive, but received "
+            f"{rotary_position_emb} {fixed_position_emb} and {axial_position_emb}."
+        )
+        if rotary_position_emb or fixed_position_emb or axial_position_emb or tie_embed or emb_dropout:
+            raise NotImplementedError("performer on MI355X implements the absolute positional embedding path (README configuration)")
+        if conditioning_num_tokens and conditioning_type == TransformerConditioningType.PREPENDING.value:
+            raise NotImplementedError("conditioning_type='prepending'")
+        self.max_seq_len = max_seq_len
+        self.token_emb = nn.Embedding(num_tokens, dim)
+        self.pos_emb = AbsolutePositionalEmbedding(dim, self.max_seq_len)
+        self.ordering = ordering
+        self.spatial_position_emb = nn.ModuleList()
+        if spatial_position_emb:
+            assert spatial_position_emb in ["fixed", "absolute"], (
+                f"spatial_position_emb must be either 'fixed' or  'absolute', but got {spatial_position_emb}")
+            if spatial_position_emb == "fixed":
+                raise NotImplementedError("spatial_position_emb='fixed'")
+            coords = np.array(np.meshgrid(*tuple(np.arange(0, s) for s in spatial_shape), indexing="ij"))
+            for axis in range(len(spatial_shape)):
+                seq = self.ordering(torch.from_numpy(coords[axis, ...].flatten()))
+                self.spatial_position_emb.append(AbsoluteSpatialPositionalEmbedding(dim=dim, spatial_indices_sequence=seq))
+        self.conditioning_emb = nn.ModuleList()
+        self.conditioning_type = conditioning_type
+        if conditioning_num_tokens:
+            for cnt in conditioning_num_tokens:
+                self.conditioning_emb.append(nn.Embedding(cnt, dim))
+        self.dropout = nn.Dropout(emb_dropout)
+        self.performer = BasePerformer(dim, depth, heads, dim_head, local_attn_heads, local_window_size, causal, ff_mult, nb_features,
+                                       feature_redraw_interval, reversible, ff_chunks, generalized_attention, kernel_fn, use_scalenorm, use_rezero,
+                                       ff_glu, ff_dropout, attn_dropout, cross_attend, no_projection, auto_check_redraw, qkv_bias, attn_out_bias)
+        self.norm = nn.LayerNorm(dim)
+        self.to_out = nn.Linear(dim, num_tokens)
+        self.dim, self.compute_dtype = dim, compute_dtype
+        self._chain = _StackChain(self.performer, dim, compute_dtype)
+        self._out_op = _lin(self.to_out, compute_dtype)
+        self._idx_cache = {}
+
+    def check_redraw_projections(self):
+        self.performer.check_redraw_projections()
+
+    def fix_projection_matrices_(self):
+        self.performer.fix_projection_matrices_()
+
+    def set_grad_sink(self, sink):
+        self._chain.grad_sink = sink
+
+    def invalidate_packed_weights(self):
+        self._chain.invalidate()
+        self._out_op.invalidate()
+
+    # ------------------------------------------------------------------------------------------------
+    def _position_indices(self, n, dev):
+        key = (n, str(dev))
+        if key not in self._idx_cache:
+            pos = torch.arange(n, device=dev, dtype=torch.int64)
+            sp = []
+            for mod in self.spatial_position_emb:
+                seq = mod.spatial_indices_sequence.to(dev).long()
+                ix = torch.full((n,), -1, device=dev, dtype=torch.int64)  # position 0 is zero-padded (performer.py:31,38)
+                cnt = min(n - 1, seq.numel())
+                if cnt > 0:
+                    ix[1:1 + cnt] = seq[:cnt]
+                sp.append(ix)
+            self._idx_cache[key] = (pos, sp)
+        return self._idx_cache[key]
+
+    def forward(self, x: torch.Tensor, conditionings: Sequence[torch.Tensor] = None, return_encodings: bool = False, **kwargs):
+        b, n = x.shape
+        assert n <= self.max_seq_len, f"sequence length {n} must be less than the max sequence length {self.max_seq_len}"
+        dev = self.token_emb.weight.device
+        tok = x.to(dev).long().contiguous().view(-1)
+        pos, sp = self._position_indices(n, dev)
+        tables = [self.token_emb.weight] + [m.emb.weight for m in self.spatial_position_emb] + [self.pos_emb.emb.weight]
+        idx = [tok] + sp + [pos]
+        per_pos = [0] + [1] * len(sp) + [1]
+        h = _EmbedFn.apply(tables, idx, per_pos, b, n, *tables)
+        if conditionings and self.conditioning_type == TransformerConditioningType.BOSREPLACEMENT.value:
+            # performer.py:252-261: the BOS embedding (incl. its spatial terms) is REPLACED by the summed conditioning embeddings,
+            # the absolute positional embedding is added afterwards
+            c = sum(emb(conditionings[i].to(dev))[:, 0, :] for i, emb in enumerate(self.conditioning_emb))
+            first = c + self.pos_emb.emb.weight[0]
+            h = torch.cat((first[:, None, :], h[:, 1:, :]), dim=1)
+        if self.performer.auto_check_redraw:
+            self.performer.proj_updater.redraw_projections()
+        params = self._chain.params()
+        record = torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in params))
+        h = _StackFn.apply(self._chain, record, h, *params)
+        h = _LayerNormFn.apply(h, self.norm.weight, self.norm.bias, self.norm.eps)
+        if return_encodings:
+            return h
+        return _LinearFn.apply(self._out_op, h, self.to_out.weight, self.to_out.bias)

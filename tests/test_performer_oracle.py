@@ -1,0 +1,78 @@
+"""CPU: the Performer oracle (spec by restatement, parity UNPINNED -- see oracle/performer_ref.py) checked against
+closed-form identities that need no third-party package, plus the pinned integer pieces (batch prep, sample post-processing)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ordering_ref, performer_ref as P
+
+
+def test_causal_linear_attention_scan_equals_quadratic():
+    torch.manual_seed(0)
+    qp, kp = torch.rand(2, 3, 37, 10) + 0.01, torch.rand(2, 3, 37, 10) + 0.01
+    v = torch.randn(2, 3, 37, 6)
+    a, b = P.causal_linear_attention(qp, kp, v), P.causal_linear_attention_scan(qp, kp, v)
+    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    # rows only depend on the past: perturbing the future leaves the prefix untouched
+    kp2, v2 = kp.clone(), v.clone()
+    kp2[..., 20:, :] += 1.0
+    v2[..., 20:, :] -= 3.0
+    torch.testing.assert_close(P.causal_linear_attention(qp, kp2, v2)[..., :20, :], a[..., :20, :])
+
+
+@pytest.mark.parametrize("n,window", [(23, 5), (40, 8), (17, 32), (64, 16)])
+def test_local_attention_band_equals_bucketed(n, window):
+    torch.manual_seed(n)
+    q, k, v = (torch.randn(2, 3, n, 8) for _ in range(3))
+    for rot in (False, True):
+        torch.testing.assert_close(P.local_attention(q, k, v, window, rot), P.local_attention_bucketed(q, k, v, window, rot), rtol=1e-5, atol=1e-6)
+
+
+def test_favor_approximates_softmax_attention():
+    """With many random features FAVOR+ converges to causal softmax attention (sanity of the feature map statement)."""
+    torch.manual_seed(1)
+    d, m, n = 16, 4096, 24
+    g = torch.Generator().manual_seed(2)
+    proj = P.gaussian_orthogonal_random_matrix(m, d, g)
+    q, k, v = torch.randn(1, 1, n, d) * 0.5, torch.randn(1, 1, n, d) * 0.5, torch.randn(1, 1, n, d)
+    approx = P.causal_linear_attention(P.softmax_kernel(q, proj, True, eps=0.0), P.softmax_kernel(k, proj, False, eps=0.0), v, eps=0.0)
+    dots = (q @ k.transpose(-1, -2)) * d ** -0.5
+    dots = dots.masked_fill(~torch.tril(torch.ones(n, n, dtype=torch.bool)), float("-inf"))
+    exact = dots.softmax(-1) @ v
+    assert (approx - exact).abs().max() < 0.15
+
+
+def test_projection_matrix_blocks_are_orthogonal():
+    g = torch.Generator().manual_seed(3)
+    pm = P.gaussian_orthogonal_random_matrix(266, 64, g)
+    assert pm.shape == (266, 64)
+    blk = pm[:64] / pm[:64].norm(dim=1, keepdim=True)
+    torch.testing.assert_close(blk @ blk.t(), torch.eye(64), rtol=1e-4, atol=1e-4)
+
+
+def test_forward_shapes_and_causality_tiny():
+    cfg = P.PerformerConfig(num_tokens=33, max_seq_len=24, dim=32, depth=2, heads=4, dim_head=8, local_attn_heads=2, local_window_size=6, spatial_shape=(2, 3, 4))
+    st = P.init_state(cfg, seed=0)
+    order, _ = ordering_ref.ordering("raster_scan", 3, (1, 2, 3, 4), (False,) * 3, (), ())
+    seqs = P.spatial_index_sequences(cfg.spatial_shape, order)
+    torch.manual_seed(0)
+    tok = torch.randint(0, 32, (2, 24))
+    logits = P.forward(st, cfg, tok, seqs)
+    assert logits.shape == (2, 24, 33)
+    # NOTE: the key stabiliser is a GLOBAL max, so causality holds up to the (cancelling) stabiliser and the +eps term:
+    tok2 = tok.clone()
+    tok2[:, 15:] = (tok2[:, 15:] + 7) % 32
+    l2 = P.forward(st, cfg, tok2, seqs)
+    assert (l2[:, :15] - logits[:, :15]).abs().max() < 1e-3
+    loss = P.ce_loss(logits, tok)
+    assert torch.isfinite(loss)
+
+
+def test_prepare_batch_and_sample_postprocessing_pinned():
+    g = load_golden("sample")
+    order = g["ordering"]
+    q = np.arange(2 * 24).reshape(2, 3, 4, 2) % 11
+    x_in, x_tgt = ordering_ref.prepare_batch(q, order, 11)
+    assert x_in.shape == (2, 24) and (x_in[:, 0] == 11).all()
+    assert np.array_equal(x_in[:, 1:], q.reshape(2, -1)[:, order][:, :-1]) and np.array_equal(x_tgt, q.reshape(2, -1)[:, order])
