@@ -53,6 +53,78 @@ def cpu_baseline(seconds_budget=30.0):
                       f"{crop[0]}x{crop[1]}x{crop[2]} crop = {frac:.5f} of a volume, {dt:.2f} s; scaled by voxel count"}
 
 
+PERF = dict(vocab=2048, spatial=(10, 14, 10), dim=512, depth=24, heads=16, local_heads=8, window=420)
+PERFORMER_STEP_MFLOP_PER_TOKEN = 618.7
+
+
+def bench_performer(args, rank, world, dev):
+    """Secondary metric: Performer training-step tokens/s (README.md:126-141 configuration, raster-ordered 10x14x10 latents)."""
+    import numpy as np
+
+    from synthanatomy_amd.losses.transformer import CELoss
+    from synthanatomy_amd.networks.transformers.img2seq_ordering import Ordering
+    from synthanatomy_amd.networks.transformers.performer import Performer
+    from synthanatomy_amd.runtime.ddp import GradReducer
+    from synthanatomy_amd.runtime.optim import FlatParams, FusedAdam
+
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    N = int(np.prod(PERF["spatial"]))
+    B = args.performer_batch
+    torch.manual_seed(4)
+    order = Ordering("raster_scan", 3, (1,) + PERF["spatial"], (False, False, False), ((2, 0, 1),), ((0, 1),), ("rotate_90", "transpose"))
+    net = Performer(num_tokens=PERF["vocab"] + 1, max_seq_len=N, dim=PERF["dim"], depth=PERF["depth"], heads=PERF["heads"], ordering=order,
+                    local_attn_heads=PERF["local_heads"], local_window_size=PERF["window"], feature_redraw_interval=1, use_rezero=True,
+                    spatial_position_emb="absolute", spatial_shape=PERF["spatial"], compute_dtype=dt).to(dev).train()
+    flat = FlatParams(net.parameters())
+    opt = FusedAdam(flat, lr=1e-3)
+    opt.on_step.append(net.invalidate_packed_weights)
+    reducer = GradReducer(flat)
+    net.set_grad_sink(reducer)
+    loss_fn = CELoss()
+    gen = torch.Generator(device=dev).manual_seed(4 + rank)
+    codes = torch.randint(0, PERF["vocab"], (B, N), generator=gen, device=dev)
+    seq = codes[:, torch.as_tensor(order.get_sequence_ordering(), device=dev)]
+    seq = torch.nn.functional.pad(seq, (1, 0), value=PERF["vocab"])
+    x_in, x_tgt = seq[:, :-1].contiguous(), seq[:, 1:].contiguous()
+
+    def step():
+        flat.zero_grad()
+        logits = net(x_in)
+        loss = loss_fn(logits.transpose(1, 2), x_tgt)
+        loss.backward()
+        opt.step(grad_scale=reducer.finish())
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dtm = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dtm], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dtm = float(t.item())
+    toks = B * N * world * args.steps / dtm
+    res = {"metric": "performer_train_tokens_per_sec", "value": round(toks, 1), "unit": "tokens/s", "ms_per_step": round(dtm / args.steps * 1e3, 3),
+           "dtype": args.dtype, "scaling": "weak", "final_loss": round(float(loss.item()), 5),
+           "tflops_per_gpu": round(toks / world * PERFORMER_STEP_MFLOP_PER_TOKEN / 1e6, 2),
+           "config": {"workload": "performer n_embd=512 n_layers=24 n_head=16 local_attn_heads=8 local_window=420 vocab=2048, N=1400 raster-ordered "
+                                  "10x14x10 latents, training step = fwd + CE + bwd + Adam, projections redrawn every other step", "batch_per_gpu": B,
+                      "global_batch": B * world, "seq_len": N, "parallelism": f"dp{world}"}}
+    del net, flat, opt, reducer
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,6 +134,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--performer-batch", type=int, default=6, help="sequences per GPU per step (README.md:119)")
+    ap.add_argument("--no-performer", action="store_true", help="skip the secondary Performer tokens/s measurement")
+    ap.add_argument("--only-performer", action="store_true", help="dev/profiling: measure only the Performer workload")
     args = ap.parse_args()
 
     from synthanatomy_amd import engine
@@ -74,6 +149,15 @@ def main():
     assert world == args.gpus or (world == 1 and args.gpus == 1), f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    if args.only_performer:
+        res = bench_performer(args, rank, world, dev)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     torch.manual_seed(4)
     net = BaselineVQVAE(**NET, compute_dtype=dtype).to(dev).train()
@@ -151,6 +235,14 @@ def main():
             line["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+    secondary = None
+    if not args.no_performer:
+        del net, flat, opt, reducer, x
+        torch.cuda.empty_cache()
+        secondary = bench_performer(args, rank, world, dev)
+    if rank == 0:
+        if secondary is not None:
+            line["secondary"] = secondary
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

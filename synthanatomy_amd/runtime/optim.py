@@ -19,7 +19,8 @@ class FlatParams:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         assert self.params, "no trainable parameters"
         dev = self.params[0].device
-        assert dev.type == "cuda", "FlatParams lives in HBM"
+        # (the buffers live in HBM in production; host tensors are accepted so that the bucketing / reduction logic can be
+        #  exercised with the gloo backend -- FusedAdam itself is HIP-only)
         self.offsets = []
         n = 0
         for p in self.params:

@@ -1,0 +1,69 @@
+"""CPU, world_size 2 (gloo): the N>1 path -- bucketed gradient all-reduce overlapping 'backward', and the EMA statistics
+exchange (sum over ranks, baseline.py:70-72) giving every rank the codebook a single rank would compute on the full batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from synthanatomy_amd.runtime.ddp import GradReducer, init_distributed
+    from synthanatomy_amd.runtime.optim import FlatParams
+    r, l, w = init_distributed(backend="gloo")
+    assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(*s)) for s in [(64, 3), (17,), (8, 8), (5,)]]
+    flat = FlatParams(ps)
+    red = GradReducer(flat, bucket_bytes=300)
+    assert len(red.buckets) >= 2
+    # "backward": last parameter first, each rank contributes rank+1
+    for p in reversed(ps):
+        red.buffer(p).add_(float(rank + 1))
+        red.ready(p)
+    scale = red.finish()
+    ok_grad = bool(torch.allclose(flat.grad[: ps[0].numel()], torch.full((ps[0].numel(),), 3.0))) and scale == 0.5
+
+    # EMA statistics: each rank quantizes its half of the batch; the packed [counts | dw] buffer is summed
+    from oracle import vqvae_ref
+    cfg = vqvae_ref.VQVAEConfig(n_embed=32, embed_dim=8, vq_decay=0.5)
+    g = torch.Generator().manual_seed(1)
+    W0 = torch.randn(32, 8, generator=g)
+    z = torch.randn(4, 8, 3, 3, 3, generator=g)
+    st = {"quantizer.0.impl.weight": W0.clone(), "quantizer.0.impl.N": torch.zeros(32), "quantizer.0.impl.embed_avg": W0.clone()}
+    _, _, _, aux = vqvae_ref.quantize({k: v.clone() for k, v in st.items()}, cfg, z[2 * rank: 2 * rank + 2], training=False)
+    packed = torch.cat([aux["counts"], aux["dw"].reshape(-1)])
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    vqvae_ref.quantize(st, cfg, z[2 * rank: 2 * rank + 2], training=True, world_stats=(packed[:32], packed[32:].view(32, 8)))
+    full = {"quantizer.0.impl.weight": W0.clone(), "quantizer.0.impl.N": torch.zeros(32), "quantizer.0.impl.embed_avg": W0.clone()}
+    vqvae_ref.quantize(full, cfg, z, training=True)
+    ok_ema = all(torch.allclose(st[k], full[k], rtol=1e-5, atol=1e-6) for k in st)
+    q.put((rank, ok_grad, ok_ema))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_reducer_and_ema_statistics():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True, True), (1, True, True)], res
