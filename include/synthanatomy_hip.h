@@ -167,6 +167,16 @@ int sa_local_attn_bwd(const float *q, int q_stride, int q_off, const float *k, i
 int sa_cross_entropy(const float *logits, const int64_t *target, int64_t R, int V, float *loss_sum, void *dlogits, int d_dtype, float gscale,
                      void *stream);
 
+/* ==== discriminator normalisation (reference src/networks/discriminator/baseline.py:52-79: nn.BatchNorm3d + LeakyReLU) ====
+ * x, y, g, dx: channels-last [M, C] of dtype.  training: batch statistics (+ running-stat update, momentum, unbiased variance);
+ * eval: running statistics.  mean/rstd [C] are outputs kept for the backward; sums_ws is 2*C floats of scratch. */
+int sa_bn_forward(const void *x, int dtype, int64_t M, int C, const float *w, const float *b, float *running_mean, float *running_var,
+                  float momentum, float eps, int training, float slope, void *y, float *mean, float *rstd, float *sums_ws, void *stream);
+int sa_bn_backward(const void *x, const void *g, int dtype, int64_t M, int C, const float *w, const float *mean, const float *rstd,
+                   int training, void *dx, float *dw, float *db, float *sums_ws, void *stream);
+/* g = dy * (y > 0 ? 1 : slope) */
+int sa_lrelu_mask(const void *dy, const void *y, int dtype, void *g, int64_t n, float slope, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,10 @@ _SIGS = {
                                   c_int, c_int, c_void_p]),
     "sa_local_attn_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "sa_bn_forward": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_float, c_void_p, c_void_p,
+                              c_void_p, c_void_p, c_void_p]),
+    "sa_bn_backward": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sa_lrelu_mask": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_float, c_void_p]),
     "sa_cross_entropy": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p]),
 }
 

@@ -157,3 +157,40 @@ def test_training_step_bf16_decreases_loss_and_matches_oracle_grads():
             assert gr is not None and torch.isfinite(gr).all(), k
             worst = max(worst, _relerr(gr.cpu().numpy(), p.grad.numpy()))
         assert worst < 8e-2, worst  # bf16 activations/gradients vs the fp32-accumulated oracle
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_discriminator_matches_reference_fixture(dtype):
+    from synthanatomy_amd.networks.discriminator.baseline import BaselineDiscriminator
+    g = load_golden("discriminator")
+    net = BaselineDiscriminator(input_nc=1, ndf=8, n_layers=3, compute_dtype=dtype)
+    sd = state_from_golden(g)
+    net.load_state_dict(sd, strict=False)
+    net = net.cuda().train()
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = net(x)
+    tol = REL if dtype == torch.float32 else 3e-2
+    assert y.shape == tuple(g["train/logits"].shape) and _relerr(y.detach().cpu().numpy(), g["train/logits"]) < tol
+    sd2 = net.state_dict()
+    for k in g.files:
+        if k.startswith("train/sd/"):
+            assert _relerr(sd2[k[len("train/sd/"):]].cpu().numpy(), g[k]) < tol, k
+    # gradients against the CPU oracle (training-mode BatchNorm)
+    from oracle import vqvae_ref
+    st = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in state_from_golden(g).items()}
+    xr = torch.from_numpy(g["x"]).requires_grad_(True)
+    yr = vqvae_ref.discriminator_forward(st, xr, training=True)
+    w = torch.randn(yr.shape, generator=torch.Generator().manual_seed(0))
+    (yr * w).sum().backward()
+    (y * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    gtol = 3e-3 if dtype == torch.float32 else 0.25  # bf16 through 3 tiny-batch BatchNorms: sanity only, fp32 is the parity gate
+    for k, p in net.named_parameters():
+        assert _relerr(p.grad.cpu().numpy(), st[k].grad.numpy()) < gtol, k
+    assert _relerr(x.grad.cpu().numpy(), xr.grad.numpy()) < gtol
+    net.eval()
+    with torch.no_grad():
+        ye = net(torch.from_numpy(g["x"]).cuda())
+    if dtype == torch.float32:
+        # eval uses the running statistics updated by the single training forward above, as in the fixture
+        assert _relerr(ye.cpu().numpy(), g["eval/logits"]) < 5e-3
