@@ -177,6 +177,13 @@ int sa_bn_backward(const void *x, const void *g, int dtype, int64_t M, int C, co
 /* g = dy * (y > 0 ? 1 : slope) */
 int sa_lrelu_mask(const void *dy, const void *y, int dtype, void *g, int64_t n, float slope, void *stream);
 
+/* ==== final decoder layer nn.ConvTranspose3d(128 -> 1, k4 s2 p1) (baseline.py:283-293, last level): HBM-bound direct kernels ====
+ * x [N,D,H,W,128] (dtype), w [128][64] fp32 (the reference weight [Cin,1,4,4,4]), out / g [N,2D,2H,2W] fp32.
+ * sa_convt1_bwd: dx = dgrad * (relu_mask > 0) (dx may be NULL), dw += wgrad, db += sum g. */
+int sa_convt1_fwd(const void *x, int dtype, const float *w, const float *bias, float *out, int N, int D, int H, int W, int C, void *stream);
+int sa_convt1_bwd(const void *x, int dtype, const float *w, const float *g, const void *relu_mask, void *dx, float *dw, float *db, int N,
+                  int D, int H, int W, int C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

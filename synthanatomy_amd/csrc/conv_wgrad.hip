@@ -293,22 +293,41 @@ __global__ void wgrad_reduce_kernel(const WgradArgs a, uint32_t splits) {
     *d += s;
 }
 
-__global__ void colsum_kernel(const void* gp, int dtype, int64_t M, int C, int cstride, float* db, int64_t rows_per_block) {
-    // block (32 channel lanes x 8 row lanes); each block reduces rows_per_block rows of a 32-channel stripe
-    const int c = blockIdx.y * 32 + (threadIdx.x & 31);
+// db[c] += sum_m g[m][c].  Block = 16 channel-vectors (16 bytes each) x 16 row lanes; 16-byte coalesced loads.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ gp, int64_t M, int C, int cstride, float* __restrict__ db,
+                                                     int64_t rows_per_block) {
+    constexpr int VEC = DT<T>::VEC;
+    const int cv = blockIdx.y * 16 + (threadIdx.x & 15);   // channel vector
+    const int rl = threadIdx.x >> 4;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    float s = 0.f;
-    if (c < C)
-        for (int64_t r = r0 + (threadIdx.x >> 5); r < r1; r += 8) s += load_as_f32(gp, dtype, r * cstride + c);
-    __shared__ float red[256];
-    red[threadIdx.x] = s;
+    float s[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) s[k] = 0.f;
+    if (cv * VEC < cstride) {
+        for (int64_t r = r0 + rl; r < r1; r += 16) {
+            const u32x4 v = *(const u32x4*)(gp + r * cstride + cv * VEC);
+            if constexpr (VEC == 4) {
+                s[0] += __uint_as_float(v.x); s[1] += __uint_as_float(v.y); s[2] += __uint_as_float(v.z); s[3] += __uint_as_float(v.w);
+            } else {
+                s[0] += __uint_as_float(v.x << 16); s[1] += __uint_as_float(v.x & 0xffff0000u);
+                s[2] += __uint_as_float(v.y << 16); s[3] += __uint_as_float(v.y & 0xffff0000u);
+                s[4] += __uint_as_float(v.z << 16); s[5] += __uint_as_float(v.z & 0xffff0000u);
+                s[6] += __uint_as_float(v.w << 16); s[7] += __uint_as_float(v.w & 0xffff0000u);
+            }
+        }
+    }
+    __shared__ float red[16][16 * VEC + 1];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) red[rl][(threadIdx.x & 15) * VEC + k] = s[k];
     __syncthreads();
-    if (threadIdx.x < 32) {
+    if (threadIdx.x < 16 * VEC) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[threadIdx.x + 32 * k];
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        const int c = blockIdx.y * 16 * VEC + threadIdx.x;
         if (c < C) unsafeAtomicAdd(db + c, t);
     }
 }
@@ -396,10 +415,13 @@ extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, c
 extern "C" int sa_colsum(const void* gp, int dtype, int64_t M, int C, int cstride, float* db, void* stream) {
     using namespace sa;
     if (!gp || !db || M <= 0 || C <= 0) return SA_EINVAL;
-    int64_t rows_per_block = (M + 1023) / 1024;
+    const int vec = dtype == SA_F32 ? 4 : 8;
+    if (cstride % vec) return SA_EINVAL;
+    int64_t rows_per_block = (M + 511) / 512;
     if (rows_per_block < 64) rows_per_block = 64;
-    dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (C + 31) / 32);
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, gp, dtype, M, C, cstride, db, rows_per_block);
+    dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (cstride / vec + 15) / 16);
+    if (dtype == SA_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)gp, M, C, cstride, db, rows_per_block);
+    else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gp, M, C, cstride, db, rows_per_block);
     SA_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,262 @@
+// Final decoder layer: nn.ConvTranspose3d(128 -> 1, k4 s2 p1)  (reference src/networks/vqvae/baseline.py:283-293, last level).
+//
+// With ONE output channel the implicit GEMM wastes 15/16 of every MFMA tile and the 8 output-parity launches re-read the
+// 128-channel input 8 times; the layer is HBM-bound (reads 256 B per input voxel, writes 32 B).  These direct kernels read
+// every input row once, coalesced, with lanes = channel pairs, and keep the 64 taps x 2 channels of the weight (or of its
+// gradient) in registers:
+//   fwd   : per input-grid cell m the 27 neighbour rows x[m+d] feed the 8 outputs o = 2m + par  (each of the 64 taps once)
+//   dgrad : dx[i][c] = sum_k g[2i-1+k] w[c][k]  (* relu mask)
+//   wgrad : dw[c][k] += sum_i x[i][c] g[2i-1+k],  db += sum g
+// out[o] = b + sum_{i,k : 2i-1+k = o} x[i] . w[:,k]   per dimension (k = 0..3).
+#include "sa_common.h"
+
+namespace sa {
+
+struct CT1Args {
+    const void* x;      // [N, D, H, W, 128] T
+    const float* w;     // [128][64] fp32  (ConvTranspose3d weight [Cin, 1, 4,4,4])
+    const float* bias;  // [1] or NULL
+    float* out;         // fwd: [N, 2D, 2H, 2W] fp32
+    const float* g;     // bwd: [N, 2D, 2H, 2W] fp32 gradient wrt out
+    void* dx;           // dgrad out [N, D, H, W, 128] T
+    const void* mask;   // dgrad: relu mask tensor (same layout as x) or NULL
+    float* dw;          // [128][64] fp32 (accumulates)
+    float* db;          // [1] (accumulates) or NULL
+    int32_t N, D, H, W;
+    FastDiv dW_, dH_, dD_;
+    uint32_t cells;
+};
+
+template <typename T>
+__device__ __forceinline__ void load_pair(const T* p, float& a, float& b);
+template <>
+__device__ __forceinline__ void load_pair<float>(const float* p, float& a, float& b) {
+    const float2 v = *(const float2*)p;
+    a = v.x;
+    b = v.y;
+}
+template <>
+__device__ __forceinline__ void load_pair<bf16_t>(const bf16_t* p, float& a, float& b) {
+    const uint32_t v = *(const uint32_t*)p;
+    a = __uint_as_float(v << 16);
+    b = __uint_as_float(v & 0xffff0000u);
+}
+template <typename T>
+__device__ __forceinline__ void store_pair(T* p, float a, float b);
+template <>
+__device__ __forceinline__ void store_pair<float>(float* p, float a, float b) { *(float2*)p = make_float2(a, b); }
+template <>
+__device__ __forceinline__ void store_pair<bf16_t>(bf16_t* p, float a, float b) { *(uint32_t*)p = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+
+__device__ __forceinline__ void decode_cell(uint32_t m, const CT1Args& a, int& n, int& d, int& h, int& w) {
+    uint32_t q = fdiv(m, a.dW_);
+    w = (int)(m - q * a.W);
+    uint32_t q2 = fdiv(q, a.dH_);
+    h = (int)(q - q2 * a.H);
+    n = (int)fdiv(q2, a.dD_);
+    d = (int)(q2 - (uint32_t)n * a.D);
+}
+
+// per dimension tap k reads input offset DLT[k] and feeds output parity PAR[k]:  k=0 -> (+1, 1)  1 -> (0, 0)  2 -> (0, 1)  3 -> (-1, 0)
+__device__ __forceinline__ constexpr int tap_dlt(int k) { return k == 0 ? 1 : (k == 3 ? -1 : 0); }
+__device__ __forceinline__ constexpr int tap_par(int k) { return (k == 0 || k == 2) ? 1 : 0; }
+
+__device__ __forceinline__ float bcast(float v, int srclane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void convt1_fwd_kernel(const CT1Args a) {
+    __shared__ float2 sw[64][64];  // [tap][lane] = weights of channels (2 lane, 2 lane + 1)
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int k = e >> 6, l = e & 63;
+        sw[k][l] = make_float2(a.w[(2 * l) * 64 + k], a.w[(2 * l + 1) * 64 + k]);
+    }
+    __syncthreads();
+    const float b = a.bias ? a.bias[0] : 0.f;
+    const T* x = (const T*)a.x;
+    for (uint32_t m = wave; m < a.cells; m += nwaves) {
+        int n, d, h, w;
+        decode_cell(m, a, n, d, h, w);
+        float xa[27], xb[27];
+#pragma unroll
+        for (int r = 0; r < 27; ++r) {
+            const int id = d + r / 9 - 1, ih = h + (r / 3) % 3 - 1, iw = w + r % 3 - 1;
+            const bool ok = (unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            // branch-free: a conditional load would make hipcc drain vmcnt at every join and serialise the 27 row fetches
+            const int cd = min(max(id, 0), a.D - 1), ch = min(max(ih, 0), a.H - 1), cw = min(max(iw, 0), a.W - 1);
+            load_pair<T>(x + ((((int64_t)n * a.D + cd) * a.H + ch) * a.W + cw) * 128 + 2 * lane, xa[r], xb[r]);
+            xa[r] = ok ? xa[r] : 0.f;
+            xb[r] = ok ? xb[r] : 0.f;
+        }
+        float acc[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+#pragma unroll
+        for (int kd = 0; kd < 4; ++kd)
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw) {
+                    const int r = (tap_dlt(kd) + 1) * 9 + (tap_dlt(kh) + 1) * 3 + (tap_dlt(kw) + 1);
+                    const int o = (tap_par(kd) * 2 + tap_par(kh)) * 2 + tap_par(kw);
+                    const float2 wv = sw[(kd * 4 + kh) * 4 + kw][lane];
+                    acc[o] = fmaf(xa[r], wv.x, fmaf(xb[r], wv.y, acc[o]));
+                }
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[o] = wave_sum(acc[o]);
+        if (lane < 4) {  // lane = (pd, ph): write the two w-parities as one 8-byte store
+            const int pd = lane >> 1, ph = lane & 1;
+            const int64_t o = (((int64_t)n * 2 * a.D + 2 * d + pd) * 2 * a.H + 2 * h + ph) * 2 * a.W + 2 * w;
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (lane == q) {
+                    v0 = acc[q * 2];
+                    v1 = acc[q * 2 + 1];
+                }
+            *(float2*)(a.out + o) = make_float2(v0 + b, v1 + b);
+        }
+    }
+}
+
+// lane k holds g[2i-1+k] of the current input voxel; broadcast with readlane
+__device__ __forceinline__ float load_g_tap(const CT1Args& a, int n, int d, int h, int w, int lane) {
+    const int kd = lane >> 4, kh = (lane >> 2) & 3, kw = lane & 3;
+    const int od = 2 * d - 1 + kd, oh = 2 * h - 1 + kh, ow = 2 * w - 1 + kw;
+    const bool ok = (unsigned)od < (unsigned)(2 * a.D) && (unsigned)oh < (unsigned)(2 * a.H) && (unsigned)ow < (unsigned)(2 * a.W);
+    const int cd = min(max(od, 0), 2 * a.D - 1), ch = min(max(oh, 0), 2 * a.H - 1), cw = min(max(ow, 0), 2 * a.W - 1);
+    const float v = a.g[(((int64_t)n * 2 * a.D + cd) * 2 * a.H + ch) * 2 * a.W + cw];
+    return ok ? v : 0.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void convt1_dgrad_kernel(const CT1Args a) {
+    __shared__ float2 sw[64][64];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int k = e >> 6, l = e & 63;
+        sw[k][l] = make_float2(a.w[(2 * l) * 64 + k], a.w[(2 * l + 1) * 64 + k]);
+    }
+    __syncthreads();
+    T* dx = (T*)a.dx;
+    const T* mk = (const T*)a.mask;
+    for (uint32_t m = wave; m < a.cells; m += nwaves) {
+        int n, d, h, w;
+        decode_cell(m, a, n, d, h, w);
+        const float gv = load_g_tap(a, n, d, h, w, lane);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            const float gk = bcast(gv, k);
+            const float2 wv = sw[k][lane];
+            s0 = fmaf(gk, wv.x, s0);
+            s1 = fmaf(gk, wv.y, s1);
+        }
+        const int64_t o = (int64_t)m * 128 + 2 * lane;
+        if (mk) {
+            float ma, mb;
+            load_pair<T>(mk + o, ma, mb);
+            s0 = ma > 0.f ? s0 : 0.f;
+            s1 = mb > 0.f ? s1 : 0.f;
+        }
+        store_pair<T>(dx + o, s0, s1);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void convt1_wgrad_kernel(const CT1Args a) {
+    __shared__ float red[64][65];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t wave = blockIdx.x * 4 + wv, nwaves = gridDim.x * 4;
+    float a0[64], a1[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) a0[k] = a1[k] = 0.f;
+    float gsum = 0.f;
+    const T* x = (const T*)a.x;
+    for (uint32_t m = wave; m < a.cells; m += nwaves) {
+        int n, d, h, w;
+        decode_cell(m, a, n, d, h, w);
+        const float gv = load_g_tap(a, n, d, h, w, lane);
+        // every output voxel o = 2i + par is covered exactly once by the taps (kd,kh,kw) in {1,2}^3 of its cell
+        const int kd = lane >> 4, kh = (lane >> 2) & 3, kw = lane & 3;
+        if ((kd == 1 || kd == 2) && (kh == 1 || kh == 2) && (kw == 1 || kw == 2)) gsum += gv;
+        float xa, xb;
+        load_pair<T>(x + (int64_t)m * 128 + 2 * lane, xa, xb);
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            const float gk = bcast(gv, k);
+            a0[k] = fmaf(xa, gk, a0[k]);
+            a1[k] = fmaf(xb, gk, a1[k]);
+        }
+    }
+    // block reduction over the 4 waves (taking turns on one LDS tile), then one atomic per (channel, tap) per block
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int turn = 0; turn < 4; ++turn) {
+            if (wv == turn) {
+#pragma unroll
+                for (int k = 0; k < 64; ++k) {
+                    const float v = pass ? a1[k] : a0[k];
+                    red[lane][k] = turn == 0 ? v : red[lane][k] + v;
+                }
+            }
+            __syncthreads();
+        }
+        for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+            const int l = e >> 6, k = e & 63;
+            unsafeAtomicAdd(a.dw + (2 * l + pass) * 64 + k, red[l][k]);
+        }
+        __syncthreads();
+    }
+    if (a.db) {
+        gsum = wave_sum(gsum);
+        if (lane == 0) unsafeAtomicAdd(a.db, gsum);
+    }
+}
+
+static int fill_ct1(CT1Args& a, int N, int D, int H, int W) {
+    const int64_t cells = (int64_t)N * D * H * W;
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || cells >= (1ll << 31)) return SA_EINVAL;
+    a.N = N; a.D = D; a.H = H; a.W = W;
+    a.dW_ = make_fastdiv(W); a.dH_ = make_fastdiv(H); a.dD_ = make_fastdiv(D);
+    a.cells = (uint32_t)cells;
+    return 0;
+}
+
+}  // namespace sa
+
+using namespace sa;
+
+extern "C" int sa_convt1_fwd(const void* x, int dtype, const float* w, const float* bias, float* out, int N, int D, int H, int W, int C, void* stream) {
+    if (!x || !w || !out) return SA_EINVAL;
+    if (C != 128 || (dtype != SA_F32 && dtype != SA_BF16)) return SA_EUNSUPPORTED;
+    CT1Args a = {};
+    if (fill_ct1(a, N, D, H, W)) return SA_EINVAL;
+    a.x = x; a.w = w; a.bias = bias; a.out = out;
+    const dim3 grid(2048);
+    if (dtype == SA_F32) hipLaunchKernelGGL(convt1_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(convt1_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_convt1_bwd(const void* x, int dtype, const float* w, const float* g, const void* relu_mask, void* dx, float* dw, float* db, int N,
+                             int D, int H, int W, int C, void* stream) {
+    if (!x || !w || !g || !dw) return SA_EINVAL;
+    if (C != 128 || (dtype != SA_F32 && dtype != SA_BF16)) return SA_EUNSUPPORTED;
+    CT1Args a = {};
+    if (fill_ct1(a, N, D, H, W)) return SA_EINVAL;
+    a.x = x; a.w = w; a.g = g; a.dx = dx; a.mask = relu_mask; a.dw = dw; a.db = db;
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) {
+        if (dtype == SA_F32) hipLaunchKernelGGL(convt1_dgrad_kernel<float>, dim3(2048), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(convt1_dgrad_kernel<bf16_t>, dim3(2048), dim3(256), 0, st, a);
+        SA_CHECK_LAUNCH();
+    }
+    if (dtype == SA_F32) hipLaunchKernelGGL(convt1_wgrad_kernel<float>, dim3(512), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(convt1_wgrad_kernel<bf16_t>, dim3(512), dim3(256), 0, st, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}

@@ -228,6 +228,41 @@ class _ConvStage:
         return self.op.dgrad(G, tuple(x.shape[1:4]), mask=x if self.in_act else None, mask_mode=MASK_POS)
 
 
+class _ConvT1Stage:
+    """Final ConvTranspose3d(128 -> 1, k4 s2 p1): HBM-bound direct kernels (csrc/convt1.hip) instead of 8 parity GEMMs."""
+
+    def __init__(self, mod: nn.ConvTranspose3d, in_act, dtype):
+        self.mod, self.in_act, self.dtype = mod, in_act, dtype
+
+    @staticmethod
+    def applicable(mod) -> bool:
+        return (isinstance(mod, nn.ConvTranspose3d) and mod.in_channels == 128 and mod.out_channels == 1 and mod.kernel_size == (4, 4, 4)
+                and mod.stride == (2, 2, 2) and mod.padding == (1, 1, 1))
+
+    def params(self):
+        return [self.mod.weight, self.mod.bias]
+
+    def fwd(self, x, tape):
+        N, D, H, W, C = x.shape
+        out = torch.empty((N, 2 * D, 2 * H, 2 * W, 1), dtype=torch.float32, device=x.device)
+        _ffi.check(_ffi.lib().sa_convt1_fwd(_ffi.ptr(x), _ffi.dtype_id(x.dtype), _ffi.ptr(self.mod.weight), _ffi.ptr(self.mod.bias), _ffi.ptr(out), N, D, H, W, C,
+                                            _ffi.stream()), "sa_convt1_fwd")
+        if tape is not None:
+            tape.append((x,))
+        return out
+
+    def bwd(self, G, saved, grads):
+        (x,) = saved
+        N, D, H, W, C = x.shape
+        G = G.float().contiguous()
+        dx = torch.empty_like(x)
+        dw, db = grads.buf(self.mod.weight), grads.buf(self.mod.bias)
+        _ffi.check(_ffi.lib().sa_convt1_bwd(_ffi.ptr(x), _ffi.dtype_id(x.dtype), _ffi.ptr(self.mod.weight), _ffi.ptr(G), _ffi.ptr(x) if self.in_act else None,
+                                            _ffi.ptr(dx), _ffi.ptr(dw), _ffi.ptr(db), N, D, H, W, C, _ffi.stream()), "sa_convt1_bwd")
+        grads.done(self.mod.weight, self.mod.bias)
+        return dx
+
+
 class _ResStage:
     def __init__(self, mod: ResidualLayer, in_act, dtype):
         c3, c1 = mod[0], mod[3]
@@ -438,7 +473,10 @@ class BaselineVQVAE(VQVAEBase, nn.Module):
             res, up = mods[i], mods[i + 1]
             for j, r in enumerate(res):
                 stages.append(_ResStage(r, in_act=not (lvl == 0 and j == 0), dtype=dt))
-            stages.append(_ConvStage(up, "convT", ACT_NONE if last else ACT_RELU, in_act=True, dtype=dt, out_f32=last))
+            if last and _ConvT1Stage.applicable(up):
+                stages.append(_ConvT1Stage(up, in_act=True, dtype=dt))
+            else:
+                stages.append(_ConvStage(up, "convT", ACT_NONE if last else ACT_RELU, in_act=True, dtype=dt, out_f32=last))
             i += 2 if last else 3
         return _Chain(stages, dt, in_channels=self.embed_dim)
 

@@ -268,3 +268,32 @@ def test_abi_rejects_bad_arguments():
     ep = _ffi.Epilogue()
     x = torch.zeros(8, device="cuda")
     assert lib.sa_conv_fprop(ctypes.byref(g), 7, _ffi.ptr(x), _ffi.ptr(x), _ffi.ptr(x), ctypes.byref(ep), None) == -2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_convt1_direct_kernels(dtype):
+    """ConvTranspose3d(128 -> 1, k4 s2 p1) direct kernels against torch CPU (forward, dgrad with relu mask, wgrad, bias grad)."""
+    _ffi, engine = _ops()
+    lib, st = _ffi.lib(), _ffi.stream()
+    torch.manual_seed(7)
+    N, dims = 2, (3, 5, 4)
+    x = _rt(torch.randn(N, 128, *dims), dtype)
+    w = torch.randn(128, 1, 4, 4, 4) * 0.1
+    b = torch.tensor([0.3])
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv_transpose3d(xr, wr, br, stride=2, padding=1)
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    xd = _cl(x).cuda().to(dtype)
+    wd, bd = w.cuda(), b.cuda()
+    out = torch.empty(N, *[2 * d for d in dims], device="cuda")
+    _ffi.check(lib.sa_convt1_fwd(_ffi.ptr(xd), _ffi.dtype_id(dtype), _ffi.ptr(wd), _ffi.ptr(bd), _ffi.ptr(out), N, *dims, 128, st))
+    _close(out.cpu(), yr.detach()[:, 0], dtype, "convt1 fwd")
+    gd = g[:, 0].contiguous().cuda()
+    dx = torch.empty_like(xd)
+    dw, db = torch.zeros_like(wd), torch.zeros_like(bd)
+    _ffi.check(lib.sa_convt1_bwd(_ffi.ptr(xd), _ffi.dtype_id(dtype), _ffi.ptr(wd), _ffi.ptr(gd), _ffi.ptr(xd), _ffi.ptr(dx), _ffi.ptr(dw), _ffi.ptr(db), N, *dims, 128, st))
+    torch.cuda.synchronize()
+    _close(dx.float().cpu(), _cl(xr.grad * (x > 0)), torch.bfloat16 if dtype == torch.bfloat16 else dtype, "convt1 dgrad")
+    _close(dw.cpu(), wr.grad, dtype, "convt1 wgrad")
+    _close(db.cpu(), br.grad, dtype, "convt1 bgrad")
