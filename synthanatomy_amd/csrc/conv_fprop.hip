@@ -12,6 +12,8 @@
 // channels of one voxel -> 8/16-byte channels-last stores.
 //   bf16: __builtin_amdgcn_mfma_f32_16x16x32_bf16   (one per 64 bytes of K)
 //   f32 : __builtin_amdgcn_mfma_f32_16x16x4f32 x4   (exact fp32 fma chain; parity mode)
+#include <stdlib.h>
+
 #include "sa_common.h"
 
 namespace sa {
@@ -29,6 +31,8 @@ struct FpropArgs {
     uint32_t ntaps;
     uint32_t nk;          // K-slabs
     uint32_t nblk_m;
+    FastDiv dCin;         // element k -> (tap, channel)
+    uint32_t in_bytes, w_bytes;
 };
 
 template <typename T>
@@ -48,6 +52,126 @@ __device__ __forceinline__ void mma_slab<float>(float4_t& acc, const u32x4& wa, 
 
 // byte offset of 16-byte vector `vec` (0..7) of row `row` inside a [rows][128 B] swizzled tile
 __device__ __forceinline__ uint32_t tile_off(uint32_t row, uint32_t vec) { return row * 128u + ((vec ^ (row & 7u)) << 4); }
+
+// ---- epilogue shared by both mainloops, staged through LDS so that HBM sees full channel rows
+template <int BM, int BN, int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void fprop_epilogue(const FpropArgs& a, float4_t (&acc)[NI][MI], unsigned char* smem, uint32_t tid, uint32_t wm, uint32_t wn,
+                                               uint32_t frow, uint32_t fq, uint32_t m_base, uint32_t n_base) {
+    const sa_conv_geom& g = a.g;
+    //  A) every lane parks its 4x(acc + bias) for one voxel in an fp32 tile [BM][BN+4] (stride padded: conflict-free b128)
+    //  B) the block re-reads the tile voxel-row-wise, 4 channels per thread: addend / activation / mask are applied with
+    //     8- or 16-byte coalesced loads and the result leaves as 8-byte (bf16) or 16-byte (fp32) coalesced stores.
+    constexpr int LDT = BN + 4;
+    float* sT = (float*)smem;
+    long long* sOv = (long long*)(smem + BM * LDT * 4);
+    const sa_epilogue& ep = a.ep;
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+        const uint32_t row = wm * (MI * 16) + j * 16 + frow;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const uint32_t col = wn * (NI * 16) + i * 16 + fq * 4;
+            float4_t v = acc[i][j];
+            if (ep.bias) {
+                const float4_t bv = *(const float4_t*)(ep.bias + n_base + col);
+                v += bv;
+            }
+            *(float4_t*)(sT + row * LDT + col) = v;
+        }
+    }
+    if (tid < BM) {
+        const uint32_t m = m_base + tid;
+        long long ov = -1;
+        if (m < a.M) {
+            uint32_t q = fdiv(m, a.dW);
+            const uint32_t wmx = m - q * g.Wm;
+            uint32_t q2 = fdiv(q, a.dH);
+            const uint32_t hmx = q - q2 * g.Hm;
+            const uint32_t n = fdiv(q2, a.dD);
+            const uint32_t dmx = q2 - n * g.Dm;
+            ov = (((long long)n * g.Do + (dmx * g.out_mult[0] + g.out_off[0])) * g.Ho + (hmx * g.out_mult[1] + g.out_off[1])) * g.Wo +
+                 (wmx * g.out_mult[2] + g.out_off[2]);
+        }
+        sOv[tid] = ov;
+    }
+    __syncthreads();
+    const float alpha = ep.alpha ? *ep.alpha : 1.f;
+    const bool vec_ok = (g.Cout & 3) == 0;
+    constexpr int NG = BN / 4;           // 4-channel groups per voxel row
+    constexpr int RPP = 256 / NG;        // rows per pass
+    const uint32_t grp = tid % NG, r0 = tid / NG;
+    const uint32_t co0 = n_base + grp * 4;
+    if (co0 < (uint32_t)g.cout_valid) {
+#pragma unroll 4
+        for (int it = 0; it < BM / RPP; ++it) {
+            const uint32_t row = r0 + it * RPP;
+            const long long ov = sOv[row];
+            if (ov < 0) continue;
+            const int64_t o = ov * g.Cout + co0;
+            const float4_t tv = *(const float4_t*)(sT + row * LDT + grp * 4);
+            float v[4] = {tv[0], tv[1], tv[2], tv[3]};
+            const bool full = vec_ok && co0 + 3 < (uint32_t)g.cout_valid;
+            float ad[4] = {0.f, 0.f, 0.f, 0.f}, mk[4] = {1.f, 1.f, 1.f, 1.f};
+            if (full) {
+                if (ep.addend) {
+                    if (ep.add_dtype == SA_F32) {
+                        const float4_t t4 = *(const float4_t*)((const float*)ep.addend + o);
+                        ad[0] = t4[0]; ad[1] = t4[1]; ad[2] = t4[2]; ad[3] = t4[3];
+                    } else {
+                        const uint2 t2 = *(const uint2*)((const bf16_t*)ep.addend + o);
+                        ad[0] = __uint_as_float(t2.x << 16); ad[1] = __uint_as_float(t2.x & 0xffff0000u);
+                        ad[2] = __uint_as_float(t2.y << 16); ad[3] = __uint_as_float(t2.y & 0xffff0000u);
+                    }
+                }
+                if (ep.mask_mode != SA_MASK_NONE) {
+                    if (ep.mask_dtype == SA_F32) {
+                        const float4_t t4 = *(const float4_t*)((const float*)ep.mask + o);
+                        mk[0] = t4[0]; mk[1] = t4[1]; mk[2] = t4[2]; mk[3] = t4[3];
+                    } else {
+                        const uint2 t2 = *(const uint2*)((const bf16_t*)ep.mask + o);
+                        mk[0] = __uint_as_float(t2.x << 16); mk[1] = __uint_as_float(t2.x & 0xffff0000u);
+                        mk[2] = __uint_as_float(t2.y << 16); mk[3] = __uint_as_float(t2.y & 0xffff0000u);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (co0 + r >= (uint32_t)g.cout_valid) continue;
+                    if (ep.addend) ad[r] = load_as_f32(ep.addend, ep.add_dtype, o + r);
+                    if (ep.mask_mode != SA_MASK_NONE) mk[r] = load_as_f32(ep.mask, ep.mask_dtype, o + r);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = v[r];
+                if (ep.add_before_act) x += ad[r];
+                if (ep.act == SA_ACT_RELU) x = fmaxf(x, 0.f);
+                else if (ep.act == SA_ACT_LRELU) x = x > 0.f ? x : x * ep.slope;
+                else if (ep.act == SA_ACT_GELU) x = gelu_f(x);
+                x *= alpha;
+                if (!ep.add_before_act) x += ad[r];
+                if (ep.mask_mode == SA_MASK_POS) x = mk[r] > 0.f ? x : 0.f;
+                else if (ep.mask_mode == SA_MASK_LRELU) x = mk[r] > 0.f ? x : x * ep.slope;
+                else if (ep.mask_mode == SA_MASK_GELU) x *= gelu_grad_f(mk[r]);
+                v[r] = x;
+            }
+            if (full) {
+                if (ep.out_dtype == SA_F32) {
+                    *(float4_t*)((float*)a.out + o) = (float4_t){v[0], v[1], v[2], v[3]};
+                } else {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *(uint2*)((bf16_t*)a.out + o) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co0 + r < (uint32_t)g.cout_valid) store_from_f32(a.out, ep.out_dtype, o + r, v[r]);
+            }
+        }
+    }
+}
 
 template <typename T, int WM, int WN, int MI, int NI>
 __global__ __launch_bounds__(256) void conv_fprop_kernel(const FpropArgs a) {
@@ -173,31 +297,51 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const FpropArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue, staged through LDS so that HBM sees full channel rows:
-    //  A) every lane parks its 4x(acc + bias) for one voxel in an fp32 tile [BM][BN+4] (stride padded: conflict-free b128)
-    //  B) the block re-reads the tile voxel-row-wise, 4 channels per thread: addend / activation / mask are applied with
-    //     8- or 16-byte coalesced loads and the result leaves as 8-byte (bf16) or 16-byte (fp32) coalesced stores.
-    constexpr int LDT = BN + 4;
-    float* sT = (float*)smem;
-    long long* sOv = (long long*)(smem + BM * LDT * 4);
-    const sa_epilogue& ep = a.ep;
+    fprop_epilogue<BM, BN, WM, WN, MI, NI>(a, acc, smem, tid, wm, wn, frow, fq, m_base, n_base);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Mainloop v2: LDS-DMA staging.  Both tiles go HBM/L2 -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR round trip, no
+// ds_write pass, no exec-masked branches): out-of-range taps / rows use an out-of-bounds buffer offset, which the hardware
+// turns into zeros.  The DMA writes lane-linearly (wave-uniform base + lane*16), so the XOR swizzle is applied to the SOURCE:
+// lane l of an 8-row x 128-byte piece fetches 16-byte vector (l&7) ^ (l>>3) of row (l>>3).  When a 128-byte K-slab never
+// straddles two taps (Cin*sizeof(T) % 128 == 0, UNIFORM) the tap decode is scalar (SALU) work.
+// Needs every operand < 4 GiB (32-bit buffer offsets); the register-staged kernel above is the fallback.
+constexpr uint32_t OOB_OFF = 0xfffffff0u;
+
+template <typename T, int WM, int WN, int MI, int NI, bool UNIFORM>
+__global__ __launch_bounds__(256) void conv_fprop_dma_kernel(const FpropArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins only exist in the device pass; the host pass needs just the stub
+    constexpr int BM = WM * MI * 16;
+    constexpr int BN = WN * NI * 16;
+    static_assert(BM == 128 && WM * WN == 4, "tile");
+    constexpr int SZ = sizeof(T);
+    constexpr int BKE = 128 / SZ;
+    constexpr int B_PIECES = BN / 8;                       // 1 KiB pieces (8 rows) of the weight tile
+    constexpr int B_PER_WAVE = (B_PIECES + 3) / 4;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wm = wave / WN, wn = wave % WN;
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
+    const uint32_t m_base = bm * BM, n_base = bn * BN;
+    const sa_conv_geom& g = a.g;
+
+    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (int)a.w_bytes, 0x00020000);
+
+    // ---- this lane's fixed role inside every 8-row piece
+    const uint32_t prow = lane >> 3;                       // row within the piece
+    const uint32_t lv = (lane & 7u) ^ prow;                // SOURCE 16-byte vector (swizzle on the source side)
+    uint32_t rowoff[4], vm[4];
 #pragma unroll
-    for (int j = 0; j < MI; ++j) {
-        const uint32_t row = wm * (MI * 16) + j * 16 + frow;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const uint32_t col = wn * (NI * 16) + i * 16 + fq * 4;
-            float4_t v = acc[i][j];
-            if (ep.bias) {
-                const float4_t bv = *(const float4_t*)(ep.bias + n_base + col);
-                v += bv;
-            }
-            *(float4_t*)(sT + row * LDT + col) = v;
-        }
-    }
-    if (tid < BM) {
-        const uint32_t m = m_base + tid;
-        long long ov = -1;
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t m = m_base + (wave * 4 + j) * 8 + prow;
+        rowoff[j] = 0;
+        vm[j] = 0;
         if (m < a.M) {
             uint32_t q = fdiv(m, a.dW);
             const uint32_t wmx = m - q * g.Wm;
@@ -205,88 +349,99 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const FpropArgs a) {
             const uint32_t hmx = q - q2 * g.Hm;
             const uint32_t n = fdiv(q2, a.dD);
             const uint32_t dmx = q2 - n * g.Dm;
-            ov = (((long long)n * g.Do + (dmx * g.out_mult[0] + g.out_off[0])) * g.Ho + (hmx * g.out_mult[1] + g.out_off[1])) * g.Wo +
-                 (wmx * g.out_mult[2] + g.out_off[2]);
+            const int32_t id0 = (int32_t)dmx * g.in_mult[0] + g.in_off[0];
+            const int32_t ih0 = (int32_t)hmx * g.in_mult[1] + g.in_off[1];
+            const int32_t iw0 = (int32_t)wmx * g.in_mult[2] + g.in_off[2];
+            // modular 32-bit byte offset of the (possibly virtual) base voxel
+            rowoff[j] = (uint32_t)((((int32_t)n * g.Di + id0) * g.Hi + ih0) * g.Wi + iw0) * (uint32_t)(g.Cin * SZ);
+            uint32_t mk = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < g.KT[0] && (uint32_t)(id0 + t * g.tap_step[0]) < (uint32_t)g.Di) mk |= 1u << t;
+                if (t < g.KT[1] && (uint32_t)(ih0 + t * g.tap_step[1]) < (uint32_t)g.Hi) mk |= 16u << t;
+                if (t < g.KT[2] && (uint32_t)(iw0 + t * g.tap_step[2]) < (uint32_t)g.Wi) mk |= 256u << t;
+            }
+            vm[j] = mk;
         }
-        sOv[tid] = ov;
     }
+    uint32_t boff[B_PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < B_PER_WAVE; ++j) boff[j] = (n_base + (wave * B_PER_WAVE + j) * 8 + prow) * (uint32_t)(g.Kpad * SZ) + lv * 16u;
+
+    auto issue = [&](uint32_t s, uint32_t buf) __attribute__((always_inline)) {
+        unsigned char* pa = smem + buf * (BM * 128);
+        unsigned char* pb = smem + 2 * BM * 128 + buf * (BN * 128);
+        uint32_t sel, koff;
+        bool tap_ok;
+        if constexpr (UNIFORM) {
+            const uint32_t ke = s * BKE;                    // scalar: first K element of the slab
+            const uint32_t tap = fdiv(ke, a.dCin);
+            const uint32_t c0 = ke - tap * g.Cin;
+            const uint32_t td = fdiv(tap, a.dThw);
+            const uint32_t t2 = tap - td * a.dThw.d;
+            const uint32_t th = fdiv(t2, a.dTw);
+            const uint32_t tw = t2 - th * a.dTw.d;
+            const int32_t vox = (((int32_t)td * g.tap_step[0]) * g.Hi + (int32_t)th * g.tap_step[1]) * g.Wi + (int32_t)tw * g.tap_step[2];
+            koff = (uint32_t)vox * (uint32_t)(g.Cin * SZ) + c0 * SZ + lv * 16u;
+            sel = (1u << td) | (16u << th) | (256u << tw);
+            tap_ok = tap < a.ntaps;
+        } else {
+            const uint32_t kv = s * 8u + lv;
+            const uint32_t tap = fdiv(kv, a.dCv);
+            const uint32_t cv = kv - tap * a.dCv.d;
+            const uint32_t td = fdiv(tap, a.dThw);
+            const uint32_t t2 = tap - td * a.dThw.d;
+            const uint32_t th = fdiv(t2, a.dTw);
+            const uint32_t tw = t2 - th * a.dTw.d;
+            const int32_t vox = (((int32_t)td * g.tap_step[0]) * g.Hi + (int32_t)th * g.tap_step[1]) * g.Wi + (int32_t)tw * g.tap_step[2];
+            koff = (uint32_t)vox * (uint32_t)(g.Cin * SZ) + cv * 16u;
+            sel = (1u << td) | (16u << th) | (256u << tw);
+            tap_ok = tap < a.ntaps;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = tap_ok && (vm[j] & sel) == sel;
+            const uint32_t voff = ok ? rowoff[j] + koff : OOB_OFF;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(pa + (wave * 4 + j) * 1024), 16, voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER_WAVE; ++j) {
+            if (B_PIECES >= 4 || wave * B_PER_WAVE + j < (uint32_t)B_PIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(pb + (wave * B_PER_WAVE + j) * 1024), 16, boff[j],
+                                                         s * 128u, 0, 0);
+        }
+    };
+
+    float4_t acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    issue(0, 0);
     __syncthreads();
-    const float alpha = ep.alpha ? *ep.alpha : 1.f;
-    const bool vec_ok = (g.Cout & 3) == 0;
-    constexpr int NG = BN / 4;           // 4-channel groups per voxel row
-    constexpr int RPP = 256 / NG;        // rows per pass
-    const uint32_t grp = tid % NG, r0 = tid / NG;
-    const uint32_t co0 = n_base + grp * 4;
-    if (co0 < (uint32_t)g.cout_valid) {
-#pragma unroll 4
-        for (int it = 0; it < BM / RPP; ++it) {
-            const uint32_t row = r0 + it * RPP;
-            const long long ov = sOv[row];
-            if (ov < 0) continue;
-            const int64_t o = ov * g.Cout + co0;
-            const float4_t tv = *(const float4_t*)(sT + row * LDT + grp * 4);
-            float v[4] = {tv[0], tv[1], tv[2], tv[3]};
-            const bool full = vec_ok && co0 + 3 < (uint32_t)g.cout_valid;
-            float ad[4] = {0.f, 0.f, 0.f, 0.f}, mk[4] = {1.f, 1.f, 1.f, 1.f};
-            if (full) {
-                if (ep.addend) {
-                    if (ep.add_dtype == SA_F32) {
-                        const float4_t t4 = *(const float4_t*)((const float*)ep.addend + o);
-                        ad[0] = t4[0]; ad[1] = t4[1]; ad[2] = t4[2]; ad[3] = t4[3];
-                    } else {
-                        const uint2 t2 = *(const uint2*)((const bf16_t*)ep.addend + o);
-                        ad[0] = __uint_as_float(t2.x << 16); ad[1] = __uint_as_float(t2.x & 0xffff0000u);
-                        ad[2] = __uint_as_float(t2.y << 16); ad[3] = __uint_as_float(t2.y & 0xffff0000u);
-                    }
-                }
-                if (ep.mask_mode != SA_MASK_NONE) {
-                    if (ep.mask_dtype == SA_F32) {
-                        const float4_t t4 = *(const float4_t*)((const float*)ep.mask + o);
-                        mk[0] = t4[0]; mk[1] = t4[1]; mk[2] = t4[2]; mk[3] = t4[3];
-                    } else {
-                        const uint2 t2 = *(const uint2*)((const bf16_t*)ep.mask + o);
-                        mk[0] = __uint_as_float(t2.x << 16); mk[1] = __uint_as_float(t2.x & 0xffff0000u);
-                        mk[2] = __uint_as_float(t2.y << 16); mk[3] = __uint_as_float(t2.y & 0xffff0000u);
-                    }
-                }
-            } else {
+    const uint32_t frow = lane & 15u, fq = lane >> 4;
+    for (uint32_t s = 0; s < a.nk; ++s) {
+        const uint32_t buf = s & 1u;
+        if (s + 1 < a.nk) issue(s + 1, buf ^ 1u);
+        const unsigned char* pa = smem + buf * (BM * 128);
+        const unsigned char* pb = smem + 2 * BM * 128 + buf * (BN * 128);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (co0 + r >= (uint32_t)g.cout_valid) continue;
-                    if (ep.addend) ad[r] = load_as_f32(ep.addend, ep.add_dtype, o + r);
-                    if (ep.mask_mode != SA_MASK_NONE) mk[r] = load_as_f32(ep.mask, ep.mask_dtype, o + r);
-                }
-            }
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 xf[MI], wf[NI];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = v[r];
-                if (ep.add_before_act) x += ad[r];
-                if (ep.act == SA_ACT_RELU) x = fmaxf(x, 0.f);
-                else if (ep.act == SA_ACT_LRELU) x = x > 0.f ? x : x * ep.slope;
-                else if (ep.act == SA_ACT_GELU) x = gelu_f(x);
-                x *= alpha;
-                if (!ep.add_before_act) x += ad[r];
-                if (ep.mask_mode == SA_MASK_POS) x = mk[r] > 0.f ? x : 0.f;
-                else if (ep.mask_mode == SA_MASK_LRELU) x = mk[r] > 0.f ? x : x * ep.slope;
-                else if (ep.mask_mode == SA_MASK_GELU) x *= gelu_grad_f(mk[r]);
-                v[r] = x;
-            }
-            if (full) {
-                if (ep.out_dtype == SA_F32) {
-                    *(float4_t*)((float*)a.out + o) = (float4_t){v[0], v[1], v[2], v[3]};
-                } else {
-                    uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                    *(uint2*)((bf16_t*)a.out + o) = pk;
-                }
-            } else {
+            for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(pa + tile_off(wm * (MI * 16) + j * 16 + frow, ks * 4 + fq));
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (co0 + r < (uint32_t)g.cout_valid) store_from_f32(a.out, ep.out_dtype, o + r, v[r]);
-            }
+            for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + tile_off(wn * (NI * 16) + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
         }
+        __syncthreads();  // (the DMA in flight makes hipcc drain vmcnt(0) here: next slab landed, this one free)
     }
+    fprop_epilogue<BM, BN, WM, WN, MI, NI>(a, acc, smem, tid, wm, wn, frow, fq, m_base, n_base);
+#endif
 }
 
 template <typename T, int WM, int WN, int MI, int NI>
@@ -299,6 +454,13 @@ static int launch_fprop(const FpropArgs& a, hipStream_t st) {
     const size_t pipe = 2 * (BM + BN) * 128, epi = (size_t)BM * (BN + 4) * 4 + BM * 8;
     const size_t lds = pipe > epi ? pipe : epi;
     dim3 grid(a.nblk_m * nbn_valid);
+    if (a.in_bytes != 0) {  // every operand addressable with 32-bit buffer offsets -> LDS-DMA mainloop
+        const bool uniform = ((size_t)a.g.Cin * sizeof(T)) % 128 == 0;
+        if (uniform) hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, false>), grid, dim3(256), lds, st, a);
+        SA_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL((conv_fprop_kernel<T, WM, WN, MI, NI>), grid, dim3(256), lds, st, a);
     SA_CHECK_LAUNCH();
     return 0;
@@ -344,6 +506,14 @@ extern "C" int sa_conv_fprop(const sa_conv_geom* g, int dtype, const void* in, c
     a.ntaps = ntaps;
     a.nk = g->Kpad / bke;
     a.nblk_m = (uint32_t)((M + 127) / 128);
+    a.dCin = make_fastdiv(g->Cin);
+    {
+        const int sz = dtype == SA_F32 ? 4 : 2;
+        const uint64_t ib = (uint64_t)g->N * g->Di * g->Hi * g->Wi * g->Cin * sz, wb = (uint64_t)g->CoutPad * g->Kpad * sz;
+        const bool fits = ib < 0xfffffff0ull - 4096 && wb < 0xfffffff0ull && getenv("SA_NO_DMA") == nullptr;
+        a.in_bytes = fits ? (uint32_t)ib : 0u;
+        a.w_bytes = fits ? (uint32_t)wb : 0u;
+    }
     hipStream_t st = (hipStream_t)stream;
     return dtype == SA_F32 ? dispatch_fprop<float>(a, st) : dispatch_fprop<bf16_t>(a, st);
 }
