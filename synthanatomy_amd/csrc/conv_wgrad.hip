@@ -10,6 +10,8 @@
 //         into "lane = channel, 4 consecutive voxels"; two reads make one mfma_f32_16x16x32_bf16 operand.  32-byte chunks
 //         are XOR-swizzled with (m & 7) so the 8 rows a half-wave touches cover all 64 banks exactly once;
 //   f32 : tiles stay [m][c]; mfma_f32_16x16x4f32 takes one float per lane so fragments are plain ds_read_b32.
+#include <stdlib.h>
+
 #include "sa_common.h"
 
 namespace sa {
@@ -25,6 +27,7 @@ struct WgradArgs {
     uint32_t M, ntaps, ktot;       // ktot = ntaps * Cin
     uint32_t chunks_per_split, nchunks;
     uint32_t nkt, ntiles;
+    uint32_t in_bytes, g_bytes;   // non-zero: both operands addressable with 32-bit buffer offsets (LDS-DMA loader)
     float* ws;            // [split][tile][co 128][kidx 128] partial tiles, or NULL -> fp32 atomics straight into dw
 };
 
@@ -274,6 +277,162 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int MK = WG<T>::MK;
+    constexpr bool IS_BF16 = sizeof(T) == 2;
+    constexpr int TILE_BYTES = IS_BF16 ? 128 * 128 : MK * 128 * 4;  // 16 KB / 8 KB
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem;                   // 2 x TILE
+    unsigned char* sG = smem + 2 * TILE_BYTES;  // 2 x TILE
+
+    const sa_conv_geom& g = a.g;
+    const T* __restrict__ in = (const T*)a.in;
+    const T* __restrict__ go = (const T*)a.gout;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wm = wave >> 1, wn = wave & 1u;
+    // XCD-aware order: block b runs on XCD b % 8 (observed dispatch; speed only).  All (tap, co) tiles of one voxel split are
+    // issued back-to-back on ONE XCD so that the X / G voxel rows they all re-read are served by that XCD's L2 instead
+    // of being fetched once per tap from HBM.
+    const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
+    const uint32_t tile = seq % a.ntiles, split = (seq / a.ntiles) * 8u + xcd;
+    const uint32_t kt = tile % a.nkt, ct = tile / a.nkt;
+    const uint32_t chunk0 = split * a.chunks_per_split;
+    uint32_t chunk1 = chunk0 + a.chunks_per_split;
+    if (chunk1 > a.nchunks) chunk1 = a.nchunks;
+    if (chunk0 >= chunk1) return;
+
+    float4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    // ------------------------------------------------------------------ LDS-DMA loader (buffer_load ... lds)
+    // A 1 KiB piece is 4 voxel rows x 256 B (bf16) or 2 rows x 512 B (fp32); wave w owns pieces 4w..4w+3 (bf16) / 2w, 2w+1 (fp32)
+    // of both tiles.  The DMA writes lane-linearly, so the swizzle is applied to the SOURCE column: bf16 lane l fetches 16-byte
+    // vector (((l&15)>>1) ^ (m&7))*2 + (l&1) of row m (two variants: even / odd piece), fp32 lane l fetches (l&31) ^ ((l>>5)<<2).
+    constexpr int SZ = sizeof(T);
+    constexpr int NPIECE = IS_BF16 ? 4 : 2;      // pieces per wave per tile
+    constexpr int ROWS_PP = IS_BF16 ? 4 : 2;     // rows per piece
+    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)a.gout, 0, (int)a.g_bytes, 0x00020000);
+    const uint32_t prow = IS_BF16 ? (lane >> 4) : (lane >> 5);
+    TapPos tp[2];
+    uint32_t gcol[2];
+    bool gok[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        uint32_t vec;  // source 16-byte vector of the 128-channel row
+        if constexpr (IS_BF16) vec = ((((lane & 15u) >> 1) ^ ((v * 4u + prow) & 7u)) << 1) | (lane & 1u);
+        else vec = (lane & 31u) ^ (prow << 2);
+        constexpr int VE = 16 / SZ;
+        tp[v] = decode_k(kt * 128u + vec * VE, a);
+        if (kt * 128u + vec * VE >= a.ktot) tp[v].ok = false;
+        gcol[v] = ct * 128u + vec * VE;
+        gok[v] = gcol[v] + VE <= (uint32_t)g.Cout;
+    }
+    auto issue = [&](uint32_t chunk, uint32_t buf) __attribute__((always_inline)) {
+        unsigned char* px = sX + buf * TILE_BYTES;
+        unsigned char* pg = sG + buf * TILE_BYTES;
+        const uint32_t mb = chunk * MK;
+#pragma unroll
+        for (int j = 0; j < NPIECE; ++j) {
+            const uint32_t piece = wave * NPIECE + j;
+            const int v = IS_BF16 ? (j & 1) : 0;
+            RowPos r = decode_row(mb + piece * ROWS_PP + prow, a);
+            const bool okx = in_range(r, tp[v], g);
+            const uint32_t xoff = okx ? (uint32_t)(r.ibase + tp[v].off) * (uint32_t)(g.Cin * SZ) + tp[v].c0 * SZ : 0xfffffff0u;
+            const uint32_t goff = (r.ok && gok[v]) ? (uint32_t)r.ovox * (uint32_t)(g.Cout * SZ) + gcol[v] * SZ : 0xfffffff0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)(px + piece * 1024), 16, xoff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, (__attribute__((address_space(3))) void*)(pg + piece * 1024), 16, goff, 0, 0, 0);
+        }
+    };
+
+    issue(chunk0, 0);
+    __syncthreads();
+    const uint32_t frow = lane & 15u, fq = lane >> 4;
+    for (uint32_t c = chunk0; c < chunk1; ++c) {
+        const uint32_t buf = (c - chunk0) & 1u;
+        if (c + 1 < chunk1) issue(c + 1, buf ^ 1u);
+        const unsigned char* px = sX + buf * TILE_BYTES;
+        const unsigned char* pg = sG + buf * TILE_BYTES;
+        if constexpr (IS_BF16) {
+            // lane (group gq = lane>>4, s = lane&15) addresses voxel row 4*gq + (s>>2) and channels 4*(s&3)..+3 of each 16x(4 m) block
+            const uint32_t trow = fq * 4u + (frow >> 2), tcol = (frow & 3u) * 4u;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                short8_t xf[4], gf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const v4s_t lo = lds_tr16(px + roff(ks * 32 + trow, wm * 64 + i * 16 + tcol));
+                    const v4s_t hi = lds_tr16(px + roff(ks * 32 + 16 + trow, wm * 64 + i * 16 + tcol));
+                    xf[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const v4s_t lo = lds_tr16(pg + roff(ks * 32 + trow, wn * 64 + j * 16 + tcol));
+                    const v4s_t hi = lds_tr16(pg + roff(ks * 32 + 16 + trow, wn * 64 + j * 16 + tcol));
+                    gf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], gf[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const uint32_t m = kk * 4u + fq;
+                const uint32_t sw = (m & 1u) << 4;
+                float xf[4], gf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xf[i] = *(const float*)(px + m * 512u + (((wm * 64 + i * 16 + frow) ^ sw) << 2));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gf[j] = *(const float*)(pg + m * 512u + (((wn * 64 + j * 16 + frow) ^ sw) << 2));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[i], gf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // drains the DMA (vmcnt(0)) and frees this buffer
+    }
+
+    // ---- epilogue: lane holds rows kidx = .. + fq*4 + r (4 consecutive ci of one tap), column co = .. + frow
+    if (a.ws) {
+        // partial tile to the workspace (plain 16-byte stores); wgrad_reduce_kernel sums the splits and scatters into dw
+        float* wt = a.ws + ((size_t)split * a.ntiles + tile) * (128 * 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(float4_t*)(wt + (wn * 64 + j * 16 + frow) * 128 + wm * 64 + i * 16 + fq * 4) = acc[i][j];
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t k0 = kt * 128u + wm * 64u + i * 16u + fq * 4u;
+        if (k0 >= a.ktot) continue;
+        const uint32_t tap = fdiv(k0, a.dCin);
+        const uint32_t c0 = k0 - tap * g.Cin;
+        const int64_t tapo = a.lut[tap];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t co = ct * 128u + wn * 64u + j * 16u + frow;
+            if (co >= (uint32_t)g.cout_valid) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (c0 + r >= (uint32_t)g.cin_valid) continue;
+                unsafeAtomicAdd(a.dw + co * a.s_row + (int64_t)(c0 + r) * a.s_red + tapo, acc[i][j][r]);
+            }
+        }
+    }
+#endif
+}
+
 // dw[co][ci][tap] += sum_split ws[split][tile][co][kidx]   (one thread per output element; no atomics)
 __global__ void wgrad_reduce_kernel(const WgradArgs a, uint32_t splits) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;  // tile*16384 + co_l*128 + k_l
@@ -402,8 +561,20 @@ extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, c
     const uint32_t splits8 = (splits + 7u) & ~7u;  // blocks of the padded splits exit immediately
     dim3 grid(a.ntiles * splits8);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SA_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, a);
+    {
+        const int sz = dtype == SA_F32 ? 4 : 2;
+        const uint64_t ib = (uint64_t)g->N * g->Di * g->Hi * g->Wi * g->Cin * sz, gb = (uint64_t)g->N * g->Do * g->Ho * g->Wo * g->Cout * sz;
+        const bool fits = ib < 0xffffff00ull && gb < 0xffffff00ull && getenv("SA_NO_DMA") == nullptr;
+        a.in_bytes = fits ? (uint32_t)ib : 0u;
+        a.g_bytes = fits ? (uint32_t)gb : 0u;
+    }
+    if (a.in_bytes) {
+        if (dtype == SA_F32) hipLaunchKernelGGL(conv_wgrad_dma_kernel<float>, grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(conv_wgrad_dma_kernel<bf16_t>, grid, dim3(256), lds, st, a);
+    } else {
+        if (dtype == SA_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, a);
+    }
     SA_CHECK_LAUNCH();
     if (a.ws) {
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((a.ntiles * 16384u + 255) / 256), dim3(256), 0, st, a, splits);
