@@ -54,7 +54,7 @@ __device__ __forceinline__ void mma_slab<float>(float4_t& acc, const u32x4& wa, 
 __device__ __forceinline__ uint32_t tile_off(uint32_t row, uint32_t vec) { return row * 128u + ((vec ^ (row & 7u)) << 4); }
 
 // ---- epilogue shared by both mainloops, staged through LDS so that HBM sees full channel rows
-template <int BM, int BN, int WM, int WN, int MI, int NI>
+template <int BM, int BN, int WM, int WN, int MI, int NI, int NT = 256>
 __device__ __forceinline__ void fprop_epilogue(const FpropArgs& a, float4_t (&acc)[NI][MI], unsigned char* smem, uint32_t tid, uint32_t wm, uint32_t wn,
                                                uint32_t frow, uint32_t fq, uint32_t m_base, uint32_t n_base) {
     const sa_conv_geom& g = a.g;
@@ -98,7 +98,7 @@ __device__ __forceinline__ void fprop_epilogue(const FpropArgs& a, float4_t (&ac
     const float alpha = ep.alpha ? *ep.alpha : 1.f;
     const bool vec_ok = (g.Cout & 3) == 0;
     constexpr int NG = BN / 4;           // 4-channel groups per voxel row
-    constexpr int RPP = 256 / NG;        // rows per pass
+    constexpr int RPP = NT / NG;         // rows per pass
     const uint32_t grp = tid % NG, r0 = tid / NG;
     const uint32_t co0 = n_base + grp * 4;
     if (co0 < (uint32_t)g.cout_valid) {
@@ -444,6 +444,149 @@ __global__ __launch_bounds__(256) void conv_fprop_dma_kernel(const FpropArgs a) 
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Mainloop v3 (Cout >= 65): 8 waves, tile 256 voxels x 128 channels, THREE-stage LDS ring filled by LDS-DMA two K-slabs
+// ahead.  One raw s_barrier per slab; the DMA queue is never drained inside the loop: `s_waitcnt vmcnt(P)` (P = this wave's
+// pieces per slab) retires exactly the slab about to be read while the next one stays in flight across the barrier.
+//   RAW: slab s is read only after every wave executed vmcnt(P) for it and passed the barrier.
+//   WAR: slab s+2 overwrites the buffer read in step s-1; it is issued after the step-s barrier, which every wave reaches only
+//        after its step s-1 fragment reads have returned (they feed the MFMAs issued before the barrier).
+template <typename T, bool UNIFORM>
+__global__ __launch_bounds__(512) void conv_fprop_dma3_kernel(const FpropArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int WM = 4, WN = 2, MI = 4, NI = 4;
+    constexpr int BM = 256, BN = 128;
+    constexpr int SZ = sizeof(T);
+    constexpr int BKE = 128 / SZ;
+    constexpr int STAGE = (BM + BN) * 128;                 // 48 KiB
+    constexpr int A_PER_WAVE = 4, B_PER_WAVE = 2, P = A_PER_WAVE + B_PER_WAVE;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wm = wave / WN, wn = wave % WN;
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
+    const uint32_t m_base = bm * BM, n_base = bn * BN;
+    const sa_conv_geom& g = a.g;
+
+    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (int)a.w_bytes, 0x00020000);
+
+    const uint32_t prow = lane >> 3;
+    const uint32_t lv = (lane & 7u) ^ prow;
+    uint32_t rowoff[A_PER_WAVE], vm[A_PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j) {
+        const uint32_t m = m_base + (wave * A_PER_WAVE + j) * 8 + prow;
+        rowoff[j] = 0;
+        vm[j] = 0;
+        if (m < a.M) {
+            uint32_t q = fdiv(m, a.dW);
+            const uint32_t wmx = m - q * g.Wm;
+            uint32_t q2 = fdiv(q, a.dH);
+            const uint32_t hmx = q - q2 * g.Hm;
+            const uint32_t n = fdiv(q2, a.dD);
+            const uint32_t dmx = q2 - n * g.Dm;
+            const int32_t id0 = (int32_t)dmx * g.in_mult[0] + g.in_off[0];
+            const int32_t ih0 = (int32_t)hmx * g.in_mult[1] + g.in_off[1];
+            const int32_t iw0 = (int32_t)wmx * g.in_mult[2] + g.in_off[2];
+            rowoff[j] = (uint32_t)((((int32_t)n * g.Di + id0) * g.Hi + ih0) * g.Wi + iw0) * (uint32_t)(g.Cin * SZ);
+            uint32_t mk = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < g.KT[0] && (uint32_t)(id0 + t * g.tap_step[0]) < (uint32_t)g.Di) mk |= 1u << t;
+                if (t < g.KT[1] && (uint32_t)(ih0 + t * g.tap_step[1]) < (uint32_t)g.Hi) mk |= 16u << t;
+                if (t < g.KT[2] && (uint32_t)(iw0 + t * g.tap_step[2]) < (uint32_t)g.Wi) mk |= 256u << t;
+            }
+            vm[j] = mk;
+        }
+    }
+    uint32_t boff[B_PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < B_PER_WAVE; ++j) boff[j] = (n_base + (wave * B_PER_WAVE + j) * 8 + prow) * (uint32_t)(g.Kpad * SZ) + lv * 16u;
+
+    auto issue = [&](uint32_t s, uint32_t buf) __attribute__((always_inline)) {
+        unsigned char* pa = smem + buf * STAGE;
+        unsigned char* pb = pa + BM * 128;
+        uint32_t sel, koff;
+        bool tap_ok;
+        if constexpr (UNIFORM) {
+            const uint32_t ke = s * BKE;
+            const uint32_t tap = fdiv(ke, a.dCin);
+            const uint32_t c0 = ke - tap * g.Cin;
+            const uint32_t td = fdiv(tap, a.dThw);
+            const uint32_t t2 = tap - td * a.dThw.d;
+            const uint32_t th = fdiv(t2, a.dTw);
+            const uint32_t tw = t2 - th * a.dTw.d;
+            const int32_t vox = (((int32_t)td * g.tap_step[0]) * g.Hi + (int32_t)th * g.tap_step[1]) * g.Wi + (int32_t)tw * g.tap_step[2];
+            koff = (uint32_t)vox * (uint32_t)(g.Cin * SZ) + c0 * SZ + lv * 16u;
+            sel = (1u << td) | (16u << th) | (256u << tw);
+            tap_ok = tap < a.ntaps;
+        } else {
+            const uint32_t kv = s * 8u + lv;
+            const uint32_t tap = fdiv(kv, a.dCv);
+            const uint32_t cv = kv - tap * a.dCv.d;
+            const uint32_t td = fdiv(tap, a.dThw);
+            const uint32_t t2 = tap - td * a.dThw.d;
+            const uint32_t th = fdiv(t2, a.dTw);
+            const uint32_t tw = t2 - th * a.dTw.d;
+            const int32_t vox = (((int32_t)td * g.tap_step[0]) * g.Hi + (int32_t)th * g.tap_step[1]) * g.Wi + (int32_t)tw * g.tap_step[2];
+            koff = (uint32_t)vox * (uint32_t)(g.Cin * SZ) + cv * 16u;
+            sel = (1u << td) | (16u << th) | (256u << tw);
+            tap_ok = tap < a.ntaps;
+        }
+#pragma unroll
+        for (int j = 0; j < A_PER_WAVE; ++j) {
+            const bool ok = tap_ok && (vm[j] & sel) == sel;
+            const uint32_t voff = ok ? rowoff[j] + koff : OOB_OFF;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(pa + (wave * A_PER_WAVE + j) * 1024), 16, voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER_WAVE; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(pb + (wave * B_PER_WAVE + j) * 1024), 16, boff[j], s * 128u,
+                                                     0, 0);
+    };
+
+    float4_t acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t nk = a.nk;
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    const uint32_t frow = lane & 15u, fq = lane >> 4;
+    uint32_t buf = 0;
+    for (uint32_t s = 0; s < nk; ++s) {
+        // retire slab s (keep slab s+1 in flight), then rendezvous
+        if (s + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 2 < nk) issue(s + 2, buf >= 1 ? buf - 1 : 2);  // (s+2) % 3 == (buf + 2) % 3
+        const unsigned char* pa = smem + buf * STAGE;
+        const unsigned char* pb = pa + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 xf[MI], wf[NI];
+#pragma unroll
+            for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(pa + tile_off(wm * (MI * 16) + j * 16 + frow, ks * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + tile_off(wn * (NI * 16) + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    __syncthreads();  // every wave is done reading the ring before the epilogue reuses it
+    fprop_epilogue<BM, BN, WM, WN, MI, NI, 512>(a, acc, smem, tid, wm, wn, frow, fq, m_base, n_base);
+#endif
+}
+
 template <typename T, int WM, int WN, int MI, int NI>
 static int launch_fprop(const FpropArgs& a, hipStream_t st) {
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
@@ -467,8 +610,32 @@ static int launch_fprop(const FpropArgs& a, hipStream_t st) {
 }
 
 template <typename T>
+static int launch_fprop3(FpropArgs a, hipStream_t st) {
+    a.nblk_m = (a.M + 255) / 256;
+    const uint32_t nbn_valid = ((uint32_t)a.g.cout_valid + 127) / 128;
+    const size_t ring = 3 * (256 + 128) * 128, epi = (size_t)256 * (128 + 4) * 4 + 256 * 8;
+    const size_t lds = ring > epi ? ring : epi;
+    const bool uniform = ((size_t)a.g.Cin * sizeof(T)) % 128 == 0;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)conv_fprop_dma3_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)conv_fprop_dma3_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    dim3 grid(a.nblk_m * nbn_valid);
+    if (uniform) hipLaunchKernelGGL((conv_fprop_dma3_kernel<T, true>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((conv_fprop_dma3_kernel<T, false>), grid, dim3(512), lds, st, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
 static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
     const int cv = a.g.cout_valid;
+    // v3 (3-stage ring, 8 waves) measured equal to v2 (2 stages, 4 waves, 2 blocks/CU) on MI355X: 741/844 vs 763/849 TFLOP/s on
+    // the 3x3x3 C=128 layer -- the DMA latency is not what bounds this loop -- so v2 stays the default (SA_DMA3=1 selects v3).
+    static const bool use3 = getenv("SA_DMA3") != nullptr;
+    if (cv > 64 && a.in_bytes != 0 && a.M >= 256 * 256 && use3) return launch_fprop3<T>(a, st);
     if (cv > 64) return launch_fprop<T, 2, 2, 4, 4>(a, st);
     if (cv > 32) return launch_fprop<T, 4, 1, 2, 4>(a, st);
     if (cv > 16) return launch_fprop<T, 4, 1, 2, 2>(a, st);

@@ -10,6 +10,7 @@ Everything here runs on the HIP device through the C ABI; there is no CPU path.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -49,10 +50,17 @@ class KernelTimer:
 TIMER: Optional[KernelTimer] = None  # set by bench.py around the timed region
 
 
-def _fprop_instance(dtype, cout_valid):
+def _fprop_instance(dtype, g):
+    """Name of the kernel instance csrc/conv_fprop.hip's dispatch picks for this geometry (same granularity as rocprofv3)."""
     t = "f32" if dtype == torch.float32 else "bf16"
-    tile = "2,2,4,4" if cout_valid > 64 else ("4,1,2,4" if cout_valid > 32 else ("4,1,2,2" if cout_valid > 16 else "4,1,2,1"))
-    return f"conv_fprop_kernel<{t},{tile}>"
+    cv = g.cout_valid
+    m = g.N * g.Dm * g.Hm * g.Wm
+    sz = 4 if dtype == torch.float32 else 2
+    fits = g.N * g.Di * g.Hi * g.Wi * g.Cin * sz < 0xfffffff0 - 4096
+    if cv > 64 and fits and m >= 256 * 256 and os.environ.get("SA_DMA3"):
+        return f"conv_fprop_dma3_kernel<{t}>"
+    tile = "2,2,4,4" if cv > 64 else ("4,1,2,4" if cv > 32 else ("4,1,2,2" if cv > 16 else "4,1,2,1"))
+    return f"conv_fprop_dma_kernel<{t},{tile}>" if fits else f"conv_fprop_kernel<{t},{tile}>"
 
 
 def _geom_flops(g) -> float:
@@ -254,7 +262,7 @@ class ConvOp:
         ep = self._epilogue(self._bias_padded() if use_bias else None, addend, mask, alpha, act, mask_mode, add_before_act, out_dtype, slope)
         lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
         for pl in plans["fwd"]:
-            _launch(_fprop_instance(self.dtype, pl.geom.cout_valid), _geom_flops(pl.geom),
+            _launch(_fprop_instance(self.dtype, pl.geom), _geom_flops(pl.geom),
                     lambda pl=pl: _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(x), _ffi.ptr(pl.wpk), _ffi.ptr(out), ctypes.byref(ep), st),
                                              "sa_conv_fprop"))
         return out
@@ -277,7 +285,7 @@ class ConvOp:
         ep = self._epilogue(None, addend, mask, None, ACT_NONE, mask_mode, False, out_dtype, slope)
         lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
         for pl in plans["dgrad"]:
-            _launch(_fprop_instance(self.dtype, pl.geom.cout_valid), _geom_flops(pl.geom),
+            _launch(_fprop_instance(self.dtype, pl.geom), _geom_flops(pl.geom),
                     lambda pl=pl: _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(g), _ffi.ptr(pl.wpk), _ffi.ptr(dx), ctypes.byref(ep), st),
                                              "sa_conv_fprop(dgrad)"))
         return dx
@@ -289,7 +297,7 @@ class ConvOp:
         assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.shape == self.weight.shape
         plans = self._get_plans(N, (D, H, W), fwd_out_stride or self.cout, g.shape[-1])
         lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
-        wname = "conv_wgrad_kernel<%s>" % ("f32" if self.dtype == torch.float32 else "bf16")
+        wname = "conv_wgrad_dma_kernel<%s>" % ("f32" if self.dtype == torch.float32 else "bf16")
         for pl in plans["wgrad"]:
             nbytes = lib.sa_conv_wgrad_workspace_bytes(ctypes.byref(pl.geom), did)
             if nbytes < 0:
