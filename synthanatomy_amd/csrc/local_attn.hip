@@ -1,0 +1,288 @@
+// Causal local-window attention on the exact-fp32 MFMA (mfma_f32_16x16x4f32) -- replaces local_attention.LocalAttention
+// (window W, look_backward = 1, look_forward = 0, causal) behind performer_pytorch's SelfAttention for the local heads
+// (reference src/networks/transformers/performer.py:194-219 with local_attn_heads > 0).  q and k arrive already rotated (sa_rotary).
+//
+// Query i attends keys j with  max(0, (i/W - 1) W) <= j <= i.  Flash-style tiling, 64 queries x 64 keys per step, fp32 throughout:
+//   forward   block = 64 queries of one (batch, head); wave = 16 queries.  S^T = K Q^T (keys on MFMA rows, queries on columns) so that
+//             every lane owns ONE query: the online softmax is a per-lane max/sum over its 16 scores plus two cross-group shuffles,
+//             and the probabilities feed O^T += V^T P^T straight from the accumulator registers (no transposition through LDS).
+//   backward  dq: same walk with dP^T = V dO^T, dS = P (dP - D), dQ^T += K^T dS^T.
+//             dk/dv: block = 64 keys (wave = 16 keys held in registers), walking the query tiles that can see them:
+//             S = Q K^T, dV^T += dO^T P, dK^T += Q^T dS.
+// Alg. FLOPs: 4 * 64 per (query, key) pair forward, 10 * 64 backward.
+#include "sa_common.h"
+
+namespace sa {
+
+struct LAArgs {
+    const float *q, *k, *v, *out, *dout, *lse_in, *Dbuf_in;
+    float *o, *lse_out, *dq, *dk, *dv, *Dbuf_out;
+    int32_t q_stride, q_off, k_stride, k_off, v_stride, v_off, o_stride, o_off;
+    int32_t B, N, L, W;
+    float scale;
+};
+
+constexpr int LT = 64;   // tile edge
+constexpr int LLD = 68;  // LDS row stride in floats
+
+// rows [row0, row0+64) x 64 floats of head block (stride, off) -> LDS tile, zero beyond N, optional scale
+__device__ __forceinline__ void la_load_tile(float* dst, const float* src, int stride, int off, int64_t rowbase, int row0, int N, float scale, int tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = (tid >> 4) + 16 * it, c4 = tid & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < N) v = *(const float4*)(src + (rowbase + row0 + r) * stride + off + c4 * 4);
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        *(float4*)(dst + r * LLD + c4 * 4) = v;
+    }
+}
+
+__device__ __forceinline__ bool la_allowed(int i, int j, int W, int N) {
+    const int lo = max(0, (i / W - 1) * W);
+    return j <= i && j >= lo && j < N && i < N;
+}
+
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// MODE 0: forward (o, lse)   MODE 1: backward wrt q (dq, D)
+template <int MODE>
+__global__ __launch_bounds__(256) void local_attn_q_kernel(const LAArgs a) {
+    __shared__ __attribute__((aligned(16))) float sK[LT * LLD], sV[LT * LLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = lane & 15, g = lane >> 4;
+    const int nqt = (a.N + LT - 1) / LT;
+    const int qt = blockIdx.x % nqt, h = (blockIdx.x / nqt) % a.L, b = blockIdx.x / (nqt * a.L);
+    const int q0 = qt * LT;
+    const int iq = q0 + wave * 16 + qi;
+    const bool vq = iq < a.N;
+    const int64_t rb = (int64_t)b * a.N;
+    const int qoff = a.q_off + h * 64, koff = a.k_off + h * 64, voff = a.v_off + h * 64, ooff = a.o_off + h * 64;
+
+    float Qreg[16], Greg[16];  // B operands: scaled q (and dO in backward) of this lane's query, d = dd*4 + g
+    float lse = 0.f, Dv = 0.f;
+#pragma unroll
+    for (int dd = 0; dd < 16; ++dd) {
+        Qreg[dd] = vq ? a.q[(rb + iq) * a.q_stride + qoff + dd * 4 + g] * a.scale : 0.f;
+        Greg[dd] = 0.f;
+    }
+    if (MODE == 1) {
+        float part = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < 16; ++dd) {
+            const float dov = vq ? a.dout[(rb + iq) * a.o_stride + ooff + dd * 4 + g] : 0.f;
+            const float ov = vq ? a.out[(rb + iq) * a.o_stride + ooff + dd * 4 + g] : 0.f;
+            Greg[dd] = dov;
+            part += dov * ov;
+        }
+        Dv = group_sum(part);
+        lse = vq ? a.lse_in[(rb + iq) * a.L + h] : 0.f;
+        if (vq && g == 0) a.Dbuf_out[(rb + iq) * a.L + h] = Dv;
+    }
+    float m_run = -1e30f, l_run = 0.f;
+    float4_t acc[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) acc[df] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int kt_lo = max(0, (q0 / a.W - 1) * a.W) / LT;
+    const int kt_hi = min(a.N - 1, q0 + LT - 1) / LT;
+    for (int kt = kt_lo; kt <= kt_hi; ++kt) {
+        __syncthreads();
+        la_load_tile(sK, a.k, a.k_stride, koff, rb, kt * LT, a.N, 1.f, tid);
+        la_load_tile(sV, a.v, a.v_stride, voff, rb, kt * LT, a.N, 1.f, tid);
+        __syncthreads();
+        float4_t s[4], dp[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            dp[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dd = 0; dd < 16; ++dd) {
+                s[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(sK[(f * 16 + qi) * LLD + dd * 4 + g], Qreg[dd], s[f], 0, 0, 0);
+                if (MODE == 1) dp[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(sV[(f * 16 + qi) * LLD + dd * 4 + g], Greg[dd], dp[f], 0, 0, 0);
+            }
+        }
+        // lane element (f, r) <-> key j = kt*64 + f*16 + g*4 + r, query iq
+        float4_t p[4];
+        if (MODE == 0) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (la_allowed(iq, kt * LT + f * 16 + g * 4 + r, a.W, a.N)) mx = fmaxf(mx, s[f][r]);
+            mx = group_max(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __expf(m_run - m_new);
+            float ls = 0.f;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = la_allowed(iq, kt * LT + f * 16 + g * 4 + r, a.W, a.N) ? __expf(s[f][r] - m_new) : 0.f;
+                    p[f][r] = pv;
+                    ls += pv;
+                }
+            ls = group_sum(ls);
+            l_run = l_run * alpha + ls;
+            m_run = m_new;
+#pragma unroll
+            for (int df = 0; df < 4; ++df) acc[df] *= alpha;
+        } else {
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = la_allowed(iq, kt * LT + f * 16 + g * 4 + r, a.W, a.N) ? __expf(s[f][r] - lse) : 0.f;
+                    p[f][r] = pv * (dp[f][r] - Dv);  // dS
+                }
+        }
+        const float* sR = MODE == 0 ? sV : sK;  // forward: O^T += V^T P^T ; backward: dQ^T += K^T dS^T
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(sR[(f * 16 + g * 4 + r) * LLD + df * 16 + qi], p[f][r], acc[df], 0, 0, 0);
+    }
+    if (!vq) return;
+    if (MODE == 0) {
+        const float inv = 1.f / l_run;
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+            *(float4*)(a.o + (rb + iq) * a.o_stride + ooff + df * 16 + g * 4) = make_float4(acc[df][0] * inv, acc[df][1] * inv, acc[df][2] * inv, acc[df][3] * inv);
+        if (g == 0) a.lse_out[(rb + iq) * a.L + h] = m_run + __logf(l_run);
+    } else {
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+            *(float4*)(a.dq + (rb + iq) * a.q_stride + qoff + df * 16 + g * 4) =
+                make_float4(acc[df][0] * a.scale, acc[df][1] * a.scale, acc[df][2] * a.scale, acc[df][3] * a.scale);
+    }
+}
+
+// dk / dv: block = 64 keys of one (batch, head); wave = 16 keys (K, V rows in registers as MFMA B operands)
+__global__ __launch_bounds__(256) void local_attn_kv_kernel(const LAArgs a) {
+    __shared__ __attribute__((aligned(16))) float sQ[LT * LLD], sG[LT * LLD];
+    __shared__ float sLse[LT], sD[LT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kc = lane & 15, g = lane >> 4;
+    const int nkt = (a.N + LT - 1) / LT;
+    const int kt = blockIdx.x % nkt, h = (blockIdx.x / nkt) % a.L, b = blockIdx.x / (nkt * a.L);
+    const int kj = kt * LT + wave * 16 + kc;
+    const bool vk = kj < a.N;
+    const int64_t rb = (int64_t)b * a.N;
+    const int qoff = a.q_off + h * 64, koff = a.k_off + h * 64, voff = a.v_off + h * 64, ooff = a.o_off + h * 64;
+    float Kreg[16], Vreg[16];
+#pragma unroll
+    for (int dd = 0; dd < 16; ++dd) {
+        Kreg[dd] = vk ? a.k[(rb + kj) * a.k_stride + koff + dd * 4 + g] : 0.f;
+        Vreg[dd] = vk ? a.v[(rb + kj) * a.v_stride + voff + dd * 4 + g] : 0.f;
+    }
+    float4_t dka[4], dva[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+        dka[df] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        dva[df] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    const int last_key = min(a.N - 1, kt * LT + LT - 1);
+    const int hi = min(a.N - 1, (last_key / a.W + 2) * a.W - 1);  // last query that can see a key of this tile
+    for (int qt = kt; qt <= hi / LT; ++qt) {
+        __syncthreads();
+        la_load_tile(sQ, a.q, a.q_stride, qoff, rb, qt * LT, a.N, a.scale, tid);
+        la_load_tile(sG, a.dout, a.o_stride, ooff, rb, qt * LT, a.N, 1.f, tid);
+        if (tid < LT) {
+            const int i = qt * LT + tid;
+            sLse[tid] = i < a.N ? a.lse_in[(rb + i) * a.L + h] : 0.f;
+            sD[tid] = i < a.N ? a.Dbuf_in[(rb + i) * a.L + h] : 0.f;
+        }
+        __syncthreads();
+        float4_t s[4], dp[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            dp[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dd = 0; dd < 16; ++dd) {
+                s[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(sQ[(f * 16 + kc) * LLD + dd * 4 + g], Kreg[dd], s[f], 0, 0, 0);
+                dp[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(sG[(f * 16 + kc) * LLD + dd * 4 + g], Vreg[dd], dp[f], 0, 0, 0);
+            }
+        }
+        // lane element (f, r) <-> query i = qt*64 + f*16 + g*4 + r, key kj
+        float4_t p[4], ds[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int il = f * 16 + g * 4 + r;
+                const float pv = la_allowed(qt * LT + il, kj, a.W, a.N) ? __expf(s[f][r] - sLse[il]) : 0.f;
+                p[f][r] = pv;
+                ds[f][r] = pv * (dp[f][r] - sD[il]);
+            }
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = (f * 16 + g * 4 + r) * LLD + df * 16 + kc;
+                    dva[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(sG[row], p[f][r], dva[df], 0, 0, 0);
+                    dka[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(sQ[row], ds[f][r], dka[df], 0, 0, 0);
+                }
+    }
+    if (!vk) return;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+        *(float4*)(a.dv + (rb + kj) * a.v_stride + voff + df * 16 + g * 4) = make_float4(dva[df][0], dva[df][1], dva[df][2], dva[df][3]);
+        *(float4*)(a.dk + (rb + kj) * a.k_stride + koff + df * 16 + g * 4) = make_float4(dka[df][0], dka[df][1], dka[df][2], dka[df][3]);
+    }
+}
+
+static int fill_la(LAArgs& a, int q_stride, int q_off, int k_stride, int k_off, int v_stride, int v_off, int o_stride, int o_off, int B, int N, int L, int W,
+                   int dh) {
+    if (dh != 64 || B <= 0 || N <= 0 || L <= 0 || W <= 0) return SA_EUNSUPPORTED;
+    if ((q_stride | q_off | k_stride | k_off | v_stride | v_off | o_stride | o_off) & 3) return SA_EINVAL;  // 16-byte rows
+    a.q_stride = q_stride; a.q_off = q_off; a.k_stride = k_stride; a.k_off = k_off; a.v_stride = v_stride; a.v_off = v_off; a.o_stride = o_stride; a.o_off = o_off;
+    a.B = B; a.N = N; a.L = L; a.W = W;
+    a.scale = 1.f / sqrtf((float)dh);
+    return 0;
+}
+
+}  // namespace sa
+
+using namespace sa;
+
+extern "C" int sa_local_attn_fwd(const float* q, int q_stride, int q_off, const float* k, int k_stride, int k_off, const float* v, int v_stride, int v_off,
+                                 float* o, int o_stride, int o_off, float* lse, int B, int N, int L, int W, int dh, void* stream) {
+    if (!q || !k || !v || !o || !lse) return SA_EINVAL;
+    LAArgs a = {};
+    const int rc = fill_la(a, q_stride, q_off, k_stride, k_off, v_stride, v_off, o_stride, o_off, B, N, L, W, dh);
+    if (rc) return rc;
+    a.q = q; a.k = k; a.v = v; a.o = o; a.lse_out = lse;
+    const unsigned nblk = (unsigned)(B * L * ((N + LT - 1) / LT));
+    hipLaunchKernelGGL(local_attn_q_kernel<0>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_local_attn_bwd(const float* q, int q_stride, int q_off, const float* k, int k_stride, int k_off, const float* v, int v_stride, int v_off,
+                                 const float* out, const float* dout, int o_stride, int o_off, const float* lse, float* dq, float* dk, float* dv,
+                                 float* Dbuf, int B, int N, int L, int W, int dh, void* stream) {
+    if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !Dbuf) return SA_EINVAL;
+    LAArgs a = {};
+    const int rc = fill_la(a, q_stride, q_off, k_stride, k_off, v_stride, v_off, o_stride, o_off, B, N, L, W, dh);
+    if (rc) return rc;
+    a.q = q; a.k = k; a.v = v; a.out = out; a.dout = dout; a.lse_in = lse; a.dq = dq; a.dk = dk; a.dv = dv; a.Dbuf_out = Dbuf; a.Dbuf_in = Dbuf;
+    const unsigned nblk = (unsigned)(B * L * ((N + LT - 1) / LT));
+    hipLaunchKernelGGL(local_attn_q_kernel<1>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    SA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(local_attn_kv_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}

@@ -480,160 +480,6 @@ __global__ void rotary_kernel(const float* __restrict__ x, int stride, int off, 
     }
 }
 
-// ------------------------------------------------------------------------------------------------ local window attention
-// q,k,v rows: [B*N, stride] with the local head hl at column off + hl*64 (dh == 64).  One wave per (b, n, hl).
-struct LocalArgs {
-    const float *q, *k, *v, *dout, *out, *lse;
-    float *o, *lse_out, *dq, *dk, *dv, *Dbuf;
-    int32_t q_stride, q_off, k_stride, k_off, v_stride, v_off, o_stride, o_off;
-    int32_t B, N, L, W;
-    float scale;
-};
-
-constexpr int LOC_MAXK = 1024;  // >= 2 * window
-
-__global__ __launch_bounds__(256) void local_attn_fwd_kernel(const LocalArgs a) {
-    __shared__ float sp[4][LOC_MAXK];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + w;
-    if (wid >= (int64_t)a.B * a.N * a.L) return;
-    const int hl = (int)(wid % a.L);
-    const int n = (int)((wid / a.L) % a.N);
-    const int b = (int)(wid / ((int64_t)a.L * a.N));
-    const int lo = max(0, (n / a.W - 1) * a.W);
-    const int nk = n - lo + 1;
-    const int64_t rq = (int64_t)b * a.N + n;
-    const float* qp = a.q + rq * a.q_stride + a.q_off + hl * 64;
-    float qv[64];
-#pragma unroll
-    for (int d = 0; d < 64; d += 4) {
-        const float4 t4 = *(const float4*)(qp + d);
-        qv[d] = t4.x; qv[d + 1] = t4.y; qv[d + 2] = t4.z; qv[d + 3] = t4.w;
-    }
-    float mx = -INFINITY;
-    for (int j0 = 0; j0 < nk; j0 += 64) {
-        const int j = j0 + lane;
-        float s = -INFINITY;
-        if (j < nk) {
-            const float* kp = a.k + ((int64_t)b * a.N + lo + j) * a.k_stride + a.k_off + hl * 64;
-            float acc = 0.f;
-#pragma unroll
-            for (int d = 0; d < 64; d += 4) {
-                const float4 t4 = *(const float4*)(kp + d);
-                acc = fmaf(qv[d], t4.x, acc); acc = fmaf(qv[d + 1], t4.y, acc); acc = fmaf(qv[d + 2], t4.z, acc); acc = fmaf(qv[d + 3], t4.w, acc);
-            }
-            s = acc * a.scale;
-            sp[w][j] = s;
-        }
-        mx = fmaxf(mx, s);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    float sum = 0.f;
-    for (int j = lane; j < nk; j += 64) {
-        const float p = __expf(sp[w][j] - mx);
-        sp[w][j] = p;
-        sum += p;
-    }
-    sum = wave_sum(sum);
-    float acc = 0.f;  // lane = output column
-    for (int j = 0; j < nk; ++j) acc = fmaf(sp[w][j], a.v[((int64_t)b * a.N + lo + j) * a.v_stride + a.v_off + hl * 64 + lane], acc);
-    a.o[rq * a.o_stride + a.o_off + hl * 64 + lane] = acc / sum;
-    if (lane == 0) a.lse_out[rq * a.L + hl] = mx + __logf(sum);
-}
-
-// dq_i = scale * sum_j dS_ij k_j,  dS_ij = p_ij (dO_i.v_j - D_i),  D_i = dO_i.O_i  (also written to Dbuf for the kv pass)
-__global__ __launch_bounds__(256) void local_attn_bwd_q_kernel(const LocalArgs a) {
-    __shared__ float sp[4][LOC_MAXK];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + w;
-    if (wid >= (int64_t)a.B * a.N * a.L) return;
-    const int hl = (int)(wid % a.L);
-    const int n = (int)((wid / a.L) % a.N);
-    const int b = (int)(wid / ((int64_t)a.L * a.N));
-    const int lo = max(0, (n / a.W - 1) * a.W);
-    const int nk = n - lo + 1;
-    const int64_t rq = (int64_t)b * a.N + n;
-    const float* qp = a.q + rq * a.q_stride + a.q_off + hl * 64;
-    const float* dop = a.dout + rq * a.o_stride + a.o_off + hl * 64;
-    const float* op = a.out + rq * a.o_stride + a.o_off + hl * 64;
-    float qv[64], dov[64];
-#pragma unroll
-    for (int d = 0; d < 64; ++d) {
-        qv[d] = qp[d];
-        dov[d] = dop[d];
-    }
-    const float D = wave_sum(dop[lane] * op[lane]);
-    const float lse = a.lse[rq * a.L + hl];
-    if (lane == 0) a.Dbuf[rq * a.L + hl] = D;
-    for (int j0 = 0; j0 < nk; j0 += 64) {
-        const int j = j0 + lane;
-        if (j < nk) {
-            const int64_t rk = (int64_t)b * a.N + lo + j;
-            const float* kp = a.k + rk * a.k_stride + a.k_off + hl * 64;
-            const float* vp = a.v + rk * a.v_stride + a.v_off + hl * 64;
-            float s = 0.f, dp = 0.f;
-#pragma unroll
-            for (int d = 0; d < 64; ++d) {
-                s = fmaf(qv[d], kp[d], s);
-                dp = fmaf(dov[d], vp[d], dp);
-            }
-            const float p = __expf(s * a.scale - lse);
-            sp[w][j] = p * (dp - D);
-        }
-    }
-    float acc = 0.f;
-    for (int j = 0; j < nk; ++j) acc = fmaf(sp[w][j], a.k[((int64_t)b * a.N + lo + j) * a.k_stride + a.k_off + hl * 64 + lane], acc);
-    a.dq[rq * a.q_stride + a.q_off + hl * 64 + lane] = acc * a.scale;
-}
-
-// one wave per key j: queries i in [j, min(N-1, (j/W + 2) W - 1)];  dv_j = sum_i p_ij dO_i ; dk_j = scale * sum_i dS_ij q_i
-__global__ __launch_bounds__(256) void local_attn_bwd_kv_kernel(const LocalArgs a) {
-    __shared__ float sp[4][LOC_MAXK], sd[4][LOC_MAXK];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + w;
-    if (wid >= (int64_t)a.B * a.N * a.L) return;
-    const int hl = (int)(wid % a.L);
-    const int j = (int)((wid / a.L) % a.N);
-    const int b = (int)(wid / ((int64_t)a.L * a.N));
-    const int hi = min(a.N - 1, (j / a.W + 2) * a.W - 1);
-    const int nq = hi - j + 1;
-    const int64_t rk = (int64_t)b * a.N + j;
-    const float* kp = a.k + rk * a.k_stride + a.k_off + hl * 64;
-    const float* vp = a.v + rk * a.v_stride + a.v_off + hl * 64;
-    float kv_[64], vv[64];
-#pragma unroll
-    for (int d = 0; d < 64; ++d) {
-        kv_[d] = kp[d];
-        vv[d] = vp[d];
-    }
-    for (int i0 = 0; i0 < nq; i0 += 64) {
-        const int i = i0 + lane;
-        if (i < nq) {
-            const int64_t rq = (int64_t)b * a.N + j + i;
-            const float* qp = a.q + rq * a.q_stride + a.q_off + hl * 64;
-            const float* dop = a.dout + rq * a.o_stride + a.o_off + hl * 64;
-            float s = 0.f, dp = 0.f;
-#pragma unroll
-            for (int d = 0; d < 64; ++d) {
-                s = fmaf(qp[d], kv_[d], s);
-                dp = fmaf(dop[d], vv[d], dp);
-            }
-            const float p = __expf(s * a.scale - a.lse[rq * a.L + hl]);
-            sp[w][i] = p;
-            sd[w][i] = p * (dp - a.Dbuf[rq * a.L + hl]);
-        }
-    }
-    float accv = 0.f, acck = 0.f;
-    for (int i = 0; i < nq; ++i) {
-        const int64_t rq = (int64_t)b * a.N + j + i;
-        accv = fmaf(sp[w][i], a.dout[rq * a.o_stride + a.o_off + hl * 64 + lane], accv);
-        acck = fmaf(sd[w][i], a.q[rq * a.q_stride + a.q_off + hl * 64 + lane], acck);
-    }
-    a.dv[rk * a.v_stride + a.v_off + hl * 64 + lane] = accv;
-    a.dk[rk * a.k_stride + a.k_off + hl * 64 + lane] = acck * a.scale;
-}
-
 // ------------------------------------------------------------------------------------------------ cross entropy (one wave per row)
 __global__ void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, int64_t R, int V, float* __restrict__ loss_sum,
                           void* dlogits, int d_dtype, float gscale) {
@@ -828,42 +674,6 @@ extern "C" int sa_rotary(const float* x, int stride, int off, int L, int dh, con
     if (!x || !cosb || !sinb || !y || L <= 0 || dh <= 0 || (dh & 1) || R <= 0) return SA_EINVAL;
     hipLaunchKernelGGL(rotary_kernel, dim3(grid1d(R * L * dh)), dim3(256), 0, ST(stream), x, stride, off, L, dh, cosb, sinb, y, y_stride, y_off, N, R,
                        transpose, accumulate);
-    SA_CHECK_LAUNCH();
-    return 0;
-}
-
-static int fill_local(LocalArgs& a, int q_stride, int q_off, int k_stride, int k_off, int v_stride, int v_off, int o_stride, int o_off, int B, int N, int L, int W,
-                      int dh) {
-    if (dh != 64 || 2 * W > LOC_MAXK || B <= 0 || N <= 0 || L <= 0 || W <= 0) return SA_EUNSUPPORTED;
-    a.q_stride = q_stride; a.q_off = q_off; a.k_stride = k_stride; a.k_off = k_off; a.v_stride = v_stride; a.v_off = v_off; a.o_stride = o_stride; a.o_off = o_off;
-    a.B = B; a.N = N; a.L = L; a.W = W;
-    a.scale = 1.f / sqrtf((float)dh);
-    return 0;
-}
-
-extern "C" int sa_local_attn_fwd(const float* q, int q_stride, int q_off, const float* k, int k_stride, int k_off, const float* v, int v_stride, int v_off,
-                                 float* o, int o_stride, int o_off, float* lse, int B, int N, int L, int W, int dh, void* stream) {
-    if (!q || !k || !v || !o || !lse) return SA_EINVAL;
-    LocalArgs a = {};
-    if (fill_local(a, q_stride, q_off, k_stride, k_off, v_stride, v_off, o_stride, o_off, B, N, L, W, dh)) return SA_EUNSUPPORTED;
-    a.q = q; a.k = k; a.v = v; a.o = o; a.lse_out = lse;
-    const int64_t waves = (int64_t)B * N * L;
-    hipLaunchKernelGGL(local_attn_fwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ST(stream), a);
-    SA_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int sa_local_attn_bwd(const float* q, int q_stride, int q_off, const float* k, int k_stride, int k_off, const float* v, int v_stride, int v_off,
-                                 const float* out, const float* dout, int o_stride, int o_off, const float* lse, float* dq, float* dk, float* dv,
-                                 float* Dbuf, int B, int N, int L, int W, int dh, void* stream) {
-    if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !Dbuf) return SA_EINVAL;
-    LocalArgs a = {};
-    if (fill_local(a, q_stride, q_off, k_stride, k_off, v_stride, v_off, o_stride, o_off, B, N, L, W, dh)) return SA_EUNSUPPORTED;
-    a.q = q; a.k = k; a.v = v; a.out = out; a.dout = dout; a.lse = lse; a.dq = dq; a.dk = dk; a.dv = dv; a.Dbuf = Dbuf;
-    const int64_t waves = (int64_t)B * N * L;
-    hipLaunchKernelGGL(local_attn_bwd_q_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ST(stream), a);
-    SA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(local_attn_bwd_kv_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ST(stream), a);
     SA_CHECK_LAUNCH();
     return 0;
 }

@@ -163,3 +163,27 @@ def test_sample_post_processing_and_greedy_path():
         x = torch.cat((x, nxt), 1)
     ref = x[:, 1:][:, o.get_revert_sequence_ordering()].reshape(2, *shape)
     assert torch.equal(got.cpu(), ref)
+
+
+@pytest.mark.parametrize("N,W", [(23, 5), (100, 420), (150, 64), (200, 70)])
+def test_local_attention_backward_kernels_against_autograd(N, W):
+    from synthanatomy_amd import _ffi
+    lib, st = _ffi.lib(), _ffi.stream()
+    torch.manual_seed(N + W)
+    B, L, dh = 2, 2, 64
+    q, k, v = (torch.randn(B, L, N, dh, requires_grad=True) for _ in range(3))
+    ref = P.local_attention(q, k, v, W, rotary=False)
+    go = torch.randn_like(ref)
+    ref.backward(go)
+    pack = lambda t: t.detach().permute(0, 2, 1, 3).reshape(B * N, L * dh).contiguous().cuda()
+    qd, kd, vd, god = pack(q), pack(k), pack(v), pack(go)
+    o = torch.empty_like(qd)
+    lse = torch.empty(B * N * L, device="cuda")
+    _ffi.check(lib.sa_local_attn_fwd(_ffi.ptr(qd), L * dh, 0, _ffi.ptr(kd), L * dh, 0, _ffi.ptr(vd), L * dh, 0, _ffi.ptr(o), L * dh, 0, _ffi.ptr(lse), B, N, L, W, dh, st))
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    Db = torch.empty(B * N * L, device="cuda")
+    _ffi.check(lib.sa_local_attn_bwd(_ffi.ptr(qd), L * dh, 0, _ffi.ptr(kd), L * dh, 0, _ffi.ptr(vd), L * dh, 0, _ffi.ptr(o), _ffi.ptr(god), L * dh, 0, _ffi.ptr(lse),
+                                     _ffi.ptr(dq), _ffi.ptr(dk), _ffi.ptr(dv), _ffi.ptr(Db), B, N, L, W, dh, st))
+    unpack = lambda t: t.view(B, N, L, dh).permute(0, 2, 1, 3)
+    assert _rel(unpack(o), ref) < 1e-4
+    assert _rel(unpack(dq), q.grad) < 1e-4 and _rel(unpack(dk), k.grad) < 1e-4 and _rel(unpack(dv), v.grad) < 1e-4
