@@ -143,13 +143,17 @@ int sa_favor_features_bwd(const float *dfeat, const float *feat, const float *dd
 int sa_favor_projection(const float *blocks, const float *rows, float *out, int nblk, int m, int d, void *stream);
 /* causal running-state scans replacing fast_transformers' CausalDotProduct (forward and both backward directions):
  *   scan_a: T[m][d] += a_i[m] b_i[d] ; y_i[d] = (sum_m c_i[m] T[m][d]) * y_scale_i        (a, c: [B,N,G,LDF]; b, y: strided head blocks)
- *   scan_b: T[m][d] += a_i[m] b_i[d] ; y_i[m] = sum_d T[m][d] c_i[d] + ex_scale_i (ex_vec_i[m] + ex_const)   (y: [B,N,G,LDF]) */
+ *   scan_b: T[m][d] += a_i[m] b_i[d] ; y_i[m] = sum_d T[m][d] c_i[d] + ex_scale_i (ex_vec_i[m] + ex_const)   (y: [B,N,G,LDF])
+ * state_ws (sa_favor_scan_workspace_bytes; NULL = one block per (b, g) walks all N positions) lets <= 16 segments of ~128
+ * positions be scanned by independent blocks: segment state sums -> exclusive prefix -> segment scans from the prefix. */
+int64_t sa_favor_scan_workspace_bytes(int B, int N, int G, int LDF, int dv);
 int sa_favor_scan_a(const float *a, const float *c, const float *b, int b_stride, int b_off, const float *b_scale, float *y, int y_stride,
-                    int y_off, const float *y_scale, int B, int N, int G, int LDF, int dv, int reverse, int accumulate, void *stream);
+                    int y_off, const float *y_scale, int B, int N, int G, int LDF, int dv, int reverse, int accumulate, float *state_ws,
+                    void *stream);
 int sa_favor_scan_b(const float *a, const float *b, int b_stride, int b_off, const float *b_scale, const float *c, int c_stride, int c_off,
                     const float *c_scale, float *y, const float *ex_scale, const float *ex_vec, float ex_const, int B, int N, int G,
-                    int LDF, int dv, int reverse, void *stream);
-int sa_cumsum_rows(const float *x, const float *scale, float *out, int B, int N, int G, int LDF, int reverse, void *stream);
+                    int LDF, int dv, int reverse, float *state_ws, void *stream);
+int sa_cumsum_rows(const float *x, const float *scale, float *out, int B, int N, int G, int LDF, int reverse, float *seg_ws, void *stream);
 int sa_favor_den(const float *q, const float *z, float eps, float *inv, int64_t rows, int m, int LDF, void *stream);
 int sa_favor_dden(const float *dout, const float *out, int stride, int off, int G, int dv, const float *inv, float *dden, int64_t rows,
                   void *stream);

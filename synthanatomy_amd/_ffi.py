@@ -69,11 +69,12 @@ _SIGS = {
     "sa_favor_features_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int64, c_int, c_int, c_void_p]),
     "sa_favor_projection": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sa_favor_scan_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "sa_favor_scan_a": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                c_int, c_int, c_void_p]),
+                                c_int, c_int, c_void_p, c_void_p]),
     "sa_favor_scan_b": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
-                                c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "sa_cumsum_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                                c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "sa_cumsum_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sa_favor_den": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "sa_favor_dden": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "sa_rotary": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p]),

@@ -297,6 +297,11 @@ struct ScanArgs {
     const float* ex_vec;    // scan B optional [B,N,G,LDF]
     float ex_const;
     int32_t B, N, G, LDF, dv, b_stride, b_off, c_stride, c_off, y_stride, y_off, reverse, accumulate;
+    // segment parallelism: the N positions are cut into S segments scanned by independent blocks.
+    // pass 0: one segment, no state buffer.  pass 1: accumulate only the segment's state sum into `state`.
+    // (scan_state_prefix_kernel turns the sums into exclusive prefixes.)  pass 2: start from the prefix and emit y.
+    float* state;         // [B, G, S, LDF, dv]
+    int32_t pass, S, seg_len;
 };
 
 constexpr int SCAN_TB = 8;  // positions staged per barrier
@@ -306,19 +311,22 @@ __global__ __launch_bounds__(256) void favor_scan_a_kernel(const ScanArgs s) {
     constexpr int NR = 17;  // LDF <= 272
     __shared__ float sa_[SCAN_TB][272], sc_[SCAN_TB][272], sb_[SCAN_TB][16], sp_[SCAN_TB][16][17];
     const int nsl = s.dv / 16;
-    const int sl = blockIdx.x % nsl, g = (blockIdx.x / nsl) % s.G, b = blockIdx.x / (nsl * s.G);
+    const int seg = blockIdx.x % s.S, bx = blockIdx.x / s.S;
+    const int sl = bx % nsl, g = (bx / nsl) % s.G, b = bx / (nsl * s.G);
     const int t = threadIdx.x, dl = t & 15, mg = t >> 4;
+    float* st = s.state ? s.state + (((int64_t)b * s.G + g) * s.S + seg) * s.LDF * s.dv : nullptr;
     float T[NR];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) T[r] = 0.f;
-    for (int i0 = 0; i0 < s.N; i0 += SCAN_TB) {
-        const int nb = min(SCAN_TB, s.N - i0);
+    for (int r = 0; r < NR; ++r) T[r] = (s.pass == 2 && mg + 16 * r < s.LDF) ? st[(mg + 16 * r) * s.dv + sl * 16 + dl] : 0.f;
+    const int p0 = seg * s.seg_len, p1 = min(s.N, p0 + s.seg_len);
+    for (int i0 = p0; i0 < p1; i0 += SCAN_TB) {
+        const int nb = min(SCAN_TB, p1 - i0);
         for (int e = t; e < nb * s.LDF; e += 256) {
             const int k = e / s.LDF, c = e - k * s.LDF;
             const int i = s.reverse ? s.N - 1 - (i0 + k) : i0 + k;
             const int64_t row = ((int64_t)b * s.N + i) * s.G + g;
             sa_[k][c] = s.a[row * s.LDF + c];
-            sc_[k][c] = s.c_feat[row * s.LDF + c];
+            if (s.pass != 1) sc_[k][c] = s.c_feat[row * s.LDF + c];
         }
         if (t < nb * 16) {
             const int k = t >> 4, d = t & 15;
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(256) void favor_scan_a_kernel(const ScanArgs s) {
             sp_[k][mg][dl] = p;
         }
         __syncthreads();
-        if (t < nb * 16) {
+        if (s.pass != 1 && t < nb * 16) {
             const int k = t >> 4, d = t & 15;
             float y = 0.f;
 #pragma unroll
@@ -357,20 +365,28 @@ __global__ __launch_bounds__(256) void favor_scan_a_kernel(const ScanArgs s) {
         }
         __syncthreads();
     }
+    if (s.pass == 1) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (mg + 16 * r < s.LDF) st[(mg + 16 * r) * s.dv + sl * 16 + dl] = T[r];
+    }
 }
 
 // scan B: block = (b, g, 64-feature slice); thread = (feature ml = t>>2, column quarter dq = t&3)
 __global__ __launch_bounds__(256) void favor_scan_b_kernel(const ScanArgs s) {
     __shared__ float sa_[SCAN_TB][64], sb_[SCAN_TB][64], sc_[SCAN_TB][64];
     const int nsl = (s.LDF + 63) / 64;
-    const int sl = blockIdx.x % nsl, g = (blockIdx.x / nsl) % s.G, b = blockIdx.x / (nsl * s.G);
+    const int seg = blockIdx.x % s.S, bx = blockIdx.x / s.S;
+    const int sl = bx % nsl, g = (bx / nsl) % s.G, b = bx / (nsl * s.G);
     const int t = threadIdx.x, ml = t >> 2, dq = t & 3;
     const int mrow = sl * 64 + ml;
+    float* st = s.state ? s.state + (((int64_t)b * s.G + g) * s.S + seg) * s.LDF * s.dv : nullptr;
     float T[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) T[j] = 0.f;
-    for (int i0 = 0; i0 < s.N; i0 += SCAN_TB) {
-        const int nb = min(SCAN_TB, s.N - i0);
+    for (int j = 0; j < 16; ++j) T[j] = (s.pass == 2 && mrow < s.LDF) ? st[mrow * s.dv + dq * 16 + j] : 0.f;
+    const int p0 = seg * s.seg_len, p1 = min(s.N, p0 + s.seg_len);
+    for (int i0 = p0; i0 < p1; i0 += SCAN_TB) {
+        const int nb = min(SCAN_TB, p1 - i0);
         for (int e = t; e < nb * 64; e += 256) {
             const int k = e >> 6, c = e & 63;
             const int i = s.reverse ? s.N - 1 - (i0 + k) : i0 + k;
@@ -380,8 +396,11 @@ __global__ __launch_bounds__(256) void favor_scan_b_kernel(const ScanArgs s) {
             float bv = s.b[r * s.b_stride + s.b_off + g * s.dv + c];
             if (s.b_scale) bv *= s.b_scale[row];
             sb_[k][c] = bv;
-            float cv = s.c_col[r * s.c_stride + s.c_off + g * s.dv + c];
-            if (s.c_scale) cv *= s.c_scale[row];
+            float cv = 0.f;
+            if (s.pass != 1) {
+                cv = s.c_col[r * s.c_stride + s.c_off + g * s.dv + c];
+                if (s.c_scale) cv *= s.c_scale[row];
+            }
             sc_[k][c] = cv;
         }
         __syncthreads();
@@ -395,7 +414,7 @@ __global__ __launch_bounds__(256) void favor_scan_b_kernel(const ScanArgs s) {
             }
             p += __shfl_xor(p, 1, 64);
             p += __shfl_xor(p, 2, 64);
-            if (dq == 0 && mrow < s.LDF) {
+            if (s.pass != 1 && dq == 0 && mrow < s.LDF) {
                 const int i = s.reverse ? s.N - 1 - (i0 + k) : i0 + k;
                 const int64_t row = ((int64_t)b * s.N + i) * s.G + g;
                 if (s.ex_vec) p += (s.ex_scale ? s.ex_scale[row] : 1.f) * (s.ex_vec[row * s.LDF + mrow] + s.ex_const);
@@ -404,25 +423,50 @@ __global__ __launch_bounds__(256) void favor_scan_b_kernel(const ScanArgs s) {
         }
         __syncthreads();
     }
+    if (s.pass == 1 && mrow < s.LDF) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) st[mrow * s.dv + dq * 16 + j] = T[j];
+    }
+}
+
+// state[b,g,seg] <- sum of the states of the segments before it (exclusive prefix along S), one thread per element
+__global__ void scan_state_prefix_kernel(float* __restrict__ state, int64_t BG, int S, int64_t elems) {
+    const int64_t tix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tix >= BG * elems) return;
+    const int64_t bg = tix / elems, e = tix - bg * elems;
+    float* p = state + bg * S * elems + e;
+    float acc = 0.f;
+    for (int k = 0; k < S; ++k) {
+        const float v = p[k * elems];
+        p[k * elems] = acc;
+        acc += v;
+    }
 }
 
 // running (or reverse-running) sum along N of x[b,n,g,:] * scale[b,n,g]
-__global__ void cumsum_rows_kernel(const float* __restrict__ x, const float* __restrict__ scale, float* __restrict__ out, int B, int N, int G, int LDF,
-                                   int reverse) {
+// pass 1 (segsum != NULL, out == NULL): per-segment totals.  pass 2: each segment starts from the sum of the totals before it.
+__global__ void cumsum_rows_kernel(const float* __restrict__ x, const float* __restrict__ scale, float* __restrict__ out, float* __restrict__ segsum,
+                                   int B, int N, int G, int LDF, int reverse, int S, int seg_len) {
     const int64_t tix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tix >= (int64_t)B * G * LDF) return;
+    if (tix >= (int64_t)B * G * LDF * S) return;
     const int c = (int)(tix % LDF);
-    const int g = (int)((tix / LDF) % G);
-    const int b = (int)(tix / ((int64_t)LDF * G));
+    const int seg = (int)((tix / LDF) % S);
+    const int g = (int)((tix / ((int64_t)LDF * S)) % G);
+    const int b = (int)(tix / ((int64_t)LDF * S * G));
+    float* ss = segsum ? segsum + (((int64_t)b * G + g) * S) * LDF + c : nullptr;
     float acc = 0.f;
-    for (int k = 0; k < N; ++k) {
+    if (out && ss)
+        for (int k = 0; k < seg; ++k) acc += ss[(int64_t)k * LDF];
+    const int p0 = seg * seg_len, p1 = min(N, p0 + seg_len);
+    for (int k = p0; k < p1; ++k) {
         const int i = reverse ? N - 1 - k : k;
         const int64_t row = ((int64_t)b * N + i) * G + g;
         float v = x[row * LDF + c];
         if (scale) v *= scale[row];
         acc += v;
-        out[row * LDF + c] = acc;
+        if (out) out[row * LDF + c] = acc;
     }
+    if (!out) ss[(int64_t)seg * LDF] = acc;
 }
 
 // den[row] = sum_{c<m} q[row][c] * (z[row][c] + eps) ; inv[row] = 1/den    (one wave per row)
@@ -621,35 +665,77 @@ extern "C" int sa_favor_projection(const float* blocks, const float* rows, float
 
 static int check_scan(int B, int N, int G, int LDF, int dv) { return (B > 0 && N > 0 && G > 0 && LDF > 0 && LDF <= 272 && dv == 64) ? 0 : SA_EUNSUPPORTED; }
 
+static void scan_segments(int N, int& S, int& seg_len, const void* ws) {
+    S = ws ? (N + 127) / 128 : 1;      // ~128 positions per block
+    if (S > 16) S = 16;
+    if (S < 1) S = 1;
+    seg_len = (N + S - 1) / S;
+    S = (N + seg_len - 1) / seg_len;
+}
+
+extern "C" int64_t sa_favor_scan_workspace_bytes(int B, int N, int G, int LDF, int dv) {
+    int S, seg_len;
+    scan_segments(N, S, seg_len, (const void*)1);
+    return (int64_t)B * G * S * LDF * dv * 4;
+}
+
+template <typename K>
+static int run_scan(K kernel, ScanArgs& s, unsigned base_blocks, float* ws, hipStream_t st) {
+    scan_segments(s.N, s.S, s.seg_len, ws);
+    s.state = ws;
+    if (s.S == 1) {
+        s.pass = 0;
+        s.state = nullptr;
+        hipLaunchKernelGGL(kernel, dim3(base_blocks), dim3(256), 0, st, s);
+        SA_CHECK_LAUNCH();
+        return 0;
+    }
+    s.pass = 1;
+    hipLaunchKernelGGL(kernel, dim3(base_blocks * s.S), dim3(256), 0, st, s);
+    SA_CHECK_LAUNCH();
+    const int64_t elems = (int64_t)s.LDF * s.dv, bg = (int64_t)s.B * s.G;
+    hipLaunchKernelGGL(scan_state_prefix_kernel, dim3((unsigned)((bg * elems + 255) / 256)), dim3(256), 0, st, ws, bg, s.S, elems);
+    SA_CHECK_LAUNCH();
+    s.pass = 2;
+    hipLaunchKernelGGL(kernel, dim3(base_blocks * s.S), dim3(256), 0, st, s);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int sa_favor_scan_a(const float* a, const float* c, const float* b, int b_stride, int b_off, const float* b_scale, float* y, int y_stride,
-                               int y_off, const float* y_scale, int B, int N, int G, int LDF, int dv, int reverse, int accumulate, void* stream) {
+                               int y_off, const float* y_scale, int B, int N, int G, int LDF, int dv, int reverse, int accumulate, float* state_ws,
+                               void* stream) {
     if (!a || !c || !b || !y) return SA_EINVAL;
     if (check_scan(B, N, G, LDF, dv)) return SA_EUNSUPPORTED;
     ScanArgs s = {};
     s.a = a; s.c_feat = c; s.b = b; s.b_scale = b_scale; s.y = y; s.y_scale = y_scale;
     s.B = B; s.N = N; s.G = G; s.LDF = LDF; s.dv = dv; s.b_stride = b_stride; s.b_off = b_off; s.y_stride = y_stride; s.y_off = y_off;
     s.reverse = reverse; s.accumulate = accumulate;
-    hipLaunchKernelGGL(favor_scan_a_kernel, dim3(B * G * (dv / 16)), dim3(256), 0, ST(stream), s);
-    SA_CHECK_LAUNCH();
-    return 0;
+    return run_scan(favor_scan_a_kernel, s, (unsigned)(B * G * (dv / 16)), state_ws, ST(stream));
 }
 
 extern "C" int sa_favor_scan_b(const float* a, const float* b, int b_stride, int b_off, const float* b_scale, const float* c, int c_stride, int c_off,
                                const float* c_scale, float* y, const float* ex_scale, const float* ex_vec, float ex_const, int B, int N, int G,
-                               int LDF, int dv, int reverse, void* stream) {
+                               int LDF, int dv, int reverse, float* state_ws, void* stream) {
     if (!a || !c || !b || !y) return SA_EINVAL;
     if (check_scan(B, N, G, LDF, dv)) return SA_EUNSUPPORTED;
     ScanArgs s = {};
     s.a = a; s.b = b; s.c_col = c; s.b_scale = b_scale; s.c_scale = c_scale; s.y = y; s.ex_scale = ex_scale; s.ex_vec = ex_vec; s.ex_const = ex_const;
     s.B = B; s.N = N; s.G = G; s.LDF = LDF; s.dv = dv; s.b_stride = b_stride; s.b_off = b_off; s.c_stride = c_stride; s.c_off = c_off; s.reverse = reverse;
-    hipLaunchKernelGGL(favor_scan_b_kernel, dim3(B * G * ((LDF + 63) / 64)), dim3(256), 0, ST(stream), s);
-    SA_CHECK_LAUNCH();
-    return 0;
+    return run_scan(favor_scan_b_kernel, s, (unsigned)(B * G * ((LDF + 63) / 64)), state_ws, ST(stream));
 }
 
-extern "C" int sa_cumsum_rows(const float* x, const float* scale, float* out, int B, int N, int G, int LDF, int reverse, void* stream) {
+extern "C" int sa_cumsum_rows(const float* x, const float* scale, float* out, int B, int N, int G, int LDF, int reverse, float* seg_ws, void* stream) {
     if (!x || !out || B <= 0 || N <= 0 || G <= 0 || LDF <= 0) return SA_EINVAL;
-    hipLaunchKernelGGL(cumsum_rows_kernel, dim3((unsigned)(((int64_t)B * G * LDF + 63) / 64)), dim3(64), 0, ST(stream), x, scale, out, B, N, G, LDF, reverse);
+    int S, seg_len;
+    scan_segments(N, S, seg_len, seg_ws);   // seg_ws: B*G*S*LDF floats (<= 1/dv of the scan workspace)
+    const int64_t threads = (int64_t)B * G * LDF * S;
+    const unsigned nblk = (unsigned)((threads + 255) / 256);
+    if (S > 1) {
+        hipLaunchKernelGGL(cumsum_rows_kernel, dim3(nblk), dim3(256), 0, ST(stream), x, scale, (float*)nullptr, seg_ws, B, N, G, LDF, reverse, S, seg_len);
+        SA_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(cumsum_rows_kernel, dim3(nblk), dim3(256), 0, ST(stream), x, scale, out, S > 1 ? seg_ws : (float*)nullptr, B, N, G, LDF, reverse, S, seg_len);
     SA_CHECK_LAUNCH();
     return 0;
 }

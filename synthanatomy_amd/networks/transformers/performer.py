@@ -269,6 +269,7 @@ class _LayerEngine:
         self._pop = None
         self._rot = None
         self._one = None
+        self._ws = None
 
     def invalidate(self):
         for op in self.ops.values():
@@ -298,6 +299,13 @@ class _LayerEngine:
             fr = torch.cat((fr, fr), dim=-1)
             self._rot = ((N, dev), fr.cos().contiguous(), fr.sin().contiguous())
         return self._rot[1], self._rot[2]
+
+    def _scan_ws(self, B, N, G, dev):
+        """scratch for the segment-parallel scans (states of <= 16 segments per (batch, head)); reused by every call of this layer"""
+        n = _ffi.lib().sa_favor_scan_workspace_bytes(B, N, G, self.LDF, self.dh) // 4
+        if self._ws is None or self._ws.numel() < n or self._ws.device != dev:
+            self._ws = torch.empty(n, dtype=torch.float32, device=dev)
+        return self._ws
 
     def _gate(self, wrap, dev):
         if self.rezero:
@@ -342,11 +350,12 @@ class _LayerEngine:
             _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddq), _ffi.ptr(qg), G * dh, 0, G, dh, 1, _ffi.ptr(qf), None, R * G, m, LDF, st), "favor_features(q)")
             _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddk), _ffi.ptr(kg), G * dh, 0, G, dh, 0, _ffi.ptr(kf), _ffi.ptr(gws), R * G, m, LDF, st), "favor_features(k)")
             Z = torch.empty_like(kf)
-            _ck(lib.sa_cumsum_rows(_ffi.ptr(kf), None, _ffi.ptr(Z), B, N, G, LDF, 0, st), "sa_cumsum_rows")
+            ws = self._scan_ws(B, N, G, dev)
+            _ck(lib.sa_cumsum_rows(_ffi.ptr(kf), None, _ffi.ptr(Z), B, N, G, LDF, 0, _ffi.ptr(ws), st), "sa_cumsum_rows")
             inv = torch.empty(R * G, dtype=f32, device=dev)
             _ck(lib.sa_favor_den(_ffi.ptr(qf), _ffi.ptr(Z), 1e-6, _ffi.ptr(inv), R * G, m, LDF, st), "sa_favor_den")
-            _ck(lib.sa_favor_scan_a(_ffi.ptr(kf), _ffi.ptr(qf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(attn), inner, 0, _ffi.ptr(inv), B, N, G, LDF, dh, 0, 0, st),
-                "sa_favor_scan_a")
+            _ck(lib.sa_favor_scan_a(_ffi.ptr(kf), _ffi.ptr(qf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(attn), inner, 0, _ffi.ptr(inv), B, N, G, LDF, dh, 0, 0,
+                                    _ffi.ptr(ws), st), "sa_favor_scan_a")
             sv.update(qg=qg, kg=kg, ddq=ddq, ddk=ddk, qf=qf, kf=kf, gws=gws, Z=Z, inv=inv)
         if L > 0:
             cosb, sinb = self._rot_tables(N, dev)
@@ -435,16 +444,17 @@ class _LayerEngine:
             qf, kf, Z, inv = sv["qf"], sv["kf"], sv["Z"], sv["inv"]
             dden = torch.empty(R * G, dtype=f32, device=dev)
             _ck(lib.sa_favor_dden(_ffi.ptr(dattn), _ffi.ptr(attn), inner, 0, G, dh, _ffi.ptr(inv), _ffi.ptr(dden), R * G, st), "sa_favor_dden")
+            ws = self._scan_ws(B, N, G, dev)
             dqf = torch.empty_like(qf)
             _ck(lib.sa_favor_scan_b(_ffi.ptr(kf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dqf), _ffi.ptr(dden), _ffi.ptr(Z),
-                                    1e-6, B, N, G, LDF, dh, 0, st), "sa_favor_scan_b(dq')")
+                                    1e-6, B, N, G, LDF, dh, 0, _ffi.ptr(ws), st), "sa_favor_scan_b(dq')")
             rr = torch.empty_like(qf)
-            _ck(lib.sa_cumsum_rows(_ffi.ptr(qf), _ffi.ptr(dden), _ffi.ptr(rr), B, N, G, LDF, 1, st), "sa_cumsum_rows(rev)")
+            _ck(lib.sa_cumsum_rows(_ffi.ptr(qf), _ffi.ptr(dden), _ffi.ptr(rr), B, N, G, LDF, 1, _ffi.ptr(ws), st), "sa_cumsum_rows(rev)")
             dkf = torch.empty_like(kf)
             _ck(lib.sa_favor_scan_b(_ffi.ptr(qf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dkf), None, _ffi.ptr(rr), 0.0,
-                                    B, N, G, LDF, dh, 1, st), "sa_favor_scan_b(dk')")
-            _ck(lib.sa_favor_scan_a(_ffi.ptr(qf), _ffi.ptr(kf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dv), inner, 0, None, B, N, G, LDF, dh, 1, 0, st),
-                "sa_favor_scan_a(dv)")
+                                    B, N, G, LDF, dh, 1, _ffi.ptr(ws), st), "sa_favor_scan_b(dk')")
+            _ck(lib.sa_favor_scan_a(_ffi.ptr(qf), _ffi.ptr(kf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dv), inner, 0, None, B, N, G, LDF, dh, 1, 0,
+                                    _ffi.ptr(ws), st), "sa_favor_scan_a(dv)")
             pop = self._proj_op()
             dqg = torch.zeros(R, G * dh, dtype=f32, device=dev)
             dkg = torch.zeros(R, G * dh, dtype=f32, device=dev)

@@ -86,11 +86,12 @@ def test_bf16_projections_close_to_fp32_oracle():
     assert _rel(out, P.forward(st, cfg, tok, seqs)) < 3e-2
 
 
-def test_causal_scan_kernels_against_quadratic_form():
+@pytest.mark.parametrize("N,segmented", [(37, False), (37, True), (300, True), (1400, True)])
+def test_causal_scan_kernels_against_quadratic_form(N, segmented):
     from synthanatomy_amd import _ffi
     lib, st = _ffi.lib(), _ffi.stream()
     torch.manual_seed(2)
-    B, N, G, m, LDF, dv = 2, 37, 3, 266, 272, 64
+    B, G, m, LDF, dv = 2, 3, 266, 272, 64
     qf = torch.zeros(B, N, G, LDF)
     kf = torch.zeros(B, N, G, LDF)
     qf[..., :m] = torch.rand(B, N, G, m) + 0.01
@@ -101,9 +102,11 @@ def test_causal_scan_kernels_against_quadratic_form():
     Z = torch.empty_like(kd)
     inv = torch.empty(B * N * G, device="cuda")
     out = torch.zeros(B * N, 2 * G * dv, device="cuda")
-    _ffi.check(lib.sa_cumsum_rows(_ffi.ptr(kd), None, _ffi.ptr(Z), B, N, G, LDF, 0, st))
+    ws = torch.empty(lib.sa_favor_scan_workspace_bytes(B, N, G, LDF, dv) // 4, device="cuda") if segmented else None
+    _ffi.check(lib.sa_cumsum_rows(_ffi.ptr(kd), None, _ffi.ptr(Z), B, N, G, LDF, 0, _ffi.ptr(ws), st))
     _ffi.check(lib.sa_favor_den(_ffi.ptr(qd), _ffi.ptr(Z), 1e-6, _ffi.ptr(inv), B * N * G, m, LDF, st))
-    _ffi.check(lib.sa_favor_scan_a(_ffi.ptr(kd), _ffi.ptr(qd), _ffi.ptr(vd), 2 * G * dv, 0, None, _ffi.ptr(out), 2 * G * dv, 0, _ffi.ptr(inv), B, N, G, LDF, dv, 0, 0, st))
+    _ffi.check(lib.sa_favor_scan_a(_ffi.ptr(kd), _ffi.ptr(qd), _ffi.ptr(vd), 2 * G * dv, 0, None, _ffi.ptr(out), 2 * G * dv, 0, _ffi.ptr(inv), B, N, G, LDF, dv, 0, 0,
+                                   _ffi.ptr(ws), st))
     got = out[:, :G * dv].view(B, N, G, dv).permute(0, 2, 1, 3)
     assert _rel(got, ref) < 1e-4
     assert float(out[:, G * dv:].abs().max()) == 0.0  # only the addressed head block is written
