@@ -137,10 +137,11 @@ int sa_axpy(float *y, const float *x, float alpha, int64_t n, void *stream);
 int sa_favor_features_fwd(const float *dd, const float *src, int src_stride, int h0, int G, int dh, int is_query, float *feat, void *gmax_ws,
                           int64_t rows, int m, int LDF, void *stream);
 int sa_favor_features_bwd(const float *dfeat, const float *feat, const float *dd, const float *src, int src_stride, int h0, int G, int dh,
-                          int is_query, float *ddd, float *dsrc, const void *gmax_ws, float *tsum_ws, int64_t rows, int m, int LDF,
+                          int is_query, float *ddd, float *dsrc, const void *gmax_ws, float *tsum_ws /* [rows] */, int64_t rows, int m, int LDF,
                           void *stream);
-/* FastAttention.redraw_projection_matrix: out[m,d] = rowwise-orthonormalised Gaussian blocks [nblk,d,d] scaled by |rows[r]| */
-int sa_favor_projection(const float *blocks, const float *rows, float *out, int nblk, int m, int d, void *stream);
+/* FastAttention.redraw_projection_matrix for nmat layers at once: out[nmat,m,d] = rowwise-orthonormalised Gaussian blocks
+ * [nmat,nblk,d,d] scaled by |rows[nmat,m,d]| */
+int sa_favor_projection(const float *blocks, const float *rows, float *out, int nmat, int nblk, int m, int d, void *stream);
 /* causal running-state scans replacing fast_transformers' CausalDotProduct (forward and both backward directions):
  *   scan_a: T[m][d] += a_i[m] b_i[d] ; y_i[d] = (sum_m c_i[m] T[m][d]) * y_scale_i        (a, c: [B,N,G,LDF]; b, y: strided head blocks)
  *   scan_b: T[m][d] += a_i[m] b_i[d] ; y_i[m] = sum_d T[m][d] c_i[d] + ex_scale_i (ex_vec_i[m] + ex_const)   (y: [B,N,G,LDF])

@@ -68,7 +68,7 @@ _SIGS = {
     "sa_favor_features_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "sa_favor_features_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int64, c_int, c_int, c_void_p]),
-    "sa_favor_projection": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sa_favor_projection": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sa_favor_scan_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "sa_favor_scan_a": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_int, c_void_p, c_void_p]),

@@ -242,16 +242,28 @@ __global__ void favor_feat_bwd_kernel(const float* __restrict__ dfeat, const flo
         }
         if (lane == 0) ddd[rp * LDF + am] -= t;
     } else if (lane == 0) {
-        unsafeAtomicAdd(tsum, t);  // the global-max element receives -sum over the whole tensor (favor_key_stab_kernel)
+        tsum[rp] = t;  // per-row partial; favor_key_stab_kernel reduces them (67k same-address atomics were 10x the kernel)
     }
     const float* x = src + r * src_stride + (h0 + h) * dh;
     float* dx = dsrc + r * src_stride + (h0 + h) * dh;
     for (int d = lane; d < dh; d += 64) dx[d] += -t * c2 * x[d];
 }
 
-__global__ void favor_key_stab_kernel(float* __restrict__ ddd, const unsigned long long* __restrict__ gmax, const float* __restrict__ tsum) {
-    const uint32_t idx = 0xffffffffu - (uint32_t)(*gmax & 0xffffffffull);
-    ddd[idx] -= tsum[0];
+// the global-max element receives -sum_rows t (d feat / d stab = -e for every element of the key tensor)
+__global__ __launch_bounds__(1024) void favor_key_stab_kernel(float* __restrict__ ddd, const unsigned long long* __restrict__ gmax,
+                                                              const float* __restrict__ trow, int64_t rows) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int64_t r = threadIdx.x; r < rows; r += 1024) s += trow[r];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        const uint32_t idx = 0xffffffffu - (uint32_t)(*gmax & 0xffffffffull);
+        ddd[idx] -= t;
+    }
 }
 
 
@@ -259,10 +271,12 @@ __global__ void favor_key_stab_kernel(float* __restrict__ ddd, const unsigned lo
 // gaussian_orthogonal_random_matrix(m, d, scaling=0): each d x d Gaussian block is orthonormalised row by row (modified
 // Gram-Schmidt = the Q of a QR up to signs) and row r is rescaled by the norm of an independent Gaussian row.  One wave per block.
 __global__ __launch_bounds__(64) void favor_projection_kernel(const float* __restrict__ blocks, const float* __restrict__ rows, float* __restrict__ out,
-                                                               int m, int d) {
+                                                               int m, int d, int nblk) {
     __shared__ float Q[64][65];
-    const int t = threadIdx.x, blk = blockIdx.x;
-    const float* A = blocks + (size_t)blk * d * d;
+    const int t = threadIdx.x, blk = blockIdx.x % nblk, mat = blockIdx.x / nblk;   // `mat`: one projection matrix per layer
+    const float* A = blocks + (size_t)blockIdx.x * d * d;
+    rows += (size_t)mat * m * d;
+    out += (size_t)mat * m * d;
     for (int j = 0; j < d; ++j) {
         float v = t < d ? A[j * d + t] : 0.f;
         for (int i = 0; i < j; ++i) {
@@ -645,20 +659,19 @@ extern "C" int sa_favor_features_bwd(const float* dfeat, const float* feat, cons
                                      void* stream) {
     if (!dfeat || !feat || !dd || !src || !ddd || !dsrc || rows <= 0 || (!is_query && (!gmax_ws || !tsum_ws))) return SA_EINVAL;
     const float c = powf((float)dh, -0.25f), ratio = 1.f / sqrtf((float)m);
-    if (!is_query) hipMemsetAsync(tsum_ws, 0, 4, ST(stream));
     hipLaunchKernelGGL(favor_feat_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), dfeat, feat, dd, src, src_stride, h0, G, dh,
                        is_query, ddd, dsrc, tsum_ws, rows, m, LDF, c * c, ratio * 1e-4f);
     SA_CHECK_LAUNCH();
     if (!is_query) {
-        hipLaunchKernelGGL(favor_key_stab_kernel, dim3(1), dim3(1), 0, ST(stream), ddd, (const unsigned long long*)gmax_ws, tsum_ws);
+        hipLaunchKernelGGL(favor_key_stab_kernel, dim3(1), dim3(1024), 0, ST(stream), ddd, (const unsigned long long*)gmax_ws, tsum_ws, rows);
         SA_CHECK_LAUNCH();
     }
     return 0;
 }
 
-extern "C" int sa_favor_projection(const float* blocks, const float* rows, float* out, int nblk, int m, int d, void* stream) {
-    if (!blocks || !rows || !out || nblk <= 0 || m <= 0 || d <= 0 || d > 64 || nblk * d < m) return SA_EINVAL;
-    hipLaunchKernelGGL(favor_projection_kernel, dim3(nblk), dim3(64), 0, ST(stream), blocks, rows, out, m, d);
+extern "C" int sa_favor_projection(const float* blocks, const float* rows, float* out, int nmat, int nblk, int m, int d, void* stream) {
+    if (!blocks || !rows || !out || nmat <= 0 || nblk <= 0 || m <= 0 || d <= 0 || d > 64 || nblk * d < m) return SA_EINVAL;
+    hipLaunchKernelGGL(favor_projection_kernel, dim3(nmat * nblk), dim3(64), 0, ST(stream), blocks, rows, out, m, d, nblk);
     SA_CHECK_LAUNCH();
     return 0;
 }

@@ -90,7 +90,7 @@ class FastAttention(nn.Module):
         if pm.is_cuda:
             blocks = torch.randn(nblk, d, d, generator=generator, device=pm.device)
             rows = torch.randn(m, d, generator=generator, device=pm.device)
-            _ck(_ffi.lib().sa_favor_projection(_ffi.ptr(blocks), _ffi.ptr(rows), _ffi.ptr(pm), nblk, m, d, _ffi.stream()), "sa_favor_projection")
+            _ck(_ffi.lib().sa_favor_projection(_ffi.ptr(blocks), _ffi.ptr(rows), _ffi.ptr(pm), 1, nblk, m, d, _ffi.stream()), "sa_favor_projection")
         else:  # construction time on the host (before .to(device)); plain torch, not a compute fallback of the hot path
             blocks = torch.randn(nblk, d, d, generator=generator)
             q = torch.linalg.qr(blocks.transpose(1, 2))[0].transpose(1, 2).reshape(nblk * d, d)[:m]
@@ -162,10 +162,24 @@ class ProjectionUpdater(nn.Module):
             return
         if self.feature_redraw_interval is not None and self._calls >= self.feature_redraw_interval:
             self._redraws += 1
-            for li, mod in enumerate(m for m in self.instance[0].modules() if isinstance(m, FastAttention)):
-                dev = mod.projection_matrix.device
-                gen = torch.Generator(device=dev).manual_seed((self.base_seed + 7919 * self._redraws + li) % (2 ** 31))
-                mod.redraw_projection_matrix(dev, gen)
+            mods = [m for m in self.instance[0].modules() if isinstance(m, FastAttention)]
+            dev = mods[0].projection_matrix.device
+            gen = torch.Generator(device=dev).manual_seed((self.base_seed + 7919 * self._redraws) % (2 ** 31))
+            same = all(m.nb_features == mods[0].nb_features and m.dim_heads == mods[0].dim_heads for m in mods)
+            if dev.type == "cuda" and same:
+                # all layers in ONE launch (one wave per 64x64 block); every rank uses the same seed -> identical matrices
+                nl, m_, d_ = len(mods), mods[0].nb_features, mods[0].dim_heads
+                nblk = (m_ + d_ - 1) // d_
+                blocks = torch.randn(nl * nblk, d_, d_, generator=gen, device=dev)
+                rows = torch.randn(nl * m_, d_, generator=gen, device=dev)
+                out = torch.empty(nl, m_, d_, device=dev)
+                _ck(_ffi.lib().sa_favor_projection(_ffi.ptr(blocks), _ffi.ptr(rows), _ffi.ptr(out), nl, nblk, m_, d_, _ffi.stream()), "sa_favor_projection")
+                for i, mod in enumerate(mods):
+                    mod.projection_matrix.copy_(out[i])
+                    mod.projection_matrix._sa_epoch = getattr(mod.projection_matrix, "_sa_epoch", 0) + 1
+            else:
+                for mod in mods:
+                    mod.redraw_projection_matrix(dev, gen)
             self._calls = 0
             self.calls_since_last_redraw.zero_()
             return
@@ -459,7 +473,7 @@ class _LayerEngine:
             dqg = torch.zeros(R, G * dh, dtype=f32, device=dev)
             dkg = torch.zeros(R, G * dh, dtype=f32, device=dev)
             dddq, dddk = torch.empty_like(qf), torch.empty_like(kf)
-            tsum = torch.zeros(1, dtype=f32, device=dev)
+            tsum = torch.empty(R * G, dtype=f32, device=dev)
             _ck(lib.sa_favor_features_bwd(_ffi.ptr(dqf), _ffi.ptr(qf), _ffi.ptr(sv["ddq"]), _ffi.ptr(sv["qg"]), G * dh, 0, G, dh, 1, _ffi.ptr(dddq), _ffi.ptr(dqg),
                                           None, None, R * G, m, LDF, st), "favor_features_bwd(q)")
             _ck(lib.sa_favor_features_bwd(_ffi.ptr(dkf), _ffi.ptr(kf), _ffi.ptr(sv["ddk"]), _ffi.ptr(sv["kg"]), G * dh, 0, G, dh, 0, _ffi.ptr(dddk), _ffi.ptr(dkg),
