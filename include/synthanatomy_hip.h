@@ -74,6 +74,13 @@ int sa_pack_weights(const float *w, void *wpk, int dtype, int rows, int red, int
 int sa_conv_fprop(const sa_conv_geom *g, int dtype, const void *in, const void *wpk, void *out, const sa_epilogue *ep,
                   void *stream);
 
+/* ---- ResidualLayer forward in ONE launch (baseline.py:150-160), bf16, 128 channels, k3 s1 p1 geometry `g`:
+ *   h = relu(conv3x3x3(x) + bias1)  (stored to h_out when non-NULL: the backward pass needs it)
+ *   y = epilogue(h . w1pk^T)  with ep = {bias = b2, addend = x, add_before_act = 1, act = RELU} for the reference block.
+ * w3pk / w1pk are sa_pack_weights operands ([128][27*128] and [128][128]).  SA_EUNSUPPORTED for other shapes: use two sa_conv_fprop. */
+int sa_resblock_fprop(const sa_conv_geom *g, int dtype, const void *x, const void *w3pk, const float *bias1, const void *w1pk, void *h_out,
+                      void *y_out, const sa_epilogue *ep, void *stream);
+
 /* ---- weight gradient: dw[r*s_row + c*s_red + tap_lut[t]] += sum_m in[gather(m,t)][c] * gout[out(m)][r]  (accumulates:
  * caller zeroes dw).  Replaces cuDNN wgrad behind the same modules' autograd. */
 int sa_conv_wgrad(const sa_conv_geom *g, int dtype, const void *in, const void *gout, float *dw, const int32_t *tap_lut_host,

@@ -33,6 +33,12 @@ struct FpropArgs {
     uint32_t nblk_m;
     FastDiv dCin;         // element k -> (tap, channel)
     uint32_t in_bytes, w_bytes;
+    // fused residual block (bf16, 128 channels): after the main loop  h = relu(acc + bias1)  is kept on chip, optionally stored to
+    // `h_out`, and multiplied by the 1x1x1 weights `w2pk` [128][128]; the regular epilogue (bias2 = ep.bias, addend, act) then runs on
+    // that second product.
+    const void* w2pk;
+    const float* bias1;
+    void* h_out;
 };
 
 template <typename T>
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const FpropArgs a) {
 // Needs every operand < 4 GiB (32-bit buffer offsets); the register-staged kernel above is the fallback.
 constexpr uint32_t OOB_OFF = 0xfffffff0u;
 
-template <typename T, int WM, int WN, int MI, int NI, bool UNIFORM>
+template <typename T, int WM, int WN, int MI, int NI, bool UNIFORM, bool FUSE = false>
 __global__ __launch_bounds__(256) void conv_fprop_dma_kernel(const FpropArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins only exist in the device pass; the host pass needs just the stub
     constexpr int BM = WM * MI * 16;
@@ -439,6 +445,60 @@ __global__ __launch_bounds__(256) void conv_fprop_dma_kernel(const FpropArgs a) 
                 for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
         }
         __syncthreads();  // (the DMA in flight makes hipcc drain vmcnt(0) here: next slab landed, this one free)
+    }
+    if constexpr (FUSE) {
+        static_assert(!FUSE || (sizeof(T) == 2 && BM == 128 && BN == 128), "fused residual block: bf16, 128 x 128 tile");
+        // ---- second GEMM of the residual block on chip:  out2[m][co] = sum_c relu(acc[m][c] + b1[c]) * W2[co][c]
+        // W2 (two 128-byte K-slabs) streams into the weight buffers while h is converted and parked in the activation buffers.
+        __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2pk, 0, 128 * 128 * 2, 0x00020000);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(smem + 2 * BM * 128 + sl * (BN * 128) + (wave * 4 + j) * 1024), 16,
+                                                         ((wave * 4 + j) * 8 + prow) * 256u + lv * 16u, sl * 128u, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const uint32_t c0 = wn * (NI * 16) + i * 16 + fq * 4;       // 4 consecutive hidden channels of this lane
+            const float4_t b1 = *(const float4_t*)(a.bias1 + c0);
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                const uint32_t row = wm * (MI * 16) + j * 16 + frow;
+                const float4_t v = acc[i][j] + b1;
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(fmaxf(v[0], 0.f)) | ((uint32_t)f32_to_bf16(fmaxf(v[1], 0.f)) << 16);
+                pk.y = (uint32_t)f32_to_bf16(fmaxf(v[2], 0.f)) | ((uint32_t)f32_to_bf16(fmaxf(v[3], 0.f)) << 16);
+                *(uint2*)(smem + (c0 >> 6) * (BM * 128) + tile_off(row, (c0 & 63u) >> 3) + (c0 & 7u) * 2) = pk;
+                acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();  // h tile complete (and the W2 DMA drained)
+        if (a.h_out) {    // training: the hidden activation is needed by the backward pass -> full 256-byte rows
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const uint32_t row = (tid >> 4) + 16u * it, sl = (tid >> 3) & 1u, vec = tid & 7u;
+                const uint32_t m = m_base + row;
+                if (m < a.M) *(u32x4*)((bf16_t*)a.h_out + (size_t)m * 128 + sl * 64 + vec * 8) = *(const u32x4*)(smem + sl * (BM * 128) + tile_off(row, vec));
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const unsigned char* pa = smem + sl * (BM * 128);
+            const unsigned char* pb = smem + 2 * BM * 128 + sl * (BN * 128);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 xf[MI], wf[NI];
+#pragma unroll
+                for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(pa + tile_off(wm * (MI * 16) + j * 16 + frow, ks * 4 + fq));
+#pragma unroll
+                for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + tile_off(wn * (NI * 16) + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
+            }
+        }
+        __syncthreads();  // all waves done with the h / W2 tiles before the epilogue reuses the LDS
     }
     fprop_epilogue<BM, BN, WM, WN, MI, NI>(a, acc, smem, tid, wm, wn, frow, fq, m_base, n_base);
 #endif
@@ -674,6 +734,9 @@ extern "C" int sa_conv_fprop(const sa_conv_geom* g, int dtype, const void* in, c
     a.nk = g->Kpad / bke;
     a.nblk_m = (uint32_t)((M + 127) / 128);
     a.dCin = make_fastdiv(g->Cin);
+    a.w2pk = nullptr;
+    a.bias1 = nullptr;
+    a.h_out = nullptr;
     {
         const int sz = dtype == SA_F32 ? 4 : 2;
         const uint64_t ib = (uint64_t)g->N * g->Di * g->Hi * g->Wi * g->Cin * sz, wb = (uint64_t)g->CoutPad * g->Kpad * sz;
@@ -683,4 +746,49 @@ extern "C" int sa_conv_fprop(const sa_conv_geom* g, int dtype, const void* in, c
     }
     hipStream_t st = (hipStream_t)stream;
     return dtype == SA_F32 ? dispatch_fprop<float>(a, st) : dispatch_fprop<bf16_t>(a, st);
+}
+
+// Residual block forward in ONE launch (reference src/networks/vqvae/baseline.py:150-160):
+//   y = relu(x + conv1x1x1(relu(conv3x3x3(x) + b1)) + b2);  h = relu(conv3x3x3(x) + b1) optionally stored for the backward pass.
+extern "C" int sa_resblock_fprop(const sa_conv_geom* g, int dtype, const void* x, const void* w3pk, const float* bias1, const void* w1pk, void* h_out,
+                                 void* y_out, const sa_epilogue* ep, void* stream) {
+    using namespace sa;
+    if (!g || !x || !w3pk || !bias1 || !w1pk || !y_out || !ep) return SA_EINVAL;
+    if (dtype != SA_BF16 || g->cout_valid != 128 || g->Cout != 128 || g->cin_valid != 128 || g->Cin != 128) return SA_EUNSUPPORTED;
+    const int ntaps = g->KT[0] * g->KT[1] * g->KT[2];
+    if (g->Kpad % 64 || g->Kpad < ntaps * g->Cin || g->CoutPad != 128 || ntaps < 1 || ntaps > SA_MAX_TAPS) return SA_EINVAL;
+    // the fused kernel writes h and y at the linear voxel index: identity output map only
+    for (int d = 0; d < 3; ++d)
+        if (g->out_mult[d] != 1 || g->out_off[d] != 0) return SA_EUNSUPPORTED;
+    if (g->Dm != g->Do || g->Hm != g->Ho || g->Wm != g->Wo) return SA_EUNSUPPORTED;
+    const int64_t M = (int64_t)g->N * g->Dm * g->Hm * g->Wm;
+    if (M <= 0 || M >= (1ll << 31)) return SA_EINVAL;
+    const uint64_t ib = (uint64_t)g->N * g->Di * g->Hi * g->Wi * g->Cin * 2, wb = (uint64_t)g->CoutPad * g->Kpad * 2;
+    if (ib >= 0xfffffff0ull - 4096) return SA_EUNSUPPORTED;
+    FpropArgs a;
+    a.in = x;
+    a.wpk = w3pk;
+    a.out = y_out;
+    a.ep = *ep;
+    a.g = *g;
+    a.dW = make_fastdiv(g->Wm);
+    a.dH = make_fastdiv(g->Hm);
+    a.dD = make_fastdiv(g->Dm);
+    a.dTw = make_fastdiv(g->KT[2]);
+    a.dThw = make_fastdiv(g->KT[1] * g->KT[2]);
+    a.dCv = make_fastdiv(g->Cin / 8);
+    a.dCin = make_fastdiv(g->Cin);
+    a.M = (uint32_t)M;
+    a.ntaps = ntaps;
+    a.nk = g->Kpad / 64;
+    a.nblk_m = (uint32_t)((M + 127) / 128);
+    a.in_bytes = (uint32_t)ib;
+    a.w_bytes = (uint32_t)wb;
+    a.w2pk = w1pk;
+    a.bias1 = bias1;
+    a.h_out = h_out;
+    const size_t pipe = 2 * (128 + 128) * 128, epi = (size_t)128 * (128 + 4) * 4 + 128 * 8;
+    hipLaunchKernelGGL((conv_fprop_dma_kernel<bf16_t, 2, 2, 4, 4, true, true>), dim3(a.nblk_m), dim3(256), pipe > epi ? pipe : epi, (hipStream_t)stream, a);
+    SA_CHECK_LAUNCH();
+    return 0;
 }

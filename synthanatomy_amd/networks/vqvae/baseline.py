@@ -14,6 +14,7 @@ masks and residual adds fused into the GEMM epilogues.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Sequence, Tuple, Union
 
 import torch
@@ -277,10 +278,37 @@ class _ResStage:
         self.c3.weight, self.c3.bias = self.c3m.weight, self.c3m.bias
         self.c1.weight, self.c1.bias = self.c1m.weight, self.c1m.bias
 
+    def _fused_ok(self, x):
+        return (self.dtype == torch.bfloat16 and self.c3.cin == 128 and self.c3.cout == 128 and self.c1.cout == 128
+                and x.numel() * 2 < 0xfffffff0 - 4096 and os.environ.get("SA_NO_FUSED_RES") is None)
+
+    def _fwd_fused(self, x, need_h):
+        """3x3x3 conv + ReLU + 1x1x1 conv + residual + ReLU in one launch (csrc/conv_fprop.hip, FUSE=true)."""
+        import ctypes
+        N, D, H, W, C = x.shape
+        p3 = self.c3._get_plans(N, (D, H, W), 128, 128)
+        p1 = self.c1._get_plans(N, (D, H, W), 128, 128)
+        self.c3._ensure_packed(p3["fwd"])
+        self.c1._ensure_packed(p1["fwd"])
+        y = torch.empty_like(x)
+        h = torch.empty_like(x) if need_h else None
+        ep = ConvOp._epilogue(self.c1._bias_padded(), x, None, None, ACT_RELU, 0, True, self.dtype, 0.2)
+        from ... import engine
+        b1 = self.c3._bias_padded()
+        st = _ffi.stream()
+        engine._launch("conv_fprop_dma_kernel<bf16,2,2,4,4,fused_resblock>", engine._geom_flops(p3["fwd"][0].geom) + engine._geom_flops(p1["fwd"][0].geom),
+                       lambda: _ffi.check(_ffi.lib().sa_resblock_fprop(ctypes.byref(p3["fwd"][0].geom), _ffi.dtype_id(self.dtype), _ffi.ptr(x),
+                                                                       _ffi.ptr(p3["fwd"][0].wpk), _ffi.ptr(b1), _ffi.ptr(p1["fwd"][0].wpk), _ffi.ptr(h), _ffi.ptr(y),
+                                                                       ctypes.byref(ep), st), "sa_resblock_fprop"))
+        return y, h
+
     def fwd(self, x, tape):
         self._sync()
-        h = self.c3.fprop(x, act=ACT_RELU)
-        y = self.c1.fprop(h, act=ACT_RELU, addend=x, add_before_act=True)
+        if self._fused_ok(x):
+            y, h = self._fwd_fused(x, tape is not None)
+        else:
+            h = self.c3.fprop(x, act=ACT_RELU)
+            y = self.c1.fprop(h, act=ACT_RELU, addend=x, add_before_act=True)
         if tape is not None:
             tape.append((x, h))
         return y
