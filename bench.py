@@ -74,13 +74,14 @@ def bench_performer(args, rank, world, dev):
     from synthanatomy_amd.runtime.optim import FlatParams, FusedAdam
 
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    N = int(np.prod(PERF["spatial"]))
+    spatial = tuple(int(v) for v in args.performer_shape.split(","))
+    N = int(np.prod(spatial))
     B = args.performer_batch
     torch.manual_seed(4)
-    order = Ordering("raster_scan", 3, (1,) + PERF["spatial"], (False, False, False), ((2, 0, 1),), ((0, 1),), ("rotate_90", "transpose"))
+    order = Ordering("raster_scan", 3, (1,) + spatial, (False, False, False), ((2, 0, 1),), ((0, 1),), ("rotate_90", "transpose"))
     net = Performer(num_tokens=PERF["vocab"] + 1, max_seq_len=N, dim=PERF["dim"], depth=PERF["depth"], heads=PERF["heads"], ordering=order,
                     local_attn_heads=PERF["local_heads"], local_window_size=PERF["window"], feature_redraw_interval=1, use_rezero=True,
-                    spatial_position_emb="absolute", spatial_shape=PERF["spatial"], compute_dtype=dt).to(dev).train()
+                    spatial_position_emb="absolute", spatial_shape=spatial, compute_dtype=dt).to(dev).train()
     flat = FlatParams(net.parameters())
     opt = FusedAdam(flat, lr=1e-3)
     opt.on_step.append(net.invalidate_packed_weights)
@@ -123,8 +124,8 @@ def bench_performer(args, rank, world, dev):
     res = {"metric": "performer_train_tokens_per_sec", "value": round(toks, 1), "unit": "tokens/s", "ms_per_step": round(dtm / args.steps * 1e3, 3),
            "dtype": args.dtype, "scaling": "weak", "final_loss": round(float(loss.item()), 5),
            "tflops_per_gpu": round(toks / world * PERFORMER_STEP_MFLOP_PER_TOKEN / 1e6, 2),
-           "config": {"workload": "performer n_embd=512 n_layers=24 n_head=16 local_attn_heads=8 local_window=420 vocab=2048, N=1400 raster-ordered "
-                                  "10x14x10 latents, training step = fwd + CE + bwd + Adam, projections redrawn every other step", "batch_per_gpu": B,
+           "config": {"workload": f"performer n_embd=512 n_layers=24 n_head=16 local_attn_heads=8 local_window=420 vocab=2048, N={N} raster-ordered "
+                                  f"{'x'.join(map(str, spatial))} latents, training step = fwd + CE + bwd + Adam, projections redrawn every other step", "batch_per_gpu": B,
                       "global_batch": B * world, "seq_len": N, "parallelism": f"dp{world}"}}
     del net, flat, opt, reducer
     torch.cuda.empty_cache()
@@ -143,6 +144,7 @@ def main():
     ap.add_argument("--performer-batch", type=int, default=6, help="sequences per GPU per step (README.md:119)")
     ap.add_argument("--no-performer", action="store_true", help="skip the secondary Performer tokens/s measurement")
     ap.add_argument("--only-performer", action="store_true", help="dev/profiling: measure only the Performer workload")
+    ap.add_argument("--performer-shape", default="10,14,10", help="latent grid of the Performer workload (20,28,25 = the 14 000-token variant)")
     args = ap.parse_args()
 
     from synthanatomy_amd import engine

@@ -51,16 +51,17 @@ TIMER: Optional[KernelTimer] = None  # set by bench.py around the timed region
 
 
 def _fprop_instance(dtype, g):
-    """Name of the kernel instance csrc/conv_fprop.hip's dispatch picks for this geometry (same granularity as rocprofv3)."""
-    t = "f32" if dtype == torch.float32 else "bf16"
+    """Name of the kernel instance csrc/conv_fprop.hip's dispatch picks for this geometry, spelled like rocprofv3 prints it."""
+    t = "float" if dtype == torch.float32 else "unsigned short"
     cv = g.cout_valid
     m = g.N * g.Dm * g.Hm * g.Wm
     sz = 4 if dtype == torch.float32 else 2
     fits = g.N * g.Di * g.Hi * g.Wi * g.Cin * sz < 0xfffffff0 - 4096
+    uniform = "true" if (g.Cin * sz) % 128 == 0 else "false"
     if cv > 64 and fits and m >= 256 * 256 and os.environ.get("SA_DMA3"):
-        return f"conv_fprop_dma3_kernel<{t}>"
-    tile = "2,2,4,4" if cv > 64 else ("4,1,2,4" if cv > 32 else ("4,1,2,2" if cv > 16 else "4,1,2,1"))
-    return f"conv_fprop_dma_kernel<{t},{tile}>" if fits else f"conv_fprop_kernel<{t},{tile}>"
+        return f"conv_fprop_dma3_kernel<{t}, {uniform}>"
+    tile = "2, 2, 4, 4" if cv > 64 else ("4, 1, 2, 4" if cv > 32 else ("4, 1, 2, 2" if cv > 16 else "4, 1, 2, 1"))
+    return f"conv_fprop_dma_kernel<{t}, {tile}, {uniform}, false>" if fits else f"conv_fprop_kernel<{t}, {tile}>"
 
 
 def _geom_flops(g) -> float:
@@ -297,7 +298,7 @@ class ConvOp:
         assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.shape == self.weight.shape
         plans = self._get_plans(N, (D, H, W), fwd_out_stride or self.cout, g.shape[-1])
         lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
-        wname = "conv_wgrad_dma_kernel<%s>" % ("f32" if self.dtype == torch.float32 else "bf16")
+        wname = "conv_wgrad_dma_kernel<%s>" % ("float" if self.dtype == torch.float32 else "unsigned short")
         for pl in plans["wgrad"]:
             nbytes = lib.sa_conv_wgrad_workspace_bytes(ctypes.byref(pl.geom), did)
             if nbytes < 0:
