@@ -11,6 +11,8 @@
 //   scan A  "reduce over features":  T[m][d] += a_i[m] b_i[d];  y_i[d] = sum_m c_i[m] T[m][d]     (block = 16 columns d)
 //   scan B  "reduce over columns" :  T[m][d] += a_i[m] b_i[d];  y_i[m] = sum_d T[m][d] c_i[d]     (block = 64 features m)
 // forward numerator = A(k', v, q'); dv = A(q', dnum, k') reversed; dq' = B(k', v, dnum); dk' = B(q', dnum, v) reversed.
+#include <stdlib.h>
+
 #include "sa_common.h"
 
 namespace sa {
@@ -443,6 +445,219 @@ __global__ __launch_bounds__(256) void favor_scan_b_kernel(const ScanArgs s) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ FAVOR+ scans on the fp32 MFMA
+// Chunked form of the same scans (64 positions per chunk, every chunk an independent block):
+//   1) chunk state sums      U_c = A_c^T B_c                    (favor_chunk_state_kernel)
+//   2) exclusive prefix over the chunks of one (batch, head)   (scan_state_prefix_kernel)  ->  T_prev(c)
+//   3) chunk outputs         scan A: y^T[d][i] = sum_m T_prev[m][d] c_i[m] + sum_{j<=i} b_j[d] (a_j . c_i)
+//                            scan B: y^T[m][i] = sum_d T_prev[m][d] c_i[d] + sum_{j<=i} a_j[m] (b_j . c_i)
+// Wave w of a block owns positions i = 16 w + (lane & 15) (MFMA columns), so the masked pair products P[j][i] leave the first MFMA
+// already in B-operand form for the second one.  All fp32 (mfma_f32_16x16x4f32).
+__device__ __forceinline__ int scan_pos(const ScanArgs& s, int p) { return s.reverse ? s.N - 1 - p : p; }
+
+// Loads are unconditional on clamped addresses and masked by a select afterwards: a conditional load becomes a branch whose join
+// waits for vmcnt(0), which serialises every load of the loop.  LDF % 16 == 0 (the host checks), so rows are float4-addressable.
+// The MFMA k index of a feature contraction is the permutation m = g4 * (LDF/4) + mm, so each lane reads contiguous floats.
+__global__ __launch_bounds__(256) void favor_chunk_state_kernel(const ScanArgs s) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fr = lane & 15, g4 = lane >> 4;
+    const int chunk = blockIdx.x % s.S, g = (blockIdx.x / s.S) % s.G, b = blockIdx.x / (s.S * s.G);
+    const int nmf = s.LDF >> 4;
+    float4_t acc[17];
+#pragma unroll
+    for (int mf = 0; mf < 17; ++mf) acc[mf] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int kk = 0; kk < 16; ++kk) {
+        const int p = chunk * 64 + kk * 4 + g4;
+        const bool ok = p < s.N;
+        const int i = scan_pos(s, ok ? p : 0);
+        const int64_t r = (int64_t)b * s.N + i, row = r * s.G + g;
+        float bv = s.b[r * s.b_stride + s.b_off + g * s.dv + w * 16 + fr];
+        if (s.b_scale) bv *= s.b_scale[row];
+        bv = ok ? bv : 0.f;
+        const float* ap = s.a + row * s.LDF + fr;
+        float av[17];
+#pragma unroll
+        for (int mf = 0; mf < 17; ++mf) av[mf] = ap[(mf < nmf ? mf : 0) * 16];
+#pragma unroll
+        for (int mf = 0; mf < 17; ++mf) acc[mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(mf < nmf ? av[mf] : 0.f, bv, acc[mf], 0, 0, 0);
+    }
+    float* st = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * s.LDF * s.dv;
+#pragma unroll
+    for (int mf = 0; mf < 17; ++mf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mf * 16 + g4 * 4 + r;
+            if (m < s.LDF) st[m * s.dv + w * 16 + fr] = acc[mf][r];
+        }
+}
+
+// b tile of one chunk (with its per-position scale), zero beyond N
+__device__ __forceinline__ void scan_load_b_tile(const ScanArgs& s, float (*sB)[68], int b, int g, int chunk, int tid) {
+    for (int e = tid; e < 64 * 16; e += 256) {
+        const int j = e >> 4, c4 = e & 15;
+        const int p = chunk * 64 + j;
+        const bool ok = p < s.N;
+        const int64_t r = (int64_t)b * s.N + scan_pos(s, ok ? p : 0);
+        float4 v = *(const float4*)(s.b + r * s.b_stride + s.b_off + g * s.dv + c4 * 4);
+        const float sc = ok ? (s.b_scale ? s.b_scale[r * s.G + g] : 1.f) : 0.f;
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        *(float4*)&sB[j][c4 * 4] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void favor_chunk_out_a_kernel(const ScanArgs s) {
+    __shared__ float sB[64][68];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, g4 = lane >> 4;
+    const int chunk = blockIdx.x % s.S, g = (blockIdx.x / s.S) % s.G, b = blockIdx.x / (s.S * s.G);
+    const int q4 = s.LDF >> 4;  // float4 groups per lane quarter: features g4*(LDF/4) + [0, LDF/4)
+    const int span = s.LDF >> 2;
+    scan_load_b_tile(s, sB, b, g, chunk, tid);
+    const int pi = chunk * 64 + w * 16 + fr;    // this lane's position (scan order)
+    const bool vi = pi < s.N;
+    const int64_t ri = (int64_t)b * s.N + scan_pos(s, vi ? pi : 0), rowi = ri * s.G + g;
+    float Creg[68];
+    {
+        const float4* cp = (const float4*)(s.c_feat + rowi * s.LDF + g4 * span);
+#pragma unroll
+        for (int t = 0; t < 17; ++t) {
+            const float4 v = cp[t < q4 ? t : 0];
+            const bool k = vi && t < q4;
+            Creg[t * 4 + 0] = k ? v.x : 0.f; Creg[t * 4 + 1] = k ? v.y : 0.f; Creg[t * 4 + 2] = k ? v.z : 0.f; Creg[t * 4 + 3] = k ? v.w : 0.f;
+        }
+    }
+    __syncthreads();
+    // P[j][i] = a_j . c_i for the 64 positions j of the chunk, masked to j <= i
+    float4_t P[4];
+#pragma unroll
+    for (int jf = 0; jf < 4; ++jf) {
+        P[jf] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        const int pj = chunk * 64 + jf * 16 + fr;
+        const bool vj = pj < s.N;
+        const float4* ap = (const float4*)(s.a + (((int64_t)b * s.N + scan_pos(s, vj ? pj : 0)) * s.G + g) * s.LDF + g4 * span);
+#pragma unroll
+        for (int t = 0; t < 17; ++t) {
+            const float4 v = ap[t < q4 ? t : 0];
+            P[jf] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, Creg[t * 4 + 0], P[jf], 0, 0, 0);
+            P[jf] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, Creg[t * 4 + 1], P[jf], 0, 0, 0);
+            P[jf] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, Creg[t * 4 + 2], P[jf], 0, 0, 0);
+            P[jf] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, Creg[t * 4 + 3], P[jf], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (!vj || jf * 16 + g4 * 4 + r > w * 16 + fr) P[jf][r] = 0.f;
+    }
+    const float* st = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * s.LDF * s.dv + (int64_t)g4 * span * s.dv + fr;
+    float4_t acc[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) acc[df] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mm = 0; mm < 68; ++mm) {  // inter-chunk: T_prev^T c_i   (Creg is zero beyond span, the row index is only clamped)
+        float tv[4];
+#pragma unroll
+        for (int df = 0; df < 4; ++df) tv[df] = st[(mm < span ? mm : 0) * s.dv + df * 16];
+#pragma unroll
+        for (int df = 0; df < 4; ++df) acc[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(tv[df], Creg[mm], acc[df], 0, 0, 0);
+    }
+#pragma unroll
+    for (int df = 0; df < 4; ++df)
+#pragma unroll
+        for (int jf = 0; jf < 4; ++jf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(sB[jf * 16 + g4 * 4 + r][df * 16 + fr], P[jf][r], acc[df], 0, 0, 0);
+    if (!vi) return;
+    const float ys = s.y_scale ? s.y_scale[rowi] : 1.f;
+    float* yp = s.y + ri * s.y_stride + s.y_off + g * s.dv;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+        float4 o = make_float4(acc[df][0] * ys, acc[df][1] * ys, acc[df][2] * ys, acc[df][3] * ys);
+        float4* d4 = (float4*)(yp + df * 16 + g4 * 4);
+        if (s.accumulate) {
+            const float4 old = *d4;
+            o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *d4 = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void favor_chunk_out_b_kernel(const ScanArgs s) {
+    __shared__ float sB[64][68];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, g4 = lane >> 4;
+    const int chunk = blockIdx.x % s.S, g = (blockIdx.x / s.S) % s.G, b = blockIdx.x / (s.S * s.G);
+    const int nmf = s.LDF >> 4;
+    scan_load_b_tile(s, sB, b, g, chunk, tid);
+    const int pi = chunk * 64 + w * 16 + fr;
+    const bool vi = pi < s.N;
+    const int64_t ri = (int64_t)b * s.N + scan_pos(s, vi ? pi : 0), rowi = ri * s.G + g;
+    float Creg[16];  // k index of the d contraction: d = g4 * 16 + dd
+    {
+        const float cs = vi ? (s.c_scale ? s.c_scale[rowi] : 1.f) : 0.f;
+        const float4* cp = (const float4*)(s.c_col + ri * s.c_stride + s.c_off + g * s.dv + g4 * 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 v = cp[t];
+            Creg[t * 4 + 0] = v.x * cs; Creg[t * 4 + 1] = v.y * cs; Creg[t * 4 + 2] = v.z * cs; Creg[t * 4 + 3] = v.w * cs;
+        }
+    }
+    __syncthreads();
+    float4_t P[4];  // P[j][i] = b_j . c_i, masked to j <= i (rows beyond N are zero in sB)
+#pragma unroll
+    for (int jf = 0; jf < 4; ++jf) {
+        P[jf] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 v = *(const float4*)&sB[jf * 16 + fr][g4 * 16 + t * 4];
+            P[jf] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, Creg[t * 4 + 0], P[jf], 0, 0, 0);
+            P[jf] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, Creg[t * 4 + 1], P[jf], 0, 0, 0);
+            P[jf] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, Creg[t * 4 + 2], P[jf], 0, 0, 0);
+            P[jf] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, Creg[t * 4 + 3], P[jf], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (jf * 16 + g4 * 4 + r > w * 16 + fr) P[jf][r] = 0.f;
+    }
+    const float* st = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * s.LDF * s.dv + g4 * 16;
+    // a rows of the 16 positions j = jf*16 + g4*4 + r this lane feeds as the MFMA k index (clamped; P is zero for j beyond N)
+    const float* arow[16];
+#pragma unroll
+    for (int jf = 0; jf < 4; ++jf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pj = chunk * 64 + jf * 16 + g4 * 4 + r;
+            arow[jf * 4 + r] = s.a + (((int64_t)b * s.N + scan_pos(s, pj < s.N ? pj : 0)) * s.G + g) * s.LDF + fr;
+            if (pj >= s.N) P[jf][r] = 0.f;
+        }
+    const float exs = (vi && s.ex_vec) ? (s.ex_scale ? s.ex_scale[rowi] : 1.f) : 0.f;
+    const float* evp = s.ex_vec ? s.ex_vec + rowi * s.LDF + g4 * 4 : nullptr;
+    float* yp = s.y + rowi * s.LDF + g4 * 4;
+    for (int mf = 0; mf < nmf; ++mf) {
+        float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f};
+        float av[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) av[q] = arow[q][mf * 16];
+        const float4* tp = (const float4*)(st + (int64_t)(mf * 16 + fr) * s.dv);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {  // inter-chunk: T_prev c_i
+            const float4 v = tp[t];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, Creg[t * 4 + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, Creg[t * 4 + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, Creg[t * 4 + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, Creg[t * 4 + 3], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int jf = 0; jf < 4; ++jf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jf * 4 + r], P[jf][r], acc, 0, 0, 0);
+        if (vi) {
+            float4 o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            if (evp) {
+                const float4 ev = *(const float4*)(evp + mf * 16);
+                o.x += exs * (ev.x + s.ex_const); o.y += exs * (ev.y + s.ex_const); o.z += exs * (ev.z + s.ex_const); o.w += exs * (ev.w + s.ex_const);
+            }
+            *(float4*)(yp + mf * 16) = o;
+        }
+    }
+}
+
 // state[b,g,seg] <- sum of the states of the segments before it (exclusive prefix along S), one thread per element
 __global__ void scan_state_prefix_kernel(float* __restrict__ state, int64_t BG, int S, int64_t elems) {
     const int64_t tix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -679,7 +894,7 @@ extern "C" int sa_favor_projection(const float* blocks, const float* rows, float
 static int check_scan(int B, int N, int G, int LDF, int dv) { return (B > 0 && N > 0 && G > 0 && LDF > 0 && LDF <= 272 && dv == 64) ? 0 : SA_EUNSUPPORTED; }
 
 static void scan_segments(int N, int& S, int& seg_len, const void* ws) {
-    S = ws ? (N + 127) / 128 : 1;      // ~128 positions per block
+    S = ws ? (N + 127) / 128 : 1;      // VALU path: ~128 positions per block
     if (S > 16) S = 16;
     if (S < 1) S = 1;
     seg_len = (N + S - 1) / S;
@@ -687,30 +902,42 @@ static void scan_segments(int N, int& S, int& seg_len, const void* ws) {
 }
 
 extern "C" int64_t sa_favor_scan_workspace_bytes(int B, int N, int G, int LDF, int dv) {
-    int S, seg_len;
-    scan_segments(N, S, seg_len, (const void*)1);
-    return (int64_t)B * G * S * LDF * dv * 4;
+    return (int64_t)B * G * ((N + 63) / 64) * LDF * dv * 4;  // one state per 64-position chunk
 }
 
+// which == 0: scan A, 1: scan B.  With a workspace: chunked MFMA path (3 launches); without: one VALU block per (b, g).
 template <typename K>
-static int run_scan(K kernel, ScanArgs& s, unsigned base_blocks, float* ws, hipStream_t st) {
-    scan_segments(s.N, s.S, s.seg_len, ws);
-    s.state = ws;
-    if (s.S == 1) {
-        s.pass = 0;
-        s.state = nullptr;
-        hipLaunchKernelGGL(kernel, dim3(base_blocks), dim3(256), 0, st, s);
+static int run_scan(K valu_kernel, int which, ScanArgs& s, unsigned base_blocks, float* ws, hipStream_t st) {
+    static const bool no_mfma = getenv("SA_SCAN_VALU") != nullptr;
+    if (!ws) {
+        s.S = 1; s.seg_len = s.N; s.pass = 0; s.state = nullptr;
+        hipLaunchKernelGGL(valu_kernel, dim3(base_blocks), dim3(256), 0, st, s);
         SA_CHECK_LAUNCH();
         return 0;
     }
-    s.pass = 1;
-    hipLaunchKernelGGL(kernel, dim3(base_blocks * s.S), dim3(256), 0, st, s);
-    SA_CHECK_LAUNCH();
+    s.state = ws;
     const int64_t elems = (int64_t)s.LDF * s.dv, bg = (int64_t)s.B * s.G;
+    if (!no_mfma && (s.LDF & 15) == 0 && s.LDF <= 272 && s.dv == 64) {
+        s.S = (s.N + 63) / 64;
+        s.seg_len = 64;
+        const unsigned nblk = (unsigned)(bg * s.S);
+        hipLaunchKernelGGL(favor_chunk_state_kernel, dim3(nblk), dim3(256), 0, st, s);
+        SA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(scan_state_prefix_kernel, dim3((unsigned)((bg * elems + 255) / 256)), dim3(256), 0, st, ws, bg, s.S, elems);
+        SA_CHECK_LAUNCH();
+        if (which == 0) hipLaunchKernelGGL(favor_chunk_out_a_kernel, dim3(nblk), dim3(256), 0, st, s);
+        else hipLaunchKernelGGL(favor_chunk_out_b_kernel, dim3(nblk), dim3(256), 0, st, s);
+        SA_CHECK_LAUNCH();
+        return 0;
+    }
+    scan_segments(s.N, s.S, s.seg_len, ws);
+    s.pass = 1;
+    hipLaunchKernelGGL(valu_kernel, dim3(base_blocks * s.S), dim3(256), 0, st, s);
+    SA_CHECK_LAUNCH();
     hipLaunchKernelGGL(scan_state_prefix_kernel, dim3((unsigned)((bg * elems + 255) / 256)), dim3(256), 0, st, ws, bg, s.S, elems);
     SA_CHECK_LAUNCH();
     s.pass = 2;
-    hipLaunchKernelGGL(kernel, dim3(base_blocks * s.S), dim3(256), 0, st, s);
+    hipLaunchKernelGGL(valu_kernel, dim3(base_blocks * s.S), dim3(256), 0, st, s);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -724,7 +951,7 @@ extern "C" int sa_favor_scan_a(const float* a, const float* c, const float* b, i
     s.a = a; s.c_feat = c; s.b = b; s.b_scale = b_scale; s.y = y; s.y_scale = y_scale;
     s.B = B; s.N = N; s.G = G; s.LDF = LDF; s.dv = dv; s.b_stride = b_stride; s.b_off = b_off; s.y_stride = y_stride; s.y_off = y_off;
     s.reverse = reverse; s.accumulate = accumulate;
-    return run_scan(favor_scan_a_kernel, s, (unsigned)(B * G * (dv / 16)), state_ws, ST(stream));
+    return run_scan(favor_scan_a_kernel, 0, s, (unsigned)(B * G * (dv / 16)), state_ws, ST(stream));
 }
 
 extern "C" int sa_favor_scan_b(const float* a, const float* b, int b_stride, int b_off, const float* b_scale, const float* c, int c_stride, int c_off,
@@ -735,7 +962,7 @@ extern "C" int sa_favor_scan_b(const float* a, const float* b, int b_stride, int
     ScanArgs s = {};
     s.a = a; s.b = b; s.c_col = c; s.b_scale = b_scale; s.c_scale = c_scale; s.y = y; s.ex_scale = ex_scale; s.ex_vec = ex_vec; s.ex_const = ex_const;
     s.B = B; s.N = N; s.G = G; s.LDF = LDF; s.dv = dv; s.b_stride = b_stride; s.b_off = b_off; s.c_stride = c_stride; s.c_off = c_off; s.reverse = reverse;
-    return run_scan(favor_scan_b_kernel, s, (unsigned)(B * G * ((LDF + 63) / 64)), state_ws, ST(stream));
+    return run_scan(favor_scan_b_kernel, 1, s, (unsigned)(B * G * ((LDF + 63) / 64)), state_ws, ST(stream));
 }
 
 extern "C" int sa_cumsum_rows(const float* x, const float* scale, float* out, int B, int N, int G, int LDF, int reverse, float* seg_ws, void* stream) {

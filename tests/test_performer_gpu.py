@@ -112,6 +112,48 @@ def test_causal_scan_kernels_against_quadratic_form(N, segmented):
     assert float(out[:, G * dv:].abs().max()) == 0.0  # only the addressed head block is written
 
 
+@pytest.mark.parametrize("N,reverse", [(37, 0), (37, 1), (200, 1), (1400, 0)])
+def test_causal_scan_variants_against_einsum(N, reverse):
+    """Every mode the backward uses: reversed order, per-position scales, accumulate, scan B with its extra term; VALU path == MFMA path."""
+    from synthanatomy_amd import _ffi
+    lib, st = _ffi.lib(), _ffi.stream()
+    torch.manual_seed(5)
+    B, G, m, LDF, dv = 2, 2, 266, 272, 64
+    a = torch.zeros(B, N, G, LDF, dtype=torch.float64)
+    c = torch.zeros(B, N, G, LDF, dtype=torch.float64)
+    a[..., :m] = torch.rand(B, N, G, m) + 0.01
+    c[..., :m] = torch.rand(B, N, G, m) + 0.01
+    bb = torch.randn(B, N, G, dv, dtype=torch.float64)
+    cc = torch.randn(B, N, G, dv, dtype=torch.float64)
+    bs = torch.rand(B, N, G, dtype=torch.float64) + 0.5
+    ys = torch.rand(B, N, G, dtype=torch.float64) + 0.5
+    ev = torch.zeros(B, N, G, LDF, dtype=torch.float64)
+    ev[..., :m] = torch.randn(B, N, G, m)
+    y0 = torch.randn(B, N, G, dv, dtype=torch.float64)
+    tri = torch.tril(torch.ones(N, N, dtype=torch.float64))
+    if reverse:
+        tri = tri.t()                                  # j >= i
+    bsc = bb * bs[..., None]
+    refA = torch.einsum("bigm,bjgm,ij,bjgd->bigd", c, a, tri, bsc) * ys[..., None] + y0
+    refB = torch.einsum("bjgm,bjgd,ij,bigd->bigm", a, bsc, tri, cc * ys[..., None]) + bs[..., None] * (ev + 0.25)
+    refB[..., m:] = refB[..., m:]                      # padding columns carry only the extra term
+    f = lambda t: t.float().cuda().contiguous()
+    ad, cd, bd, ccd, bsd, ysd, evd = f(a), f(c), f(bb.reshape(B * N, G * dv)), f(cc.reshape(B * N, G * dv)), f(bs), f(ys), f(ev)
+    ws = torch.empty(lib.sa_favor_scan_workspace_bytes(B, N, G, LDF, dv) // 4, device="cuda")
+    outs = []
+    for w in (ws, None):
+        ya = f(y0.reshape(B * N, G * dv))
+        _ffi.check(lib.sa_favor_scan_a(_ffi.ptr(ad), _ffi.ptr(cd), _ffi.ptr(bd), G * dv, 0, _ffi.ptr(bsd), _ffi.ptr(ya), G * dv, 0, _ffi.ptr(ysd), B, N, G, LDF, dv,
+                                       reverse, 1, _ffi.ptr(w), st))
+        yb = torch.zeros(B, N, G, LDF, device="cuda")
+        _ffi.check(lib.sa_favor_scan_b(_ffi.ptr(ad), _ffi.ptr(bd), G * dv, 0, _ffi.ptr(bsd), _ffi.ptr(ccd), G * dv, 0, _ffi.ptr(ysd), _ffi.ptr(yb), _ffi.ptr(bsd),
+                                       _ffi.ptr(evd), 0.25, B, N, G, LDF, dv, reverse, _ffi.ptr(w), st))
+        outs.append((ya, yb))
+        assert _rel(ya.view(B, N, G, dv).cpu().double(), refA) < 1e-4
+        assert _rel(yb[..., :m].cpu().double(), refB[..., :m]) < 1e-4
+    assert _rel(outs[0][0], outs[1][0]) < 1e-4 and _rel(outs[0][1][..., :m], outs[1][1][..., :m]) < 1e-4
+
+
 @pytest.mark.parametrize("N,W", [(23, 5), (40, 8), (17, 32), (100, 420)])
 def test_local_attention_kernel_against_dense_band(N, W):
     from synthanatomy_amd import _ffi
