@@ -18,6 +18,7 @@ LIB = os.path.join(HERE, "libsynthanatomy_hip.so")
 OBJ = os.path.join(HERE, "_obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off", "-Wno-unused-value"]
+FLAGS += os.environ.get("SA_EXTRA_HIPCC_FLAGS", "").split()  # dev: e.g. -DSA_PP_DEBUG_VARIANTS
 
 
 def _sources():

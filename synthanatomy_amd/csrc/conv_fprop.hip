@@ -39,6 +39,8 @@ struct FpropArgs {
     const void* w2pk;
     const float* bias1;
     void* h_out;
+    uint32_t HP, WP;      // halo mainloop: patches per plane along H (8 voxels) and W (16 voxels)
+    uint32_t dbg;         // dev only (SA_PP_DBG): bit0 skip activation DMA, bit1 skip weight DMA, bit2 skip fragment reads, bit3 skip MFMAs
 };
 
 template <typename T>
@@ -60,9 +62,24 @@ __device__ __forceinline__ void mma_slab<float>(float4_t& acc, const u32x4& wa, 
 __device__ __forceinline__ uint32_t tile_off(uint32_t row, uint32_t vec) { return row * 128u + ((vec ^ (row & 7u)) << 4); }
 
 // ---- epilogue shared by both mainloops, staged through LDS so that HBM sees full channel rows
-template <int BM, int BN, int WM, int WN, int MI, int NI, int NT = 256>
-__device__ __forceinline__ void fprop_epilogue(const FpropArgs& a, float4_t (&acc)[NI][MI], unsigned char* smem, uint32_t tid, uint32_t wm, uint32_t wn,
-                                               uint32_t frow, uint32_t fq, uint32_t m_base, uint32_t n_base) {
+// output voxel (linear index into [N, Do, Ho, Wo]) of GEMM row m of the launch grid, or -1 beyond M
+__device__ __forceinline__ long long linear_row_voxel(const FpropArgs& a, uint32_t m) {
+    const sa_conv_geom& g = a.g;
+    if (m >= a.M) return -1;
+    uint32_t q = fdiv(m, a.dW);
+    const uint32_t wmx = m - q * g.Wm;
+    uint32_t q2 = fdiv(q, a.dH);
+    const uint32_t hmx = q - q2 * g.Hm;
+    const uint32_t n = fdiv(q2, a.dD);
+    const uint32_t dmx = q2 - n * g.Dm;
+    return (((long long)n * g.Do + (dmx * g.out_mult[0] + g.out_off[0])) * g.Ho + (hmx * g.out_mult[1] + g.out_off[1])) * g.Wo +
+           (wmx * g.out_mult[2] + g.out_off[2]);
+}
+
+// `row_ov(row)` -> output voxel of tile row `row` (or -1): the linear launch grid, or the 2-D patch of the halo mainloop
+template <int BM, int BN, int WM, int WN, int MI, int NI, int NT, typename RowOv>
+__device__ __forceinline__ void fprop_epilogue_ov(const FpropArgs& a, float4_t (&acc)[NI][MI], unsigned char* smem, uint32_t tid, uint32_t wm, uint32_t wn,
+                                                  uint32_t frow, uint32_t fq, uint32_t n_base, RowOv row_ov) {
     const sa_conv_geom& g = a.g;
     //  A) every lane parks its 4x(acc + bias) for one voxel in an fp32 tile [BM][BN+4] (stride padded: conflict-free b128)
     //  B) the block re-reads the tile voxel-row-wise, 4 channels per thread: addend / activation / mask are applied with
@@ -85,21 +102,7 @@ __device__ __forceinline__ void fprop_epilogue(const FpropArgs& a, float4_t (&ac
             *(float4_t*)(sT + row * LDT + col) = v;
         }
     }
-    if (tid < BM) {
-        const uint32_t m = m_base + tid;
-        long long ov = -1;
-        if (m < a.M) {
-            uint32_t q = fdiv(m, a.dW);
-            const uint32_t wmx = m - q * g.Wm;
-            uint32_t q2 = fdiv(q, a.dH);
-            const uint32_t hmx = q - q2 * g.Hm;
-            const uint32_t n = fdiv(q2, a.dD);
-            const uint32_t dmx = q2 - n * g.Dm;
-            ov = (((long long)n * g.Do + (dmx * g.out_mult[0] + g.out_off[0])) * g.Ho + (hmx * g.out_mult[1] + g.out_off[1])) * g.Wo +
-                 (wmx * g.out_mult[2] + g.out_off[2]);
-        }
-        sOv[tid] = ov;
-    }
+    if (tid < BM) sOv[tid] = row_ov(tid);
     __syncthreads();
     const float alpha = ep.alpha ? *ep.alpha : 1.f;
     const bool vec_ok = (g.Cout & 3) == 0;
@@ -177,6 +180,13 @@ __device__ __forceinline__ void fprop_epilogue(const FpropArgs& a, float4_t (&ac
             }
         }
     }
+}
+
+template <int BM, int BN, int WM, int WN, int MI, int NI, int NT = 256>
+__device__ __forceinline__ void fprop_epilogue(const FpropArgs& a, float4_t (&acc)[NI][MI], unsigned char* smem, uint32_t tid, uint32_t wm, uint32_t wn,
+                                               uint32_t frow, uint32_t fq, uint32_t m_base, uint32_t n_base) {
+    fprop_epilogue_ov<BM, BN, WM, WN, MI, NI, NT>(a, acc, smem, tid, wm, wn, frow, fq, n_base,
+                                                  [&](uint32_t row) __attribute__((always_inline)) { return linear_row_voxel(a, m_base + row); });
 }
 
 template <typename T, int WM, int WN, int MI, int NI>
@@ -306,6 +316,67 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(const FpropArgs a) {
     fprop_epilogue<BM, BN, WM, WN, MI, NI>(a, acc, smem, tid, wm, wn, frow, fq, m_base, n_base);
 }
 
+// Second GEMM of the fused residual block, on chip (bf16, 128 x 128 tile, 4 waves of 64 x 64):
+//   out2[m][co] = sum_c relu(acc[m][c] + b1[c]) * W2[co][c]
+// W2 (two 128-byte K-slabs) streams into LDS [32 KiB, 64 KiB) while h is converted and parked in [0, 32 KiB); `row_vox(row)` gives
+// the voxel a tile row belongs to (for the optional h store), or -1.  Leaves the second product in `acc`; LDS is free on return.
+template <int MI, int NI, typename RowVox>
+__device__ __forceinline__ void resblock_second_gemm(const FpropArgs& a, float4_t (&acc)[NI][MI], unsigned char* smem, uint32_t tid, uint32_t wave, uint32_t wm,
+                                                     uint32_t wn, uint32_t frow, uint32_t fq, uint32_t prow, uint32_t lv, RowVox row_vox) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 128, BN = 128;
+    __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2pk, 0, 128 * 128 * 2, 0x00020000);
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(smem + 2 * BM * 128 + sl * (BN * 128) + (wave * 4 + j) * 1024), 16,
+                                                     ((wave * 4 + j) * 8 + prow) * 256u + lv * 16u, sl * 128u, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const uint32_t c0 = wn * (NI * 16) + i * 16 + fq * 4;       // 4 consecutive hidden channels of this lane
+        const float4_t b1 = *(const float4_t*)(a.bias1 + c0);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+            const uint32_t row = wm * (MI * 16) + j * 16 + frow;
+            const float4_t v = acc[i][j] + b1;
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(fmaxf(v[0], 0.f)) | ((uint32_t)f32_to_bf16(fmaxf(v[1], 0.f)) << 16);
+            pk.y = (uint32_t)f32_to_bf16(fmaxf(v[2], 0.f)) | ((uint32_t)f32_to_bf16(fmaxf(v[3], 0.f)) << 16);
+            *(uint2*)(smem + (c0 >> 6) * (BM * 128) + tile_off(row, (c0 & 63u) >> 3) + (c0 & 7u) * 2) = pk;
+            acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();  // h tile complete (and the W2 DMA drained)
+    if (a.h_out) {    // training: the hidden activation is needed by the backward pass -> full 256-byte rows
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const uint32_t row = (tid >> 4) + 16u * it, sl = (tid >> 3) & 1u, vec = tid & 7u;
+            const long long vox = row_vox(row);
+            if (vox >= 0) *(u32x4*)((bf16_t*)a.h_out + (size_t)vox * 128 + sl * 64 + vec * 8) = *(const u32x4*)(smem + sl * (BM * 128) + tile_off(row, vec));
+        }
+    }
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const unsigned char* pa = smem + sl * (BM * 128);
+        const unsigned char* pb = smem + 2 * BM * 128 + sl * (BN * 128);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 xf[MI], wf[NI];
+#pragma unroll
+            for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(pa + tile_off(wm * (MI * 16) + j * 16 + frow, ks * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + tile_off(wn * (NI * 16) + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) mma_slab<bf16_t>(acc[i][j], wf[i], xf[j]);
+        }
+    }
+    __syncthreads();  // all waves done with the h / W2 tiles before the epilogue reuses the LDS
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // Mainloop v2: LDS-DMA staging.  Both tiles go HBM/L2 -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR round trip, no
 // ds_write pass, no exec-masked branches): out-of-range taps / rows use an out-of-bounds buffer offset, which the hardware
@@ -408,10 +479,16 @@ __global__ __launch_bounds__(256) void conv_fprop_dma_kernel(const FpropArgs a) 
         for (int j = 0; j < 4; ++j) {
             const bool ok = tap_ok && (vm[j] & sel) == sel;
             const uint32_t voff = ok ? rowoff[j] + koff : OOB_OFF;
+#ifdef SA_PP_DEBUG_VARIANTS
+            if (a.dbg & 64u) continue;
+#endif
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(pa + (wave * 4 + j) * 1024), 16, voff, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < B_PER_WAVE; ++j) {
+#ifdef SA_PP_DEBUG_VARIANTS
+            if (a.dbg & 128u) continue;
+#endif
             if (B_PIECES >= 4 || wave * B_PER_WAVE + j < (uint32_t)B_PIECES)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(pb + (wave * B_PER_WAVE + j) * 1024), 16, boff[j],
                                                          s * 128u, 0, 0);
@@ -448,57 +525,8 @@ __global__ __launch_bounds__(256) void conv_fprop_dma_kernel(const FpropArgs a) 
     }
     if constexpr (FUSE) {
         static_assert(!FUSE || (sizeof(T) == 2 && BM == 128 && BN == 128), "fused residual block: bf16, 128 x 128 tile");
-        // ---- second GEMM of the residual block on chip:  out2[m][co] = sum_c relu(acc[m][c] + b1[c]) * W2[co][c]
-        // W2 (two 128-byte K-slabs) streams into the weight buffers while h is converted and parked in the activation buffers.
-        __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2pk, 0, 128 * 128 * 2, 0x00020000);
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(smem + 2 * BM * 128 + sl * (BN * 128) + (wave * 4 + j) * 1024), 16,
-                                                         ((wave * 4 + j) * 8 + prow) * 256u + lv * 16u, sl * 128u, 0, 0);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const uint32_t c0 = wn * (NI * 16) + i * 16 + fq * 4;       // 4 consecutive hidden channels of this lane
-            const float4_t b1 = *(const float4_t*)(a.bias1 + c0);
-#pragma unroll
-            for (int j = 0; j < MI; ++j) {
-                const uint32_t row = wm * (MI * 16) + j * 16 + frow;
-                const float4_t v = acc[i][j] + b1;
-                uint2 pk;
-                pk.x = (uint32_t)f32_to_bf16(fmaxf(v[0], 0.f)) | ((uint32_t)f32_to_bf16(fmaxf(v[1], 0.f)) << 16);
-                pk.y = (uint32_t)f32_to_bf16(fmaxf(v[2], 0.f)) | ((uint32_t)f32_to_bf16(fmaxf(v[3], 0.f)) << 16);
-                *(uint2*)(smem + (c0 >> 6) * (BM * 128) + tile_off(row, (c0 & 63u) >> 3) + (c0 & 7u) * 2) = pk;
-                acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        __syncthreads();  // h tile complete (and the W2 DMA drained)
-        if (a.h_out) {    // training: the hidden activation is needed by the backward pass -> full 256-byte rows
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const uint32_t row = (tid >> 4) + 16u * it, sl = (tid >> 3) & 1u, vec = tid & 7u;
-                const uint32_t m = m_base + row;
-                if (m < a.M) *(u32x4*)((bf16_t*)a.h_out + (size_t)m * 128 + sl * 64 + vec * 8) = *(const u32x4*)(smem + sl * (BM * 128) + tile_off(row, vec));
-            }
-        }
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-            const unsigned char* pa = smem + sl * (BM * 128);
-            const unsigned char* pb = smem + 2 * BM * 128 + sl * (BN * 128);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                u32x4 xf[MI], wf[NI];
-#pragma unroll
-                for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(pa + tile_off(wm * (MI * 16) + j * 16 + frow, ks * 4 + fq));
-#pragma unroll
-                for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + tile_off(wn * (NI * 16) + i * 16 + frow, ks * 4 + fq));
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
-            }
-        }
-        __syncthreads();  // all waves done with the h / W2 tiles before the epilogue reuses the LDS
+        resblock_second_gemm<MI, NI>(a, acc, smem, tid, wave, wm, wn, frow, fq, prow, lv,
+                                     [&](uint32_t row) __attribute__((always_inline)) { return m_base + row < a.M ? (long long)(m_base + row) : -1ll; });
     }
     fprop_epilogue<BM, BN, WM, WN, MI, NI>(a, acc, smem, tid, wm, wn, frow, fq, m_base, n_base);
 #endif
@@ -647,6 +675,318 @@ __global__ __launch_bounds__(512) void conv_fprop_dma3_kernel(const FpropArgs a)
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Mainloop v4 "ping-pong" (Cout >= 65, Cin * sizeof(T) a multiple of 128): 8 waves, tile 256 voxels x 128 channels, the v3
+// three-stage LDS-DMA ring, but every K-slab is two PHASES (K = 32 each) of
+//     [ds_read the 4 + 4 fragments | issue half of the slab two ahead]  s_barrier  [16 MFMA at priority 1]  s_barrier
+// and waves 4-7 run ONE barrier behind waves 0-3.  Waves w and w + 4 share a SIMD, so while one of them owns the matrix pipe
+// its partner is in the LDS/DMA segment: the pipe never waits for a wave that is fetching.
+//   RAW  a wave waits `vmcnt(6)` (slab s+1 landed, slab s+2 in flight) before the first barrier of phase (s,1); slab s+1 is
+//        first read after that phase's second barrier, i.e. after every wave of both groups has executed its wait.
+//   WAR  slab s+2 overwrites the stage last read in phase (s-1,1); those reads are retired (lgkmcnt(0)) before that phase's
+//        first barrier, which both groups have passed when the first DMA of phase (s,0) is issued.
+template <typename T, int DBG = 0>
+__global__ __launch_bounds__(512) void conv_fprop_pp_kernel(const FpropArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int WM = 4, WN = 2, MI = 4, NI = 4;
+    constexpr int BM = 256, BN = 128;
+    constexpr int SZ = sizeof(T);
+    constexpr int BKE = 128 / SZ;
+    constexpr int STAGE = (BM + BN) * 128;                 // 48 KiB
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t grp = wave >> 2;
+    const uint32_t wm = wave / WN, wn = wave % WN;
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
+    const uint32_t m_base = bm * BM, n_base = bn * BN;
+    const sa_conv_geom& g = a.g;
+
+    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (int)a.w_bytes, 0x00020000);
+
+    const uint32_t prow = lane >> 3;
+    const uint32_t lv = (lane & 7u) ^ prow;
+    uint32_t rowoff[4], vm[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t m = m_base + (wave * 4 + j) * 8 + prow;
+        rowoff[j] = 0;
+        vm[j] = 0;
+        if (m < a.M) {
+            uint32_t q = fdiv(m, a.dW);
+            const uint32_t wmx = m - q * g.Wm;
+            uint32_t q2 = fdiv(q, a.dH);
+            const uint32_t hmx = q - q2 * g.Hm;
+            const uint32_t n = fdiv(q2, a.dD);
+            const uint32_t dmx = q2 - n * g.Dm;
+            const int32_t id0 = (int32_t)dmx * g.in_mult[0] + g.in_off[0];
+            const int32_t ih0 = (int32_t)hmx * g.in_mult[1] + g.in_off[1];
+            const int32_t iw0 = (int32_t)wmx * g.in_mult[2] + g.in_off[2];
+            rowoff[j] = (uint32_t)((((int32_t)n * g.Di + id0) * g.Hi + ih0) * g.Wi + iw0) * (uint32_t)(g.Cin * SZ) + lv * 16u;
+            uint32_t mk = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < g.KT[0] && (uint32_t)(id0 + t * g.tap_step[0]) < (uint32_t)g.Di) mk |= 1u << t;
+                if (t < g.KT[1] && (uint32_t)(ih0 + t * g.tap_step[1]) < (uint32_t)g.Hi) mk |= 16u << t;
+                if (t < g.KT[2] && (uint32_t)(iw0 + t * g.tap_step[2]) < (uint32_t)g.Wi) mk |= 256u << t;
+            }
+            vm[j] = mk;
+        }
+    }
+    uint32_t boff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) boff[j] = (n_base + (wave * 2 + j) * 8 + prow) * (uint32_t)(g.Kpad * SZ) + lv * 16u;
+
+    // half h of slab s: activation pieces 2h, 2h+1 and weight piece h of this wave
+    auto issue_half = [&](uint32_t s, uint32_t buf, int h) __attribute__((always_inline)) {
+        unsigned char* pa = smem + buf * STAGE;
+        unsigned char* pb = pa + BM * 128;
+        const uint32_t ke = s * BKE;
+        const uint32_t tap = fdiv(ke, a.dCin);
+        const uint32_t c0 = ke - tap * g.Cin;
+        const uint32_t td = fdiv(tap, a.dThw);
+        const uint32_t t2 = tap - td * a.dThw.d;
+        const uint32_t th = fdiv(t2, a.dTw);
+        const uint32_t tw = t2 - th * a.dTw.d;
+        const int32_t vox = (((int32_t)td * g.tap_step[0]) * g.Hi + (int32_t)th * g.tap_step[1]) * g.Wi + (int32_t)tw * g.tap_step[2];
+        const uint32_t koff = (uint32_t)vox * (uint32_t)(g.Cin * SZ) + c0 * SZ;
+        const uint32_t sel = tap < a.ntaps ? (1u << td) | (16u << th) | (256u << tw) : 0xffffffffu;  // padding taps match no row
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * h + jj;
+            const uint32_t voff = (vm[j] & sel) == sel ? rowoff[j] + koff : OOB_OFF;
+            if constexpr (!(DBG & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(pa + (wave * 4 + j) * 1024), 16, voff, 0, 0, 0);
+        }
+        if constexpr (!(DBG & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(pb + (wave * 2 + h) * 1024), 16, boff[h], s * 128u, 0, 0);
+    };
+
+    float4_t acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t nk = (DBG & 128) ? 2u : a.nk;
+    issue_half(0, 0, 0);
+    issue_half(0, 0, 1);
+    if (nk > 1) {
+        issue_half(1, 1, 0);
+        issue_half(1, 1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();              // slab 0 landed for every wave
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier behind group 0
+    const uint32_t frow = lane & 15u, fq = lane >> 4;
+    const uint32_t a_off = tile_off(wm * (MI * 16) + frow, fq), b_off = tile_off(wn * (NI * 16) + frow, fq);  // + j*2048 per fragment
+    uint32_t buf = 0;
+    for (uint32_t s = 0; s < nk; ++s) {
+        const unsigned char* pa = smem + buf * STAGE;
+        const unsigned char* pb = pa + BM * 128;
+        const uint32_t nbuf = buf >= 1 ? buf - 1 : 2;       // (s + 2) % 3
+        const bool more = s + 2 < nk;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 xf[MI], wf[NI];
+            // (row & 7) is unchanged by + 16 j, and vec = ks*4 + fq only flips bit 2 of the swizzled vector index
+            if constexpr (!(DBG & 4)) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + ((b_off + i * 2048u) ^ (ks * 64u)));
+#pragma unroll
+                for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(pa + ((a_off + j * 2048u) ^ (ks * 64u)));
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) wf[i] = (u32x4){s, lane, s, lane};
+#pragma unroll
+                for (int j = 0; j < MI; ++j) xf[j] = (u32x4){lane, s, lane, s};
+            }
+            if constexpr (!(DBG & 32)) {
+                if (more) issue_half(s + 2, nbuf, ks);
+            }
+            if (ks == 1) {
+                if (more) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(DBG & 16)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            if constexpr (!(DBG & 8)) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
+            } else {
+                acc[0][0][0] += __uint_as_float(wf[0][0] ^ xf[1][1] ^ wf[2][2] ^ xf[3][3] ^ wf[1][0] ^ xf[0][1] ^ wf[3][2] ^ xf[2][3]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(DBG & 16)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
+    __syncthreads();  // every wave is done reading the ring before the epilogue reuses it
+    if constexpr (DBG & 64) {
+        if (acc[0][0][0] == 123.f) *(float*)a.out = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];
+        return;
+    }
+    fprop_epilogue<BM, BN, WM, WN, MI, NI, 512>(a, acc, smem, tid, wm, wn, frow, fq, m_base, n_base);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Mainloop v5 "halo" (3x3x3, stride 1, `same` geometry; Cin * sizeof(T) a multiple of 128; Cout >= 65): the 27-tap im2col
+// re-read of the activations is what bounds v2 (the L2 -> LDS path, not the MFMA), so this loop stages every activation byte
+// ONCE per (kd, channel-chunk).  A tile is a 2-D patch of 8 (H) x 16 (W) output voxels of one depth plane; its halo image
+// (10 x 18 input voxels x 128 bytes of channels, zero-filled outside the volume by the DMA's out-of-bounds rule) sits in LDS and
+// the nine (kh, kw) taps of the group are nine K-slabs that read it at shifted rows.  No boundary masks anywhere: the padding
+// is physically in the halo.  K order = (kd, chunk, kh, kw); the packed weights keep their (tap, channel) order and are
+// addressed by column.  Per slab a wave issues 4 weight pieces and at most one halo piece of the NEXT group (double-buffered),
+// against 4 + 4 in v2.  LDS: 2 x 23 KiB halo + 2 x 16 KiB weights = 78 KiB -> two blocks per CU.
+template <typename T, bool FUSE>
+__global__ __launch_bounds__(256) void conv_fprop_halo_kernel(const FpropArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int WM = 2, WN = 2, MI = 4, NI = 4;
+    constexpr int BM = 128, BN = 128;
+    constexpr int PW = 16, HW_ = 18, HROWS = 180, HPIECES = 23;   // patch 8 x 16, halo 10 x 18 = 180 rows in 23 pieces
+    constexpr int SZ = sizeof(T);
+    constexpr int HALO_BYTES = HPIECES * 1024;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const sA = smem;                       // 2 halo images
+    unsigned char* const sB = smem + 2 * HALO_BYTES;      // 2 weight slabs
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wm = wave / WN, wn = wave % WN;
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
+    const uint32_t n_base = bn * BN;
+    const sa_conv_geom& g = a.g;
+    // patch -> (n, d, h0, w0)
+    const uint32_t wp = bm % a.WP, t1 = bm / a.WP;
+    const uint32_t hp = t1 % a.HP, t2 = t1 / a.HP;
+    const uint32_t pd = t2 % (uint32_t)g.Dm, pn = t2 / (uint32_t)g.Dm;
+    const int32_t h0 = (int32_t)hp * 8, w0 = (int32_t)wp * PW;
+    // halo origin and per-dimension tap direction: input = output + in_off + t * tap_step, t = 0..2
+    const int32_t oh = g.in_off[1] + (g.tap_step[1] < 0 ? 2 * g.tap_step[1] : 0), ow = g.in_off[2] + (g.tap_step[2] < 0 ? 2 * g.tap_step[2] : 0);
+
+    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (int)a.w_bytes, 0x00020000);
+
+    const uint32_t prow = lane >> 3;
+    const uint32_t lv = (lane & 7u) ^ prow;
+    // this wave's halo pieces: wave*6 + i, i < 6 (the last wave has 5)
+    uint32_t hoff[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const uint32_t r = (wave * 6 + i) * 8 + prow;
+        const uint32_t hh = r / HW_, ww = r - hh * HW_;
+        const int32_t ih = h0 + oh + (int32_t)hh, iw = w0 + ow + (int32_t)ww;
+        const bool ok = r < (uint32_t)HROWS && (uint32_t)ih < (uint32_t)g.Hi && (uint32_t)iw < (uint32_t)g.Wi;
+        hoff[i] = ok ? (uint32_t)(((int32_t)pn * g.Di * g.Hi + ih) * g.Wi + iw) * (uint32_t)(g.Cin * SZ) + lv * 16u : OOB_OFF;
+    }
+    uint32_t boff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) boff[j] = (n_base + (wave * 4 + j) * 8 + prow) * (uint32_t)(g.Kpad * SZ) + lv * 16u;
+
+    const uint32_t nchunk = (uint32_t)(g.Cin * SZ) / 128u;
+    const uint32_t ngroups = 3u * nchunk;
+    const uint32_t plane_bytes = (uint32_t)(g.Hi * g.Wi * g.Cin * SZ);
+
+    // halo piece i of group gi -> image gi & 1
+    auto issue_halo = [&](uint32_t gi, int i) __attribute__((always_inline)) {
+        const uint32_t td = gi / nchunk, ch = gi - td * nchunk;
+        const int32_t id = (int32_t)pd + g.in_off[0] + (int32_t)td * g.tap_step[0];
+        const bool dok = (uint32_t)id < (uint32_t)g.Di;
+        const uint32_t goff = (uint32_t)id * plane_bytes + ch * 128u;
+        const uint32_t voff = dok && hoff[i] != OOB_OFF ? hoff[i] + goff : OOB_OFF;
+        if (wave * 6 + i < (uint32_t)HPIECES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(sA + (gi & 1u) * HALO_BYTES + (wave * 6 + i) * 1024), 16, voff, 0, 0, 0);
+    };
+    // weight slab of (group gi, tap t9) -> buffer `buf`
+    auto issue_w = [&](uint32_t gi, uint32_t t9, uint32_t buf) __attribute__((always_inline)) {
+        const uint32_t td = gi / nchunk, ch = gi - td * nchunk;
+        const uint32_t col = ((td * 9u + t9) * (uint32_t)g.Cin) * SZ + ch * 128u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(sB + buf * (BN * 128) + (wave * 4 + j) * 1024), 16, boff[j], col, 0, 0);
+    };
+
+    float4_t acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t frow = lane & 15u, fq = lane >> 4;
+    // unswizzled byte address of (patch row wm*4 + j, column frow) in a halo image, vector fq
+    uint32_t a0[MI];
+#pragma unroll
+    for (int j = 0; j < MI; ++j) a0[j] = ((wm * 4 + j) * HW_ + frow) * 128u + fq * 16u;
+    const uint32_t b_off = tile_off(wn * (NI * 16) + frow, fq);
+    // halo row offset of tap t along a dimension: (in_off + t*step) - origin = t or 2 - t
+    const bool fh = g.tap_step[1] < 0, fw = g.tap_step[2] < 0;
+
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue_halo(0, i);
+    issue_w(0, 0, 0);
+    __syncthreads();
+    uint32_t buf = 0;
+    for (uint32_t gi = 0; gi < ngroups; ++gi) {
+        const unsigned char* pa = sA + (gi & 1u) * HALO_BYTES;
+        const bool next_group = gi + 1 < ngroups;
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+            // ---- prefetch: next weight slab, and one piece of the next group's halo image
+            if (t9 < 8) issue_w(gi, t9 + 1, buf ^ 1u);
+            else if (next_group) issue_w(gi + 1, 0, buf ^ 1u);
+            if (t9 < 6 && next_group) issue_halo(gi + 1, t9);
+            // ---- this slab
+            const int th = t9 / 3, tw = t9 % 3;
+            const uint32_t tapoff = (uint32_t)((fh ? 2 - th : th) * HW_ + (fw ? 2 - tw : tw)) * 128u;
+            const unsigned char* pb = sB + buf * (BN * 128);
+            uint32_t ax[MI];
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                const uint32_t ad = a0[j] + tapoff;
+                ax[j] = ad ^ (((ad >> 7) & 7u) << 4);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 xf[MI], wf[NI];
+#pragma unroll
+                for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(pa + (ax[j] ^ (ks * 64u)));
+#pragma unroll
+                for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + ((b_off + i * 2048u) ^ (ks * 64u)));
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
+            }
+            __syncthreads();  // drains this wave's DMA (vmcnt(0)): next slab / halo pieces landed, this slab's buffers free
+            buf ^= 1u;
+        }
+    }
+    auto row_vox = [&](uint32_t row) __attribute__((always_inline)) {
+        const uint32_t h = (uint32_t)h0 + (row >> 4), w = (uint32_t)w0 + (row & 15u);
+        return h < (uint32_t)g.Ho && w < (uint32_t)g.Wo ? (((long long)pn * g.Do + pd) * g.Ho + h) * g.Wo + w : -1ll;
+    };
+    if constexpr (FUSE) {
+        static_assert(!FUSE || sizeof(T) == 2, "fused residual block: bf16");
+        resblock_second_gemm<MI, NI>(a, acc, smem, tid, wave, wm, wn, frow, fq, prow, lv, row_vox);
+    }
+    fprop_epilogue_ov<BM, BN, WM, WN, MI, NI, 256>(a, acc, smem, tid, wm, wn, frow, fq, n_base, row_vox);
+#endif
+}
+
 template <typename T, int WM, int WN, int MI, int NI>
 static int launch_fprop(const FpropArgs& a, hipStream_t st) {
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
@@ -689,9 +1029,87 @@ static int launch_fprop3(FpropArgs a, hipStream_t st) {
     return 0;
 }
 
+template <typename T, int DBG>
+static int launch_fprop_pp_dbg(const FpropArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)conv_fprop_pp_kernel<T, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_fprop_pp_kernel<T, DBG>), grid, dim3(512), lds, st, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
+static int launch_fprop_pp(FpropArgs a, hipStream_t st) {
+    a.nblk_m = (a.M + 255) / 256;
+    const uint32_t nbn_valid = ((uint32_t)a.g.cout_valid + 127) / 128;
+    const size_t ring = 3 * (256 + 128) * 128, epi = (size_t)256 * (128 + 4) * 4 + 256 * 8;
+    const size_t lds = ring > epi ? ring : epi;
+    const dim3 grid(a.nblk_m * nbn_valid);
+#ifdef SA_PP_DEBUG_VARIANTS
+    if constexpr (sizeof(T) == 2) {
+        switch (a.dbg) {
+            case 3: return launch_fprop_pp_dbg<T, 3>(a, grid, lds, st);
+            case 7: return launch_fprop_pp_dbg<T, 7>(a, grid, lds, st);
+            case 15: return launch_fprop_pp_dbg<T, 15>(a, grid, lds, st);
+            case 31: return launch_fprop_pp_dbg<T, 31>(a, grid, lds, st);
+            case 47: return launch_fprop_pp_dbg<T, 47>(a, grid, lds, st);
+            case 63: return launch_fprop_pp_dbg<T, 63>(a, grid, lds, st);
+            case 79: return launch_fprop_pp_dbg<T, 79>(a, grid, lds, st);
+            case 143: return launch_fprop_pp_dbg<T, 143>(a, grid, lds, st);
+            case 207: return launch_fprop_pp_dbg<T, 207>(a, grid, lds, st);
+            case 64: return launch_fprop_pp_dbg<T, 64>(a, grid, lds, st);
+            case 8: return launch_fprop_pp_dbg<T, 8>(a, grid, lds, st);
+            case 11: return launch_fprop_pp_dbg<T, 11>(a, grid, lds, st);
+            default: break;
+        }
+    }
+#endif
+    return launch_fprop_pp_dbg<T, 0>(a, grid, lds, st);
+}
+
+// the halo mainloop applies to 3x3x3 / stride 1 / `same` geometry (forward, and the data gradient with the taps reversed)
+static bool halo_eligible(const FpropArgs& a, int sz) {
+    const sa_conv_geom& g = a.g;
+    const bool off = getenv("SA_NO_HALO") != nullptr;  // (read per launch: the tests flip it)
+    if (off || a.in_bytes == 0 || g.cout_valid <= 64 || ((size_t)g.Cin * sz) % 128 != 0) return false;
+    for (int d = 0; d < 3; ++d) {
+        if (g.KT[d] != 3 || g.in_mult[d] != 1 || g.out_mult[d] != 1 || g.out_off[d] != 0) return false;
+        if (g.tap_step[d] != 1 && g.tap_step[d] != -1) return false;
+        if (g.in_off[d] + (g.tap_step[d] < 0 ? 2 * g.tap_step[d] : 0) != -1) return false;  // halo origin one voxel before the patch
+    }
+    if (g.Dm != g.Do || g.Hm != g.Ho || g.Wm != g.Wo || g.Di != g.Do || g.Hi != g.Ho || g.Wi != g.Wo) return false;
+    if ((size_t)g.Kpad != (size_t)27 * g.Cin) return false;
+    const int hp = (g.Ho + 7) / 8, wp = (g.Wo + 15) / 16;
+    const double eff = (double)g.Ho * g.Wo / ((double)hp * 8 * wp * 16);
+    return eff >= 0.8 && (int64_t)g.N * g.Dm * hp * wp >= 512;
+}
+
+template <typename T, bool FUSE>
+static int launch_fprop_halo(FpropArgs a, hipStream_t st) {
+    a.HP = (uint32_t)(a.g.Ho + 7) / 8;
+    a.WP = (uint32_t)(a.g.Wo + 15) / 16;
+    a.nblk_m = (uint32_t)a.g.N * (uint32_t)a.g.Dm * a.HP * a.WP;
+    const uint32_t nbn_valid = ((uint32_t)a.g.cout_valid + 127) / 128;
+    const size_t pipe = 2 * 23 * 1024 + 2 * 128 * 128, epi = (size_t)128 * (128 + 4) * 4 + 128 * 8;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)conv_fprop_halo_kernel<T, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_fprop_halo_kernel<T, FUSE>), dim3(a.nblk_m * nbn_valid), dim3(256), pipe > epi ? pipe : epi, st, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T>
 static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
     const int cv = a.g.cout_valid;
+    if (halo_eligible(a, (int)sizeof(T))) return launch_fprop_halo<T, false>(a, st);
+    static const bool no_pp = getenv("SA_PP") == nullptr;  // v4 measured 7% slower than v2 on the 3x3x3 C=128 layer: opt-in only
+    if (cv > 64 && a.in_bytes != 0 && a.M >= 256 * 256 && !no_pp && ((size_t)a.g.Cin * sizeof(T)) % 128 == 0) return launch_fprop_pp<T>(a, st);
     // v3 (3-stage ring, 8 waves) measured equal to v2 (2 stages, 4 waves, 2 blocks/CU) on MI355X: 741/844 vs 763/849 TFLOP/s on
     // the 3x3x3 C=128 layer -- the DMA latency is not what bounds this loop -- so v2 stays the default (SA_DMA3=1 selects v3).
     static const bool use3 = getenv("SA_DMA3") != nullptr;
@@ -737,6 +1155,10 @@ extern "C" int sa_conv_fprop(const sa_conv_geom* g, int dtype, const void* in, c
     a.w2pk = nullptr;
     a.bias1 = nullptr;
     a.h_out = nullptr;
+    {
+        const char* d = getenv("SA_PP_DBG");
+        a.dbg = d ? (uint32_t)atoi(d) : 0u;
+    }
     {
         const int sz = dtype == SA_F32 ? 4 : 2;
         const uint64_t ib = (uint64_t)g->N * g->Di * g->Hi * g->Wi * g->Cin * sz, wb = (uint64_t)g->CoutPad * g->Kpad * sz;
@@ -787,6 +1209,8 @@ extern "C" int sa_resblock_fprop(const sa_conv_geom* g, int dtype, const void* x
     a.w2pk = w1pk;
     a.bias1 = bias1;
     a.h_out = h_out;
+    a.dbg = 0;
+    if (halo_eligible(a, 2)) return launch_fprop_halo<bf16_t, true>(a, (hipStream_t)stream);
     const size_t pipe = 2 * (128 + 128) * 128, epi = (size_t)128 * (128 + 4) * 4 + 128 * 8;
     hipLaunchKernelGGL((conv_fprop_dma_kernel<bf16_t, 2, 2, 4, 4, true, true>), dim3(a.nblk_m), dim3(256), pipe > epi ? pipe : epi, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();

@@ -122,6 +122,42 @@ def test_conv_large_m_tail():
     _close(y.cpu(), _cl(F.conv3d(x, w, None, padding=1)), torch.float32, "fprop tail")
 
 
+@pytest.mark.parametrize("dtype,kind,cin,cout,k,st,dims", [
+    (torch.bfloat16, "conv", 128, 128, 3, 1, (33, 45, 47)),
+    (torch.bfloat16, "conv", 64, 136, 3, 1, (29, 48, 50)),
+    (torch.float32, "conv", 32, 128, 3, 1, (33, 45, 47)),
+    (torch.bfloat16, "conv", 128, 128, 4, 2, (82, 84, 86)),
+    (torch.bfloat16, "convT", 128, 128, 4, 2, (21, 40, 42)),
+    (torch.bfloat16, "conv", 128, 128, 1, 1, (33, 45, 47)),
+])
+def test_conv_big_m_mainloop(dtype, kind, cin, cout, k, st, dims):
+    """M >= 65536 rows with Cin*sizeof a multiple of 128 B selects the 8-wave ping-pong LDS-DMA mainloop (256-voxel tiles, M tail, padding
+    rows, stride-2 and transposed geometry, fused epilogue) and the dgrad that runs on it with the roles swapped."""
+    _ffi, engine = _ops()
+    torch.manual_seed(7)
+    pad = 0 if k == 1 else 1
+    wshape = (cout, cin, k, k, k) if kind == "conv" else (cin, cout, k, k, k)
+    w = _rt(torch.randn(wshape) * 0.05, dtype)
+    b = torch.randn(cout) * 0.1
+    x = _rt(torch.randn(1, cin, *dims), dtype)
+    op = engine.ConvOp(kind, cin, cout, k, st, pad, w.cuda(), b.cuda(), dtype)
+    xin = engine.cast_pad(_cl(x).cuda(), dtype, op.cs_in())
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv3d(xr, w, b, stride=st, padding=pad) if kind == "conv" else F.conv_transpose3d(xr, w, b, stride=st, padding=pad)
+    y = op.fprop(xin, out_dtype=torch.float32, out_channels_stride=cout)
+    torch.cuda.synchronize()
+    _close(y.cpu()[..., :cout], _cl(yr.detach()), dtype, "fprop")
+    add = _rt(torch.randn(1, *y.shape[1:4], cout), dtype)
+    y3 = op.fprop(xin, act=_ffi.ACT_RELU, addend=add.cuda().to(dtype), add_before_act=True)
+    _close(y3.float().cpu(), F.relu(_cl(yr.detach()) + add), torch.bfloat16 if dtype == torch.bfloat16 else dtype, "fprop+add+relu")
+    if cout % engine.vec_of(dtype) == 0 and not (kind == "conv" and st == 2 and any(d % 2 for d in dims)):
+        g = _rt(torch.randn_like(yr), dtype)
+        yr.backward(g)
+        dx = op.dgrad(_cl(g).cuda().to(dtype), dims, out_dtype=torch.float32)
+        torch.cuda.synchronize()
+        _close(dx.cpu()[..., :cin], _cl(xr.grad), dtype, "dgrad")
+
+
 def test_linear_as_one_tap_conv():
     _ffi, engine = _ops()
     torch.manual_seed(2)

@@ -199,24 +199,31 @@ def test_discriminator_matches_reference_fixture(dtype):
         assert _relerr(ye.cpu().numpy(), g["eval/logits"]) < 5e-3
 
 
-def test_fused_residual_block_matches_two_launch_path():
-    """sa_resblock_fprop (one launch) against the two-launch path of the same stage: y and the stored hidden activation."""
+@pytest.mark.parametrize("shape", [(2, 9, 10, 11), (2, 33, 32, 44)])
+def test_fused_residual_block_matches_two_launch_path(shape):
+    """sa_resblock_fprop (one launch) against the two-launch path of the same stage: y and the stored hidden activation.  The larger
+    shape runs on the halo mainloop (8 x 16 patches, ragged in W); its reference path is forced onto the im2col-order kernels."""
     import os
     from synthanatomy_amd.networks.vqvae.baseline import ResidualLayer, _ResStage
     torch.manual_seed(3)
     mod = ResidualLayer(128, 128, 0.0).cuda()
     st = _ResStage(mod, in_act=True, dtype=torch.bfloat16)
-    x = torch.relu(torch.randn(2, 9, 10, 11, 128, device="cuda")).to(torch.bfloat16)
+    x = torch.relu(torch.randn(*shape, 128, device="cuda")).to(torch.bfloat16)
     tape = []
     y_f = st.fwd(x, tape)
     h_f = tape[0][1]
     os.environ["SA_NO_FUSED_RES"] = "1"
+    os.environ["SA_NO_HALO"] = "1"
     try:
         tape2 = []
         y_r = st.fwd(x, tape2)
     finally:
         del os.environ["SA_NO_FUSED_RES"]
-    assert torch.equal(h_f, tape2[0][1])                 # same 3x3x3 accumulation + rounding
+        del os.environ["SA_NO_HALO"]
+    # same products, fp32 accumulation in a different K order on the halo path -> bf16 rounding may differ in the last bit
+    assert _relerr(h_f.float().cpu().numpy(), tape2[0][1].float().cpu().numpy()) < 1e-2
+    if shape[1] < 16:
+        assert torch.equal(h_f, tape2[0][1])             # same 3x3x3 accumulation + rounding
     assert _relerr(y_f.float().cpu().numpy(), y_r.float().cpu().numpy()) < 1e-2  # h enters the 1x1 GEMM as the same bf16 values
     y_e = st.fwd(x, None)                                # eval: h is not written
     assert torch.equal(y_e, y_f)
