@@ -60,6 +60,9 @@ typedef struct sa_epilogue {
 int sa_abi_version(void);
 /* last hipError_t seen by this thread's launches, as text */
 const char *sa_last_error(void);
+/* kernel instance (rocprofv3 spelling) the calling thread's last sa_conv_fprop / sa_resblock_fprop / sa_conv_wgrad launched:
+ * lets a profiler key its per-kernel timings exactly as the dispatcher decided, without mirroring the dispatch rules */
+const char *sa_last_conv_kernel(void);
 
 /* ---- weights: reference layout (fp32 nn.Parameter) -> packed [CoutPad][Kpad] GEMM operand ------------------------
  * element (row r, reduce channel c, tap t) is read at  w[r*s_row + c*s_red + tap_lut[t]]  (tap_lut NULL = identity).

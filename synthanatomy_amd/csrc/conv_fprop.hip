@@ -14,6 +14,8 @@
 //   f32 : __builtin_amdgcn_mfma_f32_16x16x4f32 x4   (exact fp32 fma chain; parity mode)
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include "sa_common.h"
 
 namespace sa {
@@ -999,11 +1001,13 @@ static int launch_fprop(const FpropArgs& a, hipStream_t st) {
     dim3 grid(a.nblk_m * nbn_valid);
     if (a.in_bytes != 0) {  // every operand addressable with 32-bit buffer offsets -> LDS-DMA mainloop
         const bool uniform = ((size_t)a.g.Cin * sizeof(T)) % 128 == 0;
+        snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma_kernel<%s, %d, %d, %d, %d, %s, false>", tname<T>(), WM, WN, MI, NI, uniform ? "true" : "false");
         if (uniform) hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, true>), grid, dim3(256), lds, st, a);
         else hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, false>), grid, dim3(256), lds, st, a);
         SA_CHECK_LAUNCH();
         return 0;
     }
+    snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_kernel<%s, %d, %d, %d, %d>", tname<T>(), WM, WN, MI, NI);
     hipLaunchKernelGGL((conv_fprop_kernel<T, WM, WN, MI, NI>), grid, dim3(256), lds, st, a);
     SA_CHECK_LAUNCH();
     return 0;
@@ -1023,6 +1027,7 @@ static int launch_fprop3(FpropArgs a, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid(a.nblk_m * nbn_valid);
+    snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma3_kernel<%s, %s>", tname<T>(), uniform ? "true" : "false");
     if (uniform) hipLaunchKernelGGL((conv_fprop_dma3_kernel<T, true>), grid, dim3(512), lds, st, a);
     else hipLaunchKernelGGL((conv_fprop_dma3_kernel<T, false>), grid, dim3(512), lds, st, a);
     SA_CHECK_LAUNCH();
@@ -1036,6 +1041,7 @@ static int launch_fprop_pp_dbg(const FpropArgs& a, dim3 grid, size_t lds, hipStr
         hipFuncSetAttribute((const void*)conv_fprop_pp_kernel<T, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
+    snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_pp_kernel<%s, %d>", tname<T>(), DBG);
     hipLaunchKernelGGL((conv_fprop_pp_kernel<T, DBG>), grid, dim3(512), lds, st, a);
     SA_CHECK_LAUNCH();
     return 0;
@@ -1099,6 +1105,7 @@ static int launch_fprop_halo(FpropArgs a, hipStream_t st) {
         hipFuncSetAttribute((const void*)conv_fprop_halo_kernel<T, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_done = true;
     }
+    snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo_kernel<%s, %s>", tname<T>(), FUSE ? "true" : "false");
     hipLaunchKernelGGL((conv_fprop_halo_kernel<T, FUSE>), dim3(a.nblk_m * nbn_valid), dim3(256), pipe > epi ? pipe : epi, st, a);
     SA_CHECK_LAUNCH();
     return 0;
@@ -1212,6 +1219,7 @@ extern "C" int sa_resblock_fprop(const sa_conv_geom* g, int dtype, const void* x
     a.dbg = 0;
     if (halo_eligible(a, 2)) return launch_fprop_halo<bf16_t, true>(a, (hipStream_t)stream);
     const size_t pipe = 2 * (128 + 128) * 128, epi = (size_t)128 * (128 + 4) * 4 + 128 * 8;
+    snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma_kernel<unsigned short, 2, 2, 4, 4, true, true>");
     hipLaunchKernelGGL((conv_fprop_dma_kernel<bf16_t, 2, 2, 4, 4, true, true>), dim3(a.nblk_m), dim3(256), pipe > epi ? pipe : epi, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     return 0;

@@ -10,6 +10,7 @@
 //         into "lane = channel, 4 consecutive voxels"; two reads make one mfma_f32_16x16x32_bf16 operand.  32-byte chunks
 //         are XOR-swizzled with (m & 7) so the 8 rows a half-wave touches cover all 64 banks exactly once;
 //   f32 : tiles stay [m][c]; mfma_f32_16x16x4f32 takes one float per lane so fragments are plain ds_read_b32.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "sa_common.h"
@@ -29,6 +30,9 @@ struct WgradArgs {
     uint32_t nkt, ntiles;
     uint32_t in_bytes, g_bytes;   // non-zero: both operands addressable with 32-bit buffer offsets (LDS-DMA loader)
     float* ws;            // [split][tile][co 128][kidx 128] partial tiles, or NULL -> fp32 atomics straight into dw
+    // halo kernel (3x3x3 stride 1, bf16, Cin = 128): the voxel range is walked in steps of 4 (H) x 16 (W) voxels
+    uint32_t HQ, WP, nsteps, steps_per_split, halo;
+    FastDiv dWP, dHQ;
 };
 
 template <typename T> struct WG;
@@ -433,6 +437,143 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) 
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Halo weight gradient (3x3x3, stride 1, `same`; bf16; Cin = 128): the im2col-order kernel above reads every activation and
+// every output-gradient row once per TAP (27 x), which makes it L2-bound (~10 TB/s of LDS-DMA traffic at 550-650 TFLOP/s).
+// Here a block owns one (kd, kh) pair and a range of voxel steps; a step is 4 (H) x 16 (W) voxels of one plane: the gradient tile
+// [64][128 co] and the activation halo tile [4 x 18][128 ci] (one extra voxel on either side in W, zero-filled outside the
+// volume by the DMA) are staged once and feed the THREE kw taps (PHS = 8: steps of 8 x 16 voxels, half the barriers).  12 waves: wave = (kw, 64-ci half, 64-co half), each a
+// 64 x 64 accumulator like the kernel above; the tap only shifts the halo rows a wave transposes out of LDS.
+// Operand traffic drops 3 x; the partial tiles go to the same workspace layout (tile = tap) and the same reduce kernel.
+template <int PHS>  // voxel rows (H) per step: 4 or 8
+__global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int XP = PHS * 18 / 4, GP = PHS * 4, NP = XP + GP, PPW = (NP + 11) / 12;   // 1 KiB pieces: activation halo, gradient
+    constexpr int XT = XP * 1024, GT = GP * 1024, STAGE = XT + GT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const sa_conv_geom& g = a.g;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t tw = wave >> 2, wm = (wave >> 1) & 1u, wn = wave & 1u;
+    // block -> (split, kd*3+kh, co tile); an XCD (block b -> XCD b % 8) walks a contiguous range of splits and runs the nine
+    // (kd, kh) blocks of a split back to back, so their common rows are L2 hits
+    const uint32_t nct = a.ntiles / a.nkt;
+    const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
+    const uint32_t per_split = 9u * nct;
+    const uint32_t nsplit = (a.nsteps + a.steps_per_split - 1) / a.steps_per_split;
+    const uint32_t spx = (nsplit + 7u) >> 3;                       // splits per XCD
+    const uint32_t sl = seq / per_split, rem = seq - sl * per_split;
+    const uint32_t split = xcd * spx + sl;
+    if (sl >= spx || split >= nsplit) return;
+    const uint32_t tdth = rem % 9u, ct = rem / 9u;
+    const uint32_t td = tdth / 3u, th = tdth - td * 3u;
+    const uint32_t step0 = split * a.steps_per_split;
+    uint32_t step1 = step0 + a.steps_per_split;
+    if (step1 > a.nsteps) step1 = a.nsteps;
+
+    float4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)a.gout, 0, (int)a.g_bytes, 0x00020000);
+    // NP one-KiB pieces per step (a piece = 4 rows x 256 B): wave w moves pieces w, w+12, w+24, ...
+    // Source-side swizzle as in the kernel above: lane l fetches 16-byte vector ((((l&15)>>1) ^ (row&7))<<1 | (l&1)) of its row.
+    const uint32_t prow = lane >> 4;
+    int32_t p_h[PPW], p_w[PPW];      // row coordinates relative to the step origin (h0, w0) [input coordinates for activation pieces]
+    uint32_t p_off[PPW];           // byte offset relative to the step's base voxel, + the lane's vector
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const uint32_t q = wave + 12u * i;
+        const bool isx = q < (uint32_t)XP;
+        const uint32_t r = (isx ? q : q - (uint32_t)XP) * 4u + prow;     // tile row
+        const uint32_t vec = ((((lane & 15u) >> 1) ^ (r & 7u)) << 1) | (lane & 1u);
+        if (isx) {
+            const uint32_t hh = r / 18u, ww = r - hh * 18u;
+            p_h[i] = (int32_t)hh + (int32_t)th + g.in_off[1];
+            p_w[i] = (int32_t)ww + g.in_off[2];
+            p_off[i] = (uint32_t)((p_h[i] * g.Wi + p_w[i]) * (g.Cin * 2)) + vec * 16u;
+        } else {
+            p_h[i] = (int32_t)(r >> 4);
+            p_w[i] = (int32_t)(r & 15u);
+            p_off[i] = (uint32_t)((p_h[i] * g.Wo + p_w[i]) * (g.Cout * 2)) + ct * 256u + vec * 16u;
+        }
+    }
+    auto issue = [&](uint32_t step, uint32_t buf) __attribute__((always_inline)) {
+        unsigned char* ps = smem + buf * STAGE;
+        uint32_t q1 = fdiv(step, a.dWP);
+        const uint32_t wp = step - q1 * a.WP;
+        uint32_t q2 = fdiv(q1, a.dHQ);
+        const uint32_t hq = q1 - q2 * a.HQ;
+        const uint32_t n = fdiv(q2, a.dD);
+        const uint32_t d = q2 - n * (uint32_t)g.Dm;
+        const int32_t h0 = (int32_t)hq * PHS, w0 = (int32_t)wp * 16;
+        const int32_t id = (int32_t)d + g.in_off[0] + (int32_t)td;
+        const bool dok = (uint32_t)id < (uint32_t)g.Di;
+        const uint32_t xbase = (uint32_t)((((int32_t)n * g.Di + id) * g.Hi + h0) * g.Wi + w0) * (uint32_t)(g.Cin * 2);
+        const uint32_t gbase = (uint32_t)((((int32_t)n * g.Do + (int32_t)d) * g.Ho + h0) * g.Wo + w0) * (uint32_t)(g.Cout * 2);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const uint32_t q = wave + 12u * i;
+            if (q >= (uint32_t)NP) break;
+            const int32_t hh = h0 + p_h[i], ww = w0 + p_w[i];
+            if (q < (uint32_t)XP) {
+                const bool ok = dok && (uint32_t)hh < (uint32_t)g.Hi && (uint32_t)ww < (uint32_t)g.Wi;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)(ps + q * 1024), 16, ok ? xbase + p_off[i] : 0xfffffff0u, 0, 0, 0);
+            } else {
+                const bool ok = (uint32_t)hh < (uint32_t)g.Ho && (uint32_t)ww < (uint32_t)g.Wo;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, (__attribute__((address_space(3))) void*)(ps + XT + (q - (uint32_t)XP) * 1024), 16, ok ? gbase + p_off[i] : 0xfffffff0u, 0, 0,
+                                                         0);
+            }
+        }
+    };
+
+    issue(step0, 0);
+    __syncthreads();
+    const uint32_t frow = lane & 15u, fq = lane >> 4;
+    // transposing reads: lane (gq = lane>>4, s = lane&15) addresses row 4*gq + (s>>2), channels 4*(s&3)..+3 of a [16 rows][16 ch] block
+    const uint32_t trow = fq * 4u + (frow >> 2), tcol = (frow & 3u) * 4u;
+    for (uint32_t st = step0; st < step1; ++st) {
+        const uint32_t buf = (st - step0) & 1u;
+        if (st + 1 < step1) issue(st + 1, buf ^ 1u);
+        const unsigned char* px = smem + buf * STAGE;
+        const unsigned char* pg = px + XT;
+#pragma unroll
+        for (int ks = 0; ks < PHS / 2; ++ks) {
+            short8_t xf[4], gf[4];
+            // k = voxel (ph, pw) = (2*ks + half, 0..15)  ->  halo row ph*18 + pw + kw, gradient row ph*16 + pw
+            const uint32_t xr0 = (uint32_t)(2 * ks) * 18u + tw + trow, xr1 = xr0 + 18u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const v4s_t lo = lds_tr16(px + roff(xr0, wm * 64 + i * 16 + tcol));
+                const v4s_t hi = lds_tr16(px + roff(xr1, wm * 64 + i * 16 + tcol));
+                xf[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v4s_t lo = lds_tr16(pg + roff(ks * 32 + trow, wn * 64 + j * 16 + tcol));
+                const v4s_t hi = lds_tr16(pg + roff(ks * 32 + 16 + trow, wn * 64 + j * 16 + tcol));
+                gf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], gf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();  // drains the DMA (vmcnt(0)) and frees this buffer
+    }
+    // partial tile of tap (kd, kh, kw) -> workspace [split][tile = tap + 27*ct][co 128][ci 128]
+    const uint32_t tile = (td * 3u + th) * 3u + tw + a.nkt * ct;
+    float* wt = a.ws + ((size_t)split * a.ntiles + tile) * (128 * 128);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(float4_t*)(wt + (wn * 64 + j * 16 + frow) * 128 + wm * 64 + i * 16 + fq * 4) = acc[i][j];
+#endif
+}
+
 // dw[co][ci][tap] += sum_split ws[split][tile][co][kidx]   (one thread per output element; no atomics)
 __global__ void wgrad_reduce_kernel(const WgradArgs a, uint32_t splits) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;  // tile*16384 + co_l*128 + k_l
@@ -534,6 +675,37 @@ static int plan_wgrad(const sa_conv_geom* g, int dtype, WgradArgs& a, uint32_t& 
     if (splits < 1) splits = 1;
     a.chunks_per_split = (a.nchunks + splits - 1) / splits;
     splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    // halo kernel: 3x3x3 / stride 1 / same, bf16, 128 input channels, both operands addressable with 32-bit offsets
+    a.halo = 0;
+    {
+        bool ok = dtype == SA_BF16 && g->Cin == 128 && g->cin_valid == 128 && g->Cout % 128 == 0 && getenv("SA_NO_HALO") == nullptr && getenv("SA_NO_DMA") == nullptr;
+        for (int d = 0; d < 3 && ok; ++d)
+            ok = g->KT[d] == 3 && g->in_mult[d] == 1 && g->tap_step[d] == 1 && g->in_off[d] == -1 && g->out_mult[d] == 1 && g->out_off[d] == 0;
+        ok = ok && g->Dm == g->Do && g->Hm == g->Ho && g->Wm == g->Wo && g->Di == g->Do && g->Hi == g->Ho && g->Wi == g->Wo;
+        const uint64_t ib = (uint64_t)g->N * g->Di * g->Hi * g->Wi * g->Cin * 2, gb = (uint64_t)g->N * g->Do * g->Ho * g->Wo * g->Cout * 2;
+        ok = ok && ib < 0xffffff00ull - (1u << 20) && gb < 0xffffff00ull - (1u << 20);
+        if (ok) {
+            static const int phs_env = getenv("SA_WGRAD_HALO_ROWS") ? atoi(getenv("SA_WGRAD_HALO_ROWS")) : 4;  // 8-row steps measured slower (168 VGPRs + spills)
+            const uint32_t phs = (phs_env == 8 && g->Ho % 8 == 0) ? 8u : 4u;
+            const uint32_t hq = (uint32_t)(g->Ho + phs - 1) / phs, wp = (uint32_t)(g->Wo + 15) / 16;
+            const double eff = (double)g->Ho * g->Wo / ((double)hq * phs * wp * 16);
+            const uint64_t nsteps = (uint64_t)g->N * g->Dm * hq * wp;
+            if (eff >= 0.8 && nsteps >= 1024) {
+                a.halo = phs;
+                a.HQ = hq;
+                a.WP = wp;
+                a.nsteps = (uint32_t)nsteps;
+                a.dWP = make_fastdiv(wp);
+                a.dHQ = make_fastdiv(hq);
+                static const int want = getenv("SA_WGRAD_HALO_SPLITS") ? atoi(getenv("SA_WGRAD_HALO_SPLITS")) : 256;
+                uint32_t sp = (uint32_t)want;
+                if (sp > a.nsteps / 16) sp = a.nsteps / 16;   // at least 16 steps per block
+                if (sp < 1) sp = 1;
+                a.steps_per_split = (a.nsteps + sp - 1) / sp;
+                splits = (a.nsteps + a.steps_per_split - 1) / a.steps_per_split;
+            }
+        }
+    }
     return 0;
 }
 }  // namespace sa
@@ -577,10 +749,23 @@ extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, c
         a.in_bytes = fits ? (uint32_t)ib : 0u;
         a.g_bytes = fits ? (uint32_t)gb : 0u;
     }
-    if (a.in_bytes) {
+    if (a.halo && a.ws) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024);
+            hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 68 * 1024);
+            attr_done = true;
+        }
+        const uint32_t nct = a.ntiles / a.nkt, spx = (splits + 7u) / 8u;
+        snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_halo_kernel<%d>", (int)a.halo);
+        if (a.halo == 8) hipLaunchKernelGGL(conv_wgrad_halo_kernel<8>, dim3(8u * spx * 9u * nct), dim3(768), 2 * 68 * 1024, st, a);
+        else hipLaunchKernelGGL(conv_wgrad_halo_kernel<4>, dim3(8u * spx * 9u * nct), dim3(768), 2 * 34 * 1024, st, a);
+    } else if (a.in_bytes) {
+        snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_dma_kernel<%s>", dtype == SA_F32 ? "float" : "unsigned short");
         if (dtype == SA_F32) hipLaunchKernelGGL(conv_wgrad_dma_kernel<float>, grid, dim3(256), lds, st, a);
         else hipLaunchKernelGGL(conv_wgrad_dma_kernel<bf16_t>, grid, dim3(256), lds, st, a);
     } else {
+        snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_kernel<%s>", dtype == SA_F32 ? "float" : "unsigned short");
         if (dtype == SA_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, st, a);
         else hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, a);
     }

@@ -4,6 +4,7 @@
 namespace sa {
 
 thread_local hipError_t g_last_error = hipSuccess;
+thread_local char g_last_conv_kernel[128] = "";
 
 struct PackArgs {
     const float* w;
@@ -79,6 +80,7 @@ static inline unsigned grid_for(int64_t n, int block = 256, unsigned cap = 4096)
 
 extern "C" int sa_abi_version(void) { return SA_ABI_VERSION; }
 extern "C" const char* sa_last_error(void) { return hipGetErrorString(sa::g_last_error); }
+extern "C" const char* sa_last_conv_kernel(void) { return sa::g_last_conv_kernel; }
 
 extern "C" int sa_pack_weights(const float* w, void* wpk, int dtype, int rows, int red, int ntaps, const int32_t* tap_lut_host, int64_t s_row,
                                int64_t s_red, int rows_pad, int red_stride, int Kpad, void* stream) {

@@ -13,6 +13,9 @@ typedef __attribute__((ext_vector_type(4))) float float4_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 extern thread_local hipError_t g_last_error;
+// name of the convolution kernel instance the last sa_conv_fprop / sa_resblock_fprop / sa_conv_wgrad call launched (rocprofv3 spelling)
+extern thread_local char g_last_conv_kernel[128];
+template <typename T> inline const char* tname() { return sizeof(T) == 4 ? "float" : "unsigned short"; }
 
 #define SA_CHECK_LAUNCH()                         \
     do {                                          \

@@ -34,6 +34,8 @@ class KernelTimer:
         e0.record()
         fn()
         e1.record()
+        if key is None or key == "+wgrad_reduce_kernel":  # convolution launches: the dispatcher says which instance it picked
+            key = _ffi.lib().sa_last_conv_kernel().decode() + (key or "")
         self.pending.append((key, flops, e0, e1))
 
     def collect(self):
@@ -48,20 +50,6 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None  # set by bench.py around the timed region
-
-
-def _fprop_instance(dtype, g):
-    """Name of the kernel instance csrc/conv_fprop.hip's dispatch picks for this geometry, spelled like rocprofv3 prints it."""
-    t = "float" if dtype == torch.float32 else "unsigned short"
-    cv = g.cout_valid
-    m = g.N * g.Dm * g.Hm * g.Wm
-    sz = 4 if dtype == torch.float32 else 2
-    fits = g.N * g.Di * g.Hi * g.Wi * g.Cin * sz < 0xfffffff0 - 4096
-    uniform = "true" if (g.Cin * sz) % 128 == 0 else "false"
-    if cv > 64 and fits and m >= 256 * 256 and os.environ.get("SA_DMA3"):
-        return f"conv_fprop_dma3_kernel<{t}, {uniform}>"
-    tile = "2, 2, 4, 4" if cv > 64 else ("4, 1, 2, 4" if cv > 32 else ("4, 1, 2, 2" if cv > 16 else "4, 1, 2, 1"))
-    return f"conv_fprop_dma_kernel<{t}, {tile}, {uniform}, false>" if fits else f"conv_fprop_kernel<{t}, {tile}>"
 
 
 def _geom_flops(g) -> float:
@@ -263,7 +251,7 @@ class ConvOp:
         ep = self._epilogue(self._bias_padded() if use_bias else None, addend, mask, alpha, act, mask_mode, add_before_act, out_dtype, slope)
         lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
         for pl in plans["fwd"]:
-            _launch(_fprop_instance(self.dtype, pl.geom), _geom_flops(pl.geom),
+            _launch(None, _geom_flops(pl.geom),
                     lambda pl=pl: _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(x), _ffi.ptr(pl.wpk), _ffi.ptr(out), ctypes.byref(ep), st),
                                              "sa_conv_fprop"))
         return out
@@ -286,7 +274,7 @@ class ConvOp:
         ep = self._epilogue(None, addend, mask, None, ACT_NONE, mask_mode, False, out_dtype, slope)
         lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
         for pl in plans["dgrad"]:
-            _launch(_fprop_instance(self.dtype, pl.geom), _geom_flops(pl.geom),
+            _launch(None, _geom_flops(pl.geom),
                     lambda pl=pl: _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(g), _ffi.ptr(pl.wpk), _ffi.ptr(dx), ctypes.byref(ep), st),
                                              "sa_conv_fprop(dgrad)"))
         return dx
@@ -298,13 +286,12 @@ class ConvOp:
         assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.shape == self.weight.shape
         plans = self._get_plans(N, (D, H, W), fwd_out_stride or self.cout, g.shape[-1])
         lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
-        wname = "conv_wgrad_dma_kernel<%s>" % ("float" if self.dtype == torch.float32 else "unsigned short")
         for pl in plans["wgrad"]:
             nbytes = lib.sa_conv_wgrad_workspace_bytes(ctypes.byref(pl.geom), did)
             if nbytes < 0:
                 _ffi.check(int(nbytes), "sa_conv_wgrad_workspace_bytes")
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)  # caching allocator: stream-ordered scratch
-            _launch(wname, _geom_flops(pl.geom),
+            _launch("+wgrad_reduce_kernel", _geom_flops(pl.geom),
                     lambda pl=pl, ws=ws, nbytes=nbytes: _ffi.check(
                         lib.sa_conv_wgrad(ctypes.byref(pl.geom), did, _ffi.ptr(x), _ffi.ptr(g), _ffi.ptr(dw), pl.lut_c, pl.s_row, pl.s_red, _ffi.ptr(ws), nbytes, st),
                         "sa_conv_wgrad"))

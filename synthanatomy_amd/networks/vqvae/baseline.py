@@ -296,7 +296,7 @@ class _ResStage:
         from ... import engine
         b1 = self.c3._bias_padded()
         st = _ffi.stream()
-        engine._launch("conv_fprop_dma_kernel<unsigned short, 2, 2, 4, 4, true, true>", engine._geom_flops(p3["fwd"][0].geom) + engine._geom_flops(p1["fwd"][0].geom),
+        engine._launch(None, engine._geom_flops(p3["fwd"][0].geom) + engine._geom_flops(p1["fwd"][0].geom),
                        lambda: _ffi.check(_ffi.lib().sa_resblock_fprop(ctypes.byref(p3["fwd"][0].geom), _ffi.dtype_id(self.dtype), _ffi.ptr(x),
                                                                        _ffi.ptr(p3["fwd"][0].wpk), _ffi.ptr(b1), _ffi.ptr(p1["fwd"][0].wpk), _ffi.ptr(h), _ffi.ptr(y),
                                                                        ctypes.byref(ep), st), "sa_resblock_fprop"))

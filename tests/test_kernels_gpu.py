@@ -156,6 +156,15 @@ def test_conv_big_m_mainloop(dtype, kind, cin, cout, k, st, dims):
         dx = op.dgrad(_cl(g).cuda().to(dtype), dims, out_dtype=torch.float32)
         torch.cuda.synchronize()
         _close(dx.cpu()[..., :cin], _cl(xr.grad), dtype, "dgrad")
+        if k == 3:  # weight gradient: the 4 x 16-voxel halo steps (bf16, Cin = 128) or the im2col-order kernel
+            wr = w.clone().requires_grad_(True)
+            F.conv3d(x, wr, None, stride=st, padding=pad).backward(g)
+            dw = torch.zeros(wshape, device="cuda")
+            db = torch.zeros(cout, device="cuda")
+            op.wgrad(xin, _cl(g).cuda().to(dtype), dw, db)
+            torch.cuda.synchronize()
+            _close(dw.cpu(), wr.grad, dtype, "wgrad")
+            _close(db.cpu(), g.sum(dim=(0, 2, 3, 4)), dtype, "bgrad")
 
 
 def test_linear_as_one_tap_conv():
