@@ -198,6 +198,12 @@ int sa_lrelu_mask(const void *dy, const void *y, int dtype, void *g, int64_t n, 
 int sa_convt1_fwd(const void *x, int dtype, const float *w, const float *bias, float *out, int N, int D, int H, int W, int C, void *stream);
 int sa_convt1_bwd(const void *x, int dtype, const float *w, const float *g, const void *relu_mask, void *dx, float *dw, float *db, int N,
                   int D, int H, int W, int C, void *stream);
+/* GEMM route of the same layer: the 64 taps are the channels of a 1x1x1 convolution run by sa_conv_fprop / sa_conv_wgrad, and these
+ * two kernels move between the output voxel grid and the [cell][64 tap] matrices.
+ * sa_convt1_gather: out[o] = bias + the 8 entries of P [cells][64] (fp32) that feed output voxel o.
+ * sa_convt1_im2col: Gc[cell][tap] = g[2 cell - 1 + tap] (zero outside), stored as `dtype`; db += sum g (db may be NULL). */
+int sa_convt1_gather(const float *p, const float *bias, float *out, int N, int D, int H, int W, void *stream);
+int sa_convt1_im2col(const float *g, int dtype, void *gc, float *db, int N, int D, int H, int W, void *stream);
 
 #ifdef __cplusplus
 }

@@ -574,23 +574,37 @@ __global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradArgs a)
 #endif
 }
 
-// dw[co][ci][tap] += sum_split ws[split][tile][co][kidx]   (one thread per output element; no atomics)
-__global__ void wgrad_reduce_kernel(const WgradArgs a, uint32_t splits) {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;  // tile*16384 + co_l*128 + k_l
-    if (e >= a.ntiles * 16384u) return;
+// dw[co][ci][tap] += sum_split ws[split][tile][co][kidx]   (no atomics).  One thread owns 4 consecutive kidx of one (tile, co) and
+// streams the splits with 8 independent 16-byte loads in flight.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, uint32_t splits) {
+    const uint32_t e4 = blockIdx.x * blockDim.x + threadIdx.x;  // (tile*16384 + co_l*128 + k_l) / 4
+    if (e4 >= a.ntiles * 4096u) return;
+    const uint32_t e = e4 * 4u;
     const uint32_t tile = e >> 14, co_l = (e >> 7) & 127u, k_l = e & 127u;
     const uint32_t kt = tile % a.nkt, ct = tile / a.nkt;
     const uint32_t kidx = kt * 128u + k_l, co = ct * 128u + co_l;
     if (kidx >= a.ktot || co >= (uint32_t)a.g.cout_valid) return;
-    const uint32_t tap = fdiv(kidx, a.dCin);
-    const uint32_t c = kidx - tap * a.g.Cin;
-    if (c >= (uint32_t)a.g.cin_valid) return;
-    float s = 0.f;
+    float4_t s = (float4_t){0.f, 0.f, 0.f, 0.f};
     const float* p = a.ws + e;
     const size_t stride = (size_t)a.ntiles * 16384u;
-    for (uint32_t sp = 0; sp < splits; ++sp) s += p[sp * stride];
-    float* d = a.dw + co * a.s_row + (int64_t)c * a.s_red + a.lut[tap];
-    *d += s;
+    uint32_t sp = 0;
+    for (; sp + 8 <= splits; sp += 8) {
+        float4_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load((const float4_t*)(p + (size_t)(sp + u) * stride));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; sp < splits; ++sp) s += *(const float4_t*)(p + (size_t)sp * stride);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t kk = kidx + r;
+        if (kk >= a.ktot) break;
+        const uint32_t tap = fdiv(kk, a.dCin);
+        const uint32_t c = kk - tap * a.g.Cin;
+        if (c >= (uint32_t)a.g.cin_valid) continue;
+        a.dw[co * a.s_row + (int64_t)c * a.s_red + a.lut[tap]] += s[r];
+    }
 }
 
 // db[c] += sum_m g[m][c].  Block = 16 channel-vectors (16 bytes each) x 16 row lanes; 16-byte coalesced loads.
@@ -771,7 +785,7 @@ extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, c
     }
     SA_CHECK_LAUNCH();
     if (a.ws) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((a.ntiles * 16384u + 255) / 256), dim3(256), 0, st, a, splits);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((a.ntiles * 4096u + 255) / 256), dim3(256), 0, st, a, splits);
         SA_CHECK_LAUNCH();
     }
     return 0;

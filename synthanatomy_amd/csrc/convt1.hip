@@ -225,6 +225,113 @@ static int fill_ct1(CT1Args& a, int N, int D, int H, int W) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// GEMM route for the same layer (the default for bf16/fp32 at scale): the 64 taps become the channel dimension of a 1x1x1
+// convolution that runs on the MFMA kernels of conv_fprop.hip / conv_wgrad.hip, and two thin kernels here move between the
+// voxel grid of the output and the [cell][tap] matrices:
+//   forward : P[cell][tap] = x[cell] . w[:,tap]  (sa_conv_fprop, 128 -> 64, fp32 out);  out[o] = b + sum of its 8 P entries (gather)
+//   backward: Gc[cell][tap] = g[2 cell - 1 + tap]  (im2col, + db = sum g);  dx = Gc . w^T (* mask)  (sa_conv_fprop, 64 -> 128);
+//             dw[c][tap] = sum_cell x[cell][c] Gc[cell][tap]  (sa_conv_wgrad)
+// Every (cell, tap) pair feeds exactly one output voxel, so P / Gc are read / written once.
+struct CT1Map {
+    const float* p;     // gather: P [cells][64] fp32
+    const float* bias;
+    float* out;         // [N, 2D, 2H, 2W]
+    const float* g;     // im2col: gradient wrt out
+    void* gc;           // im2col: [cells][64] T
+    float* db;
+    int32_t N, D, H, W;
+    FastDiv dW_, dH_, dD_, d2H_, d2D_;
+    uint32_t cells, pairs;   // pairs = N * 2D * 2H * W  (two outputs along W per thread)
+};
+
+// per dimension: output o = 2q + p is fed by (cell, tap) = p ? {(q+1, 0), (q, 2)} : {(q, 1), (q-1, 3)}
+__global__ __launch_bounds__(256) void convt1_gather_kernel(const CT1Map a) {
+    const float b = a.bias ? a.bias[0] : 0.f;
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < a.pairs; t += gridDim.x * 256u) {
+        uint32_t q = fdiv(t, a.dW_);
+        const int c = (int)(t - q * (uint32_t)a.W);
+        uint32_t q2 = fdiv(q, a.d2H_);
+        const int oh = (int)(q - q2 * (uint32_t)(2 * a.H));
+        const int n = (int)fdiv(q2, a.d2D_);
+        const int od = (int)(q2 - (uint32_t)n * (uint32_t)(2 * a.D));
+        const int pd = od & 1, qd = od >> 1, ph = oh & 1, qh = oh >> 1;
+        float s0 = b, s1 = b;
+#pragma unroll
+        for (int ud = 0; ud < 2; ++ud) {
+            const int id = pd ? qd + 1 - ud : qd - ud, kd = pd ? 2 * ud : 1 + 2 * ud;
+#pragma unroll
+            for (int uh = 0; uh < 2; ++uh) {
+                const int ih = ph ? qh + 1 - uh : qh - uh, kh = ph ? 2 * uh : 1 + 2 * uh;
+                const bool ok = (unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H;
+                const int cd = min(max(id, 0), a.D - 1), chh = min(max(ih, 0), a.H - 1);
+                const float* row = a.p + ((((int64_t)n * a.D + cd) * a.H + chh) * a.W) * 64 + (kd * 4 + kh) * 4;
+                // even output 2c: (c, kw=1), (c-1, kw=3);  odd output 2c+1: (c+1, kw=0), (c, kw=2)
+                const int cm = max(c - 1, 0), cp = min(c + 1, a.W - 1);
+                const float e0 = row[c * 64 + 1], e1 = row[cm * 64 + 3], o0 = row[cp * 64 + 0], o1 = row[c * 64 + 2];
+                s0 += ok ? e0 + (c > 0 ? e1 : 0.f) : 0.f;
+                s1 += ok ? o1 + (c + 1 < a.W ? o0 : 0.f) : 0.f;
+            }
+        }
+        *(float2*)(a.out + (int64_t)t * 2) = make_float2(s0, s1);   // t enumerates (n, od, oh, c) = the output row-major order / 2
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void convt1_im2col_kernel(const CT1Map a) {
+    float gsum = 0.f;
+    T* gc = (T*)a.gc;
+    const uint32_t total = a.cells * 16u;   // thread = (cell, kd, kh): the four kw taps are 4 consecutive output voxels
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+        const uint32_t cell = t >> 4, kd = (t >> 2) & 3u, kh = t & 3u;
+        uint32_t q = fdiv(cell, a.dW_);
+        const int w = (int)(cell - q * (uint32_t)a.W);
+        uint32_t q2 = fdiv(q, a.dH_);
+        const int h = (int)(q - q2 * (uint32_t)a.H);
+        const int n = (int)fdiv(q2, a.dD_);
+        const int d = (int)(q2 - (uint32_t)n * (uint32_t)a.D);
+        const int od = 2 * d - 1 + (int)kd, oh = 2 * h - 1 + (int)kh;
+        const bool ok = (unsigned)od < (unsigned)(2 * a.D) && (unsigned)oh < (unsigned)(2 * a.H);
+        const int cd = min(max(od, 0), 2 * a.D - 1), chh = min(max(oh, 0), 2 * a.H - 1);
+        const float* row = a.g + (((int64_t)n * 2 * a.D + cd) * 2 * a.H + chh) * 2 * a.W;
+        float v[4];
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+            const int ow = 2 * w - 1 + kw;
+            const float x = row[min(max(ow, 0), 2 * a.W - 1)];
+            v[kw] = ok && (unsigned)ow < (unsigned)(2 * a.W) ? x : 0.f;
+        }
+        // every output voxel is covered exactly once by the taps {1,2}^3 of its cell
+        if ((kd == 1u || kd == 2u) && (kh == 1u || kh == 2u)) gsum += v[1] + v[2];
+        if constexpr (sizeof(T) == 4) {
+            *(float4*)((float*)gc + (size_t)t * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            *(uint2*)((bf16_t*)gc + (size_t)t * 4) = pk;
+        }
+    }
+    if (a.db) {
+        __shared__ float red[4];
+        gsum = wave_sum(gsum);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gsum;
+        __syncthreads();
+        if (threadIdx.x == 0) unsafeAtomicAdd(a.db, red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+static int fill_map(CT1Map& a, int N, int D, int H, int W) {
+    const int64_t cells = (int64_t)N * D * H * W;
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || cells * 16 >= (1ll << 32)) return SA_EINVAL;
+    a.N = N; a.D = D; a.H = H; a.W = W;
+    a.dW_ = make_fastdiv(W); a.dH_ = make_fastdiv(H); a.dD_ = make_fastdiv(D);
+    a.d2H_ = make_fastdiv(2 * H); a.d2D_ = make_fastdiv(2 * D);
+    a.cells = (uint32_t)cells;
+    a.pairs = (uint32_t)(cells * 4);
+    return 0;
+}
+
 }  // namespace sa
 
 using namespace sa;
@@ -257,6 +364,32 @@ extern "C" int sa_convt1_bwd(const void* x, int dtype, const float* w, const flo
     }
     if (dtype == SA_F32) hipLaunchKernelGGL(convt1_wgrad_kernel<float>, dim3(512), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(convt1_wgrad_kernel<bf16_t>, dim3(512), dim3(256), 0, st, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_convt1_gather(const float* p, const float* bias, float* out, int N, int D, int H, int W, void* stream) {
+    if (!p || !out) return SA_EINVAL;
+    CT1Map a = {};
+    if (fill_map(a, N, D, H, W)) return SA_EINVAL;
+    a.p = p; a.bias = bias; a.out = out;
+    unsigned blocks = (a.pairs + 255u) / 256u;
+    if (blocks > 16384u) blocks = 16384u;
+    hipLaunchKernelGGL(convt1_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_convt1_im2col(const float* g, int dtype, void* gc, float* db, int N, int D, int H, int W, void* stream) {
+    if (!g || !gc) return SA_EINVAL;
+    if (dtype != SA_F32 && dtype != SA_BF16) return SA_EUNSUPPORTED;
+    CT1Map a = {};
+    if (fill_map(a, N, D, H, W)) return SA_EINVAL;
+    a.g = g; a.gc = gc; a.db = db;
+    unsigned blocks = (unsigned)(((uint64_t)a.cells * 16u + 255u) / 256u);
+    if (blocks > 4096u) blocks = 4096u;   // one atomic per block for db
+    if (dtype == SA_F32) hipLaunchKernelGGL(convt1_im2col_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(convt1_im2col_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     return 0;
 }

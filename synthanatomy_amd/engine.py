@@ -118,8 +118,12 @@ class ConvOp:
     """kind="conv": weight [Cout, Cin, k,k,k];  kind="convT": weight [Cin, Cout, k,k,k] (k4 s2 p1 only)."""
 
     def __init__(self, kind: str, cin: int, cout: int, k: int, stride: int, pad: int, weight: torch.Tensor, bias: Optional[torch.Tensor],
-                 dtype: torch.dtype):
+                 dtype: torch.dtype, w_strides: Optional[Tuple[int, int]] = None):
+        """`w_strides` = (stride of cout, stride of cin) in elements of `weight` for a 1x1x1 "conv" whose weight is stored transposed
+        (the 64 taps of the final ConvTranspose3d as output channels): forward and wgrad only."""
         assert kind in ("conv", "convT")
+        assert w_strides is None or (kind == "conv" and k == 1)
+        self.w_strides = w_strides
         if kind == "convT" and not (k == 4 and stride == 2 and pad == 1):
             raise NotImplementedError("ConvTranspose3d is implemented for kernel 4 / stride 2 / padding 1 / output_padding 0 (the reference's setting)")
         self.kind, self.cin, self.cout, self.k, self.stride, self.pad = kind, cin, cout, k, stride, pad
@@ -155,11 +159,14 @@ class ConvOp:
         wgr: List[_Plan] = []
         one, zero = (1, 1, 1), (0, 0, 0)
         if self.kind == "conv":
+            sr, sd = self.w_strides if self.w_strides is not None else (cin * T, T)
             g = make_geom(dt, N, odims, idims, cin_s, odims, cout_s, cin, cout, (k,) * 3, (s,) * 3, one, (-p,) * 3, one, zero)
-            fwd.append(_Plan(g, cout, cin, T, None, cin * T, T))
+            fwd.append(_Plan(g, cout, cin, T, None, sr, sd))
             gw = make_geom(dt, N, odims, idims, cin_s, odims, gout_s, cin, cout, (k,) * 3, (s,) * 3, one, (-p,) * 3, one, zero)
-            wgr.append(_Plan(gw, cout, cin, T, None, cin * T, T))
-            if s == 1:
+            wgr.append(_Plan(gw, cout, cin, T, None, sr, sd))
+            if self.w_strides is not None:
+                dgr = None
+            elif s == 1:
                 g = make_geom(dt, N, idims, odims, gout_s, idims, cin_s, cout, cin, (k,) * 3, one, (-1,) * 3, (p,) * 3, one, zero)
                 dgr.append(_Plan(g, cin, cout, T, None, T, cin * T))
             elif s == 2 and k == 4 and p == 1 and all(d % 2 == 0 for d in idims):

@@ -22,7 +22,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from ... import _ffi
-from ..._ffi import ACT_NONE, ACT_RELU, MASK_POS
+from ..._ffi import ACT_NONE, ACT_RELU, MASK_NONE, MASK_POS
 from ...engine import ConvOp, cast_pad, vec_of
 from .vqvae import VQVAEBase
 
@@ -230,10 +230,17 @@ class _ConvStage:
 
 
 class _ConvT1Stage:
-    """Final ConvTranspose3d(128 -> 1, k4 s2 p1): HBM-bound direct kernels (csrc/convt1.hip) instead of 8 parity GEMMs."""
+    """Final ConvTranspose3d(128 -> 1, k4 s2 p1) (csrc/convt1.hip).  At scale the 64 taps become the channels of a 1x1x1 convolution on
+    the MFMA kernels (P = x . w per cell, then a gather onto the output grid; backward: im2col of the gradient, then the 1x1x1 dgrad /
+    wgrad); tiny inputs use the direct kernels."""
+
+    GEMM_MIN_CELLS = 4096
 
     def __init__(self, mod: nn.ConvTranspose3d, in_act, dtype):
         self.mod, self.in_act, self.dtype = mod, in_act, dtype
+        # taps as output channels: weight[c][tap] read with (cout stride, cin stride) = (1, 64)
+        self.taps_fwd = ConvOp("conv", 128, 64, 1, 1, 0, mod.weight, None, dtype, w_strides=(1, 64))
+        self.taps_bwd = ConvOp("conv", 64, 128, 1, 1, 0, mod.weight, None, dtype)
 
     @staticmethod
     def applicable(mod) -> bool:
@@ -243,11 +250,23 @@ class _ConvT1Stage:
     def params(self):
         return [self.mod.weight, self.mod.bias]
 
+    def _sync(self):
+        self.taps_fwd.weight = self.taps_bwd.weight = self.mod.weight
+
+    def _gemm(self, x):
+        return x.numel() // 128 >= self.GEMM_MIN_CELLS and os.environ.get("SA_CONVT1_DIRECT") is None
+
     def fwd(self, x, tape):
         N, D, H, W, C = x.shape
         out = torch.empty((N, 2 * D, 2 * H, 2 * W, 1), dtype=torch.float32, device=x.device)
-        _ffi.check(_ffi.lib().sa_convt1_fwd(_ffi.ptr(x), _ffi.dtype_id(x.dtype), _ffi.ptr(self.mod.weight), _ffi.ptr(self.mod.bias), _ffi.ptr(out), N, D, H, W, C,
-                                            _ffi.stream()), "sa_convt1_fwd")
+        lib, st = _ffi.lib(), _ffi.stream()
+        if self._gemm(x):
+            self._sync()
+            P = self.taps_fwd.fprop(x, out_dtype=torch.float32, use_bias=False)          # [N, D, H, W, 64]
+            _ffi.check(lib.sa_convt1_gather(_ffi.ptr(P), _ffi.ptr(self.mod.bias), _ffi.ptr(out), N, D, H, W, st), "sa_convt1_gather")
+        else:
+            _ffi.check(lib.sa_convt1_fwd(_ffi.ptr(x), _ffi.dtype_id(x.dtype), _ffi.ptr(self.mod.weight), _ffi.ptr(self.mod.bias), _ffi.ptr(out), N, D, H, W, C, st),
+                       "sa_convt1_fwd")
         if tape is not None:
             tape.append((x,))
         return out
@@ -256,10 +275,18 @@ class _ConvT1Stage:
         (x,) = saved
         N, D, H, W, C = x.shape
         G = G.float().contiguous()
-        dx = torch.empty_like(x)
         dw, db = grads.buf(self.mod.weight), grads.buf(self.mod.bias)
-        _ffi.check(_ffi.lib().sa_convt1_bwd(_ffi.ptr(x), _ffi.dtype_id(x.dtype), _ffi.ptr(self.mod.weight), _ffi.ptr(G), _ffi.ptr(x) if self.in_act else None,
-                                            _ffi.ptr(dx), _ffi.ptr(dw), _ffi.ptr(db), N, D, H, W, C, _ffi.stream()), "sa_convt1_bwd")
+        lib, st = _ffi.lib(), _ffi.stream()
+        if self._gemm(x):
+            self._sync()
+            Gc = torch.empty((N, D, H, W, 64), dtype=x.dtype, device=x.device)
+            _ffi.check(lib.sa_convt1_im2col(_ffi.ptr(G), _ffi.dtype_id(x.dtype), _ffi.ptr(Gc), _ffi.ptr(db), N, D, H, W, st), "sa_convt1_im2col")
+            dx = self.taps_bwd.fprop(Gc, mask=x if self.in_act else None, mask_mode=MASK_POS if self.in_act else MASK_NONE, use_bias=False)
+            self.taps_fwd.wgrad(x, Gc, dw, None)
+        else:
+            dx = torch.empty_like(x)
+            _ffi.check(lib.sa_convt1_bwd(_ffi.ptr(x), _ffi.dtype_id(x.dtype), _ffi.ptr(self.mod.weight), _ffi.ptr(G), _ffi.ptr(x) if self.in_act else None,
+                                         _ffi.ptr(dx), _ffi.ptr(dw), _ffi.ptr(db), N, D, H, W, C, st), "sa_convt1_bwd")
         grads.done(self.mod.weight, self.mod.bias)
         return dx
 
@@ -358,7 +385,7 @@ class _Chain:
 
     def invalidate(self):
         for s in self.stages:
-            for op in (getattr(s, "op", None), getattr(s, "c3", None), getattr(s, "c1", None)):
+            for op in (getattr(s, "op", None), getattr(s, "c3", None), getattr(s, "c1", None), getattr(s, "taps_fwd", None), getattr(s, "taps_bwd", None)):
                 if op is not None:
                     op.invalidate()
 

@@ -342,3 +342,41 @@ def test_convt1_direct_kernels(dtype):
     _close(dx.float().cpu(), _cl(xr.grad * (x > 0)), torch.bfloat16 if dtype == torch.bfloat16 else dtype, "convt1 dgrad")
     _close(dw.cpu(), wr.grad, dtype, "convt1 wgrad")
     _close(db.cpu(), br.grad, dtype, "convt1 bgrad")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_convt1_gemm_route(dtype):
+    """The same layer at a size that takes the GEMM route: taps-as-channels 1x1x1 convolution on the MFMA kernels + sa_convt1_gather, and
+    sa_convt1_im2col + the 1x1x1 dgrad / wgrad, through the stage object the network uses (odd sizes: every boundary case of the taps)."""
+    import torch.nn as nn
+    from synthanatomy_amd.networks.vqvae.baseline import _ConvT1Stage
+    torch.manual_seed(11)
+    N, dims = 2, (7, 18, 17)      # 4284 cells >= GEMM_MIN_CELLS
+    mod = nn.ConvTranspose3d(128, 1, 4, 2, 1)
+    x = _rt(torch.relu(torch.randn(N, 128, *dims)), dtype)
+    wq = _rt(mod.weight.detach(), dtype)          # the MFMA route rounds the weights to the compute dtype like every other layer
+    xr, wr, br = x.clone().requires_grad_(True), wq.clone().requires_grad_(True), mod.bias.detach().clone().requires_grad_(True)
+    yr = F.conv_transpose3d(xr, wr, br, stride=2, padding=1)
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    mod = mod.cuda()
+    st = _ConvT1Stage(mod, in_act=True, dtype=dtype)
+    assert st._gemm(torch.empty(N, *dims, 128))
+    xd = _cl(x).cuda().to(dtype)
+    tape = []
+    out = st.fwd(xd, tape)
+    _close(out[..., 0].cpu(), yr.detach()[:, 0], dtype, "convt1 fwd (gemm)")
+
+    class _G:
+        def __init__(self):
+            self.b = {id(mod.weight): torch.zeros_like(mod.weight), id(mod.bias): torch.zeros_like(mod.bias)}
+        def buf(self, p):
+            return self.b[id(p)]
+        def done(self, *ps):
+            pass
+    gr = _G()
+    dx = st.bwd(_cl(g).cuda(), tape[0], gr)
+    torch.cuda.synchronize()
+    _close(dx.float().cpu(), _cl(xr.grad * (x > 0)), torch.bfloat16 if dtype == torch.bfloat16 else dtype, "convt1 dgrad (gemm)")
+    _close(gr.buf(mod.weight).cpu(), wr.grad, dtype, "convt1 wgrad (gemm)")
+    _close(gr.buf(mod.bias).cpu(), br.grad, dtype, "convt1 bgrad (gemm)")
