@@ -85,8 +85,9 @@ int sa_resblock_fprop(const sa_conv_geom *g, int dtype, const void *x, const voi
                       void *y_out, const sa_epilogue *ep, void *stream);
 
 /* ---- weight gradient: dw[r*s_row + c*s_red + tap_lut[t]] += sum_m in[gather(m,t)][c] * gout[out(m)][r]  (accumulates:
- * caller zeroes dw).  Replaces cuDNN wgrad behind the same modules' autograd. */
-int sa_conv_wgrad(const sa_conv_geom *g, int dtype, const void *in, const void *gout, float *dw, const int32_t *tap_lut_host,
+ * caller zeroes dw), and, when db is non-NULL, the bias gradient db[r] += sum_m gout[m][r] (summed from the gradient tiles the
+ * kernel stages anyway; sa_colsum is the stand-alone form).  Replaces cuDNN wgrad / bias-grad behind the same modules' autograd. */
+int sa_conv_wgrad(const sa_conv_geom *g, int dtype, const void *in, const void *gout, float *dw, float *db, const int32_t *tap_lut_host,
                   int64_t s_row, int64_t s_red, void *workspace, int64_t workspace_bytes, void *stream);
 /* bytes of scratch sa_conv_wgrad wants for this geometry (partial tiles of the voxel splits; a second kernel reduces them
  * without atomics).  With workspace == NULL the kernel falls back to fp32 atomics straight into dw. */

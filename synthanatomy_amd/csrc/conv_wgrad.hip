@@ -30,6 +30,7 @@ struct WgradArgs {
     uint32_t nkt, ntiles;
     uint32_t in_bytes, g_bytes;   // non-zero: both operands addressable with 32-bit buffer offsets (LDS-DMA loader)
     float* ws;            // [split][tile][co 128][kidx 128] partial tiles, or NULL -> fp32 atomics straight into dw
+    float* db;            // bias gradient fused into the bf16 LDS-DMA kernels: db[co] += sum_m gout[m][co] (NULL: not wanted)
     // halo kernel (3x3x3 stride 1, bf16, Cin = 128): the voxel range is walked in steps of 4 (H) x 16 (W) voxels
     uint32_t HQ, WP, nsteps, steps_per_split, halo;
     FastDiv dWP, dHQ;
@@ -45,6 +46,35 @@ __device__ __forceinline__ uint32_t roff(uint32_t m, uint32_t c) { return m * 25
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4s_t lds_tr16(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(p));
+}
+
+// Column sums of a bf16 gradient tile [ROWS m][128 c] already in LDS (layout `roff`): thread = (channel pair tid & 63, row group tid >> 6).
+template <int ROWS, int NGROUPS>
+__device__ __forceinline__ void tile_colsum(const unsigned char* pg, uint32_t tid, float& s0, float& s1) {
+    const uint32_t cp = tid & 63u, rg = tid >> 6;
+#pragma unroll
+    for (int m = 0; m < ROWS / NGROUPS + (ROWS % NGROUPS ? 1 : 0); ++m) {
+        const uint32_t row = rg + (uint32_t)m * NGROUPS;
+        if (ROWS % NGROUPS == 0 || row < (uint32_t)ROWS) {
+            const uint32_t v = *(const uint32_t*)(pg + roff(row, 2u * cp));
+            s0 += __uint_as_float(v << 16);
+            s1 += __uint_as_float(v & 0xffff0000u);
+        }
+    }
+}
+// block-level finish: sum the row groups through LDS and add into db (one atomic per channel per block)
+template <int NGROUPS>
+__device__ __forceinline__ void colsum_finish(float* red /* [NGROUPS][128] */, uint32_t tid, float s0, float s1, float* db, uint32_t c_base, uint32_t c_valid) {
+    const uint32_t cp = tid & 63u, rg = tid >> 6;
+    red[rg * 128u + 2u * cp] = s0;
+    red[rg * 128u + 2u * cp + 1u] = s1;
+    __syncthreads();
+    if (tid < 128u) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < NGROUPS; ++r) t += red[r * 128 + tid];
+        if (c_base + tid < c_valid) unsafeAtomicAdd(db + c_base + tid, t);
+    }
 }
 
 struct RowPos {
@@ -358,12 +388,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) 
     issue(chunk0, 0);
     __syncthreads();
     const uint32_t frow = lane & 15u, fq = lane >> 4;
+    const bool do_db = IS_BF16 && a.db != nullptr && kt == 0;   // the gradient rows of this split pass through exactly one kt = 0 block per co tile
+    float bs0 = 0.f, bs1 = 0.f;
     for (uint32_t c = chunk0; c < chunk1; ++c) {
         const uint32_t buf = (c - chunk0) & 1u;
         if (c + 1 < chunk1) issue(c + 1, buf ^ 1u);
         const unsigned char* px = sX + buf * TILE_BYTES;
         const unsigned char* pg = sG + buf * TILE_BYTES;
         if constexpr (IS_BF16) {
+            if (do_db) tile_colsum<64, 4>(pg, tid, bs0, bs1);
             // lane (group gq = lane>>4, s = lane&15) addresses voxel row 4*gq + (s>>2) and channels 4*(s&3)..+3 of each 16x(4 m) block
             const uint32_t trow = fq * 4u + (frow >> 2), tcol = (frow & 3u) * 4u;
 #pragma unroll
@@ -405,6 +438,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) 
         __syncthreads();  // drains the DMA (vmcnt(0)) and frees this buffer
     }
 
+    if (do_db) colsum_finish<4>((float*)smem, tid, bs0, bs1, a.db, ct * 128u, (uint32_t)g.cout_valid);   // (the loop's last barrier freed the tiles)
     // ---- epilogue: lane holds rows kidx = .. + fq*4 + r (4 consecutive ci of one tap), column co = .. + frow
     if (a.ws) {
         // partial tile to the workspace (plain 16-byte stores); wgrad_reduce_kernel sums the splits and scatters into dw
@@ -535,11 +569,14 @@ __global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradArgs a)
     const uint32_t frow = lane & 15u, fq = lane >> 4;
     // transposing reads: lane (gq = lane>>4, s = lane&15) addresses row 4*gq + (s>>2), channels 4*(s&3)..+3 of a [16 rows][16 ch] block
     const uint32_t trow = fq * 4u + (frow >> 2), tcol = (frow & 3u) * 4u;
+    const bool do_db = a.db != nullptr && tdth == 0u;   // one of the nine (kd, kh) blocks of a split also sums the gradient rows
+    float bs0 = 0.f, bs1 = 0.f;
     for (uint32_t st = step0; st < step1; ++st) {
         const uint32_t buf = (st - step0) & 1u;
         if (st + 1 < step1) issue(st + 1, buf ^ 1u);
         const unsigned char* px = smem + buf * STAGE;
         const unsigned char* pg = px + XT;
+        if (do_db) tile_colsum<PHS * 16, 12>(pg, tid, bs0, bs1);
 #pragma unroll
         for (int ks = 0; ks < PHS / 2; ++ks) {
             short8_t xf[4], gf[4];
@@ -564,6 +601,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradArgs a)
         }
         __syncthreads();  // drains the DMA (vmcnt(0)) and frees this buffer
     }
+    if (do_db) colsum_finish<12>((float*)smem, tid, bs0, bs1, a.db, ct * 128u, (uint32_t)g.cout_valid);
     // partial tile of tap (kd, kh, kw) -> workspace [split][tile = tap + 27*ct][co 128][ci 128]
     const uint32_t tile = (td * 3u + th) * 3u + tw + a.nkt * ct;
     float* wt = a.ws + ((size_t)split * a.ntiles + tile) * (128 * 128);
@@ -604,6 +642,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, ui
         const uint32_t c = kk - tap * a.g.Cin;
         if (c >= (uint32_t)a.g.cin_valid) continue;
         a.dw[co * a.s_row + (int64_t)c * a.s_red + a.lut[tap]] += s[r];
+    }
+}
+
+// db[c] += sum over the rows m of a launch geometry of g[o(m)][c]  (fallback of the fused bias gradient for geometries whose rows are a
+// strided subset of the output voxels: the transposed convolution's parity classes).  One thread per (row lane, channel).
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_geom_kernel(const WgradArgs a, int64_t rows_per_block) {
+    const T* gp = (const T*)a.gout;
+    const int C = a.g.cout_valid, cs = a.g.Cout;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > (int64_t)a.M) r1 = a.M;
+    for (int c = threadIdx.x & 63; c < C; c += 64) {
+        float s = 0.f;
+        for (int64_t m = r0 + (threadIdx.x >> 6); m < r1; m += 4) {
+            const RowPos r = decode_row((uint32_t)m, a);
+            s += load_as_f32(gp, sizeof(T) == 4 ? SA_F32 : SA_BF16, r.ovox * cs + c);
+        }
+        unsafeAtomicAdd(a.db + c, s);
     }
 }
 
@@ -734,7 +791,9 @@ extern "C" int64_t sa_conv_wgrad_workspace_bytes(const sa_conv_geom* g, int dtyp
     return (int64_t)splits * a.ntiles * 128 * 128 * 4;
 }
 
-extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, const void* gout, float* dw, const int32_t* tap_lut_host,
+extern "C" int sa_colsum(const void* gp, int dtype, int64_t M, int C, int cstride, float* db, void* stream);
+
+extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, const void* gout, float* dw, float* db, const int32_t* tap_lut_host,
                              int64_t s_row, int64_t s_red, void* workspace, int64_t workspace_bytes, void* stream) {
     using namespace sa;
     if (!g || !in || !gout || !dw) return SA_EINVAL;
@@ -752,6 +811,7 @@ extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, c
     const int64_t need = (int64_t)splits * a.ntiles * 128 * 128 * 4;
     a.ws = (workspace && workspace_bytes >= need) ? (float*)workspace : nullptr;
     if (workspace && !a.ws) return SA_EINVAL;  // a workspace was given but is too small
+    a.db = nullptr;
     const size_t lds = dtype == SA_F32 ? 4 * 8192 : 4 * 16384;
     const uint32_t splits8 = (splits + 7u) & ~7u;  // blocks of the padded splits exit immediately
     dim3 grid(a.ntiles * splits8);
@@ -763,7 +823,9 @@ extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, c
         a.in_bytes = fits ? (uint32_t)ib : 0u;
         a.g_bytes = fits ? (uint32_t)gb : 0u;
     }
+    const bool fuse_db = db && dtype == SA_BF16 && getenv("SA_NO_FUSED_DB") == nullptr;   // the bf16 LDS-DMA kernels sum the gradient tile they stage
     if (a.halo && a.ws) {
+        if (fuse_db) a.db = db;
         static bool attr_done = false;
         if (!attr_done) {
             hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024);
@@ -775,6 +837,7 @@ extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, c
         if (a.halo == 8) hipLaunchKernelGGL(conv_wgrad_halo_kernel<8>, dim3(8u * spx * 9u * nct), dim3(768), 2 * 68 * 1024, st, a);
         else hipLaunchKernelGGL(conv_wgrad_halo_kernel<4>, dim3(8u * spx * 9u * nct), dim3(768), 2 * 34 * 1024, st, a);
     } else if (a.in_bytes) {
+        if (fuse_db) a.db = db;
         snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_dma_kernel<%s>", dtype == SA_F32 ? "float" : "unsigned short");
         if (dtype == SA_F32) hipLaunchKernelGGL(conv_wgrad_dma_kernel<float>, grid, dim3(256), lds, st, a);
         else hipLaunchKernelGGL(conv_wgrad_dma_kernel<bf16_t>, grid, dim3(256), lds, st, a);
@@ -786,6 +849,17 @@ extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, c
     SA_CHECK_LAUNCH();
     if (a.ws) {
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((a.ntiles * 4096u + 255) / 256), dim3(256), 0, st, a, splits);
+        SA_CHECK_LAUNCH();
+    }
+    if (db && !a.db) {  // not fused (fp32, or operands beyond 32-bit offsets): stand-alone column sums over THIS geometry's rows
+        bool dense = g->Dm == g->Do && g->Hm == g->Ho && g->Wm == g->Wo;
+        for (int d = 0; d < 3; ++d) dense = dense && g->out_mult[d] == 1 && g->out_off[d] == 0;
+        if (dense) return sa_colsum(gout, dtype, (int64_t)g->N * g->Do * g->Ho * g->Wo, g->cout_valid, g->Cout, db, stream);
+        a.db = db;
+        const int64_t rpb = ((int64_t)a.M + 1023) / 1024 < 64 ? 64 : ((int64_t)a.M + 1023) / 1024;
+        const unsigned nb = (unsigned)(((int64_t)a.M + rpb - 1) / rpb);
+        if (dtype == SA_F32) hipLaunchKernelGGL(colsum_geom_kernel<float>, dim3(nb), dim3(256), 0, st, a, rpb);
+        else hipLaunchKernelGGL(colsum_geom_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, a, rpb);
         SA_CHECK_LAUNCH();
     }
     return 0;

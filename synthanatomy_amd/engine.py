@@ -300,11 +300,9 @@ class ConvOp:
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)  # caching allocator: stream-ordered scratch
             _launch("+wgrad_reduce_kernel", _geom_flops(pl.geom),
                     lambda pl=pl, ws=ws, nbytes=nbytes: _ffi.check(
-                        lib.sa_conv_wgrad(ctypes.byref(pl.geom), did, _ffi.ptr(x), _ffi.ptr(g), _ffi.ptr(dw), pl.lut_c, pl.s_row, pl.s_red, _ffi.ptr(ws), nbytes, st),
+                        lib.sa_conv_wgrad(ctypes.byref(pl.geom), did, _ffi.ptr(x), _ffi.ptr(g), _ffi.ptr(dw), _ffi.ptr(db), pl.lut_c, pl.s_row, pl.s_red, _ffi.ptr(ws),
+                                          nbytes, st),
                         "sa_conv_wgrad"))
-        if db is not None:
-            M = g.numel() // g.shape[-1]
-            _ffi.check(lib.sa_colsum(_ffi.ptr(g), did, M, self.cout, g.shape[-1], _ffi.ptr(db), st), "sa_colsum")
 
 
 def cast_pad(src: torch.Tensor, dst_dtype: torch.dtype, dst_stride: int) -> torch.Tensor:
