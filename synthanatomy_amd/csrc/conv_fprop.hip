@@ -184,6 +184,100 @@ __device__ __forceinline__ void fprop_epilogue_ov(const FpropArgs& a, float4_t (
     }
 }
 
+// ---- register epilogue (no LDS, no barrier): a 4 x 4 transpose across the four 16-lane quarters of the wave (v_permlane32_swap +
+// v_permlane16_swap, gfx950) turns "lane = 4 channels of each of 4 column fragments" into "lane = 16 CONSECUTIVE channels" of its voxel
+// row, so addend / mask come in and the result leaves as 32-byte (bf16) or 64-byte (fp32) contiguous pieces, 128 / 256 B per row.
+// permlane32_swap(a, b) = {[a.q0 a.q1 b.q0 b.q1], [a.q2 a.q3 b.q2 b.q3]};  permlane16_swap(a, b) = {[a.q0 b.q0 a.q2 b.q2], [a.q1 b.q1 a.q3 b.q3]}
+// (probed on MI355X).  Requires a full 128-channel tile of valid output channels and 16-byte aligned rows; the caller checks.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void quarter_transpose(float& r0, float& r1, float& r2, float& r3) {
+    const u32x2 a = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r2), false, false);
+    const u32x2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r3), false, false);
+    const u32x2 c = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+    const u32x2 d = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+    r0 = __uint_as_float(c.x); r1 = __uint_as_float(c.y); r2 = __uint_as_float(d.x); r3 = __uint_as_float(d.y);
+}
+
+__device__ __forceinline__ void load16(const void* base, int dtype, int64_t off, float (&v)[16]) {
+    if (dtype == SA_F32) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4_t t = *(const float4_t*)((const float*)base + off + 4 * k);
+            v[4 * k] = t[0]; v[4 * k + 1] = t[1]; v[4 * k + 2] = t[2]; v[4 * k + 3] = t[3];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const u32x4 t = *(const u32x4*)((const bf16_t*)base + off + 8 * k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[8 * k + 2 * e] = __uint_as_float(t[e] << 16);
+                v[8 * k + 2 * e + 1] = __uint_as_float(t[e] & 0xffff0000u);
+            }
+        }
+    }
+}
+
+template <int MI, int NI, typename RowOv>
+__device__ __forceinline__ void fprop_epilogue_regs(const FpropArgs& a, float4_t (&acc)[NI][MI], uint32_t wm, uint32_t wn, uint32_t frow, uint32_t fq,
+                                                    uint32_t n_base, RowOv row_ov) {
+    static_assert(NI == 4, "4 column fragments per wave");
+    const sa_conv_geom& g = a.g;
+    const sa_epilogue& ep = a.ep;
+    const float alpha = ep.alpha ? *ep.alpha : 1.f;
+    if (ep.bias) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float4_t bv = *(const float4_t*)(ep.bias + n_base + wn * 64 + i * 16 + fq * 4);
+#pragma unroll
+            for (int j = 0; j < MI; ++j) acc[i][j] += bv;
+        }
+    }
+    const uint32_t c0 = n_base + wn * 64 + fq * 16;   // this lane's 16 channels after the transpose
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t0 = acc[0][j][r], t1 = acc[1][j][r], t2 = acc[2][j][r], t3 = acc[3][j][r];
+            quarter_transpose(t0, t1, t2, t3);       // t[i'] = channel fq*16 + i'*4 + r
+            v[r] = t0; v[4 + r] = t1; v[8 + r] = t2; v[12 + r] = t3;
+        }
+        const long long ov = row_ov(wm * (MI * 16) + j * 16 + frow);
+        if (ov < 0) continue;
+        const int64_t o = ov * g.Cout + c0;
+        float ad[16], mk[16];
+        if (ep.addend) load16(ep.addend, ep.add_dtype, o, ad);
+        if (ep.mask_mode != SA_MASK_NONE) load16(ep.mask, ep.mask_dtype, o, mk);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float x = v[e];
+            if (ep.addend && ep.add_before_act) x += ad[e];
+            if (ep.act == SA_ACT_RELU) x = fmaxf(x, 0.f);
+            else if (ep.act == SA_ACT_LRELU) x = x > 0.f ? x : x * ep.slope;
+            else if (ep.act == SA_ACT_GELU) x = gelu_f(x);
+            x *= alpha;
+            if (ep.addend && !ep.add_before_act) x += ad[e];
+            if (ep.mask_mode == SA_MASK_POS) x = mk[e] > 0.f ? x : 0.f;
+            else if (ep.mask_mode == SA_MASK_LRELU) x = mk[e] > 0.f ? x : x * ep.slope;
+            else if (ep.mask_mode == SA_MASK_GELU) x *= gelu_grad_f(mk[e]);
+            v[e] = x;
+        }
+        if (ep.out_dtype == SA_F32) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *(float4_t*)((float*)a.out + o + 4 * k) = (float4_t){v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                u32x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (uint32_t)f32_to_bf16(v[8 * k + 2 * e]) | ((uint32_t)f32_to_bf16(v[8 * k + 2 * e + 1]) << 16);
+                *(u32x4*)((bf16_t*)a.out + o + 8 * k) = pk;
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int MI, int NI, int NT = 256>
 __device__ __forceinline__ void fprop_epilogue(const FpropArgs& a, float4_t (&acc)[NI][MI], unsigned char* smem, uint32_t tid, uint32_t wm, uint32_t wn,
                                                uint32_t frow, uint32_t fq, uint32_t m_base, uint32_t n_base) {
@@ -852,6 +946,9 @@ __global__ __launch_bounds__(512) void conv_fprop_pp_kernel(const FpropArgs a) {
 // is physically in the halo.  K order = (kd, chunk, kh, kw); the packed weights keep their (tap, channel) order and are
 // addressed by column.  Per slab a wave issues 4 weight pieces and at most one halo piece of the NEXT group (double-buffered),
 // against 4 + 4 in v2.  LDS: 2 x 23 KiB halo + 2 x 16 KiB weights = 78 KiB -> two blocks per CU.
+// Measured dead ends (MI355X, C = 128 layer, 1.05-1.1 PFLOP/s here): a persistent 8-wave block on 16 x 16 patches (half the weight
+// traffic, cross-tile prefetch, register epilogue) ran at 0.91-0.96 PFLOP/s -- eight waves in lock-step on one barrier lose the overlap two
+// independent 4-wave blocks give each other; rotating the K-group order per block (to spread the weight reads over L2) changed nothing.
 template <typename T, bool FUSE>
 __global__ __launch_bounds__(256) void conv_fprop_halo_kernel(const FpropArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -910,6 +1007,9 @@ __global__ __launch_bounds__(256) void conv_fprop_halo_kernel(const FpropArgs a)
         const bool dok = (uint32_t)id < (uint32_t)g.Di;
         const uint32_t goff = (uint32_t)id * plane_bytes + ch * 128u;
         const uint32_t voff = dok && hoff[i] != OOB_OFF ? hoff[i] + goff : OOB_OFF;
+#ifdef SA_PP_DEBUG_VARIANTS
+        if (a.dbg & 1u) return;
+#endif
         if (wave * 6 + i < (uint32_t)HPIECES)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(sA + (gi & 1u) * HALO_BYTES + (wave * 6 + i) * 1024), 16, voff, 0, 0, 0);
     };
@@ -917,6 +1017,9 @@ __global__ __launch_bounds__(256) void conv_fprop_halo_kernel(const FpropArgs a)
     auto issue_w = [&](uint32_t gi, uint32_t t9, uint32_t buf) __attribute__((always_inline)) {
         const uint32_t td = gi / nchunk, ch = gi - td * nchunk;
         const uint32_t col = ((td * 9u + t9) * (uint32_t)g.Cin) * SZ + ch * 128u;
+#ifdef SA_PP_DEBUG_VARIANTS
+        if (a.dbg & 2u) return;
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(sB + buf * (BN * 128) + (wave * 4 + j) * 1024), 16, boff[j], col, 0, 0);
@@ -973,7 +1076,12 @@ __global__ __launch_bounds__(256) void conv_fprop_halo_kernel(const FpropArgs a)
 #pragma unroll
                     for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
             }
-            __syncthreads();  // drains this wave's DMA (vmcnt(0)): next slab / halo pieces landed, this slab's buffers free
+            // The weight pieces of the next slab must have landed; the halo piece issued AFTER them in this slab may stay in flight for
+            // one more slab (it comes from HBM, the weights from L2): vmcnt(1) instead of the vmcnt(0) a __syncthreads() would force.
+            // It is retired by the next slab's wait, and the last one (t9 = 5) by the vmcnt(0) of t9 = 6.. before the group switch.
+            if (t9 < 6 && next_group && wave * 6 + t9 < (uint32_t)HPIECES) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // (only if this wave issued one)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             buf ^= 1u;
         }
     }
@@ -981,11 +1089,20 @@ __global__ __launch_bounds__(256) void conv_fprop_halo_kernel(const FpropArgs a)
         const uint32_t h = (uint32_t)h0 + (row >> 4), w = (uint32_t)w0 + (row & 15u);
         return h < (uint32_t)g.Ho && w < (uint32_t)g.Wo ? (((long long)pn * g.Do + pd) * g.Ho + h) * g.Wo + w : -1ll;
     };
+#ifdef SA_PP_DEBUG_VARIANTS
+    if (a.dbg & 64u) {
+        if (acc[0][0][0] == 123.f) *(float*)a.out = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];
+        return;
+    }
+#endif
     if constexpr (FUSE) {
         static_assert(!FUSE || sizeof(T) == 2, "fused residual block: bf16");
         resblock_second_gemm<MI, NI>(a, acc, smem, tid, wave, wm, wn, frow, fq, prow, lv, row_vox);
     }
-    fprop_epilogue_ov<BM, BN, WM, WN, MI, NI, 256>(a, acc, smem, tid, wm, wn, frow, fq, n_base, row_vox);
+    // full tile of valid channels and 16-byte aligned channel rows -> register epilogue; otherwise the LDS-staged one (block-uniform choice)
+    const bool regs_ok = n_base + BN <= (uint32_t)g.cout_valid && (g.Cout & 7) == 0 && !(a.dbg & 256u);
+    if (regs_ok) fprop_epilogue_regs<MI, NI>(a, acc, wm, wn, frow, fq, n_base, row_vox);
+    else fprop_epilogue_ov<BM, BN, WM, WN, MI, NI, 256>(a, acc, smem, tid, wm, wn, frow, fq, n_base, row_vox);
 #endif
 }
 
