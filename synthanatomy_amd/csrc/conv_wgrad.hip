@@ -612,6 +612,160 @@ __global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradArgs a)
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Halo weight gradient, nine taps per block.  The three-tap kernel above is bound by the operand stream (L2 -> LDS fabric,
+// measured: its loads alone take 4.7 of its 5.2 ms on the C = 128 layer).  Here a block owns one kd, one 64-channel half of the input
+// channels and a range of voxel steps; a step is 8 (H) x 16 (W) voxels of one plane: the gradient tile [128][128 co] (32 pieces) and
+// the activation halo tile [10 x 18][64 ci] (128-byte rows, 23 pieces) feed all NINE (kh, kw) taps.  8 waves: wave = (16-ci fragment,
+// 64-co half), 9 taps x 4 co fragments = 36 accumulators (144 VGPRs), 144 MFMAs per step and barrier (32 above).
+// Operand bytes per FLOP: 2.9 KB/MFLOP against 5.4 (three taps) and 15.6 (im2col order).
+// 128-byte rows: 32-byte chunk c of row m sits at chunk c ^ ((m >> 1) & 3), which gives the transposing reads of 8 consecutive rows 8
+// distinct 32-byte bank groups (rows of equal parity share a 256-byte bank line).
+__device__ __forceinline__ uint32_t roff128(uint32_t m, uint32_t c) { return m * 128u + ((((c >> 4) ^ ((m >> 1) & 3u)) << 5) | ((c & 15u) << 1)); }
+
+__global__ __launch_bounds__(512) void conv_wgrad_halo9_kernel(const WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int XP = 23, GP = 32, NP = XP + GP, PPW = (NP + 7) / 8;   // 1 KiB pieces per step; 7 per wave (the last round is partial)
+    constexpr int XT = XP * 1024, GT = GP * 1024, STAGE = XT + GT;      // 55 KiB
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const sa_conv_geom& g = a.g;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t fi = wave & 3u, wn = wave >> 2;          // 16-ci fragment of this block's 64-channel half, 64-co half
+    // block -> (split, kd, ci half, co tile); an XCD walks a contiguous range of splits, the six blocks of a split back to back
+    const uint32_t nct = a.ntiles / a.nkt;
+    const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
+    const uint32_t per_split = 6u * nct;
+    const uint32_t nsplit = (a.nsteps + a.steps_per_split - 1) / a.steps_per_split;
+    const uint32_t spx = (nsplit + 7u) >> 3;
+    const uint32_t sl = seq / per_split, rem = seq - sl * per_split;
+    const uint32_t split = xcd * spx + sl;
+    if (sl >= spx || split >= nsplit) return;
+    const uint32_t tdc = rem % 6u, ct = rem / 6u;
+    const uint32_t td = tdc >> 1, cih = tdc & 1u;
+    const uint32_t step0 = split * a.steps_per_split;
+    uint32_t step1 = step0 + a.steps_per_split;
+    if (step1 > a.nsteps) step1 = a.nsteps;
+
+    float4_t acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)a.gout, 0, (int)a.g_bytes, 0x00020000);
+    // piece q = wave + 8 i: q < 23 activation halo (8 rows x 128 B: lane -> row l>>3, 16-byte slot l&7), else gradient (4 rows x 256 B:
+    // row l>>4, slot l&15).  The DMA writes lane-linearly, so each lane fetches the SOURCE vector its slot holds after the swizzle.
+    int32_t p_h[PPW], p_w[PPW];
+    uint32_t p_off[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const uint32_t q = wave + 8u * i;
+        if (q < (uint32_t)XP) {
+            const uint32_t r = q * 8u + (lane >> 3), pos = lane & 7u;
+            const uint32_t vec = ((((pos >> 1) ^ ((r >> 1) & 3u)) << 1) | (pos & 1u));
+            const uint32_t hh = r / 18u, ww = r - hh * 18u;
+            p_h[i] = (int32_t)hh + g.in_off[1];
+            p_w[i] = (int32_t)ww + g.in_off[2];
+            p_off[i] = (uint32_t)((p_h[i] * g.Wi + p_w[i]) * (g.Cin * 2)) + cih * 128u + vec * 16u;
+            if (r >= 180u) p_h[i] = -(1 << 20);   // rows 180..183 of the last piece: never valid
+        } else {
+            const uint32_t r = (q - (uint32_t)XP) * 4u + (lane >> 4);
+            const uint32_t vec = ((((lane & 15u) >> 1) ^ (r & 7u)) << 1) | (lane & 1u);
+            p_h[i] = (int32_t)(r >> 4);
+            p_w[i] = (int32_t)(r & 15u);
+            p_off[i] = (uint32_t)((p_h[i] * g.Wo + p_w[i]) * (g.Cout * 2)) + ct * 256u + vec * 16u;
+        }
+    }
+    auto issue = [&](uint32_t step, uint32_t buf) __attribute__((always_inline)) {
+        unsigned char* ps = smem + buf * STAGE;
+        uint32_t q1 = fdiv(step, a.dWP);
+        const uint32_t wp = step - q1 * a.WP;
+        uint32_t q2 = fdiv(q1, a.dHQ);
+        const uint32_t hq = q1 - q2 * a.HQ;
+        const uint32_t n = fdiv(q2, a.dD);
+        const uint32_t d = q2 - n * (uint32_t)g.Dm;
+        const int32_t h0 = (int32_t)hq * 8, w0 = (int32_t)wp * 16;
+        const int32_t id = (int32_t)d + g.in_off[0] + (int32_t)td;
+        const bool dok = (uint32_t)id < (uint32_t)g.Di;
+        const uint32_t xbase = (uint32_t)((((int32_t)n * g.Di + id) * g.Hi + h0) * g.Wi + w0) * (uint32_t)(g.Cin * 2);
+        const uint32_t gbase = (uint32_t)((((int32_t)n * g.Do + (int32_t)d) * g.Ho + h0) * g.Wo + w0) * (uint32_t)(g.Cout * 2);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const uint32_t q = wave + 8u * i;
+            if (q >= (uint32_t)NP) break;
+            const int32_t hh = h0 + p_h[i], ww = w0 + p_w[i];
+            if (q < (uint32_t)XP) {
+                const bool ok = dok && (uint32_t)hh < (uint32_t)g.Hi && (uint32_t)ww < (uint32_t)g.Wi;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)(ps + q * 1024), 16, ok ? xbase + p_off[i] : 0xfffffff0u, 0, 0, 0);
+            } else {
+                const bool ok = (uint32_t)hh < (uint32_t)g.Ho && (uint32_t)ww < (uint32_t)g.Wo;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, (__attribute__((address_space(3))) void*)(ps + XT + (q - (uint32_t)XP) * 1024), 16, ok ? gbase + p_off[i] : 0xfffffff0u, 0, 0,
+                                                         0);
+            }
+        }
+    };
+
+    issue(step0, 0);
+    __syncthreads();
+    const uint32_t frow = lane & 15u, fq = lane >> 4;
+    const uint32_t trow = fq * 4u + (frow >> 2), tcol = (frow & 3u) * 4u;
+    const bool do_db = a.db != nullptr && tdc == 0u;   // one of the six blocks of a split also sums the gradient rows
+    float bs0 = 0.f, bs1 = 0.f;
+    // Halo addresses of the 9 x 2 transposing reads of K-step 0 (voxel (ph, pw) of tap (kh, kw) reads halo row (ph + kh) * 18 + pw + kw;
+    // the low / high half of an operand are patch rows 0 / 1).  K-step ks starts 36 rows further: + 4608 bytes, and the row-dependent
+    // chunk swizzle ((m >> 1) & 3) advances by 18 ks = 2 ks mod 4, i.e. byte bit 6 flips on odd ks -- no per-step address arithmetic.
+    uint32_t xa[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const uint32_t xr0 = (uint32_t)(t / 3) * 18u + (uint32_t)(t % 3) + trow;
+        xa[t][0] = roff128(xr0, fi * 16 + tcol);
+        xa[t][1] = roff128(xr0 + 18u, fi * 16 + tcol);
+    }
+    uint32_t ga[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ga[j] = roff(trow, wn * 64 + j * 16 + tcol);   // (+ 4096 for the high half: 16 rows keep m & 7)
+    for (uint32_t st = step0; st < step1; ++st) {
+        const uint32_t buf = (st - step0) & 1u;
+        if (st + 1 < step1) issue(st + 1, buf ^ 1u);
+        const unsigned char* px = smem + buf * STAGE;
+        const unsigned char* pg = px + XT;
+        if (do_db) tile_colsum<128, 8>(pg, tid, bs0, bs1);
+#pragma unroll 1
+        for (uint32_t ks = 0; ks < 4; ++ks) {   // 32 voxels = patch rows 2 ks, 2 ks + 1  (rolled: unrolling spills the 144 accumulators)
+            short8_t gf[4];
+            const unsigned char* pgk = pg + ks * 8192u;
+            const unsigned char* pxk = px + ks * 4608u;
+            const uint32_t kx = (ks & 1u) * 64u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v4s_t lo = lds_tr16(pgk + ga[j]);
+                const v4s_t hi = lds_tr16(pgk + ga[j] + 4096);
+                gf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const v4s_t lo = lds_tr16(pxk + (xa[t][0] ^ kx));
+                const v4s_t hi = lds_tr16(pxk + (xa[t][1] ^ kx));
+                const short8_t xf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, gf[j], acc[t][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // drains the DMA (vmcnt(0)) and frees this buffer
+    }
+    if (do_db) colsum_finish<8>((float*)smem, tid, bs0, bs1, a.db, ct * 128u, (uint32_t)g.cout_valid);
+    // partial tiles of the nine taps of this kd -> workspace [split][tile = tap + 27*ct][co 128][ci 128]
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* wt = a.ws + ((size_t)split * a.ntiles + (td * 9u + t) + a.nkt * ct) * (128 * 128);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(float4_t*)(wt + (wn * 64 + j * 16 + frow) * 128 + cih * 64 + fi * 16 + fq * 4) = acc[t][j];
+    }
+#endif
+}
+
 // dw[co][ci][tap] += sum_split ws[split][tile][co][kidx]   (no atomics).  One thread owns 4 consecutive kidx of one (tile, co) and
 // streams the splits with 8 independent 16-byte loads in flight.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, uint32_t splits) {
@@ -756,19 +910,20 @@ static int plan_wgrad(const sa_conv_geom* g, int dtype, WgradArgs& a, uint32_t& 
         const uint64_t ib = (uint64_t)g->N * g->Di * g->Hi * g->Wi * g->Cin * 2, gb = (uint64_t)g->N * g->Do * g->Ho * g->Wo * g->Cout * 2;
         ok = ok && ib < 0xffffff00ull - (1u << 20) && gb < 0xffffff00ull - (1u << 20);
         if (ok) {
-            static const int phs_env = getenv("SA_WGRAD_HALO_ROWS") ? atoi(getenv("SA_WGRAD_HALO_ROWS")) : 4;  // 8-row steps measured slower (168 VGPRs + spills)
-            const uint32_t phs = (phs_env == 8 && g->Ho % 8 == 0) ? 8u : 4u;
+            // nine-tap kernel (steps of 8 x 16 voxels) by default; SA_WGRAD_HALO9=0 -> the three-tap kernel (steps of 4 x 16)
+            static const bool nine = !(getenv("SA_WGRAD_HALO9") && atoi(getenv("SA_WGRAD_HALO9")) == 0);
+            const uint32_t phs = nine ? 8u : 4u;
             const uint32_t hq = (uint32_t)(g->Ho + phs - 1) / phs, wp = (uint32_t)(g->Wo + 15) / 16;
             const double eff = (double)g->Ho * g->Wo / ((double)hq * phs * wp * 16);
             const uint64_t nsteps = (uint64_t)g->N * g->Dm * hq * wp;
-            if (eff >= 0.8 && nsteps >= 1024) {
-                a.halo = phs;
+            if (eff >= 0.8 && nsteps >= 512) {
+                a.halo = nine ? 9u : 4u;
                 a.HQ = hq;
                 a.WP = wp;
                 a.nsteps = (uint32_t)nsteps;
                 a.dWP = make_fastdiv(wp);
                 a.dHQ = make_fastdiv(hq);
-                static const int want = getenv("SA_WGRAD_HALO_SPLITS") ? atoi(getenv("SA_WGRAD_HALO_SPLITS")) : 256;
+                static const int want = getenv("SA_WGRAD_HALO_SPLITS") ? atoi(getenv("SA_WGRAD_HALO_SPLITS")) : (nine ? 128 : 256);
                 uint32_t sp = (uint32_t)want;
                 if (sp > a.nsteps / 16) sp = a.nsteps / 16;   // at least 16 steps per block
                 if (sp < 1) sp = 1;
@@ -829,13 +984,17 @@ extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, c
         static bool attr_done = false;
         if (!attr_done) {
             hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024);
-            hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 68 * 1024);
+            hipFuncSetAttribute((const void*)conv_wgrad_halo9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 55 * 1024);
             attr_done = true;
         }
         const uint32_t nct = a.ntiles / a.nkt, spx = (splits + 7u) / 8u;
-        snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_halo_kernel<%d>", (int)a.halo);
-        if (a.halo == 8) hipLaunchKernelGGL(conv_wgrad_halo_kernel<8>, dim3(8u * spx * 9u * nct), dim3(768), 2 * 68 * 1024, st, a);
-        else hipLaunchKernelGGL(conv_wgrad_halo_kernel<4>, dim3(8u * spx * 9u * nct), dim3(768), 2 * 34 * 1024, st, a);
+        if (a.halo == 9) {
+            snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_halo9_kernel");
+            hipLaunchKernelGGL(conv_wgrad_halo9_kernel, dim3(8u * spx * 6u * nct), dim3(512), 2 * 55 * 1024, st, a);
+        } else {
+            snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_halo_kernel<4>");
+            hipLaunchKernelGGL(conv_wgrad_halo_kernel<4>, dim3(8u * spx * 9u * nct), dim3(768), 2 * 34 * 1024, st, a);
+        }
     } else if (a.in_bytes) {
         if (fuse_db) a.db = db;
         snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_dma_kernel<%s>", dtype == SA_F32 ? "float" : "unsigned short");
