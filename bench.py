@@ -132,6 +132,20 @@ def bench_performer(args, rank, world, dev):
     return res
 
 
+def _pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the PMC passes of this same command (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3
+    --pmc runs; counters cannot be read from inside the process).  Recorded in profiles/r01_pmc_traffic.json with its provenance; only
+    reported for the configuration it was collected on (default batch, bf16), else null."""
+    if args.batch != 8 or args.dtype != "bf16":
+        return None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
+            rec = json.load(f)["kernels"].get(kernel)
+        return int(rec["hbm_bytes_per_launch"]) if rec else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,7 +238,8 @@ def main():
         name, (n, flops, ms) = dom
         ach = flops / (ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
-        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": _pmc_traffic(name, args),
                 "kernel": name, "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                 "kernels": {k: {"launches": v[0], "ms": round(v[2], 3), "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2) if v[2] > 0 else None}
                             for k, v in sorted(stats.items(), key=lambda kv: -kv[1][2])}}
