@@ -42,7 +42,8 @@ struct FpropArgs {
     const float* bias1;
     void* h_out;
     uint32_t HP, WP;      // halo mainloop: patches per plane along H (8 voxels) and W (16 voxels)
-    uint32_t dbg;         // dev only (SA_PP_DBG): bit0 skip activation DMA, bit1 skip weight DMA, bit2 skip fragment reads, bit3 skip MFMAs
+    uint32_t dbg;         // dev only (env SA_PP_DBG): 256 = LDS-staged epilogue instead of the register one; with -DSA_PP_DEBUG_VARIANTS also the
+                          // ablation bits (halo: 1 skip halo DMA, 2 skip weight DMA, 64 skip epilogue; im2col-order: 64 / 128 skip activation / weight DMA)
 };
 
 template <typename T>
@@ -629,315 +630,6 @@ __global__ __launch_bounds__(256) void conv_fprop_dma_kernel(const FpropArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Mainloop v3 (Cout >= 65): 8 waves, tile 256 voxels x 128 channels, THREE-stage LDS ring filled by LDS-DMA two K-slabs
-// ahead.  One raw s_barrier per slab; the DMA queue is never drained inside the loop: `s_waitcnt vmcnt(P)` (P = this wave's
-// pieces per slab) retires exactly the slab about to be read while the next one stays in flight across the barrier.
-//   RAW: slab s is read only after every wave executed vmcnt(P) for it and passed the barrier.
-//   WAR: slab s+2 overwrites the buffer read in step s-1; it is issued after the step-s barrier, which every wave reaches only
-//        after its step s-1 fragment reads have returned (they feed the MFMAs issued before the barrier).
-template <typename T, bool UNIFORM>
-__global__ __launch_bounds__(512) void conv_fprop_dma3_kernel(const FpropArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int WM = 4, WN = 2, MI = 4, NI = 4;
-    constexpr int BM = 256, BN = 128;
-    constexpr int SZ = sizeof(T);
-    constexpr int BKE = 128 / SZ;
-    constexpr int STAGE = (BM + BN) * 128;                 // 48 KiB
-    constexpr int A_PER_WAVE = 4, B_PER_WAVE = 2, P = A_PER_WAVE + B_PER_WAVE;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t wm = wave / WN, wn = wave % WN;
-    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
-    const uint32_t m_base = bm * BM, n_base = bn * BN;
-    const sa_conv_geom& g = a.g;
-
-    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (int)a.w_bytes, 0x00020000);
-
-    const uint32_t prow = lane >> 3;
-    const uint32_t lv = (lane & 7u) ^ prow;
-    uint32_t rowoff[A_PER_WAVE], vm[A_PER_WAVE];
-#pragma unroll
-    for (int j = 0; j < A_PER_WAVE; ++j) {
-        const uint32_t m = m_base + (wave * A_PER_WAVE + j) * 8 + prow;
-        rowoff[j] = 0;
-        vm[j] = 0;
-        if (m < a.M) {
-            uint32_t q = fdiv(m, a.dW);
-            const uint32_t wmx = m - q * g.Wm;
-            uint32_t q2 = fdiv(q, a.dH);
-            const uint32_t hmx = q - q2 * g.Hm;
-            const uint32_t n = fdiv(q2, a.dD);
-            const uint32_t dmx = q2 - n * g.Dm;
-            const int32_t id0 = (int32_t)dmx * g.in_mult[0] + g.in_off[0];
-            const int32_t ih0 = (int32_t)hmx * g.in_mult[1] + g.in_off[1];
-            const int32_t iw0 = (int32_t)wmx * g.in_mult[2] + g.in_off[2];
-            rowoff[j] = (uint32_t)((((int32_t)n * g.Di + id0) * g.Hi + ih0) * g.Wi + iw0) * (uint32_t)(g.Cin * SZ);
-            uint32_t mk = 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (t < g.KT[0] && (uint32_t)(id0 + t * g.tap_step[0]) < (uint32_t)g.Di) mk |= 1u << t;
-                if (t < g.KT[1] && (uint32_t)(ih0 + t * g.tap_step[1]) < (uint32_t)g.Hi) mk |= 16u << t;
-                if (t < g.KT[2] && (uint32_t)(iw0 + t * g.tap_step[2]) < (uint32_t)g.Wi) mk |= 256u << t;
-            }
-            vm[j] = mk;
-        }
-    }
-    uint32_t boff[B_PER_WAVE];
-#pragma unroll
-    for (int j = 0; j < B_PER_WAVE; ++j) boff[j] = (n_base + (wave * B_PER_WAVE + j) * 8 + prow) * (uint32_t)(g.Kpad * SZ) + lv * 16u;
-
-    auto issue = [&](uint32_t s, uint32_t buf) __attribute__((always_inline)) {
-        unsigned char* pa = smem + buf * STAGE;
-        unsigned char* pb = pa + BM * 128;
-        uint32_t sel, koff;
-        bool tap_ok;
-        if constexpr (UNIFORM) {
-            const uint32_t ke = s * BKE;
-            const uint32_t tap = fdiv(ke, a.dCin);
-            const uint32_t c0 = ke - tap * g.Cin;
-            const uint32_t td = fdiv(tap, a.dThw);
-            const uint32_t t2 = tap - td * a.dThw.d;
-            const uint32_t th = fdiv(t2, a.dTw);
-            const uint32_t tw = t2 - th * a.dTw.d;
-            const int32_t vox = (((int32_t)td * g.tap_step[0]) * g.Hi + (int32_t)th * g.tap_step[1]) * g.Wi + (int32_t)tw * g.tap_step[2];
-            koff = (uint32_t)vox * (uint32_t)(g.Cin * SZ) + c0 * SZ + lv * 16u;
-            sel = (1u << td) | (16u << th) | (256u << tw);
-            tap_ok = tap < a.ntaps;
-        } else {
-            const uint32_t kv = s * 8u + lv;
-            const uint32_t tap = fdiv(kv, a.dCv);
-            const uint32_t cv = kv - tap * a.dCv.d;
-            const uint32_t td = fdiv(tap, a.dThw);
-            const uint32_t t2 = tap - td * a.dThw.d;
-            const uint32_t th = fdiv(t2, a.dTw);
-            const uint32_t tw = t2 - th * a.dTw.d;
-            const int32_t vox = (((int32_t)td * g.tap_step[0]) * g.Hi + (int32_t)th * g.tap_step[1]) * g.Wi + (int32_t)tw * g.tap_step[2];
-            koff = (uint32_t)vox * (uint32_t)(g.Cin * SZ) + cv * 16u;
-            sel = (1u << td) | (16u << th) | (256u << tw);
-            tap_ok = tap < a.ntaps;
-        }
-#pragma unroll
-        for (int j = 0; j < A_PER_WAVE; ++j) {
-            const bool ok = tap_ok && (vm[j] & sel) == sel;
-            const uint32_t voff = ok ? rowoff[j] + koff : OOB_OFF;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(pa + (wave * A_PER_WAVE + j) * 1024), 16, voff, 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < B_PER_WAVE; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(pb + (wave * B_PER_WAVE + j) * 1024), 16, boff[j], s * 128u,
-                                                     0, 0);
-    };
-
-    float4_t acc[NI][MI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < MI; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-
-    const uint32_t nk = a.nk;
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    const uint32_t frow = lane & 15u, fq = lane >> 4;
-    uint32_t buf = 0;
-    for (uint32_t s = 0; s < nk; ++s) {
-        // retire slab s (keep slab s+1 in flight), then rendezvous
-        if (s + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (s + 2 < nk) issue(s + 2, buf >= 1 ? buf - 1 : 2);  // (s+2) % 3 == (buf + 2) % 3
-        const unsigned char* pa = smem + buf * STAGE;
-        const unsigned char* pb = pa + BM * 128;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            u32x4 xf[MI], wf[NI];
-#pragma unroll
-            for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(pa + tile_off(wm * (MI * 16) + j * 16 + frow, ks * 4 + fq));
-#pragma unroll
-            for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + tile_off(wn * (NI * 16) + i * 16 + frow, ks * 4 + fq));
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
-        }
-        buf = buf == 2 ? 0 : buf + 1;
-    }
-    __syncthreads();  // every wave is done reading the ring before the epilogue reuses it
-    fprop_epilogue<BM, BN, WM, WN, MI, NI, 512>(a, acc, smem, tid, wm, wn, frow, fq, m_base, n_base);
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-// Mainloop v4 "ping-pong" (Cout >= 65, Cin * sizeof(T) a multiple of 128): 8 waves, tile 256 voxels x 128 channels, the v3
-// three-stage LDS-DMA ring, but every K-slab is two PHASES (K = 32 each) of
-//     [ds_read the 4 + 4 fragments | issue half of the slab two ahead]  s_barrier  [16 MFMA at priority 1]  s_barrier
-// and waves 4-7 run ONE barrier behind waves 0-3.  Waves w and w + 4 share a SIMD, so while one of them owns the matrix pipe
-// its partner is in the LDS/DMA segment: the pipe never waits for a wave that is fetching.
-//   RAW  a wave waits `vmcnt(6)` (slab s+1 landed, slab s+2 in flight) before the first barrier of phase (s,1); slab s+1 is
-//        first read after that phase's second barrier, i.e. after every wave of both groups has executed its wait.
-//   WAR  slab s+2 overwrites the stage last read in phase (s-1,1); those reads are retired (lgkmcnt(0)) before that phase's
-//        first barrier, which both groups have passed when the first DMA of phase (s,0) is issued.
-template <typename T, int DBG = 0>
-__global__ __launch_bounds__(512) void conv_fprop_pp_kernel(const FpropArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int WM = 4, WN = 2, MI = 4, NI = 4;
-    constexpr int BM = 256, BN = 128;
-    constexpr int SZ = sizeof(T);
-    constexpr int BKE = 128 / SZ;
-    constexpr int STAGE = (BM + BN) * 128;                 // 48 KiB
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t grp = wave >> 2;
-    const uint32_t wm = wave / WN, wn = wave % WN;
-    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
-    const uint32_t m_base = bm * BM, n_base = bn * BN;
-    const sa_conv_geom& g = a.g;
-
-    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (int)a.w_bytes, 0x00020000);
-
-    const uint32_t prow = lane >> 3;
-    const uint32_t lv = (lane & 7u) ^ prow;
-    uint32_t rowoff[4], vm[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t m = m_base + (wave * 4 + j) * 8 + prow;
-        rowoff[j] = 0;
-        vm[j] = 0;
-        if (m < a.M) {
-            uint32_t q = fdiv(m, a.dW);
-            const uint32_t wmx = m - q * g.Wm;
-            uint32_t q2 = fdiv(q, a.dH);
-            const uint32_t hmx = q - q2 * g.Hm;
-            const uint32_t n = fdiv(q2, a.dD);
-            const uint32_t dmx = q2 - n * g.Dm;
-            const int32_t id0 = (int32_t)dmx * g.in_mult[0] + g.in_off[0];
-            const int32_t ih0 = (int32_t)hmx * g.in_mult[1] + g.in_off[1];
-            const int32_t iw0 = (int32_t)wmx * g.in_mult[2] + g.in_off[2];
-            rowoff[j] = (uint32_t)((((int32_t)n * g.Di + id0) * g.Hi + ih0) * g.Wi + iw0) * (uint32_t)(g.Cin * SZ) + lv * 16u;
-            uint32_t mk = 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (t < g.KT[0] && (uint32_t)(id0 + t * g.tap_step[0]) < (uint32_t)g.Di) mk |= 1u << t;
-                if (t < g.KT[1] && (uint32_t)(ih0 + t * g.tap_step[1]) < (uint32_t)g.Hi) mk |= 16u << t;
-                if (t < g.KT[2] && (uint32_t)(iw0 + t * g.tap_step[2]) < (uint32_t)g.Wi) mk |= 256u << t;
-            }
-            vm[j] = mk;
-        }
-    }
-    uint32_t boff[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) boff[j] = (n_base + (wave * 2 + j) * 8 + prow) * (uint32_t)(g.Kpad * SZ) + lv * 16u;
-
-    // half h of slab s: activation pieces 2h, 2h+1 and weight piece h of this wave
-    auto issue_half = [&](uint32_t s, uint32_t buf, int h) __attribute__((always_inline)) {
-        unsigned char* pa = smem + buf * STAGE;
-        unsigned char* pb = pa + BM * 128;
-        const uint32_t ke = s * BKE;
-        const uint32_t tap = fdiv(ke, a.dCin);
-        const uint32_t c0 = ke - tap * g.Cin;
-        const uint32_t td = fdiv(tap, a.dThw);
-        const uint32_t t2 = tap - td * a.dThw.d;
-        const uint32_t th = fdiv(t2, a.dTw);
-        const uint32_t tw = t2 - th * a.dTw.d;
-        const int32_t vox = (((int32_t)td * g.tap_step[0]) * g.Hi + (int32_t)th * g.tap_step[1]) * g.Wi + (int32_t)tw * g.tap_step[2];
-        const uint32_t koff = (uint32_t)vox * (uint32_t)(g.Cin * SZ) + c0 * SZ;
-        const uint32_t sel = tap < a.ntaps ? (1u << td) | (16u << th) | (256u << tw) : 0xffffffffu;  // padding taps match no row
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int j = 2 * h + jj;
-            const uint32_t voff = (vm[j] & sel) == sel ? rowoff[j] + koff : OOB_OFF;
-            if constexpr (!(DBG & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(pa + (wave * 4 + j) * 1024), 16, voff, 0, 0, 0);
-        }
-        if constexpr (!(DBG & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(pb + (wave * 2 + h) * 1024), 16, boff[h], s * 128u, 0, 0);
-    };
-
-    float4_t acc[NI][MI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < MI; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-
-    const uint32_t nk = (DBG & 128) ? 2u : a.nk;
-    issue_half(0, 0, 0);
-    issue_half(0, 0, 1);
-    if (nk > 1) {
-        issue_half(1, 1, 0);
-        issue_half(1, 1, 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();              // slab 0 landed for every wave
-    if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier behind group 0
-    const uint32_t frow = lane & 15u, fq = lane >> 4;
-    const uint32_t a_off = tile_off(wm * (MI * 16) + frow, fq), b_off = tile_off(wn * (NI * 16) + frow, fq);  // + j*2048 per fragment
-    uint32_t buf = 0;
-    for (uint32_t s = 0; s < nk; ++s) {
-        const unsigned char* pa = smem + buf * STAGE;
-        const unsigned char* pb = pa + BM * 128;
-        const uint32_t nbuf = buf >= 1 ? buf - 1 : 2;       // (s + 2) % 3
-        const bool more = s + 2 < nk;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            u32x4 xf[MI], wf[NI];
-            // (row & 7) is unchanged by + 16 j, and vec = ks*4 + fq only flips bit 2 of the swizzled vector index
-            if constexpr (!(DBG & 4)) {
-#pragma unroll
-                for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + ((b_off + i * 2048u) ^ (ks * 64u)));
-#pragma unroll
-                for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(pa + ((a_off + j * 2048u) ^ (ks * 64u)));
-            } else {
-#pragma unroll
-                for (int i = 0; i < NI; ++i) wf[i] = (u32x4){s, lane, s, lane};
-#pragma unroll
-                for (int j = 0; j < MI; ++j) xf[j] = (u32x4){lane, s, lane, s};
-            }
-            if constexpr (!(DBG & 32)) {
-                if (more) issue_half(s + 2, nbuf, ks);
-            }
-            if (ks == 1) {
-                if (more) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(DBG & 16)) __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-            if constexpr (!(DBG & 8)) {
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
-            } else {
-                acc[0][0][0] += __uint_as_float(wf[0][0] ^ xf[1][1] ^ wf[2][2] ^ xf[3][3] ^ wf[1][0] ^ xf[0][1] ^ wf[3][2] ^ xf[2][3]);
-            }
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(DBG & 16)) __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        buf = buf == 2 ? 0 : buf + 1;
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
-    __syncthreads();  // every wave is done reading the ring before the epilogue reuses it
-    if constexpr (DBG & 64) {
-        if (acc[0][0][0] == 123.f) *(float*)a.out = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];
-        return;
-    }
-    fprop_epilogue<BM, BN, WM, WN, MI, NI, 512>(a, acc, smem, tid, wm, wn, frow, fq, m_base, n_base);
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
 // Mainloop v5 "halo" (3x3x3, stride 1, `same` geometry; Cin * sizeof(T) a multiple of 128; Cout >= 65): the 27-tap im2col
 // re-read of the activations is what bounds v2 (the L2 -> LDS path, not the MFMA), so this loop stages every activation byte
 // ONCE per (kd, channel-chunk).  A tile is a 2-D patch of 8 (H) x 16 (W) output voxels of one depth plane; its halo image
@@ -969,10 +661,15 @@ __global__ __launch_bounds__(256) void conv_fprop_halo_kernel(const FpropArgs a)
     const uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
     const uint32_t n_base = bn * BN;
     const sa_conv_geom& g = a.g;
-    // patch -> (n, d, h0, w0)
-    const uint32_t wp = bm % a.WP, t1 = bm / a.WP;
-    const uint32_t hp = t1 % a.HP, t2 = t1 / a.HP;
-    const uint32_t pd = t2 % (uint32_t)g.Dm, pn = t2 / (uint32_t)g.Dm;
+    // patch -> (n, d, h0, w0).  Tile order = (n, band of 4 patch rows, d, row in band, wp): the ~64 tiles an XCD works on at once then
+    // span ~3 consecutive planes of ONE 32-row band (~3.6 MB of activations with their kd neighbours) instead of one whole plane
+    // (6.9 MB with its neighbours), so the kd = 0 / 2 re-reads of a plane hit that XCD's 4 MB L2 (measured +3-4 % on the forward).
+    const uint32_t per_vol = a.HP * a.WP * (uint32_t)g.Dm, band = 4u * a.WP * (uint32_t)g.Dm;
+    const uint32_t pn = bm / per_vol, rv = bm - pn * per_vol;
+    const uint32_t bc = rv / band, r2 = rv - bc * band;
+    const uint32_t rows_c = a.HP - 4u * bc < 4u ? a.HP - 4u * bc : 4u;
+    const uint32_t pd = r2 / (rows_c * a.WP), r3 = r2 - pd * rows_c * a.WP;
+    const uint32_t hpi = r3 / a.WP, wp = r3 - hpi * a.WP, hp = 4u * bc + hpi;
     const int32_t h0 = (int32_t)hp * 8, w0 = (int32_t)wp * PW;
     // halo origin and per-dimension tap direction: input = output + in_off + t * tap_step, t = 0..2
     const int32_t oh = g.in_off[1] + (g.tap_step[1] < 0 ? 2 * g.tap_step[1] : 0), ow = g.in_off[2] + (g.tap_step[2] < 0 ? 2 * g.tap_step[2] : 0);
@@ -1130,69 +827,6 @@ static int launch_fprop(const FpropArgs& a, hipStream_t st) {
     return 0;
 }
 
-template <typename T>
-static int launch_fprop3(FpropArgs a, hipStream_t st) {
-    a.nblk_m = (a.M + 255) / 256;
-    const uint32_t nbn_valid = ((uint32_t)a.g.cout_valid + 127) / 128;
-    const size_t ring = 3 * (256 + 128) * 128, epi = (size_t)256 * (128 + 4) * 4 + 256 * 8;
-    const size_t lds = ring > epi ? ring : epi;
-    const bool uniform = ((size_t)a.g.Cin * sizeof(T)) % 128 == 0;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)conv_fprop_dma3_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)conv_fprop_dma3_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    dim3 grid(a.nblk_m * nbn_valid);
-    snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma3_kernel<%s, %s>", tname<T>(), uniform ? "true" : "false");
-    if (uniform) hipLaunchKernelGGL((conv_fprop_dma3_kernel<T, true>), grid, dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((conv_fprop_dma3_kernel<T, false>), grid, dim3(512), lds, st, a);
-    SA_CHECK_LAUNCH();
-    return 0;
-}
-
-template <typename T, int DBG>
-static int launch_fprop_pp_dbg(const FpropArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)conv_fprop_pp_kernel<T, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_pp_kernel<%s, %d>", tname<T>(), DBG);
-    hipLaunchKernelGGL((conv_fprop_pp_kernel<T, DBG>), grid, dim3(512), lds, st, a);
-    SA_CHECK_LAUNCH();
-    return 0;
-}
-
-template <typename T>
-static int launch_fprop_pp(FpropArgs a, hipStream_t st) {
-    a.nblk_m = (a.M + 255) / 256;
-    const uint32_t nbn_valid = ((uint32_t)a.g.cout_valid + 127) / 128;
-    const size_t ring = 3 * (256 + 128) * 128, epi = (size_t)256 * (128 + 4) * 4 + 256 * 8;
-    const size_t lds = ring > epi ? ring : epi;
-    const dim3 grid(a.nblk_m * nbn_valid);
-#ifdef SA_PP_DEBUG_VARIANTS
-    if constexpr (sizeof(T) == 2) {
-        switch (a.dbg) {
-            case 3: return launch_fprop_pp_dbg<T, 3>(a, grid, lds, st);
-            case 7: return launch_fprop_pp_dbg<T, 7>(a, grid, lds, st);
-            case 15: return launch_fprop_pp_dbg<T, 15>(a, grid, lds, st);
-            case 31: return launch_fprop_pp_dbg<T, 31>(a, grid, lds, st);
-            case 47: return launch_fprop_pp_dbg<T, 47>(a, grid, lds, st);
-            case 63: return launch_fprop_pp_dbg<T, 63>(a, grid, lds, st);
-            case 79: return launch_fprop_pp_dbg<T, 79>(a, grid, lds, st);
-            case 143: return launch_fprop_pp_dbg<T, 143>(a, grid, lds, st);
-            case 207: return launch_fprop_pp_dbg<T, 207>(a, grid, lds, st);
-            case 64: return launch_fprop_pp_dbg<T, 64>(a, grid, lds, st);
-            case 8: return launch_fprop_pp_dbg<T, 8>(a, grid, lds, st);
-            case 11: return launch_fprop_pp_dbg<T, 11>(a, grid, lds, st);
-            default: break;
-        }
-    }
-#endif
-    return launch_fprop_pp_dbg<T, 0>(a, grid, lds, st);
-}
-
 // the halo mainloop applies to 3x3x3 / stride 1 / `same` geometry (forward, and the data gradient with the taps reversed)
 static bool halo_eligible(const FpropArgs& a, int sz) {
     const sa_conv_geom& g = a.g;
@@ -1232,12 +866,8 @@ template <typename T>
 static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
     const int cv = a.g.cout_valid;
     if (halo_eligible(a, (int)sizeof(T))) return launch_fprop_halo<T, false>(a, st);
-    static const bool no_pp = getenv("SA_PP") == nullptr;  // v4 measured 7% slower than v2 on the 3x3x3 C=128 layer: opt-in only
-    if (cv > 64 && a.in_bytes != 0 && a.M >= 256 * 256 && !no_pp && ((size_t)a.g.Cin * sizeof(T)) % 128 == 0) return launch_fprop_pp<T>(a, st);
-    // v3 (3-stage ring, 8 waves) measured equal to v2 (2 stages, 4 waves, 2 blocks/CU) on MI355X: 741/844 vs 763/849 TFLOP/s on
-    // the 3x3x3 C=128 layer -- the DMA latency is not what bounds this loop -- so v2 stays the default (SA_DMA3=1 selects v3).
-    static const bool use3 = getenv("SA_DMA3") != nullptr;
-    if (cv > 64 && a.in_bytes != 0 && a.M >= 256 * 256 && use3) return launch_fprop3<T>(a, st);
+    // (measured and removed: a 3-stage ring with 8 waves and counted vmcnt = the 2-stage loop; an 8-wave ping-pong with staggered
+    // barriers and s_setprio = -7 %: the L2 -> LDS operand stream bounds this loop, not the barrier structure.  DESIGN.md section 4.1)
     if (cv > 64) return launch_fprop<T, 2, 2, 4, 4>(a, st);
     if (cv > 32) return launch_fprop<T, 4, 1, 2, 4>(a, st);
     if (cv > 16) return launch_fprop<T, 4, 1, 2, 2>(a, st);
