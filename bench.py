@@ -63,8 +63,9 @@ PERF = dict(vocab=2048, spatial=(10, 14, 10), dim=512, depth=24, heads=16, local
 PERFORMER_STEP_MFLOP_PER_TOKEN = 618.7
 
 
-def bench_performer(args, rank, world, dev):
-    """Secondary metric: Performer training-step tokens/s (README.md:126-141 configuration, raster-ordered 10x14x10 latents)."""
+def bench_performer(args, rank, world, dev, shape=None, batch=None):
+    """Secondary metric: Performer training-step tokens/s (README.md:126-141 configuration, raster-ordered 10x14x10 latents; `shape` /
+    `batch` override the latent grid and the sequences per GPU: 20x28x25 = BASELINE.json's "~14k-token" variant)."""
     import numpy as np
 
     from synthanatomy_amd.losses.transformer import CELoss
@@ -74,9 +75,9 @@ def bench_performer(args, rank, world, dev):
     from synthanatomy_amd.runtime.optim import FlatParams, FusedAdam
 
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    spatial = tuple(int(v) for v in args.performer_shape.split(","))
+    spatial = tuple(shape) if shape is not None else tuple(int(v) for v in args.performer_shape.split(","))
     N = int(np.prod(spatial))
-    B = args.performer_batch
+    B = batch if batch is not None else args.performer_batch
     torch.manual_seed(4)
     order = Ordering("raster_scan", 3, (1,) + spatial, (False, False, False), ((2, 0, 1),), ((0, 1),), ("rotate_90", "transpose"))
     net = Performer(num_tokens=PERF["vocab"] + 1, max_seq_len=N, dim=PERF["dim"], depth=PERF["depth"], heads=PERF["heads"], ordering=order,
@@ -261,14 +262,42 @@ def main():
             line["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-    secondary = None
+    # "report also inference (index_quantize + decode_samples) volumes/s"
+    net.eval()
+    with torch.no_grad():
+        for _ in range(max(1, args.warmup)):
+            rec = net.decode_samples(net.index_quantize(x))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            rec = net.decode_samples(net.index_quantize(x))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dti = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([dti], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dti = float(t.item())
+    if rank == 0:
+        line["inference"] = {"metric": "vqvae_extract_decode_volumes_per_sec", "value": round(args.batch * world * args.steps / dti, 3), "unit": "volumes/s",
+                             "ms_per_step": round(dti / args.steps * 1e3, 3), "workload": "index_quantize + decode_samples (eval), same volumes"}
+    del rec
+    secondary = secondary_14k = None
     if not args.no_performer:
         del net, flat, opt, reducer, x
         torch.cuda.empty_cache()
         secondary = bench_performer(args, rank, world, dev)
+        torch.cuda.empty_cache()
+        if args.performer_shape == "10,14,10":   # BASELINE.json configs[3] says "~14k-token" latents: also the 20x28x25 grid, one sequence per GPU
+            secondary_14k = bench_performer(args, rank, world, dev, shape=(20, 28, 25), batch=1)
     if rank == 0:
         if secondary is not None:
             line["secondary"] = secondary
+        if secondary_14k is not None:
+            line["secondary_14k"] = secondary_14k
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,0 +1,84 @@
+"""GPU, BASELINE.json's full sizes: the config-2 network on 160x224x160 volumes, checked through size-independent properties
+(the oracle cannot finish these sizes in seconds): batch independence, re-quantisation idempotence, and agreement between the
+two independent kernel families (halo mainloops vs the im2col-order kernels) on every tile of the real geometry."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NET = dict(n_levels=4, downsample_parameters=((4, 2, 1, 1),) * 4, upsample_parameters=((4, 2, 1, 0, 1),) * 4, n_embed=2048, embed_dim=32, n_channels=256,
+           n_res_channels=256, n_res_layers=3)
+VOL = (160, 224, 160)
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def net():
+    from synthanatomy_amd.networks.vqvae.baseline import BaselineVQVAE
+    torch.manual_seed(4)
+    return BaselineVQVAE(**NET, compute_dtype=torch.bfloat16).cuda()
+
+
+def _grads(net, x):
+    for p in net.parameters():
+        p.grad = None
+    net.train()
+    ema = [b.clone() for b in net.quantizer[0].impl.buffers()]
+    cb = net.quantizer[0].impl.weight.detach().clone()
+    out = net(x)
+    loss = torch.nn.functional.mse_loss(out["reconstruction"][0].float(), x) + out["quantization_losses"][0]
+    loss.backward()
+    net.quantizer[0].impl.wait_ema()
+    torch.cuda.synchronize()
+    # undo the EMA side effect so that both runs start from the same codebook
+    with torch.no_grad():
+        for b, old in zip(net.quantizer[0].impl.buffers(), ema):
+            b.copy_(old)
+        net.quantizer[0].impl.weight.copy_(cb)
+    return float(loss.detach()), {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+
+
+def test_full_size_eval_properties(net):
+    net.eval()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x1 = torch.rand(1, 1, *VOL, generator=g, device="cuda")
+    x = torch.cat([x1, x1.flip(2)], 0)                      # two different volumes
+    with torch.no_grad():
+        rec = net(x)["reconstruction"][0]
+        idx = net.index_quantize(x)[0]
+        rec0 = net(x[:1])["reconstruction"][0]
+        idx1 = net.index_quantize(x[1:])[0]
+        # a codebook vector is its own nearest code: quantising the embedded indices gives the indices back (bit-exact)
+        zq = net.quantizer[0].embed(idx)
+        _, _, idx_again = net.quantizer[0].quantize(zq)
+        dec = net.decode_samples([idx])
+    assert rec.shape == x.shape and idx.shape == (2, 10, 14, 10) and idx.dtype == torch.int64
+    assert torch.isfinite(rec).all()
+    assert torch.equal(rec[:1], rec0) and torch.equal(idx[1:], idx1)          # samples do not interact, tiles are batch-agnostic
+    assert torch.equal(idx_again, idx)
+    assert torch.equal(dec, rec)                                               # decode_samples(index_quantize(x)) is the eval forward
+    assert 0 <= int(idx.min()) and int(idx.max()) < 2048
+
+
+def test_full_size_halo_kernels_agree_with_im2col_order_kernels(net):
+    """Forward, data gradients and weight gradients of the whole network, halo mainloops vs SA_NO_HALO=1 (bf16 both: the two families sum
+    the same products in a different order)."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(1, 1, *VOL, generator=g, device="cuda")
+    loss_h, gr_h = _grads(net, x)
+    os.environ["SA_NO_HALO"] = "1"
+    try:
+        loss_r, gr_r = _grads(net, x)
+    finally:
+        del os.environ["SA_NO_HALO"]
+    assert np.isfinite(loss_h) and abs(loss_h - loss_r) <= 2e-3 * abs(loss_r)
+    assert gr_h.keys() == gr_r.keys() and len(gr_h) >= 100
+    worst = max((_rel(gr_h[n], gr_r[n]), n) for n in gr_h)
+    assert worst[0] < 3e-2, worst
