@@ -122,12 +122,32 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dtm = float(t.item())
     toks = B * N * world * args.steps / dtm
+    sampling = None
+    if args.sampling and shape is None:
+        # "also report sampling tokens/s (B10)": autoregressive sample() of full N-token sequences, stateful O(N) path
+        net.eval()
+        prefix = torch.full((B, 1), PERF["vocab"], dtype=torch.long, device=dev)
+        with torch.no_grad():
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            out = net.sample(prefix, sample=True, top_k=None, temperature=1.0)
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dts], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts = float(t.item())
+        sampling = {"metric": "performer_sampling_tokens_per_sec", "value": round(B * N * world / dts, 1), "unit": "tokens/s", "seconds": round(dts, 3),
+                    "workload": f"sample() of {B} sequences x {N} tokens per GPU, stateful O(N) decoding (HIP graph per token), graph capture included"}
+        assert tuple(out.shape) == (B, *spatial)
     res = {"metric": "performer_train_tokens_per_sec", "value": round(toks, 1), "unit": "tokens/s", "ms_per_step": round(dtm / args.steps * 1e3, 3),
            "dtype": args.dtype, "scaling": "weak", "final_loss": round(float(loss.item()), 5),
            "tflops_per_gpu": round(toks / world * PERFORMER_STEP_MFLOP_PER_TOKEN / 1e6, 2),
            "config": {"workload": f"performer n_embd=512 n_layers=24 n_head=16 local_attn_heads=8 local_window=420 vocab=2048, N={N} raster-ordered "
                                   f"{'x'.join(map(str, spatial))} latents, training step = fwd + CE + bwd + Adam, projections redrawn every other step", "batch_per_gpu": B,
                       "global_batch": B * world, "seq_len": N, "parallelism": f"dp{world}"}}
+    if sampling is not None:
+        res["sampling"] = sampling
     del net, flat, opt, reducer
     torch.cuda.empty_cache()
     return res
@@ -158,6 +178,7 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--performer-batch", type=int, default=6, help="sequences per GPU per step (README.md:119)")
     ap.add_argument("--no-performer", action="store_true", help="skip the secondary Performer tokens/s measurement")
+    ap.add_argument("--no-sampling", dest="sampling", action="store_false", help="skip the autoregressive sampling tokens/s measurement")
     ap.add_argument("--only-performer", action="store_true", help="dev/profiling: measure only the Performer workload")
     ap.add_argument("--performer-shape", default="10,14,10", help="latent grid of the Performer workload (20,28,25 = the 14 000-token variant)")
     args = ap.parse_args()

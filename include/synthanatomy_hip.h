@@ -132,6 +132,25 @@ int sa_adam(float *p, const float *g, float *m, float *v, int64_t n, float lr, f
 int sa_embed_sum(int ntab, const float *const *tables, const int64_t *const *idx, const int32_t *per_position, int dim, int N,
                  int64_t R, float *out, void *stream);
 int sa_embed_scatter(const float *dy, float *dtable, const int64_t *idx, int per_position, int dim, int N, int64_t R, void *stream);
+
+/* ---- stateful O(N) decoding (replaces the O(N^2) loop of TransformerBase.sample, src/networks/transformers/transformer.py:58-101, which
+ * runs a full forward over the growing prefix per token).  One new position per call; `pos` is a DEVICE int (the index of the position
+ * being produced) so that a whole per-token step can be captured in a HIP graph and replayed.  Equal to the O(N^2) loop up to fp32
+ * rounding: the FAVOR+ key stabiliser is the running maximum of the prefix (the keys' global max of performer-pytorch 1.0.11) and the
+ * state keeps the exp part and the +eps part of phi(k) apart, so it can be rescaled when that maximum grows.
+ * sa_embed_step : out[b,:] = sum_t table_t[per_position_t ? idx_t[*pos] : idx_t[b], :]   (idx < 0 skips)
+ * sa_favor_step : global heads.  ddq / ddk [B*G, LDF] = projections of q_t / k_t (data normaliser folded in); state smax[1] (init -inf),
+ *                 E [B*G, LDF, dh], Ez [B*G, LDF], V1 [B*G, dh] (init 0); s2[2] scratch; writes the attention rows of position *pos.
+ * sa_local_attn_step : local heads.  Rotates q_t / k_t with row *pos of the rotary tables, appends (k_t, v_t) to the caches
+ *                 [B, L, N, dh] and attends over the previous and the current window up to *pos (look_backward = 1, causal). */
+int sa_embed_step(int ntab, const float *const *tables, const int64_t *const *idx, const int32_t *per_position, int dim, const int *pos, int B,
+                  float *out, void *stream);
+int sa_favor_step(const float *ddq, const float *ddk, const float *q, int q_stride, int q_off, const float *k, int k_stride, int k_off,
+                  const float *v, int v_stride, int v_off, int B, int G, int dh, int m, int LDF, float *smax, float *s2, float *E, float *Ez,
+                  float *V1, const int *pos, float *out, int out_stride, int out_off, void *stream);
+int sa_local_attn_step(const float *q, int q_stride, int q_off, const float *k, int k_stride, int k_off, const float *v, int v_stride, int v_off,
+                       const float *cosb, const float *sinb, float *kcache, float *vcache, const int *pos, int B, int N, int L, int W, int dh,
+                       float *out, int out_stride, int out_off, void *stream);
 /* nn.LayerNorm (performer.py:220,273); stats[2r] = mean, stats[2r+1] = rstd; y_lp optional copy in lp_dtype */
 int sa_layernorm_fwd(const float *x, const float *w, const float *b, float *y, void *y_lp, int lp_dtype, float *stats, int64_t R, int C,
                      float eps, void *stream);

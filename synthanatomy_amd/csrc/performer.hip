@@ -753,6 +753,194 @@ __global__ void rotary_kernel(const float* __restrict__ x, int stride, int off, 
     }
 }
 
+// ================================================================================================ stateful (O(N)) decoding, section 8(f) N3
+// One new position per call; `pos` is a DEVICE integer (index of the position being produced) so the whole per-token step can be
+// captured once in a HIP graph and replayed.  The results equal the reference's O(N^2) loop (a full forward over the growing prefix,
+// transformer.py:58-101) up to fp32 rounding: the FAVOR+ key stabiliser is the running maximum of the prefix -- the keys' global max of
+// performer-pytorch 1.0.11 -- and the state keeps the exp part and the +eps part of phi(k) apart so that it can be rescaled when that
+// maximum grows:  phi(k_j) = ratio * (exp(a_j - diag_j - s) + eps)  =>  sum_j phi(k_j) v_j = ratio * (E + eps * 1 (x) V1),
+//   E = sum_j exp(a_j - diag_j - s) (x) v_j,  Ez = sum_j exp(a_j - diag_j - s),  V1 = sum_j v_j,  and s -> s' multiplies E, Ez by exp(s - s').
+__global__ void embed_step_kernel(const EmbedArgs a, const int* __restrict__ pos, int B, float* __restrict__ out) {
+    const int p = *pos;
+    const int64_t total = (int64_t)B * a.dim;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(e / a.dim), c = (int)(e % a.dim);
+        float acc = 0.f;
+        for (int t = 0; t < a.ntab; ++t) {
+            const int64_t ix = a.idx[t][a.per_position[t] ? p : b];
+            if (ix >= 0) acc += a.table[t][ix * a.dim + c];
+        }
+        out[e] = acc;
+    }
+}
+
+// s2[0] = previous running key maximum, s2[1] = max(previous, max of this position's key projections); smax <- s2[1]
+__global__ __launch_bounds__(256) void favor_step_max_kernel(const float* __restrict__ ddk, int rows, int m, int LDF, float* __restrict__ smax, float* __restrict__ s2) {
+    __shared__ float red[4];
+    float v = -INFINITY;
+    for (int e = threadIdx.x; e < rows * m; e += 256) v = fmaxf(v, ddk[(e / m) * LDF + e % m]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float old = *smax, nw = fmaxf(old, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        s2[0] = old;
+        s2[1] = nw;
+        *smax = nw;
+    }
+}
+
+struct FavorStepArgs {
+    const float *ddq, *ddk;            // [B*G, LDF] projections (data_normalizer folded into the projection matrix)
+    const float *q, *k, *v;            // rows of the fused qkv output
+    int q_stride, q_off, k_stride, k_off, v_stride, v_off;
+    int G, dh, m, LDF;
+    const float* s2;
+    float *E, *Ez, *V1;                // state [B*G, LDF, dh], [B*G, LDF], [B*G, dh]
+    const int* pos;
+    float* out;                        // attention output rows
+    int out_stride, out_off;
+    float eps_feat, eps_den;
+};
+
+__global__ __launch_bounds__(256) void favor_step_kernel(const FavorStepArgs a) {
+    __shared__ float sq[64], sk[64], sv[64], sqf[320], sek[320], red[8], snum[4][64];
+    const int bg = blockIdx.x, b = bg / a.G, g = bg % a.G, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int dh = a.dh, m = a.m;
+    if (tid < dh) {
+        sq[tid] = a.q[(int64_t)b * a.q_stride + a.q_off + g * dh + tid];
+        sk[tid] = a.k[(int64_t)b * a.k_stride + a.k_off + g * dh + tid];
+        sv[tid] = a.v[(int64_t)b * a.v_stride + a.v_off + g * dh + tid];
+    }
+    __syncthreads();
+    const float ratio = rsqrtf((float)m), nrm = rsqrtf((float)dh) * 0.5f;   // diag = |x|^2 / 2 * dh^-1/2
+    float dq = 0.f, dk = 0.f;
+    for (int d = 0; d < dh; ++d) {
+        dq = fmaf(sq[d], sq[d], dq);
+        dk = fmaf(sk[d], sk[d], dk);
+    }
+    dq *= nrm;
+    dk *= nrm;
+    // query stabiliser: row maximum of its own projections
+    float qm = -INFINITY;
+    for (int e = tid; e < m; e += 256) qm = fmaxf(qm, a.ddq[(int64_t)bg * a.LDF + e]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qm = fmaxf(qm, __shfl_xor(qm, o, 64));
+    if (lane == 0) red[wv] = qm;
+    __syncthreads();
+    qm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float s_old = a.s2[0], s_new = a.s2[1];
+    const float scale = s_old == -INFINITY ? 0.f : __expf(s_old - s_new);
+    const int cnt = *a.pos + 1;   // keys seen including this one
+    for (int e = tid; e < m; e += 256) {
+        sqf[e] = ratio * (__expf(a.ddq[(int64_t)bg * a.LDF + e] - dq - qm) + a.eps_feat);
+        sek[e] = __expf(a.ddk[(int64_t)bg * a.LDF + e] - dk - s_new);
+    }
+    __syncthreads();
+    // state update + numerator: thread = (feature slice wv, value dim lane)
+    float* E = a.E + (int64_t)bg * a.LDF * dh;
+    float num = 0.f;
+    for (int e = wv; e < m; e += 4) {
+        const float x = fmaf(E[e * dh + lane], scale, sek[e] * sv[lane]);
+        E[e * dh + lane] = x;
+        num = fmaf(sqf[e], x, num);
+    }
+    snum[wv][lane] = num;
+    // denominator: sum_m q'[m] * (ratio * (Ez[m] + eps * cnt) + eps_den)
+    float den = 0.f, qsum = 0.f;
+    for (int e = tid; e < m; e += 256) {
+        const float z = fmaf(a.Ez[(int64_t)bg * a.LDF + e], scale, sek[e]);
+        a.Ez[(int64_t)bg * a.LDF + e] = z;
+        den = fmaf(sqf[e], ratio * (z + a.eps_feat * (float)cnt) + a.eps_den, den);
+        qsum += sqf[e];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        den += __shfl_xor(den, o, 64);
+        qsum += __shfl_xor(qsum, o, 64);
+    }
+    if (lane == 0) {
+        red[wv] = den;
+        red[4 + wv] = qsum;
+    }
+    __syncthreads();
+    if (tid < dh) {
+        den = red[0] + red[1] + red[2] + red[3];
+        qsum = red[4] + red[5] + red[6] + red[7];
+        const float v1 = a.V1[(int64_t)bg * dh + tid] + sv[tid];
+        a.V1[(int64_t)bg * dh + tid] = v1;
+        const float n = ratio * (snum[0][tid] + snum[1][tid] + snum[2][tid] + snum[3][tid] + a.eps_feat * qsum * v1);
+        a.out[(int64_t)b * a.out_stride + a.out_off + g * dh + tid] = n / den;
+    }
+}
+
+struct LocalStepArgs {
+    const float *q, *k, *v;
+    int q_stride, q_off, k_stride, k_off, v_stride, v_off;
+    const float *cosb, *sinb;          // rotary tables [N, dh]
+    float *kc, *vc;                    // caches [B, L, N, dh] (rotated keys, values)
+    const int* pos;
+    int N, W, L, dh;
+    float* out;
+    int out_stride, out_off;
+};
+
+// one block per (batch, local head): rotate q_t / k_t, append (k_t, v_t) to the cache, softmax over the keys of the previous and the
+// current window up to t (local_attention with look_backward = 1, causal), output row t
+__global__ __launch_bounds__(256) void local_attn_step_kernel(const LocalStepArgs a) {
+    extern __shared__ float sc[];      // scores [2 W]
+    __shared__ float sq[64], red[4], sacc[4][64];
+    const int bl = blockIdx.x, b = bl / a.L, l = bl % a.L, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int dh = a.dh, half = dh / 2, t = *a.pos;
+    float* kc = a.kc + ((int64_t)bl * a.N) * dh;
+    float* vc = a.vc + ((int64_t)bl * a.N) * dh;
+    if (tid < dh) {
+        const float* qr = a.q + (int64_t)b * a.q_stride + a.q_off + l * dh;
+        const float* kr = a.k + (int64_t)b * a.k_stride + a.k_off + l * dh;
+        const float cs = a.cosb[t * dh + tid], sn = a.sinb[t * dh + tid];
+        const float qrot = tid < half ? -qr[tid + half] : qr[tid - half];
+        const float krot = tid < half ? -kr[tid + half] : kr[tid - half];
+        sq[tid] = (qr[tid] * cs + qrot * sn) * rsqrtf((float)dh);
+        kc[(int64_t)t * dh + tid] = kr[tid] * cs + krot * sn;
+        vc[(int64_t)t * dh + tid] = a.v[(int64_t)b * a.v_stride + a.v_off + l * dh + tid];
+    }
+    __syncthreads();   // (the block re-reads its own global writes below: same block, after the barrier)
+    __threadfence_block();
+    const int w = t / a.W, lo = (w > 0 ? w - 1 : 0) * a.W, nk = t - lo + 1;
+    float mx = -INFINITY;
+    for (int j = tid; j < nk; j += 256) {
+        const float* kj = kc + (int64_t)(lo + j) * dh;
+        float d = 0.f;
+        for (int e = 0; e < dh; ++e) d = fmaf(sq[e], kj[e], d);
+        sc[j] = d;
+        mx = fmaxf(mx, d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int j = tid; j < nk; j += 256) {
+        const float p = __expf(sc[j] - mx);
+        sc[j] = p;
+        sum += p;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) red[wv] = sum;
+    __syncthreads();
+    sum = red[0] + red[1] + red[2] + red[3];
+    float acc = 0.f;   // thread = (key slice wv, value dim lane)
+    for (int j = wv; j < nk; j += 4) acc = fmaf(sc[j], vc[(int64_t)(lo + j) * dh + lane], acc);
+    sacc[wv][lane] = acc;
+    __syncthreads();
+    if (tid < dh) a.out[(int64_t)b * a.out_stride + a.out_off + l * dh + tid] = (sacc[0][tid] + sacc[1][tid] + sacc[2][tid] + sacc[3][tid]) / sum;
+}
+
+
 // ------------------------------------------------------------------------------------------------ cross entropy (one wave per row)
 __global__ void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, int64_t R, int V, float* __restrict__ loss_sum,
                           void* dlogits, int d_dtype, float gscale) {
@@ -1008,6 +1196,58 @@ extern "C" int sa_cross_entropy(const float* logits, const int64_t* target, int6
                                 void* stream) {
     if (!logits || !target || !loss_sum || R <= 0 || V <= 0) return SA_EINVAL;
     hipLaunchKernelGGL(ce_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, ST(stream), logits, target, R, V, loss_sum, dlogits, d_dtype, gscale);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_embed_step(int ntab, const float* const* tables, const int64_t* const* idx, const int32_t* per_position, int dim, const int* pos, int B,
+                             float* out, void* stream) {
+    if (ntab < 1 || ntab > 6 || !tables || !idx || !per_position || !pos || !out || B <= 0) return SA_EINVAL;
+    EmbedArgs a;
+    a.ntab = ntab;
+    a.dim = dim;
+    a.N = 1;
+    a.R = B;
+    for (int t = 0; t < ntab; ++t) {
+        a.table[t] = tables[t];
+        a.idx[t] = idx[t];
+        a.per_position[t] = per_position[t];
+    }
+    hipLaunchKernelGGL(embed_step_kernel, dim3(grid1d((int64_t)B * dim)), dim3(256), 0, ST(stream), a, pos, B, out);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_favor_step(const float* ddq, const float* ddk, const float* q, int q_stride, int q_off, const float* k, int k_stride, int k_off,
+                             const float* v, int v_stride, int v_off, int B, int G, int dh, int m, int LDF, float* smax, float* s2, float* E, float* Ez,
+                             float* V1, const int* pos, float* out, int out_stride, int out_off, void* stream) {
+    if (!ddq || !ddk || !q || !k || !v || !smax || !s2 || !E || !Ez || !V1 || !pos || !out) return SA_EINVAL;
+    if (dh != 64 || m > 320 || B <= 0 || G <= 0) return SA_EUNSUPPORTED;
+    hipLaunchKernelGGL(favor_step_max_kernel, dim3(1), dim3(256), 0, ST(stream), ddk, B * G, m, LDF, smax, s2);
+    SA_CHECK_LAUNCH();
+    FavorStepArgs a;
+    a.ddq = ddq; a.ddk = ddk; a.q = q; a.k = k; a.v = v;
+    a.q_stride = q_stride; a.q_off = q_off; a.k_stride = k_stride; a.k_off = k_off; a.v_stride = v_stride; a.v_off = v_off;
+    a.G = G; a.dh = dh; a.m = m; a.LDF = LDF; a.s2 = s2; a.E = E; a.Ez = Ez; a.V1 = V1; a.pos = pos;
+    a.out = out; a.out_stride = out_stride; a.out_off = out_off;
+    a.eps_feat = 1e-4f;
+    a.eps_den = 1e-6f;
+    hipLaunchKernelGGL(favor_step_kernel, dim3(B * G), dim3(256), 0, ST(stream), a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_local_attn_step(const float* q, int q_stride, int q_off, const float* k, int k_stride, int k_off, const float* v, int v_stride, int v_off,
+                                  const float* cosb, const float* sinb, float* kcache, float* vcache, const int* pos, int B, int N, int L, int W, int dh,
+                                  float* out, int out_stride, int out_off, void* stream) {
+    if (!q || !k || !v || !cosb || !sinb || !kcache || !vcache || !pos || !out) return SA_EINVAL;
+    if (dh != 64 || W <= 0 || 2 * (size_t)W * 4 > 60 * 1024 || B <= 0 || L <= 0) return SA_EUNSUPPORTED;
+    LocalStepArgs a;
+    a.q = q; a.k = k; a.v = v;
+    a.q_stride = q_stride; a.q_off = q_off; a.k_stride = k_stride; a.k_off = k_off; a.v_stride = v_stride; a.v_off = v_off;
+    a.cosb = cosb; a.sinb = sinb; a.kc = kcache; a.vc = vcache; a.pos = pos; a.N = N; a.W = W; a.L = L; a.dh = dh;
+    a.out = out; a.out_stride = out_stride; a.out_off = out_off;
+    hipLaunchKernelGGL(local_attn_step_kernel, dim3(B * L), dim3(256), 2 * (size_t)W * sizeof(float), ST(stream), a);
     SA_CHECK_LAUNCH();
     return 0;
 }

@@ -400,6 +400,69 @@ class _LayerEngine:
             tape.append(sv)
         return x2
 
+    # ---------------------------------------------------------------------------------------------- stateful decoding (one position)
+    def new_state(self, B, N, dev):
+        """Per-layer decoding state: FAVOR+ running sums of the global heads (rescalable, see csrc/performer.hip) and the rotated-key /
+        value caches of the local heads."""
+        G, L, dh, LDF = self.G, self.L, self.dh, self.LDF
+        f32 = torch.float32
+        return dict(smax=torch.full((1,), float("-inf"), dtype=f32, device=dev), s2=torch.zeros(2, dtype=f32, device=dev),
+                    E=torch.zeros(max(B * G, 1), LDF * dh, dtype=f32, device=dev), Ez=torch.zeros(max(B * G, 1), LDF, dtype=f32, device=dev),
+                    V1=torch.zeros(max(B * G, 1), dh, dtype=f32, device=dev), kc=torch.zeros(B, max(L, 1), N, dh, dtype=f32, device=dev),
+                    vc=torch.zeros(B, max(L, 1), N, dh, dtype=f32, device=dev))
+
+    @staticmethod
+    def reset_state(stt):
+        for k, v in stt.items():
+            if k == "smax":
+                v.fill_(float("-inf"))
+            else:
+                v.zero_()
+
+    def step(self, x, B, N, pos, stt):
+        """x [B, dim] fp32 = the block input at position *pos (device int32) -> block output; updates `stt`.  No host synchronisation
+        and no host-side dependence on the position, so a whole token step can be captured in a HIP graph."""
+        self._sync()
+        lib, st, dev, T = _ffi.lib(), _ffi.stream(), x.device, self.dtype
+        H, G, L, dh, m, LDF = self.H, self.G, self.L, self.dh, self.m, self.LDF
+        inner = H * dh
+        f32 = torch.float32
+        xa, _ = self._pre(self.aw, x, B)
+        xaT = _cast(xa, T)
+        q = self.ops["to_q"].fprop(_as5(xaT), out_dtype=f32).view(B, inner)
+        k = self.ops["to_k"].fprop(_as5(xaT), out_dtype=f32).view(B, inner)
+        v = self.ops["to_v"].fprop(_as5(xaT), out_dtype=f32).view(B, inner)
+        attn = torch.empty(B, inner, dtype=f32, device=dev)
+        if G > 0:
+            pop = self._proj_op()
+            qg = q[:, : G * dh].contiguous()
+            kg = k[:, : G * dh].contiguous()
+            ddq = pop.fprop(qg.view(1, 1, 1, B * G, dh), out_channels_stride=LDF, use_bias=False).view(B * G, LDF)
+            ddk = pop.fprop(kg.view(1, 1, 1, B * G, dh), out_channels_stride=LDF, use_bias=False).view(B * G, LDF)
+            _ck(lib.sa_favor_step(_ffi.ptr(ddq), _ffi.ptr(ddk), _ffi.ptr(q), inner, 0, _ffi.ptr(k), inner, 0, _ffi.ptr(v), inner, 0, B, G, dh, m, LDF,
+                                  _ffi.ptr(stt["smax"]), _ffi.ptr(stt["s2"]), _ffi.ptr(stt["E"]), _ffi.ptr(stt["Ez"]), _ffi.ptr(stt["V1"]), _ffi.ptr(pos),
+                                  _ffi.ptr(attn), inner, 0, st), "sa_favor_step")
+        if L > 0:
+            cosb, sinb = self._rot_tables(N, dev)
+            _ck(lib.sa_local_attn_step(_ffi.ptr(q), inner, G * dh, _ffi.ptr(k), inner, G * dh, _ffi.ptr(v), inner, G * dh, _ffi.ptr(cosb), _ffi.ptr(sinb),
+                                       _ffi.ptr(stt["kc"]), _ffi.ptr(stt["vc"]), _ffi.ptr(pos), B, N, L, self.W, dh, _ffi.ptr(attn), inner, G * dh, st),
+                "sa_local_attn_step")
+        attnT = _cast(attn, T)
+        Fa = self.ops["to_out"].fprop(_as5(attnT)).view(B, self.dim)
+        x1 = torch.empty_like(x)
+        ga = self._gate(self.aw, dev)
+        _ck(lib.sa_rezero_fwd(_ffi.ptr(x), _ffi.ptr(Fa), _ffi.dtype_id(Fa.dtype), _ffi.ptr(ga), _ffi.ptr(x1), None, 0, x.numel(), st), "sa_rezero_fwd")
+        xf, _ = self._pre(self.fw, x1, B)
+        xfT = _cast(xf, T)
+        u = self.ops["w1"].fprop(_as5(xfT)).view(B, -1)
+        h = torch.empty_like(u)
+        _ck(lib.sa_gelu(_ffi.ptr(u), _ffi.dtype_id(u.dtype), _ffi.ptr(h), _ffi.dtype_id(h.dtype), u.numel(), st), "sa_gelu")
+        Ff = self.ops["w2"].fprop(_as5(h)).view(B, self.dim)
+        x2 = torch.empty_like(x)
+        gf = self._gate(self.fw, dev)
+        _ck(lib.sa_rezero_fwd(_ffi.ptr(x1), _ffi.ptr(Ff), _ffi.dtype_id(Ff.dtype), _ffi.ptr(gf), _ffi.ptr(x2), None, 0, x.numel(), st), "sa_rezero_fwd")
+        return x2
+
     # ---------------------------------------------------------------------------------------------- backward
     def _post_bwd(self, wrap, dy, Fout, gc, dev):
         """through y = x + g * F: returns dF (compute dtype) and accumulates dg"""
@@ -727,6 +790,101 @@ class Performer(TransformerBase):
     def invalidate_packed_weights(self):
         self._chain.invalidate()
         self._out_op.invalidate()
+
+    # ------------------------------------------------------------------------------------------------ sampling
+    @torch.no_grad()
+    def sample(self, prefix: torch.Tensor, conditioning: torch.Tensor = None, temperature: float = 1.0, sample: bool = True, top_k: Optional[int] = None,
+               stateful: Optional[bool] = None, use_graph: bool = True) -> torch.Tensor:
+        """TransformerBase.sample (transformer.py:58-101).  ``stateful=False`` is the reference-faithful O(N^2) loop (a full forward over the
+        growing prefix per token); ``stateful=True`` (default without conditioning) carries the FAVOR+ running sums and the local-attention
+        key/value caches from token to token -- O(N), same logits up to fp32 rounding -- and replays one captured
+        HIP graph per token."""
+        if stateful is None:
+            stateful = conditioning is None
+        if not stateful:
+            return super().sample(prefix, conditioning=conditioning, temperature=temperature, sample=sample, top_k=top_k)
+        assert conditioning is None, "stateful sampling does not take conditionings (use stateful=False)"
+        return self._sample_stateful(prefix, temperature, sample, top_k, use_graph)
+
+    def _sample_stateful(self, prefix, temperature, sample, top_k, use_graph):
+        from .transformer import _top_k_logits
+        _ffi.require_gpu()
+        self.eval()
+        dev = self.token_emb.weight.device
+        lib = _ffi.lib()
+        B, P = prefix.shape
+        steps = int(np.prod(self.ordering.dimensions))
+        total = P + steps                      # tokens in the final sequence; positions 0 .. total-2 are fed through the network
+        npos = total - 1
+        assert npos <= self.max_seq_len, f"sequence length {npos} must be less than the max sequence length {self.max_seq_len}"
+        seq = torch.zeros(B, total, dtype=torch.int64, device=dev)
+        seq[:, :P] = prefix.to(dev).long()
+        seq0 = seq.clone()
+        pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        tok = torch.zeros(B, dtype=torch.int64, device=dev)
+        pidx, sp = self._position_indices(npos, dev)
+        tables = [self.token_emb.weight] + [m.emb.weight for m in self.spatial_position_emb] + [self.pos_emb.emb.weight]
+        idx = [tok] + sp + [pidx]
+        per_pos = [0] + [1] * len(sp) + [1]
+        n = len(tables)
+        tp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tables])
+        ip = (ctypes.c_void_p * n)(*[i.data_ptr() for i in idx])
+        pp = (ctypes.c_int32 * n)(*per_pos)
+        dim = tables[0].shape[1]
+        layers = self._chain.layers
+        states = [l.new_state(B, npos, dev) for l in layers]
+        col = torch.arange(total, device=dev)[None, :]
+
+        def one_step():
+            p64 = pos.to(torch.int64)
+            tok.copy_(seq.gather(1, p64.expand(B, 1)).squeeze(1))
+            x = torch.empty(B, dim, dtype=torch.float32, device=dev)
+            _ck(lib.sa_embed_step(n, tp, ip, pp, dim, _ffi.ptr(pos), B, _ffi.ptr(x), _ffi.stream()), "sa_embed_step")
+            for l, stt in zip(layers, states):
+                x = l.step(x, B, npos, pos, stt)
+            h = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
+            logits = _LinearFn.apply(self._out_op, h, self.to_out.weight, self.to_out.bias).float() / temperature
+            if top_k is not None:
+                logits = _top_k_logits(logits, top_k)
+            probs = torch.softmax(logits, dim=-1)
+            ix = torch.multinomial(probs, num_samples=1) if sample else torch.topk(probs, k=1, dim=-1)[1]
+            # position pos+1 receives the sampled token unless it still belongs to the given prefix
+            write = (col == (p64 + 1)) & (col >= P)
+            seq.copy_(torch.where(write, ix.expand(B, total), seq))
+            pos.add_(1)
+
+        graph = None
+        if use_graph:
+            try:
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):      # warm-up off the capture: packs weights, sizes the caches, sets kernel attributes
+                    one_step()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                for l, stt in zip(layers, states):
+                    l.reset_state(stt)
+                pos.zero_()
+                seq.copy_(seq0)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    one_step()
+            except Exception:                      # capture is an optimisation: fall back to eager launches of the same O(N) step
+                graph = None
+                torch.cuda.synchronize()
+                for l, stt in zip(layers, states):
+                    l.reset_state(stt)
+                pos.zero_()
+                seq.copy_(seq0)
+        for _ in range(npos):
+            if graph is not None:
+                graph.replay()
+            else:
+                one_step()
+        x = seq[:, P:]
+        x = x[:, self.ordering.get_revert_sequence_ordering()]
+        x = x.reshape(x.shape[0], *self.ordering.dimensions)
+        return torch.squeeze(x, 1)
 
     # ------------------------------------------------------------------------------------------------
     def _position_indices(self, n, dev):

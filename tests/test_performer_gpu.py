@@ -198,7 +198,7 @@ def test_sample_post_processing_and_greedy_path():
     net.load_state_dict({k: v.clone() for k, v in st.items()}, strict=False)
     net = net.cuda()
     prefix = torch.full((2, 1), 16, dtype=torch.long, device="cuda")
-    got = net.sample(prefix, sample=False)
+    got = net.sample(prefix, sample=False, stateful=False)
     assert got.shape == (2, *shape) and int(got.min()) >= 0 and int(got.max()) <= 16
     # oracle replay of the same greedy chain
     seqs = P.spatial_index_sequences(shape, o.get_sequence_ordering())
@@ -208,6 +208,44 @@ def test_sample_post_processing_and_greedy_path():
         x = torch.cat((x, nxt), 1)
     ref = x[:, 1:][:, o.get_revert_sequence_ordering()].reshape(2, *shape)
     assert torch.equal(got.cpu(), ref)
+
+
+@pytest.mark.parametrize("rezero,shape,window,local,use_graph", [(True, (2, 3, 4), 5, 1, True), (False, (3, 2, 5), 7, 2, False), (True, (2, 2, 6), 64, 0, True),
+                                                                 (True, (2, 3, 5), 4, 3, False)])
+def test_stateful_sampler_equals_the_quadratic_loop(rezero, shape, window, local, use_graph):
+    """O(N) decoding (FAVOR+ running sums with a rescalable key stabiliser, local key/value caches; one HIP graph per token) against the
+    reference-faithful loop that re-runs the network over the growing prefix, and against the CPU oracle's greedy chain."""
+    n = int(np.prod(shape))
+    heads = 4
+    cfg = P.PerformerConfig(num_tokens=19, max_seq_len=n, dim=32, depth=2, heads=heads, dim_head=64, local_attn_heads=local, local_window_size=window,
+                            spatial_shape=shape, use_rezero=rezero)
+    st = P.init_state(cfg, seed=7)
+    for k in st:   # ReZero gates start at 1e-3: make the attention matter
+        if k.endswith(".g"):
+            st[k] = torch.full_like(st[k], 0.7)
+    from synthanatomy_amd.networks.transformers.img2seq_ordering import Ordering
+    from synthanatomy_amd.networks.transformers.performer import Performer
+    o = Ordering("raster_scan", 3, (1,) + shape, (False,) * 3, (), ())
+    net = Performer(num_tokens=19, max_seq_len=n, dim=32, depth=2, heads=heads, ordering=o, dim_head=64, local_attn_heads=local, local_window_size=window,
+                    use_rezero=rezero, spatial_position_emb="absolute", spatial_shape=shape, feature_redraw_interval=None)
+    net.load_state_dict({k: v.clone() for k, v in st.items()}, strict=False)
+    net = net.cuda()
+    prefix = torch.full((3, 1), 18, dtype=torch.long, device="cuda")
+    quad = net.sample(prefix, sample=False, stateful=False)
+    fast = net.sample(prefix, sample=False, stateful=True, use_graph=use_graph)
+    assert fast.shape == (3, *shape)
+    assert torch.equal(fast, quad)
+    again = net.sample(prefix, sample=False)          # default = stateful; a second run must not see the first one's state
+    assert torch.equal(again, quad)
+    seqs = P.spatial_index_sequences(shape, o.get_sequence_ordering())
+    x = torch.full((3, 1), 18, dtype=torch.long)
+    for _ in range(n):
+        x = torch.cat((x, P.forward(st, cfg, x, seqs)[:, -1].argmax(-1, keepdim=True)), 1)
+    ref = x[:, 1:][:, o.get_revert_sequence_ordering()].reshape(3, *shape)
+    assert torch.equal(fast.cpu(), ref)
+    # stochastic path runs and stays in range
+    smp = net.sample(prefix, sample=True, top_k=5, temperature=0.9)
+    assert int(smp.min()) >= 0 and int(smp.max()) <= 18
 
 
 @pytest.mark.parametrize("N,W", [(23, 5), (100, 420), (150, 64), (200, 70)])
