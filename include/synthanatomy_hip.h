@@ -139,18 +139,26 @@ int sa_embed_scatter(const float *dy, float *dtable, const int64_t *idx, int per
  * rounding: the FAVOR+ key stabiliser is the running maximum of the prefix (the keys' global max of performer-pytorch 1.0.11) and the
  * state keeps the exp part and the +eps part of phi(k) apart, so it can be rescaled when that maximum grows.
  * sa_embed_step : out[b,:] = sum_t table_t[per_position_t ? idx_t[*pos] : idx_t[b], :]   (idx < 0 skips)
- * sa_favor_step : global heads.  ddq / ddk [B*G, LDF] = projections of q_t / k_t (data normaliser folded in); state smax[1] (init -inf),
- *                 E [B*G, LDF, dh], Ez [B*G, LDF], V1 [B*G, dh] (init 0); s2[2] scratch; writes the attention rows of position *pos.
+ * sa_favor_step : global heads.  proj [m, dh] = projection matrix with the data normaliser dh^-1/4 folded in; state smax[2] (both -inf at
+ *                 the start), kmax[2] (int; the ordered encoding of -inf, 0x807fffff, at the start), E [B*G, LDF, dh], Ez [B*G, LDF],
+ *                 V1 [B*G, dh] (0 at the start); dd [2, B*G, LDF] scratch; writes the attention rows of position *pos.
  * sa_local_attn_step : local heads.  Rotates q_t / k_t with row *pos of the rotary tables, appends (k_t, v_t) to the caches
  *                 [B, L, N, dh] and attends over the previous and the current window up to *pos (look_backward = 1, causal). */
 int sa_embed_step(int ntab, const float *const *tables, const int64_t *const *idx, const int32_t *per_position, int dim, const int *pos, int B,
                   float *out, void *stream);
-int sa_favor_step(const float *ddq, const float *ddk, const float *q, int q_stride, int q_off, const float *k, int k_stride, int k_off,
-                  const float *v, int v_stride, int v_off, int B, int G, int dh, int m, int LDF, float *smax, float *s2, float *E, float *Ez,
-                  float *V1, const int *pos, float *out, int out_stride, int out_off, void *stream);
+int sa_favor_step(const float *q, int q_stride, int q_off, const float *k, int k_stride, int k_off, const float *v, int v_stride, int v_off,
+                  const float *proj, int B, int G, int dh, int m, int LDF, float *smax, int *kmax, float *dd, float *E, float *Ez, float *V1,
+                  const int *pos, float *out, int out_stride, int out_off, void *stream);
 int sa_local_attn_step(const float *q, int q_stride, int q_off, const float *k, int k_stride, int k_off, const float *v, int v_stride, int v_off,
                        const float *cosb, const float *sinb, float *kcache, float *vcache, const int *pos, int B, int N, int L, int W, int dh,
                        float *out, int out_stride, int out_off, void *stream);
+/* small-batch dense layer of the decode step (B <= 32 rows; a stream over the fp32 nn.Linear weights, up to three tensors concatenated
+ * along the outputs, e.g. q | k | v): y[b][o] = epi(sum_i x[b][i] W[o][i] + bias[o]); act 0 none / 1 GELU; then y = res + gate * y when
+ * res is given (gate: device scalar or NULL = 1).  round_in / round_w / round_out reproduce the bf16 operand / output rounding of the
+ * MFMA path. */
+int sa_gemv_rows(const float *x, int x_stride, int in, int B, int nseg, const float *const *w, const float *const *bias, const int32_t *seg_out,
+                 float *y, int y_stride, int act, const float *res, int res_stride, const float *gate, int round_in, int round_w, int round_out,
+                 void *stream);
 /* nn.LayerNorm (performer.py:220,273); stats[2r] = mean, stats[2r+1] = rstd; y_lp optional copy in lp_dtype */
 int sa_layernorm_fwd(const float *x, const float *w, const float *b, float *y, void *y_lp, int lp_dtype, float *stats, int64_t R, int C,
                      float eps, void *stream);

@@ -774,21 +774,42 @@ __global__ void embed_step_kernel(const EmbedArgs a, const int* __restrict__ pos
     }
 }
 
-// s2[0] = previous running key maximum, s2[1] = max(previous, max of this position's key projections); smax <- s2[1]
-__global__ __launch_bounds__(256) void favor_step_max_kernel(const float* __restrict__ ddk, int rows, int m, int LDF, float* __restrict__ smax, float* __restrict__ s2) {
-    __shared__ float red[4];
-    float v = -INFINITY;
-    for (int e = threadIdx.x; e < rows * m; e += 256) v = fmaxf(v, ddk[(e / m) * LDF + e % m]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float old = *smax, nw = fmaxf(old, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
-        s2[0] = old;
-        s2[1] = nw;
-        *smax = nw;
+// Phase A of a global-head step, one block per (batch, head): projections dd[m] = x . P[m] (P carries the data normaliser) of the new
+// query and key into scratch, and the maximum of the key projections into the step's slot of the double-buffered atomic maximum
+// (order-preserving integer encoding of the float).
+__device__ __forceinline__ int f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__global__ __launch_bounds__(256) void favor_step_proj_kernel(const float* __restrict__ q, int q_stride, int q_off, const float* __restrict__ k, int k_stride,
+                                                              int k_off, const float* __restrict__ proj, int G, int dh, int m, int LDF,
+                                                              float* __restrict__ dd /* [2][B*G][LDF] */, int* __restrict__ kmax /* [2] */,
+                                                              const int* __restrict__ pos) {
+    __shared__ float sq[64], sk[64], red[4];
+    const int bg = blockIdx.x, b = bg / G, g = bg % G, tid = threadIdx.x;
+    const int64_t rows = gridDim.x;
+    if (tid < dh) {
+        sq[tid] = q[(int64_t)b * q_stride + q_off + g * dh + tid];
+        sk[tid] = k[(int64_t)b * k_stride + k_off + g * dh + tid];
     }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int e = tid; e < m; e += 256) {
+        const float* pr = proj + (int64_t)e * dh;
+        float aq = 0.f, ak = 0.f;
+        for (int d = 0; d < dh; d += 4) {
+            const float4 pv = *(const float4*)(pr + d);
+            aq = fmaf(sq[d], pv.x, fmaf(sq[d + 1], pv.y, fmaf(sq[d + 2], pv.z, fmaf(sq[d + 3], pv.w, aq))));
+            ak = fmaf(sk[d], pv.x, fmaf(sk[d + 1], pv.y, fmaf(sk[d + 2], pv.z, fmaf(sk[d + 3], pv.w, ak))));
+        }
+        dd[(int64_t)bg * LDF + e] = aq;
+        dd[(rows + bg) * LDF + e] = ak;
+        mx = fmaxf(mx, ak);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) atomicMax(kmax + (*pos & 1), f2ord(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 
 struct FavorStepArgs {
@@ -796,7 +817,8 @@ struct FavorStepArgs {
     const float *q, *k, *v;            // rows of the fused qkv output
     int q_stride, q_off, k_stride, k_off, v_stride, v_off;
     int G, dh, m, LDF;
-    const float* s2;
+    float* smax;                       // [2] running key maximum, slot (pos & 1) = before this step, slot ((pos + 1) & 1) = after
+    int* kmax;                         // [2] atomic maximum of this step's key projections (ordered-int encoding), slot pos & 1
     float *E, *Ez, *V1;                // state [B*G, LDF, dh], [B*G, LDF], [B*G, dh]
     const int* pos;
     float* out;                        // attention output rows
@@ -804,8 +826,10 @@ struct FavorStepArgs {
     float eps_feat, eps_den;
 };
 
-__global__ __launch_bounds__(256) void favor_step_kernel(const FavorStepArgs a) {
-    __shared__ float sq[64], sk[64], sv[64], sqf[320], sek[320], red[8], snum[4][64];
+__global__ __launch_bounds__(1024) void favor_step_kernel(const FavorStepArgs a) {
+    // 16 waves: wave w owns features w, w+16, ... (17 of the 266): their 64-float state rows are independent read-modify-writes, so all of
+    // a wave's loads are in flight together -- with 4 waves and 67 dependent-looking iterations this kernel took 33 us of pure latency.
+    __shared__ float sq[64], sk[64], sv[64], sqf[320], sek[320], red[32], snum[16][64];
     const int bg = blockIdx.x, b = bg / a.G, g = bg % a.G, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int dh = a.dh, m = a.m;
     if (tid < dh) {
@@ -823,37 +847,34 @@ __global__ __launch_bounds__(256) void favor_step_kernel(const FavorStepArgs a) 
     dq *= nrm;
     dk *= nrm;
     // query stabiliser: row maximum of its own projections
-    float qm = -INFINITY;
-    for (int e = tid; e < m; e += 256) qm = fmaxf(qm, a.ddq[(int64_t)bg * a.LDF + e]);
+    float qm = tid < m ? a.ddq[(int64_t)bg * a.LDF + tid] : -INFINITY;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) qm = fmaxf(qm, __shfl_xor(qm, o, 64));
     if (lane == 0) red[wv] = qm;
     __syncthreads();
-    qm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float s_old = a.s2[0], s_new = a.s2[1];
+    qm = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) qm = fmaxf(qm, red[w]);
+    const int p = *a.pos;
+    const float s_old = a.smax[p & 1], s_new = fmaxf(s_old, ord2f(a.kmax[p & 1]));
     const float scale = s_old == -INFINITY ? 0.f : __expf(s_old - s_new);
-    const int cnt = *a.pos + 1;   // keys seen including this one
-    for (int e = tid; e < m; e += 256) {
-        sqf[e] = ratio * (__expf(a.ddq[(int64_t)bg * a.LDF + e] - dq - qm) + a.eps_feat);
-        sek[e] = __expf(a.ddk[(int64_t)bg * a.LDF + e] - dk - s_new);
+    const int cnt = p + 1;   // keys seen including this one
+    __syncthreads();         // (red is reused below)
+    if (tid == 0) {          // every block writes the same values; the slots read above are not touched
+        a.smax[(p + 1) & 1] = s_new;
+        a.kmax[(p + 1) & 1] = f2ord(-INFINITY);   // ready for the next step's atomic maximum
     }
-    __syncthreads();
-    // state update + numerator: thread = (feature slice wv, value dim lane)
-    float* E = a.E + (int64_t)bg * a.LDF * dh;
-    float num = 0.f;
-    for (int e = wv; e < m; e += 4) {
-        const float x = fmaf(E[e * dh + lane], scale, sek[e] * sv[lane]);
-        E[e * dh + lane] = x;
-        num = fmaf(sqf[e], x, num);
-    }
-    snum[wv][lane] = num;
-    // denominator: sum_m q'[m] * (ratio * (Ez[m] + eps * cnt) + eps_den)
+    // features: q' and the exp part of k'; denominator sum_m q'[m] * (ratio * (Ez[m] + eps * cnt) + eps_den)
     float den = 0.f, qsum = 0.f;
-    for (int e = tid; e < m; e += 256) {
-        const float z = fmaf(a.Ez[(int64_t)bg * a.LDF + e], scale, sek[e]);
-        a.Ez[(int64_t)bg * a.LDF + e] = z;
-        den = fmaf(sqf[e], ratio * (z + a.eps_feat * (float)cnt) + a.eps_den, den);
-        qsum += sqf[e];
+    if (tid < m) {
+        const float qf = ratio * (__expf(a.ddq[(int64_t)bg * a.LDF + tid] - dq - qm) + a.eps_feat);
+        const float ek = __expf(a.ddk[(int64_t)bg * a.LDF + tid] - dk - s_new);
+        sqf[tid] = qf;
+        sek[tid] = ek;
+        const float z = fmaf(a.Ez[(int64_t)bg * a.LDF + tid], scale, ek);
+        a.Ez[(int64_t)bg * a.LDF + tid] = z;
+        den = qf * (ratio * (z + a.eps_feat * (float)cnt) + a.eps_den);
+        qsum = qf;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -862,16 +883,138 @@ __global__ __launch_bounds__(256) void favor_step_kernel(const FavorStepArgs a) 
     }
     if (lane == 0) {
         red[wv] = den;
-        red[4 + wv] = qsum;
+        red[16 + wv] = qsum;
     }
     __syncthreads();
+    // state update + numerator: thread = (feature slice wv, value dim lane)
+    float* E = a.E + (int64_t)bg * a.LDF * dh;
+    float ev[17];
+#pragma unroll
+    for (int it = 0; it < 17; ++it) {
+        const int e = wv + 16 * it;
+        ev[it] = e < m ? E[e * dh + lane] : 0.f;
+    }
+    float num = 0.f;
+#pragma unroll
+    for (int it = 0; it < 17; ++it) {
+        const int e = wv + 16 * it;
+        if (e < m) {
+            const float x = fmaf(ev[it], scale, sek[e] * sv[lane]);
+            E[e * dh + lane] = x;
+            num = fmaf(sqf[e], x, num);
+        }
+    }
+    snum[wv][lane] = num;
+    __syncthreads();
     if (tid < dh) {
-        den = red[0] + red[1] + red[2] + red[3];
-        qsum = red[4] + red[5] + red[6] + red[7];
+        den = 0.f;
+        qsum = 0.f;
+        num = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            den += red[w];
+            qsum += red[16 + w];
+            num += snum[w][tid];
+        }
         const float v1 = a.V1[(int64_t)bg * dh + tid] + sv[tid];
         a.V1[(int64_t)bg * dh + tid] = v1;
-        const float n = ratio * (snum[0][tid] + snum[1][tid] + snum[2][tid] + snum[3][tid] + a.eps_feat * qsum * v1);
-        a.out[(int64_t)b * a.out_stride + a.out_off + g * dh + tid] = n / den;
+        a.out[(int64_t)b * a.out_stride + a.out_off + g * dh + tid] = ratio * (num + a.eps_feat * qsum * v1) / den;
+    }
+}
+
+// ---- small-batch dense layer of the decode step: y[b][o] = epi( sum_i x[b][i] W[o][i] + bias[o] ), B <= 32 rows.
+// At B rows the layer is a stream over the weights (HBM bound).  Up to three weight tensors are concatenated along the output dimension
+// (q | k | v in one launch).  round_in / round_w / round_out reproduce the bf16 operand and output rounding of the MFMA path when the network computes
+// in bf16.  Epilogue: bias, GELU, then optionally y = res + gate * y (ReZero / plain residual with gate = 1).
+struct GemvArgs {
+    const float* x;
+    int x_stride, in, B;
+    const float* w[3];
+    const float* bias[3];
+    int seg[3];            // output columns of each weight tensor
+    int nseg, O;
+    float* y;
+    int y_stride;
+    int act;               // 0 none, 1 GELU
+    const float* res;      // residual rows (stride res_stride) or NULL
+    int res_stride;
+    const float* gate;     // device scalar multiplying the layer output before the residual add, or NULL (1)
+    int round_in, round_w, round_out;
+};
+
+__device__ __forceinline__ float bf16_round(float f) { return __uint_as_float((uint32_t)f32_to_bf16(f) << 16); }
+
+// One wave = 16 output columns x up to 16 batch rows on the MFMA: the weights are the A operand straight from global memory (lane =
+// (column lane & 15, k-group lane >> 4) reads 8 consecutive k: 4 lanes cover a contiguous 128 bytes of a weight row), the input rows the B
+// operand (L1 / L2 resident), and the reduction over k that a VALU dot product would finish with 6 cross-lane steps per value happens
+// inside the instruction.  BF16 = operands rounded to bf16 as on the training path (mfma_f32_16x16x32_bf16); otherwise exact fp32
+// (mfma_f32_16x16x4f32, K permuted so that a lane still reads 16 contiguous bytes).
+// The K range is split over the block's 8 waves (a single wave streaming a whole weight row is pure HBM latency: 34 us for K = 2048);
+// their partial 16 x 16 tiles are summed through LDS by wave 0, which runs the epilogue.
+template <bool BF16>
+__global__ __launch_bounds__(512) void gemv_rows_kernel(const GemvArgs a, int b0) {
+    __shared__ float part[8][64][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, fr = lane & 15, kg = lane >> 4;
+    const int o0 = blockIdx.x * 16;
+    constexpr int KSTEP = BF16 ? 32 : 16;
+    const int kspan = (((a.in + 7) >> 3) + KSTEP - 1) / KSTEP * KSTEP, kbeg = wv * kspan, kend = kbeg + kspan < a.in ? kbeg + kspan : a.in;
+    // weight row of this lane's output column
+    int o = o0 + fr, sgi = 0;
+    const bool ocol = o < a.O;
+    if (!ocol) o = a.O - 1;
+    int oo = o;
+    while (sgi + 1 < a.nseg && oo >= a.seg[sgi]) oo -= a.seg[sgi++];
+    const float* wr = a.w[sgi] + (int64_t)oo * a.in;
+    const int b = b0 + fr;
+    const bool brow = b < a.B;
+    const float* xr = a.x + (int64_t)(brow ? b : 0) * a.x_stride;
+    float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF16) {
+#pragma unroll 4
+        for (int k0 = kbeg; k0 < kend; k0 += 32) {
+            const float4 w0 = *(const float4*)(wr + k0 + kg * 8), w1 = *(const float4*)(wr + k0 + kg * 8 + 4);
+            const float4 x0 = *(const float4*)(xr + k0 + kg * 8), x1 = *(const float4*)(xr + k0 + kg * 8 + 4);
+            short8_t wa, xb;
+            wa[0] = (short)f32_to_bf16(w0.x); wa[1] = (short)f32_to_bf16(w0.y); wa[2] = (short)f32_to_bf16(w0.z); wa[3] = (short)f32_to_bf16(w0.w);
+            wa[4] = (short)f32_to_bf16(w1.x); wa[5] = (short)f32_to_bf16(w1.y); wa[6] = (short)f32_to_bf16(w1.z); wa[7] = (short)f32_to_bf16(w1.w);
+            xb[0] = (short)f32_to_bf16(x0.x); xb[1] = (short)f32_to_bf16(x0.y); xb[2] = (short)f32_to_bf16(x0.z); xb[3] = (short)f32_to_bf16(x0.w);
+            xb[4] = (short)f32_to_bf16(x1.x); xb[5] = (short)f32_to_bf16(x1.y); xb[6] = (short)f32_to_bf16(x1.z); xb[7] = (short)f32_to_bf16(x1.w);
+            if (!brow) xb = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc, 0, 0, 0);
+        }
+    } else {
+#pragma unroll 4
+        for (int k0 = kbeg; k0 < kend; k0 += 16) {   // MFMA e of a group uses k = k0 + kg*4 + e on both operands
+            const float4 w0 = *(const float4*)(wr + k0 + kg * 4);
+            float4 x0 = *(const float4*)(xr + k0 + kg * 4);
+            if (!brow) x0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, x0.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, x0.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, x0.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, x0.w, acc, 0, 0, 0);
+        }
+    }
+    // D: lane holds output columns o0 + 4*kg + r (r = 0..3) of batch row b0 + fr
+    *(float4_t*)part[wv][lane] = acc;
+    __syncthreads();
+    if (wv != 0 || !brow) return;
+#pragma unroll
+    for (int w = 1; w < 8; ++w) acc += *(const float4_t*)part[w][lane];
+    const float gate = a.gate ? *a.gate : 1.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oc = o0 + 4 * kg + r;
+        if (oc >= a.O) break;
+        int sg = 0, ol = oc;
+        while (sg + 1 < a.nseg && ol >= a.seg[sg]) ol -= a.seg[sg++];
+        float v = acc[r] + (a.bias[sg] ? a.bias[sg][ol] : 0.f);
+        if (a.round_out) v = bf16_round(v);
+        if (a.act == 1) {
+            v = gelu_f(v);
+            if (a.round_out) v = bf16_round(v);
+        }
+        if (a.res) v = a.res[(int64_t)b * a.res_stride + oc] + gate * v;
+        a.y[(int64_t)b * a.y_stride + oc] = v;
     }
 }
 
@@ -888,9 +1031,9 @@ struct LocalStepArgs {
 
 // one block per (batch, local head): rotate q_t / k_t, append (k_t, v_t) to the cache, softmax over the keys of the previous and the
 // current window up to t (local_attention with look_backward = 1, causal), output row t
-__global__ __launch_bounds__(256) void local_attn_step_kernel(const LocalStepArgs a) {
+__global__ __launch_bounds__(1024) void local_attn_step_kernel(const LocalStepArgs a) {
     extern __shared__ float sc[];      // scores [2 W]
-    __shared__ float sq[64], red[4], sacc[4][64];
+    __shared__ float sq[64], red[16], sacc[16][64];
     const int bl = blockIdx.x, b = bl / a.L, l = bl % a.L, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int dh = a.dh, half = dh / 2, t = *a.pos;
     float* kc = a.kc + ((int64_t)bl * a.N) * dh;
@@ -908,22 +1051,27 @@ __global__ __launch_bounds__(256) void local_attn_step_kernel(const LocalStepArg
     __syncthreads();   // (the block re-reads its own global writes below: same block, after the barrier)
     __threadfence_block();
     const int w = t / a.W, lo = (w > 0 ? w - 1 : 0) * a.W, nk = t - lo + 1;
-    float mx = -INFINITY;
-    for (int j = tid; j < nk; j += 256) {
-        const float* kj = kc + (int64_t)(lo + j) * dh;
-        float d = 0.f;
-        for (int e = 0; e < dh; ++e) d = fmaf(sq[e], kj[e], d);
-        sc[j] = d;
-        mx = fmaxf(mx, d);
+    // scores: one wave per key (lanes = the 64 dims, coalesced 256-byte rows), 16 keys in flight per block
+    const float ql = sq[lane];
+    for (int j = wv; j < nk; j += 16) {
+        float d = ql * kc[(int64_t)(lo + j) * dh + lane];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        if (lane == 0) sc[j] = d;
     }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = tid; j < nk; j += 1024) mx = fmaxf(mx, sc[j]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) red[wv] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = red[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
     __syncthreads();
     float sum = 0.f;
-    for (int j = tid; j < nk; j += 256) {
+    for (int j = tid; j < nk; j += 1024) {
         const float p = __expf(sc[j] - mx);
         sc[j] = p;
         sum += p;
@@ -932,12 +1080,19 @@ __global__ __launch_bounds__(256) void local_attn_step_kernel(const LocalStepArg
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     if (lane == 0) red[wv] = sum;
     __syncthreads();
-    sum = red[0] + red[1] + red[2] + red[3];
+    sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += red[i];
     float acc = 0.f;   // thread = (key slice wv, value dim lane)
-    for (int j = wv; j < nk; j += 4) acc = fmaf(sc[j], vc[(int64_t)(lo + j) * dh + lane], acc);
+    for (int j = wv; j < nk; j += 16) acc = fmaf(sc[j], vc[(int64_t)(lo + j) * dh + lane], acc);
     sacc[wv][lane] = acc;
     __syncthreads();
-    if (tid < dh) a.out[(int64_t)b * a.out_stride + a.out_off + l * dh + tid] = (sacc[0][tid] + sacc[1][tid] + sacc[2][tid] + sacc[3][tid]) / sum;
+    if (tid < dh) {
+        acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc += sacc[i][tid];
+        a.out[(int64_t)b * a.out_stride + a.out_off + l * dh + tid] = acc / sum;
+    }
 }
 
 
@@ -1218,21 +1373,21 @@ extern "C" int sa_embed_step(int ntab, const float* const* tables, const int64_t
     return 0;
 }
 
-extern "C" int sa_favor_step(const float* ddq, const float* ddk, const float* q, int q_stride, int q_off, const float* k, int k_stride, int k_off,
-                             const float* v, int v_stride, int v_off, int B, int G, int dh, int m, int LDF, float* smax, float* s2, float* E, float* Ez,
-                             float* V1, const int* pos, float* out, int out_stride, int out_off, void* stream) {
-    if (!ddq || !ddk || !q || !k || !v || !smax || !s2 || !E || !Ez || !V1 || !pos || !out) return SA_EINVAL;
-    if (dh != 64 || m > 320 || B <= 0 || G <= 0) return SA_EUNSUPPORTED;
-    hipLaunchKernelGGL(favor_step_max_kernel, dim3(1), dim3(256), 0, ST(stream), ddk, B * G, m, LDF, smax, s2);
+extern "C" int sa_favor_step(const float* q, int q_stride, int q_off, const float* k, int k_stride, int k_off, const float* v, int v_stride, int v_off,
+                             const float* proj, int B, int G, int dh, int m, int LDF, float* smax, int* kmax, float* dd, float* E, float* Ez, float* V1,
+                             const int* pos, float* out, int out_stride, int out_off, void* stream) {
+    if (!q || !k || !v || !proj || !smax || !kmax || !dd || !E || !Ez || !V1 || !pos || !out) return SA_EINVAL;
+    if (dh != 64 || m > 272 || B <= 0 || G <= 0) return SA_EUNSUPPORTED;   // 16 waves x 17 features
+    hipLaunchKernelGGL(favor_step_proj_kernel, dim3(B * G), dim3(256), 0, ST(stream), q, q_stride, q_off, k, k_stride, k_off, proj, G, dh, m, LDF, dd, kmax, pos);
     SA_CHECK_LAUNCH();
     FavorStepArgs a;
-    a.ddq = ddq; a.ddk = ddk; a.q = q; a.k = k; a.v = v;
+    a.ddq = dd; a.ddk = dd + (int64_t)B * G * LDF; a.q = q; a.k = k; a.v = v;
     a.q_stride = q_stride; a.q_off = q_off; a.k_stride = k_stride; a.k_off = k_off; a.v_stride = v_stride; a.v_off = v_off;
-    a.G = G; a.dh = dh; a.m = m; a.LDF = LDF; a.s2 = s2; a.E = E; a.Ez = Ez; a.V1 = V1; a.pos = pos;
+    a.G = G; a.dh = dh; a.m = m; a.LDF = LDF; a.smax = smax; a.kmax = kmax; a.E = E; a.Ez = Ez; a.V1 = V1; a.pos = pos;
     a.out = out; a.out_stride = out_stride; a.out_off = out_off;
     a.eps_feat = 1e-4f;
     a.eps_den = 1e-6f;
-    hipLaunchKernelGGL(favor_step_kernel, dim3(B * G), dim3(256), 0, ST(stream), a);
+    hipLaunchKernelGGL(favor_step_kernel, dim3(B * G), dim3(1024), 0, ST(stream), a);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -1247,7 +1402,31 @@ extern "C" int sa_local_attn_step(const float* q, int q_stride, int q_off, const
     a.q_stride = q_stride; a.q_off = q_off; a.k_stride = k_stride; a.k_off = k_off; a.v_stride = v_stride; a.v_off = v_off;
     a.cosb = cosb; a.sinb = sinb; a.kc = kcache; a.vc = vcache; a.pos = pos; a.N = N; a.W = W; a.L = L; a.dh = dh;
     a.out = out; a.out_stride = out_stride; a.out_off = out_off;
-    hipLaunchKernelGGL(local_attn_step_kernel, dim3(B * L), dim3(256), 2 * (size_t)W * sizeof(float), ST(stream), a);
+    hipLaunchKernelGGL(local_attn_step_kernel, dim3(B * L), dim3(1024), 2 * (size_t)W * sizeof(float), ST(stream), a);
     SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_gemv_rows(const float* x, int x_stride, int in, int B, int nseg, const float* const* w, const float* const* bias, const int32_t* seg_out,
+                            float* y, int y_stride, int act, const float* res, int res_stride, const float* gate, int round_in, int round_w, int round_out,
+                            void* stream) {
+    if (!x || !w || !seg_out || !y || nseg < 1 || nseg > 3 || B <= 0 || in <= 0 || (in & (round_in ? 31 : 15)) || (x_stride & 3)) return SA_EINVAL;   // K steps of 32 (bf16) / 16 (fp32)
+    if (round_in != round_w) return SA_EUNSUPPORTED;   // both operands in bf16 (MFMA bf16) or both exact
+    GemvArgs a;
+    a.x = x; a.x_stride = x_stride; a.in = in; a.B = B; a.nseg = nseg; a.O = 0;
+    for (int s = 0; s < 3; ++s) {
+        a.w[s] = s < nseg ? w[s] : nullptr;
+        a.bias[s] = (s < nseg && bias) ? bias[s] : nullptr;
+        a.seg[s] = s < nseg ? seg_out[s] : 0;
+        a.O += a.seg[s];
+    }
+    a.y = y; a.y_stride = y_stride; a.act = act; a.res = res; a.res_stride = res_stride; a.gate = gate;
+    a.round_in = round_in; a.round_w = round_w; a.round_out = round_out;
+    const unsigned blocks = (unsigned)((a.O + 15) / 16);
+    for (int b0 = 0; b0 < B; b0 += 16) {
+        if (round_in) hipLaunchKernelGGL(gemv_rows_kernel<true>, dim3(blocks), dim3(512), 0, ST(stream), a, b0);
+        else hipLaunchKernelGGL(gemv_rows_kernel<false>, dim3(blocks), dim3(512), 0, ST(stream), a, b0);
+        SA_CHECK_LAUNCH();
+    }
     return 0;
 }

@@ -406,61 +406,67 @@ class _LayerEngine:
         value caches of the local heads."""
         G, L, dh, LDF = self.G, self.L, self.dh, self.LDF
         f32 = torch.float32
-        return dict(smax=torch.full((1,), float("-inf"), dtype=f32, device=dev), s2=torch.zeros(2, dtype=f32, device=dev),
-                    E=torch.zeros(max(B * G, 1), LDF * dh, dtype=f32, device=dev), Ez=torch.zeros(max(B * G, 1), LDF, dtype=f32, device=dev),
-                    V1=torch.zeros(max(B * G, 1), dh, dtype=f32, device=dev), kc=torch.zeros(B, max(L, 1), N, dh, dtype=f32, device=dev),
-                    vc=torch.zeros(B, max(L, 1), N, dh, dtype=f32, device=dev))
+        stt = dict(smax=torch.empty(2, dtype=f32, device=dev), kmax=torch.empty(2, dtype=torch.int32, device=dev),
+                   dd=torch.zeros(2, max(B * G, 1), LDF, dtype=f32, device=dev),
+                   E=torch.empty(max(B * G, 1), LDF * dh, dtype=f32, device=dev), Ez=torch.empty(max(B * G, 1), LDF, dtype=f32, device=dev),
+                   V1=torch.empty(max(B * G, 1), dh, dtype=f32, device=dev), kc=torch.empty(B, max(L, 1), N, dh, dtype=f32, device=dev),
+                   vc=torch.empty(B, max(L, 1), N, dh, dtype=f32, device=dev))
+        self.reset_state(stt)
+        return stt
 
     @staticmethod
     def reset_state(stt):
         for k, v in stt.items():
             if k == "smax":
                 v.fill_(float("-inf"))
+            elif k == "kmax":
+                v.fill_(-2139095041)   # order-preserving integer encoding of -inf (0x807fffff)
             else:
                 v.zero_()
 
+    def _gemv(self, x, mods, y, act=0, res=None, gate=None, round_out=False):
+        """y[b] = epi(x[b] @ cat(W_i)^T + cat(b_i)) for the B rows of a decode step (sa_gemv_rows: streams the fp32 weights once)."""
+        lib, st = _ffi.lib(), _ffi.stream()
+        B, cin = x.shape
+        n = len(mods)
+        wp = (ctypes.c_void_p * n)(*[m.weight.data_ptr() for m in mods])
+        bp = (ctypes.c_void_p * n)(*[(m.bias.data_ptr() if m.bias is not None else None) for m in mods])
+        so = (ctypes.c_int32 * n)(*[m.weight.shape[0] for m in mods])
+        rnd = 1 if self.dtype == torch.bfloat16 else 0
+        _ck(lib.sa_gemv_rows(_ffi.ptr(x), x.stride(0), cin, B, n, wp, bp, so, _ffi.ptr(y), y.stride(0), act, _ffi.ptr(res) if res is not None else None,
+                             res.stride(0) if res is not None else 0, _ffi.ptr(gate), rnd, rnd, 1 if (round_out and rnd) else 0, st), "sa_gemv_rows")
+        return y
+
     def step(self, x, B, N, pos, stt):
-        """x [B, dim] fp32 = the block input at position *pos (device int32) -> block output; updates `stt`.  No host synchronisation
-        and no host-side dependence on the position, so a whole token step can be captured in a HIP graph."""
-        self._sync()
-        lib, st, dev, T = _ffi.lib(), _ffi.stream(), x.device, self.dtype
+        """x [B, dim] fp32 = the block input at position *pos (device int32) -> block output; updates `stt`.  Seven launches, no host
+        synchronisation and no host-side dependence on the position, so a whole token step can be captured in a HIP graph."""
+        lib, st, dev = _ffi.lib(), _ffi.stream(), x.device
+        sa, ff = self.sa, self.ff
         H, G, L, dh, m, LDF = self.H, self.G, self.L, self.dh, self.m, self.LDF
         inner = H * dh
         f32 = torch.float32
         xa, _ = self._pre(self.aw, x, B)
-        xaT = _cast(xa, T)
-        q = self.ops["to_q"].fprop(_as5(xaT), out_dtype=f32).view(B, inner)
-        k = self.ops["to_k"].fprop(_as5(xaT), out_dtype=f32).view(B, inner)
-        v = self.ops["to_v"].fprop(_as5(xaT), out_dtype=f32).view(B, inner)
+        qkv = torch.empty(B, 3 * inner, dtype=f32, device=dev)
+        self._gemv(xa, [sa.to_q, sa.to_k, sa.to_v], qkv)
         attn = torch.empty(B, inner, dtype=f32, device=dev)
         if G > 0:
-            pop = self._proj_op()
-            qg = q[:, : G * dh].contiguous()
-            kg = k[:, : G * dh].contiguous()
-            ddq = pop.fprop(qg.view(1, 1, 1, B * G, dh), out_channels_stride=LDF, use_bias=False).view(B * G, LDF)
-            ddk = pop.fprop(kg.view(1, 1, 1, B * G, dh), out_channels_stride=LDF, use_bias=False).view(B * G, LDF)
-            _ck(lib.sa_favor_step(_ffi.ptr(ddq), _ffi.ptr(ddk), _ffi.ptr(q), inner, 0, _ffi.ptr(k), inner, 0, _ffi.ptr(v), inner, 0, B, G, dh, m, LDF,
-                                  _ffi.ptr(stt["smax"]), _ffi.ptr(stt["s2"]), _ffi.ptr(stt["E"]), _ffi.ptr(stt["Ez"]), _ffi.ptr(stt["V1"]), _ffi.ptr(pos),
-                                  _ffi.ptr(attn), inner, 0, st), "sa_favor_step")
+            self._proj_op()
+            ps = self._pop[2]    # projection matrix with the data normaliser folded in
+            _ck(lib.sa_favor_step(_ffi.ptr(qkv), 3 * inner, 0, _ffi.ptr(qkv), 3 * inner, inner, _ffi.ptr(qkv), 3 * inner, 2 * inner, _ffi.ptr(ps), B, G, dh, m, LDF,
+                                  _ffi.ptr(stt["smax"]), _ffi.ptr(stt["kmax"]), _ffi.ptr(stt["dd"]), _ffi.ptr(stt["E"]), _ffi.ptr(stt["Ez"]), _ffi.ptr(stt["V1"]),
+                                  _ffi.ptr(pos), _ffi.ptr(attn), inner, 0, st), "sa_favor_step")
         if L > 0:
             cosb, sinb = self._rot_tables(N, dev)
-            _ck(lib.sa_local_attn_step(_ffi.ptr(q), inner, G * dh, _ffi.ptr(k), inner, G * dh, _ffi.ptr(v), inner, G * dh, _ffi.ptr(cosb), _ffi.ptr(sinb),
-                                       _ffi.ptr(stt["kc"]), _ffi.ptr(stt["vc"]), _ffi.ptr(pos), B, N, L, self.W, dh, _ffi.ptr(attn), inner, G * dh, st),
-                "sa_local_attn_step")
-        attnT = _cast(attn, T)
-        Fa = self.ops["to_out"].fprop(_as5(attnT)).view(B, self.dim)
+            _ck(lib.sa_local_attn_step(_ffi.ptr(qkv), 3 * inner, G * dh, _ffi.ptr(qkv), 3 * inner, inner + G * dh, _ffi.ptr(qkv), 3 * inner, 2 * inner + G * dh,
+                                       _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(stt["kc"]), _ffi.ptr(stt["vc"]), _ffi.ptr(pos), B, N, L, self.W, dh, _ffi.ptr(attn),
+                                       inner, G * dh, st), "sa_local_attn_step")
         x1 = torch.empty_like(x)
-        ga = self._gate(self.aw, dev)
-        _ck(lib.sa_rezero_fwd(_ffi.ptr(x), _ffi.ptr(Fa), _ffi.dtype_id(Fa.dtype), _ffi.ptr(ga), _ffi.ptr(x1), None, 0, x.numel(), st), "sa_rezero_fwd")
+        self._gemv(attn, [sa.to_out], x1, res=x, gate=self._gate(self.aw, dev), round_out=True)
         xf, _ = self._pre(self.fw, x1, B)
-        xfT = _cast(xf, T)
-        u = self.ops["w1"].fprop(_as5(xfT)).view(B, -1)
-        h = torch.empty_like(u)
-        _ck(lib.sa_gelu(_ffi.ptr(u), _ffi.dtype_id(u.dtype), _ffi.ptr(h), _ffi.dtype_id(h.dtype), u.numel(), st), "sa_gelu")
-        Ff = self.ops["w2"].fprop(_as5(h)).view(B, self.dim)
+        h = torch.empty(B, ff.w1.weight.shape[0], dtype=f32, device=dev)
+        self._gemv(xf, [ff.w1], h, act=1, round_out=True)
         x2 = torch.empty_like(x)
-        gf = self._gate(self.fw, dev)
-        _ck(lib.sa_rezero_fwd(_ffi.ptr(x1), _ffi.ptr(Ff), _ffi.dtype_id(Ff.dtype), _ffi.ptr(gf), _ffi.ptr(x2), None, 0, x.numel(), st), "sa_rezero_fwd")
+        self._gemv(h, [ff.w2], x2, res=x1, gate=self._gate(self.fw, dev), round_out=True)
         return x2
 
     # ---------------------------------------------------------------------------------------------- backward
@@ -807,7 +813,6 @@ class Performer(TransformerBase):
         return self._sample_stateful(prefix, temperature, sample, top_k, use_graph)
 
     def _sample_stateful(self, prefix, temperature, sample, top_k, use_graph):
-        from .transformer import _top_k_logits
         _ffi.require_gpu()
         self.eval()
         dev = self.token_emb.weight.device
@@ -843,11 +848,21 @@ class Performer(TransformerBase):
             for l, stt in zip(layers, states):
                 x = l.step(x, B, npos, pos, stt)
             h = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
-            logits = _LinearFn.apply(self._out_op, h, self.to_out.weight, self.to_out.bias).float() / temperature
-            if top_k is not None:
-                logits = _top_k_logits(logits, top_k)
+            logits = torch.empty(B, self.to_out.weight.shape[0], dtype=torch.float32, device=dev)
+            layers[0]._gemv(h, [self.to_out], logits)
+            logits = logits / temperature
+            if top_k is not None:   # transformer.py:11-17 (_top_k_logits) without the boolean-mask assignment, which cannot be captured
+                kth = torch.topk(logits, top_k)[0][:, -1:]
+                logits = torch.where(logits < kth, torch.full_like(logits, float("-inf")), logits)
             probs = torch.softmax(logits, dim=-1)
-            ix = torch.multinomial(probs, num_samples=1) if sample else torch.topk(probs, k=1, dim=-1)[1]
+            if sample:
+                # categorical draw by inverse CDF: same distribution as torch.multinomial(probs, 1) (transformer.py:37), which cannot be
+                # captured in a HIP graph (hipErrorStreamCaptureUnsupported)
+                u = torch.rand(B, 1, device=dev, dtype=probs.dtype)
+                cdf = probs.cumsum(dim=-1)
+                ix = (cdf < u * cdf[:, -1:]).sum(dim=-1, keepdim=True).clamp_(max=probs.shape[-1] - 1)
+            else:
+                ix = torch.topk(probs, k=1, dim=-1)[1]
             # position pos+1 receives the sampled token unless it still belongs to the given prefix
             write = (col == (p64 + 1)) & (col >= P)
             seq.copy_(torch.where(write, ix.expand(B, total), seq))
@@ -869,7 +884,9 @@ class Performer(TransformerBase):
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     one_step()
-            except Exception:                      # capture is an optimisation: fall back to eager launches of the same O(N) step
+            except Exception as exc:               # capture is an optimisation: fall back to eager launches of the same O(N) step
+                import warnings
+                warnings.warn(f"HIP graph capture of the decode step failed ({type(exc).__name__}: {exc}); running it eagerly")
                 graph = None
                 torch.cuda.synchronize()
                 for l, stt in zip(layers, states):

@@ -20,8 +20,10 @@ order = Ordering("raster_scan", 3, (1,) + spatial, (False, False, False), ((2, 0
 net = Performer(num_tokens=2049, max_seq_len=N, dim=512, depth=a.depth, heads=16, ordering=order, local_attn_heads=8, local_window_size=420,
                 feature_redraw_interval=1, use_rezero=True, spatial_position_emb="absolute", spatial_shape=spatial, compute_dtype=torch.bfloat16).cuda().eval()
 prefix = torch.full((a.batch, 1), 2048, dtype=torch.long, device="cuda")
-for mode in (["quadratic", "stateful"] if a.mode == "both" else [a.mode]):
-    kw = {"stateful": mode == "stateful"}
+for mode in (["quadratic", "stateful"] if a.mode == "both" else a.mode.split(",")):
+    kw = {"stateful": mode != "quadratic"}
+    if mode == "eager":
+        kw["use_graph"] = False
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = net.sample(prefix, sample=False, **kw)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
