@@ -270,3 +270,41 @@ def test_local_attention_backward_kernels_against_autograd(N, W):
     unpack = lambda t: t.view(B, N, L, dh).permute(0, 2, 1, 3)
     assert _rel(unpack(o), ref) < 1e-4
     assert _rel(unpack(dq), q.grad) < 1e-4 and _rel(unpack(dk), k.grad) < 1e-4 and _rel(unpack(dv), v.grad) < 1e-4
+
+
+@pytest.mark.parametrize("B,cin,segs,act,resid,rnd", [(1, 32, (48,), 0, False, 0), (6, 512, (1024, 1024, 1024), 0, False, 1), (17, 2048, (512,), 0, True, 1),
+                                                       (32, 512, (2048,), 1, False, 1), (5, 128, (40, 24), 1, True, 0)])
+def test_small_batch_dense_kernel(B, cin, segs, act, resid, rnd):
+    """sa_gemv_rows (the dense layers of the decode step on the MFMA, K split over 8 waves) against torch: concatenated weight tensors,
+    bias, GELU, gated residual, bf16 operand / output rounding as on the training path."""
+    import ctypes
+    from synthanatomy_amd import _ffi
+    lib, st = _ffi.lib(), _ffi.stream()
+    torch.manual_seed(B + cin)
+    x = torch.randn(B, cin)
+    ws = [torch.randn(o, cin) * cin ** -0.5 for o in segs]
+    bs = [torch.randn(o) * 0.1 for o in segs]
+    res = torch.randn(B, sum(segs)) if resid else None
+    gate = torch.tensor(0.37)
+    r = (lambda t: t.to(torch.bfloat16).float()) if rnd else (lambda t: t)
+    ref = torch.cat([r(x).double() @ r(w).double().t() + b.double() for w, b in zip(ws, bs)], 1).float()
+    if rnd:
+        ref = r(ref)
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+        if rnd:
+            ref = r(ref)
+    if resid:
+        ref = res + gate * ref
+    xd, wd, bd = x.cuda(), [w.cuda() for w in ws], [b.cuda() for b in bs]
+    resd, gd = (res.cuda() if resid else None), gate.cuda()
+    y = torch.full((B, sum(segs)), float("nan"), device="cuda")
+    n = len(segs)
+    wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in wd])
+    bp = (ctypes.c_void_p * n)(*[b.data_ptr() for b in bd])
+    so = (ctypes.c_int32 * n)(*segs)
+    _ffi.check(lib.sa_gemv_rows(_ffi.ptr(xd), cin, cin, B, n, wp, bp, so, _ffi.ptr(y), sum(segs), act, _ffi.ptr(resd), sum(segs) if resid else 0,
+                                _ffi.ptr(gd) if resid else None, rnd, rnd, rnd, st))
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    assert _rel(y.cpu(), ref) < (1.5e-2 if rnd else 1e-5)
