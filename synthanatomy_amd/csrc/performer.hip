@@ -1033,7 +1033,8 @@ struct LocalStepArgs {
 // current window up to t (local_attention with look_backward = 1, causal), output row t
 __global__ __launch_bounds__(1024) void local_attn_step_kernel(const LocalStepArgs a) {
     extern __shared__ float sc[];      // scores [2 W]
-    __shared__ float sq[64], red[16], sacc[16][64];
+    __shared__ __attribute__((aligned(16))) float sq[64];
+    __shared__ float red[16], sacc[16][64];
     const int bl = blockIdx.x, b = bl / a.L, l = bl % a.L, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int dh = a.dh, half = dh / 2, t = *a.pos;
     float* kc = a.kc + ((int64_t)bl * a.N) * dh;
@@ -1051,13 +1052,19 @@ __global__ __launch_bounds__(1024) void local_attn_step_kernel(const LocalStepAr
     __syncthreads();   // (the block re-reads its own global writes below: same block, after the barrier)
     __threadfence_block();
     const int w = t / a.W, lo = (w > 0 ? w - 1 : 0) * a.W, nk = t - lo + 1;
-    // scores: one wave per key (lanes = the 64 dims, coalesced 256-byte rows), 16 keys in flight per block
-    const float ql = sq[lane];
-    for (int j = wv; j < nk; j += 16) {
-        float d = ql * kc[(int64_t)(lo + j) * dh + lane];
+    // scores: one key per thread (at most 2 W <= 1024 keys), its 256-byte row as 16 independent 16-byte loads -- no cross-lane reduction
+    for (int j = tid; j < nk; j += 1024) {
+        const float4* kj = (const float4*)(kc + (int64_t)(lo + j) * dh);
+        float4 kv[16];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-        if (lane == 0) sc[j] = d;
+        for (int e = 0; e < 16; ++e) kv[e] = kj[e];
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float4 qv = *(const float4*)(sq + 4 * e);
+            d = fmaf(qv.x, kv[e].x, fmaf(qv.y, kv[e].y, fmaf(qv.z, kv[e].z, fmaf(qv.w, kv[e].w, d))));
+        }
+        sc[j] = d;
     }
     __syncthreads();
     float mx = -INFINITY;
@@ -1083,8 +1090,16 @@ __global__ __launch_bounds__(1024) void local_attn_step_kernel(const LocalStepAr
     sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) sum += red[i];
-    float acc = 0.f;   // thread = (key slice wv, value dim lane)
-    for (int j = wv; j < nk; j += 16) acc = fmaf(sc[j], vc[(int64_t)(lo + j) * dh + lane], acc);
+    float acc = 0.f;   // thread = (key slice wv, value dim lane); 8 value rows in flight per wave
+    int j = wv;
+    for (; j + 112 < nk; j += 128) {
+        float vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vv[u] = vc[(int64_t)(lo + j + 16 * u) * dh + lane];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(sc[j + 16 * u], vv[u], acc);
+    }
+    for (; j < nk; j += 16) acc = fmaf(sc[j], vc[(int64_t)(lo + j) * dh + lane], acc);
     sacc[wv][lane] = acc;
     __syncthreads();
     if (tid < dh) {
