@@ -89,6 +89,12 @@ int sa_resblock_fprop(const sa_conv_geom *g, int dtype, const void *x, const voi
  * kernel stages anyway; sa_colsum is the stand-alone form).  Replaces cuDNN wgrad / bias-grad behind the same modules' autograd. */
 int sa_conv_wgrad(const sa_conv_geom *g, int dtype, const void *in, const void *gout, float *dw, float *db, const int32_t *tap_lut_host,
                   int64_t s_row, int64_t s_red, void *workspace, int64_t workspace_bytes, void *stream);
+/* Backward of a 1x1x1, 128 -> 128 channel convolution whose INPUT is a post-ReLU tensor (second convolution of the residual block,
+ * baseline.py:150-160) in ONE launch: dw / db as sa_conv_wgrad, and dx[m][ci] = (in[m][ci] > 0) * sum_co gout[m][co] W[co][ci] from the same
+ * staged tiles.  dgrad_wpk = sa_pack_weights operand of the layer's data-gradient plan [128 ci][128 co].  bf16 only; workspace as for
+ * sa_conv_wgrad (required).  SA_EUNSUPPORTED for anything else: use sa_conv_wgrad + sa_conv_fprop. */
+int sa_conv1x1_backward(const sa_conv_geom *g, int dtype, const void *in, const void *gout, float *dw, float *db, int64_t s_row, int64_t s_red,
+                        void *workspace, int64_t workspace_bytes, const void *dgrad_wpk, void *dx, void *stream);
 /* bytes of scratch sa_conv_wgrad wants for this geometry (partial tiles of the voxel splits; a second kernel reduces them
  * without atomics).  With workspace == NULL the kernel falls back to fp32 atomics straight into dw. */
 int64_t sa_conv_wgrad_workspace_bytes(const sa_conv_geom *g, int dtype);

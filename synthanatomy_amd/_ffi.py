@@ -50,6 +50,8 @@ _SIGS = {
     "sa_resblock_fprop": (c_int, [POINTER(ConvGeom), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Epilogue), c_void_p]),
     "sa_conv_wgrad": (c_int, [POINTER(ConvGeom), c_int, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int32), c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "sa_conv_wgrad_workspace_bytes": (c_int64, [POINTER(ConvGeom), c_int]),
+    "sa_conv1x1_backward": (c_int, [POINTER(ConvGeom), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                    c_void_p]),
     "sa_colsum": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "sa_vq_assign": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sa_vq_ema_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p]),

@@ -190,15 +190,6 @@ __device__ __forceinline__ void fprop_epilogue_ov(const FpropArgs& a, float4_t (
 // row, so addend / mask come in and the result leaves as 32-byte (bf16) or 64-byte (fp32) contiguous pieces, 128 / 256 B per row.
 // permlane32_swap(a, b) = {[a.q0 a.q1 b.q0 b.q1], [a.q2 a.q3 b.q2 b.q3]};  permlane16_swap(a, b) = {[a.q0 b.q0 a.q2 b.q2], [a.q1 b.q1 a.q3 b.q3]}
 // (probed on MI355X).  Requires a full 128-channel tile of valid output channels and 16-byte aligned rows; the caller checks.
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void quarter_transpose(float& r0, float& r1, float& r2, float& r3) {
-    const u32x2 a = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r2), false, false);
-    const u32x2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r3), false, false);
-    const u32x2 c = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
-    const u32x2 d = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
-    r0 = __uint_as_float(c.x); r1 = __uint_as_float(c.y); r2 = __uint_as_float(d.x); r3 = __uint_as_float(d.y);
-}
-
 __device__ __forceinline__ void load16(const void* base, int dtype, int64_t off, float (&v)[16]) {
     if (dtype == SA_F32) {
 #pragma unroll

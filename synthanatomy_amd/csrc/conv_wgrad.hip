@@ -31,6 +31,9 @@ struct WgradArgs {
     uint32_t in_bytes, g_bytes;   // non-zero: both operands addressable with 32-bit buffer offsets (LDS-DMA loader)
     float* ws;            // [split][tile][co 128][kidx 128] partial tiles, or NULL -> fp32 atomics straight into dw
     float* db;            // bias gradient fused into the bf16 LDS-DMA kernels: db[co] += sum_m gout[m][co] (NULL: not wanted)
+    // fused data gradient of a 1x1x1 / 128-channel layer (sa_conv1x1_backward): dg_out[m][ci] = (in[m][ci] > 0) * sum_co gout[m][co] W[co][ci]
+    const void* dg_wpk;   // packed dgrad operand [128 ci][128 co] bf16
+    void* dg_out;         // [M][128] bf16
     // halo kernel (3x3x3 stride 1, bf16, Cin = 128): the voxel range is walked in steps of 4 (H) x 16 (W) voxels
     uint32_t HQ, WP, nsteps, steps_per_split, halo;
     FastDiv dWP, dHQ;
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
-template <typename T>
+template <typename T, bool DG = false>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int MK = WG<T>::MK;
@@ -386,8 +389,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) 
     };
 
     issue(chunk0, 0);
-    __syncthreads();
     const uint32_t frow = lane & 15u, fq = lane >> 4;
+    // DG (1x1x1, 128 channels): the block also produces the data gradient of its rows from the SAME staged gradient tile,
+    //   dX[m][ci] = (x[m][ci] > 0) * sum_co g[m][co] W[co][ci],
+    // wave (wm, wn) = rows wm*32..+31 x input channels wn*64..+63.  The weights are the MFMA A operand, held in registers for the whole
+    // block (16 fragments); the gradient tile is the B operand, read from the transposing-read layout with plain 16-byte reads
+    // (channel chunk (c >> 4) ^ (m & 7): the 16 rows x 4 k-groups of a fragment still hit 16 distinct 16-byte bank groups).
+    u32x4 dgw[DG ? 4 : 1][DG ? 4 : 1];
+    if constexpr (DG) {
+        const bf16_t* wp = (const bf16_t*)a.dg_wpk;
+#pragma unroll
+        for (int ic = 0; ic < 4; ++ic)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dgw[ic][ks] = *(const u32x4*)(wp + (wn * 64 + ic * 16 + frow) * 128 + ks * 32 + fq * 8);
+    }
+    __syncthreads();
     const bool do_db = IS_BF16 && a.db != nullptr && kt == 0;   // the gradient rows of this split pass through exactly one kt = 0 block per co tile
     float bs0 = 0.f, bs1 = 0.f;
     for (uint32_t c = chunk0; c < chunk1; ++c) {
@@ -397,6 +413,58 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) 
         const unsigned char* pg = sG + buf * TILE_BYTES;
         if constexpr (IS_BF16) {
             if (do_db) tile_colsum<64, 4>(pg, tid, bs0, bs1);
+            if constexpr (DG) {
+                float4_t ad[4][2];
+#pragma unroll
+                for (int ic = 0; ic < 4; ++ic)
+#pragma unroll
+                    for (int jr = 0; jr < 2; ++jr) ad[ic][jr] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    u32x4 gb[2];
+#pragma unroll
+                    for (int jr = 0; jr < 2; ++jr) {
+                        const uint32_t m = wm * 32 + jr * 16 + frow, cc = ks * 32 + fq * 8;
+                        gb[jr] = *(const u32x4*)(pg + m * 256u + ((((cc >> 4) ^ (m & 7u)) << 5) | ((cc & 15u) << 1)));
+                    }
+#pragma unroll
+                    for (int ic = 0; ic < 4; ++ic)
+#pragma unroll
+                        for (int jr = 0; jr < 2; ++jr)
+                            ad[ic][jr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const short8_t*)&dgw[ic][ks], *(const short8_t*)&gb[jr], ad[ic][jr], 0, 0, 0);
+                }
+                // lane = 4 channels (fq*4 + r) of 4 fragments for row frow -> quarter transpose -> 16 consecutive channels wn*64 + fq*16 ..
+#pragma unroll
+                for (int jr = 0; jr < 2; ++jr) {
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float t0 = ad[0][jr][r], t1 = ad[1][jr][r], t2 = ad[2][jr][r], t3 = ad[3][jr][r];
+                        quarter_transpose(t0, t1, t2, t3);
+                        v[r] = t0; v[4 + r] = t1; v[8 + r] = t2; v[12 + r] = t3;
+                    }
+                    const uint32_t mrow = wm * 32 + jr * 16 + frow, c0 = wn * 64 + fq * 16;
+                    const uint32_t gm = c * MK + mrow;
+                    // ReLU mask from the staged activation tile: one 32-byte chunk = these 16 channels
+                    const unsigned char* xm = px + mrow * 256u + (((c0 >> 4) ^ (mrow & 7u)) << 5);
+                    const u32x4 h0 = *(const u32x4*)xm, h1 = *(const u32x4*)(xm + 16);
+                    u32x4 o0, o1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // bf16 > 0  <=>  sign bit clear and not zero
+                        const uint32_t ha = h0[e], hb = h1[e];
+                        const float a0 = ((ha & 0xffffu) != 0 && !(ha & 0x8000u)) ? v[2 * e] : 0.f, a1 = ((ha >> 16) != 0 && !(ha & 0x80000000u)) ? v[2 * e + 1] : 0.f;
+                        const float b0 = ((hb & 0xffffu) != 0 && !(hb & 0x8000u)) ? v[8 + 2 * e] : 0.f, b1 = ((hb >> 16) != 0 && !(hb & 0x80000000u)) ? v[8 + 2 * e + 1] : 0.f;
+                        o0[e] = (uint32_t)f32_to_bf16(a0) | ((uint32_t)f32_to_bf16(a1) << 16);
+                        o1[e] = (uint32_t)f32_to_bf16(b0) | ((uint32_t)f32_to_bf16(b1) << 16);
+                    }
+                    if (gm < a.M) {
+                        bf16_t* op = (bf16_t*)a.dg_out + (size_t)gm * 128 + c0;
+                        *(u32x4*)op = o0;
+                        *(u32x4*)(op + 8) = o1;
+                    }
+                }
+            }
             // lane (group gq = lane>>4, s = lane&15) addresses voxel row 4*gq + (s>>2) and channels 4*(s&3)..+3 of each 16x(4 m) block
             const uint32_t trow = fq * 4u + (frow >> 2), tcol = (frow & 3u) * 4u;
 #pragma unroll
@@ -948,8 +1016,8 @@ extern "C" int64_t sa_conv_wgrad_workspace_bytes(const sa_conv_geom* g, int dtyp
 
 extern "C" int sa_colsum(const void* gp, int dtype, int64_t M, int C, int cstride, float* db, void* stream);
 
-extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, const void* gout, float* dw, float* db, const int32_t* tap_lut_host,
-                             int64_t s_row, int64_t s_red, void* workspace, int64_t workspace_bytes, void* stream) {
+static int conv_wgrad_impl(const sa_conv_geom* g, int dtype, const void* in, const void* gout, float* dw, float* db, const int32_t* tap_lut_host,
+                           int64_t s_row, int64_t s_red, void* workspace, int64_t workspace_bytes, const void* dg_wpk, void* dg_out, void* stream) {
     using namespace sa;
     if (!g || !in || !gout || !dw) return SA_EINVAL;
     WgradArgs a;
@@ -979,7 +1047,15 @@ extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, c
         a.g_bytes = fits ? (uint32_t)gb : 0u;
     }
     const bool fuse_db = db && dtype == SA_BF16 && getenv("SA_NO_FUSED_DB") == nullptr;   // the bf16 LDS-DMA kernels sum the gradient tile they stage
-    if (a.halo && a.ws) {
+    a.dg_wpk = dg_wpk;
+    a.dg_out = dg_out;
+    if (dg_out) {  // fused 1x1x1 data gradient: only the bf16 LDS-DMA kernel, one (tap, co) tile, rows = voxels
+        if (!dg_wpk || dtype != SA_BF16 || !a.in_bytes || a.ntiles != 1 || a.halo || g->Cin != 128 || g->Cout != 128 || g->cin_valid != 128 || g->cout_valid != 128)
+            return SA_EUNSUPPORTED;
+        if (fuse_db) a.db = db;
+        snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_dma_kernel<unsigned short, true>");
+        hipLaunchKernelGGL((conv_wgrad_dma_kernel<bf16_t, true>), grid, dim3(256), lds, st, a);
+    } else if (a.halo && a.ws) {
         if (fuse_db) a.db = db;
         static bool attr_done = false;
         if (!attr_done) {
@@ -1036,4 +1112,24 @@ extern "C" int sa_colsum(const void* gp, int dtype, int64_t M, int C, int cstrid
     else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gp, M, C, cstride, db, rows_per_block);
     SA_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int sa_conv_wgrad(const sa_conv_geom* g, int dtype, const void* in, const void* gout, float* dw, float* db, const int32_t* tap_lut_host,
+                             int64_t s_row, int64_t s_red, void* workspace, int64_t workspace_bytes, void* stream) {
+    return conv_wgrad_impl(g, dtype, in, gout, dw, db, tap_lut_host, s_row, s_red, workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+
+// Backward of a 1x1x1, 128 -> 128 channel convolution whose INPUT is a post-ReLU tensor (the second convolution of the residual block,
+// reference baseline.py:150-160), in one launch: weight gradient + bias gradient as sa_conv_wgrad, and the data gradient
+//   dx[m][ci] = (in[m][ci] > 0) * sum_co gout[m][co] W[co][ci]
+// from the same staged tiles (the two stand-alone kernels read gout twice and `in` twice).  dgrad_wpk = sa_pack_weights operand of the
+// layer's data-gradient plan ([128 ci][128 co]).  bf16 only; SA_EUNSUPPORTED otherwise (callers fall back to the two launches).
+extern "C" int sa_conv1x1_backward(const sa_conv_geom* g, int dtype, const void* in, const void* gout, float* dw, float* db, int64_t s_row, int64_t s_red,
+                                   void* workspace, int64_t workspace_bytes, const void* dgrad_wpk, void* dx, void* stream) {
+    if (!g || !dgrad_wpk || !dx) return SA_EINVAL;
+    if (g->KT[0] * g->KT[1] * g->KT[2] != 1) return SA_EUNSUPPORTED;
+    for (int d = 0; d < 3; ++d)
+        if (g->in_mult[d] != 1 || g->in_off[d] != 0 || g->out_mult[d] != 1 || g->out_off[d] != 0) return SA_EUNSUPPORTED;
+    if (g->Dm != g->Do || g->Hm != g->Ho || g->Wm != g->Wo || g->Di != g->Do || g->Hi != g->Ho || g->Wi != g->Wo) return SA_EUNSUPPORTED;
+    return conv_wgrad_impl(g, dtype, in, gout, dw, db, nullptr, s_row, s_red, workspace, workspace_bytes, dgrad_wpk, dx, stream);
 }

@@ -96,4 +96,18 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// 4 x 4 transpose across the four 16-lane quarters of a wave (gfx950 v_permlane32_swap + v_permlane16_swap; semantics probed on MI355X):
+//   permlane32_swap(a, b) = {[a.q0 a.q1 b.q0 b.q1], [a.q2 a.q3 b.q2 b.q3]};  permlane16_swap(a, b) = {[a.q0 b.q0 a.q2 b.q2], [a.q1 b.q1 a.q3 b.q3]}
+// in: lane quarter q holds r_i = element (q, i);  out: lane quarter q holds r_i = element (i, q).
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void quarter_transpose(float& r0, float& r1, float& r2, float& r3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32x2_t a = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r2), false, false);
+    const u32x2_t b = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r3), false, false);
+    const u32x2_t c = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+    const u32x2_t d = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+    r0 = __uint_as_float(c.x); r1 = __uint_as_float(c.y); r2 = __uint_as_float(d.x); r3 = __uint_as_float(d.y);
+#endif
+}
+
 }  // namespace sa

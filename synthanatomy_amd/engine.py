@@ -305,6 +305,30 @@ class ConvOp:
                         "sa_conv_wgrad"))
 
 
+def conv1x1_backward(op: "ConvOp", x: torch.Tensor, g: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """Weight, bias and (ReLU-masked) data gradient of a 1x1x1 128 -> 128 bf16 convolution in one launch (sa_conv1x1_backward); returns dx,
+    or None when the layer is not of that shape (the caller then uses wgrad + dgrad)."""
+    if not (op.kind == "conv" and op.k == 1 and op.cin == 128 and op.cout == 128 and op.dtype == torch.bfloat16 and op.w_strides is None
+            and os.environ.get("SA_NO_FUSED_1X1_BWD") is None and x.numel() * 2 < 0xffffff00 - (1 << 20)):
+        return None
+    N, D, H, W, C = x.shape
+    assert x.dtype == op.dtype and g.dtype == op.dtype and x.is_contiguous() and g.is_contiguous() and g.shape == x.shape
+    plans = op._get_plans(N, (D, H, W), 128, 128)
+    op._ensure_packed(plans["dgrad"])
+    pw, pd = plans["wgrad"][0], plans["dgrad"][0]
+    lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(op.dtype)
+    nbytes = lib.sa_conv_wgrad_workspace_bytes(ctypes.byref(pw.geom), did)
+    if nbytes <= 0:
+        return None
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    flops = 2.0 * _geom_flops(pw.geom)
+    _launch("+wgrad_reduce_kernel", flops,
+            lambda: _ffi.check(lib.sa_conv1x1_backward(ctypes.byref(pw.geom), did, _ffi.ptr(x), _ffi.ptr(g), _ffi.ptr(dw), _ffi.ptr(db), pw.s_row, pw.s_red, _ffi.ptr(ws),
+                                                        nbytes, _ffi.ptr(pd.wpk), _ffi.ptr(dx), st), "sa_conv1x1_backward"))
+    return dx
+
+
 def cast_pad(src: torch.Tensor, dst_dtype: torch.dtype, dst_stride: int) -> torch.Tensor:
     """[..., C] -> [..., dst_stride] of dst_dtype (zero channel padding) via the HIP cast kernel."""
     src = src.contiguous()

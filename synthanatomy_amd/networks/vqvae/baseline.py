@@ -344,9 +344,12 @@ class _ResStage:
         x, h = saved
         self._sync()
         dims = tuple(x.shape[1:4])
-        self.c1.wgrad(h, G, grads.buf(self.c1m.weight), grads.buf(self.c1m.bias))
+        from ...engine import conv1x1_backward
+        dp = conv1x1_backward(self.c1, h, G, grads.buf(self.c1m.weight), grads.buf(self.c1m.bias))   # dw, db and the masked dgrad in one launch
+        if dp is None:
+            self.c1.wgrad(h, G, grads.buf(self.c1m.weight), grads.buf(self.c1m.bias))
+            dp = self.c1.dgrad(G, dims, mask=h, mask_mode=MASK_POS)
         grads.done(self.c1m.weight, self.c1m.bias)
-        dp = self.c1.dgrad(G, dims, mask=h, mask_mode=MASK_POS)
         self.c3.wgrad(x, dp, grads.buf(self.c3m.weight), grads.buf(self.c3m.bias))
         grads.done(self.c3m.weight, self.c3m.bias)
         return self.c3.dgrad(dp, dims, addend=G, mask=x if self.in_act else None, mask_mode=MASK_POS)

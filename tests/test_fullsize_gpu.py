@@ -74,10 +74,12 @@ def test_full_size_halo_kernels_agree_with_im2col_order_kernels(net):
     x = torch.rand(1, 1, *VOL, generator=g, device="cuda")
     loss_h, gr_h = _grads(net, x)
     os.environ["SA_NO_HALO"] = "1"
+    os.environ["SA_NO_FUSED_1X1_BWD"] = "1"     # ... and the two-launch 1x1x1 backward instead of sa_conv1x1_backward
     try:
         loss_r, gr_r = _grads(net, x)
     finally:
         del os.environ["SA_NO_HALO"]
+        del os.environ["SA_NO_FUSED_1X1_BWD"]
     assert np.isfinite(loss_h) and abs(loss_h - loss_r) <= 2e-3 * abs(loss_r)
     assert gr_h.keys() == gr_r.keys() and len(gr_h) >= 100
     worst = max((_rel(gr_h[n], gr_r[n]), n) for n in gr_h)

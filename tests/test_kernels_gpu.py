@@ -380,3 +380,27 @@ def test_convt1_gemm_route(dtype):
     _close(dx.float().cpu(), _cl(xr.grad * (x > 0)), torch.bfloat16 if dtype == torch.bfloat16 else dtype, "convt1 dgrad (gemm)")
     _close(gr.buf(mod.weight).cpu(), wr.grad, dtype, "convt1 wgrad (gemm)")
     _close(gr.buf(mod.bias).cpu(), br.grad, dtype, "convt1 bgrad (gemm)")
+
+
+@pytest.mark.parametrize("dims", [(2, 9, 10, 11), (1, 33, 45, 47)])
+def test_conv1x1_backward_fused(dims):
+    """sa_conv1x1_backward: dw, db and the ReLU-masked data gradient of a 1x1x1 128 -> 128 bf16 convolution from one pass over the tiles,
+    against torch autograd (row counts that are not multiples of the 64-row chunk)."""
+    _ffi, engine = _ops()
+    torch.manual_seed(dims[1])
+    dt = torch.bfloat16
+    N, sp = dims[0], dims[1:]
+    w = _rt(torch.randn(128, 128, 1, 1, 1) * 0.08, dt)
+    b = torch.randn(128) * 0.1
+    x = _rt(torch.relu(torch.randn(N, 128, *sp)), dt)          # post-ReLU input: its zeros are the mask
+    g = _rt(torch.randn(N, 128, *sp), dt)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.conv3d(xr, wr, br).backward(g)
+    op = engine.ConvOp("conv", 128, 128, 1, 1, 0, w.cuda(), b.cuda(), dt)
+    dw, db = torch.zeros_like(w, device="cuda"), torch.zeros(128, device="cuda")
+    dx = engine.conv1x1_backward(op, _cl(x).cuda().to(dt), _cl(g).cuda().to(dt), dw, db)
+    assert dx is not None and dx.dtype == dt
+    torch.cuda.synchronize()
+    _close(dx.float().cpu(), _cl(xr.grad * (x > 0)), dt, "masked dgrad")
+    _close(dw.cpu(), wr.grad, dt, "wgrad")
+    _close(db.cpu(), br.grad, dt, "bgrad")
