@@ -632,6 +632,8 @@ __global__ __launch_bounds__(256) void conv_fprop_dma_kernel(const FpropArgs a) 
 // Measured dead ends (MI355X, C = 128 layer, 1.05-1.1 PFLOP/s here): a persistent 8-wave block on 16 x 16 patches (half the weight
 // traffic, cross-tile prefetch, register epilogue) ran at 0.91-0.96 PFLOP/s -- eight waves in lock-step on one barrier lose the overlap two
 // independent 4-wave blocks give each other; rotating the K-group order per block (to spread the weight reads over L2) changed nothing.
+// A 256-voxel tile with 32-channel slabs (4 waves of 128 x 64, two blocks per CU, half the weight bytes and 3 instead of 5 DMA pieces per
+// 32 MFMAs) was 5 % slower as well: what bounds this loop is the barrier interval (32 MFMAs per wave), not the weight bytes.
 template <typename T, bool FUSE>
 __global__ __launch_bounds__(256) void conv_fprop_halo_kernel(const FpropArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
