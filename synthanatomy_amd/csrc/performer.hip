@@ -459,36 +459,56 @@ __device__ __forceinline__ int scan_pos(const ScanArgs& s, int p) { return s.rev
 // waits for vmcnt(0), which serialises every load of the loop.  LDF % 16 == 0 (the host checks), so rows are float4-addressable.
 // The MFMA k index of a feature contraction is the permutation m = g4 * (LDF/4) + mm, so each lane reads contiguous floats.
 __global__ __launch_bounds__(256) void favor_chunk_state_kernel(const ScanArgs s) {
+    // wave w owns features [64 w, 64 w + 64) for ALL 64 value columns: the MFMA row index i is the permutation m = 64 w + 4 i + e, so one
+    // 16-byte load per position feeds four fragments (e = 0..3) and the feature rows are read once per block (they were read by all four
+    // waves, 4 bytes at a time).  The features beyond 256 (LDF = 272: one fragment) stay with the old mapping, value fragment w.
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fr = lane & 15, g4 = lane >> 4;
     const int chunk = blockIdx.x % s.S, g = (blockIdx.x / s.S) % s.G, b = blockIdx.x / (s.S * s.G);
-    const int nmf = s.LDF >> 4;
-    float4_t acc[17];
+    const int mlo = 64 * w + fr * 4;                       // this lane's 4 features
+    const bool has4 = mlo + 3 < s.LDF, hast = 256 + fr < s.LDF;
+    float4_t acc[4][4], acct = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int mf = 0; mf < 17; ++mf) acc[mf] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int df = 0; df < 4; ++df) acc[e][df] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
     for (int kk = 0; kk < 16; ++kk) {
         const int p = chunk * 64 + kk * 4 + g4;
         const bool ok = p < s.N;
         const int i = scan_pos(s, ok ? p : 0);
         const int64_t r = (int64_t)b * s.N + i, row = r * s.G + g;
-        float bv = s.b[r * s.b_stride + s.b_off + g * s.dv + w * 16 + fr];
-        if (s.b_scale) bv *= s.b_scale[row];
-        bv = ok ? bv : 0.f;
-        const float* ap = s.a + row * s.LDF + fr;
-        float av[17];
+        const float bs = ok ? (s.b_scale ? s.b_scale[row] : 1.f) : 0.f;
+        const float* bp = s.b + r * s.b_stride + s.b_off + g * s.dv + fr;
+        float bd[4];
 #pragma unroll
-        for (int mf = 0; mf < 17; ++mf) av[mf] = ap[(mf < nmf ? mf : 0) * 16];
+        for (int df = 0; df < 4; ++df) bd[df] = bp[df * 16] * bs;
+        const float* ap = s.a + row * s.LDF;
+        float4 a4 = *(const float4*)(ap + (has4 ? mlo : 0));
+        if (!has4) a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float at = hast ? ap[256 + fr] : 0.f;
+        const float ae[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-        for (int mf = 0; mf < 17; ++mf) acc[mf] = __builtin_amdgcn_mfma_f32_16x16x4f32(mf < nmf ? av[mf] : 0.f, bv, acc[mf], 0, 0, 0);
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int df = 0; df < 4; ++df) acc[e][df] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], bd[df], acc[e][df], 0, 0, 0);
+        acct = __builtin_amdgcn_mfma_f32_16x16x4f32(at, bd[w], acct, 0, 0, 0);
     }
     float* st = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * s.LDF * s.dv;
 #pragma unroll
-    for (int mf = 0; mf < 17; ++mf)
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = mf * 16 + g4 * 4 + r;
-            if (m < s.LDF) st[m * s.dv + w * 16 + fr] = acc[mf][r];
+            const int m = 64 * w + (g4 * 4 + r) * 4 + e;
+            if (m < s.LDF && m < 256) {
+#pragma unroll
+                for (int df = 0; df < 4; ++df) st[m * s.dv + df * 16 + fr] = acc[e][df][r];
+            }
         }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = 256 + g4 * 4 + r;
+        if (m < s.LDF) st[m * s.dv + w * 16 + fr] = acct[r];
+    }
 }
 
 // b tile of one chunk (with its per-position scale), zero beyond N
