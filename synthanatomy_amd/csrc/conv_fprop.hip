@@ -796,6 +796,140 @@ __global__ __launch_bounds__(256) void conv_fprop_halo_kernel(const FpropArgs a)
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Mainloop v8 "halo, 256 voxels": what bounds v5 is the barrier interval (32 MFMAs per wave per weight slab).  Here a tile is a 16 x 16
+// patch worked by FOUR waves of 128 x 64 outputs, so a 64-channel weight slab feeds 64 MFMAs per wave between barriers and half as many
+// weight bytes per FLOP.  To keep two independent blocks per CU (LDS <= 80 KiB) the halo image (18 x 18 x 128 B = 41 pieces) is
+// SINGLE-buffered: it is re-loaded at every (kd, chunk) switch behind a barrier, and that bubble is covered by the other block of the CU
+// (the next group's first weight slab is already in flight).  LDS 41 KiB + 2 x 16 KiB = 73 KiB.  Register epilogue only.
+// Measured on the C = 128 layer: data gradient 4.52 -> 4.30 ms (+5 %), plain forward +1.5 %; used for the non-fused launches.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_fprop_halo256_kernel(const FpropArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int MI = 8, NI = 4;
+    constexpr int BN = 128;
+    constexpr int HW_ = 18, HROWS = 324, HPIECES = 41;
+    constexpr int SZ = sizeof(T);
+    constexpr int HALO_BYTES = HPIECES * 1024;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const sA = smem;                   // 1 halo image
+    unsigned char* const sB = smem + HALO_BYTES;      // 2 weight slabs
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wm = wave >> 1, wn = wave & 1u;
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
+    const uint32_t n_base = bn * BN;
+    const sa_conv_geom& g = a.g;
+    // tile order = (n, band of 2 patch rows, d, row in band, wp)
+    const uint32_t per_vol = a.HP * a.WP * (uint32_t)g.Dm, band = 2u * a.WP * (uint32_t)g.Dm;
+    const uint32_t pn = bm / per_vol, rv = bm - pn * per_vol;
+    const uint32_t bc = rv / band, r2 = rv - bc * band;
+    const uint32_t rows_c = a.HP - 2u * bc < 2u ? a.HP - 2u * bc : 2u;
+    const uint32_t pd = r2 / (rows_c * a.WP), r3 = r2 - pd * rows_c * a.WP;
+    const uint32_t hpi = r3 / a.WP, wp = r3 - hpi * a.WP, hp = 2u * bc + hpi;
+    const int32_t h0 = (int32_t)hp * 16, w0 = (int32_t)wp * 16;
+    const int32_t oh = g.in_off[1] + (g.tap_step[1] < 0 ? 2 * g.tap_step[1] : 0), ow = g.in_off[2] + (g.tap_step[2] < 0 ? 2 * g.tap_step[2] : 0);
+
+    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (int)a.w_bytes, 0x00020000);
+
+    const uint32_t prow = lane >> 3;
+    const uint32_t lv = (lane & 7u) ^ prow;
+    uint32_t boff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) boff[j] = (n_base + (wave * 4 + j) * 8 + prow) * (uint32_t)(g.Kpad * SZ) + lv * 16u;
+
+    const uint32_t nchunk = (uint32_t)(g.Cin * SZ) / 128u;
+    const uint32_t ngroups = 3u * nchunk;
+    const uint32_t plane_bytes = (uint32_t)(g.Hi * g.Wi * g.Cin * SZ);
+    const uint32_t vox_bytes = (uint32_t)(g.Cin * SZ);
+    const uint32_t base_vox = (uint32_t)((int32_t)pn * g.Di * g.Hi * g.Wi);
+
+    // the whole halo image of group gi: pieces wave, wave + 4, ... (11 for wave 0, 10 for the others); offsets are recomputed here
+    // (no registers held across the loop: the 128 accumulators need them)
+    auto issue_halo = [&](uint32_t gi) __attribute__((always_inline)) {
+        const uint32_t td = gi / nchunk, ch = gi - td * nchunk;
+        const int32_t id = (int32_t)pd + g.in_off[0] + (int32_t)td * g.tap_step[0];
+        const bool dok = (uint32_t)id < (uint32_t)g.Di;
+        const uint32_t goff = (uint32_t)id * plane_bytes + ch * 128u + lv * 16u;
+#pragma unroll 1
+        for (uint32_t p = wave; p < (uint32_t)HPIECES; p += 4) {
+            const uint32_t r = p * 8 + prow;
+            const uint32_t hh = r / HW_, ww = r - hh * HW_;
+            const int32_t ih = h0 + oh + (int32_t)hh, iw = w0 + ow + (int32_t)ww;
+            const bool ok = dok && r < (uint32_t)HROWS && (uint32_t)ih < (uint32_t)g.Hi && (uint32_t)iw < (uint32_t)g.Wi;
+            const uint32_t voff = ok ? (base_vox + (uint32_t)(ih * g.Wi + iw)) * vox_bytes + goff : OOB_OFF;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(sA + p * 1024), 16, voff, 0, 0, 0);
+        }
+    };
+    auto issue_w = [&](uint32_t gi, uint32_t t9, uint32_t buf) __attribute__((always_inline)) {
+        const uint32_t td = gi / nchunk, ch = gi - td * nchunk;
+        const uint32_t col = ((td * 9u + t9) * (uint32_t)g.Cin) * SZ + ch * 128u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(sB + buf * (BN * 128) + (wave * 4 + j) * 1024), 16, boff[j], col, 0, 0);
+    };
+
+    float4_t acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t frow = lane & 15u, fq = lane >> 4;
+    const uint32_t a_base = ((wm * 8u) * HW_ + frow) * 128u + fq * 16u;   // unswizzled; patch row j adds 18 * 128 j
+    const uint32_t b_off = tile_off(wn * (NI * 16) + frow, fq);
+    const bool fh = g.tap_step[1] < 0, fw = g.tap_step[2] < 0;
+
+    issue_halo(0);
+    issue_w(0, 0, 0);
+    __syncthreads();
+    uint32_t buf = 0;
+    for (uint32_t gi = 0; gi < ngroups; ++gi) {
+        const bool next_group = gi + 1 < ngroups;
+#pragma unroll 1
+        for (uint32_t t9 = 0; t9 < 9; ++t9) {
+            {
+                const bool same = t9 < 8;
+                if (same || next_group) issue_w(same ? gi : gi + 1, same ? t9 + 1 : 0, buf ^ 1u);
+            }
+            const uint32_t th = t9 / 3u, tw = t9 - th * 3u;
+            const uint32_t tapoff = ((fh ? 2u - th : th) * (uint32_t)HW_ + (fw ? 2u - tw : tw)) * 128u;
+            const unsigned char* pb = sB + buf * (BN * 128);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 xf[MI], wf[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + ((b_off + i * 2048u) ^ (ks * 64u)));
+#pragma unroll
+                for (int j = 0; j < MI; ++j) {
+                    const uint32_t ad = a_base + tapoff + (uint32_t)j * (HW_ * 128u);
+                    xf[j] = *(const u32x4*)(sA + ((ad ^ (((ad >> 7) & 7u) << 4)) ^ (ks * 64u)));
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
+            }
+            __syncthreads();   // next weight slab landed (vmcnt(0)), this one free
+            buf ^= 1u;
+        }
+        if (next_group) {      // every wave is past its last read of the halo image: reload it (the first weight slab of the group is in flight)
+            issue_halo(gi + 1);
+            __syncthreads();
+        }
+    }
+    auto row_vox = [&](uint32_t row) __attribute__((always_inline)) {
+        const uint32_t h = (uint32_t)h0 + (row >> 4), w = (uint32_t)w0 + (row & 15u);
+        return h < (uint32_t)g.Ho && w < (uint32_t)g.Wo ? (((long long)pn * g.Do + pd) * g.Ho + h) * g.Wo + w : -1ll;
+    };
+    fprop_epilogue_regs<MI, NI>(a, acc, wm, wn, frow, fq, n_base, row_vox);
+#endif
+}
+
 template <typename T, int WM, int WN, int MI, int NI>
 static int launch_fprop(const FpropArgs& a, hipStream_t st) {
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
@@ -855,9 +989,38 @@ static int launch_fprop_halo(FpropArgs a, hipStream_t st) {
     return 0;
 }
 
+// the 256-voxel variant: register epilogue only (full, aligned 128-channel tiles), 16 x 16 patches that tile the plane well
+static bool halo256_eligible(const FpropArgs& a, int sz) {
+    const sa_conv_geom& g = a.g;
+    if (getenv("SA_NO_HALO256") != nullptr || !halo_eligible(a, sz)) return false;
+    if (g.cout_valid % 128 != 0 || (g.Cout & 7) != 0) return false;
+    const int hp = (g.Ho + 15) / 16, wp = (g.Wo + 15) / 16;
+    const double eff = (double)g.Ho * g.Wo / ((double)hp * 16 * wp * 16);
+    return eff >= 0.9 && (int64_t)g.N * g.Dm * hp * wp >= 256;
+}
+
+template <typename T>
+static int launch_fprop_halo256(FpropArgs a, hipStream_t st) {
+    a.HP = (uint32_t)(a.g.Ho + 15) / 16;
+    a.WP = (uint32_t)(a.g.Wo + 15) / 16;
+    a.nblk_m = (uint32_t)a.g.N * (uint32_t)a.g.Dm * a.HP * a.WP;
+    const uint32_t nbn = (uint32_t)a.g.cout_valid / 128;
+    const size_t lds = 41 * 1024 + 2 * 128 * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)conv_fprop_halo256_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_done = true;
+    }
+    snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo256_kernel<%s>", tname<T>());
+    hipLaunchKernelGGL((conv_fprop_halo256_kernel<T>), dim3(a.nblk_m * nbn), dim3(256), lds, st, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T>
 static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
     const int cv = a.g.cout_valid;
+    if (halo256_eligible(a, (int)sizeof(T))) return launch_fprop_halo256<T>(a, st);
     if (halo_eligible(a, (int)sizeof(T))) return launch_fprop_halo<T, false>(a, st);
     // (measured and removed: a 3-stage ring with 8 waves and counted vmcnt = the 2-stage loop; an 8-wave ping-pong with staggered
     // barriers and s_setprio = -7 %: the L2 -> LDS operand stream bounds this loop, not the barrier structure.  DESIGN.md section 4.1)
