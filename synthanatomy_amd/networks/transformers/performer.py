@@ -882,7 +882,8 @@ class Performer(TransformerBase):
                 pos.zero_()
                 seq.copy_(seq0)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # thread_local: other threads of the process (the RCCL watchdog of a distributed run) may call HIP during the capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     one_step()
             except Exception as exc:               # capture is an optimisation: fall back to eager launches of the same O(N) step
                 import warnings
