@@ -257,7 +257,7 @@ def main():
         # its avg_launch_us has to be comparable with rocprofv3's per-kernel average
         single = {k: v for k, v in stats.items() if "+" not in k} or stats
         dom = max(single.items(), key=lambda kv: kv[1][2])
-        name, (n, flops, ms) = dom
+        name, (n, flops, ms, _nb) = dom
         ach = flops / (ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
@@ -266,6 +266,16 @@ def main():
                 "kernels": {k: {"launches": v[0], "ms": round(v[2], 3), "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2) if v[2] > 0 else None}
                             for k, v in sorted(stats.items(), key=lambda kv: -kv[1][2])}}
 
+    roof_hbm = None
+    if timer is not None:
+        # the largest HBM-bound launch of the step (bandwidth-bound sub-kernels are reported against HBM): the fused
+        # 1x1x1 backward of the residual blocks.  Its bracket also covers the small partial-tile reduce (< 3 % of the time).
+        hb = {k: v for k, v in stats.items() if v[3] > 0}
+        if hb:
+            k, v = max(hb.items(), key=lambda kv: kv[1][2])
+            gbs = v[3] / (v[2] * 1e-3) / 1e9
+            roof_hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                        "traffic": _pmc_traffic(k.split("+")[0], args), "kernel": k, "launches": v[0], "avg_launch_us": round(v[2] * 1e3 / v[0], 2)}
     if rank == 0:
         vols = args.batch * world * args.steps
         value = vols / dt
@@ -281,6 +291,8 @@ def main():
         }
         if roof is not None:
             line["roofline"] = roof
+        if roof_hbm is not None:
+            line["roofline_hbm"] = roof_hbm
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
     # "report also inference (index_quantize + decode_samples) volumes/s"

@@ -26,25 +26,26 @@ class KernelTimer:
     FLOPs and -- after ``collect()`` -- device time."""
 
     def __init__(self):
-        self.pending = []   # (key, flops, ev0, ev1)
-        self.stats = {}     # key -> [launches, flops, ms]
+        self.pending = []   # (key, flops, ev0, ev1, bytes)
+        self.stats = {}     # key -> [launches, flops, ms, algorithmic bytes]
 
-    def wrap(self, key, flops, fn):
+    def wrap(self, key, flops, fn, nbytes=0.0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
         if key is None or key == "+wgrad_reduce_kernel":  # convolution launches: the dispatcher says which instance it picked
             key = _ffi.lib().sa_last_conv_kernel().decode() + (key or "")
-        self.pending.append((key, flops, e0, e1))
+        self.pending.append((key, flops, e0, e1, nbytes))
 
     def collect(self):
         torch.cuda.synchronize()
-        for key, flops, e0, e1 in self.pending:
-            st = self.stats.setdefault(key, [0, 0.0, 0.0])
+        for key, flops, e0, e1, nbytes in self.pending:
+            st = self.stats.setdefault(key, [0, 0.0, 0.0, 0.0])
             st[0] += 1
             st[1] += flops
             st[2] += e0.elapsed_time(e1)
+            st[3] += nbytes
         self.pending = []
         return self.stats
 
@@ -57,9 +58,9 @@ def _geom_flops(g) -> float:
     return 2.0 * m * (g.KT[0] * g.KT[1] * g.KT[2]) * g.cin_valid * g.cout_valid
 
 
-def _launch(key, flops, fn):
+def _launch(key, flops, fn, nbytes=0.0):
     if TIMER is not None:
-        TIMER.wrap(key, flops, fn)
+        TIMER.wrap(key, flops, fn, nbytes)
     else:
         fn()
 
@@ -323,8 +324,8 @@ def conv1x1_backward(op: "ConvOp", x: torch.Tensor, g: torch.Tensor, dw: torch.T
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     flops = 2.0 * _geom_flops(pw.geom)
-    _launch("+wgrad_reduce_kernel", flops,
-            lambda: _ffi.check(lib.sa_conv1x1_backward(ctypes.byref(pw.geom), did, _ffi.ptr(x), _ffi.ptr(g), _ffi.ptr(dw), _ffi.ptr(db), pw.s_row, pw.s_red, _ffi.ptr(ws),
+    _launch("+wgrad_reduce_kernel", flops, nbytes=3.0 * x.numel() * x.element_size(),   # algorithmic bytes: read x and g once, write dx once
+            fn=lambda: _ffi.check(lib.sa_conv1x1_backward(ctypes.byref(pw.geom), did, _ffi.ptr(x), _ffi.ptr(g), _ffi.ptr(dw), _ffi.ptr(db), pw.s_row, pw.s_red, _ffi.ptr(ws),
                                                         nbytes, _ffi.ptr(pd.wpk), _ffi.ptr(dx), st), "sa_conv1x1_backward"))
     return dx
 
