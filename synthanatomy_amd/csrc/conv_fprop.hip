@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256) void conv_fprop_halo_kernel(const FpropArgs a)
 // SINGLE-buffered: it is re-loaded at every (kd, chunk) switch behind a barrier, and that bubble is covered by the other block of the CU
 // (the next group's first weight slab is already in flight).  LDS 41 KiB + 2 x 16 KiB = 73 KiB.  Register epilogue only.
 // Measured on the C = 128 layer: data gradient 4.52 -> 4.30 ms (+5 %), plain forward +1.5 %; used for the non-fused launches.
-template <typename T>
+template <typename T, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_fprop_halo256_kernel(const FpropArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int MI = 8, NI = 4;
@@ -926,6 +926,54 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_halo256_kernel(const FpropA
         const uint32_t h = (uint32_t)h0 + (row >> 4), w = (uint32_t)w0 + (row & 15u);
         return h < (uint32_t)g.Ho && w < (uint32_t)g.Wo ? (((long long)pn * g.Do + pd) * g.Ho + h) * g.Wo + w : -1ll;
     };
+    if constexpr (FUSE) {
+        static_assert(!FUSE || sizeof(T) == 2, "fused residual block: bf16");
+        // Second GEMM of the residual block for the 256 rows: h = relu(acc + b1) goes to LDS as two [256][128 B] K-slabs (64 KiB, the
+        // ring is free: the loop's last barrier), the 1x1x1 weights are the MFMA A operand held in REGISTERS (16 fragments per wave, read
+        // from the packed operand [128 co][128 c]), so nothing but h needs LDS and the block stays at two per CU.
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const uint32_t c0 = wn * (NI * 16) + i * 16 + fq * 4;
+            const float4_t b1 = *(const float4_t*)(a.bias1 + c0);
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                const uint32_t row = wm * (MI * 16) + j * 16 + frow;
+                const float4_t v = acc[i][j] + b1;
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(fmaxf(v[0], 0.f)) | ((uint32_t)f32_to_bf16(fmaxf(v[1], 0.f)) << 16);
+                pk.y = (uint32_t)f32_to_bf16(fmaxf(v[2], 0.f)) | ((uint32_t)f32_to_bf16(fmaxf(v[3], 0.f)) << 16);
+                *(uint2*)(smem + (c0 >> 6) * (256 * 128) + tile_off(row, (c0 & 63u) >> 3) + (c0 & 7u) * 2) = pk;
+                acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        u32x4 w2[NI][4];
+        {
+            const bf16_t* wp = (const bf16_t*)a.w2pk;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) w2[i][ks] = *(const u32x4*)(wp + (wn * 64 + i * 16 + frow) * 128 + ks * 32 + fq * 8);
+        }
+        __syncthreads();  // h tile complete
+        if (a.h_out) {    // training: the hidden activation is needed by the backward pass -> full 256-byte rows
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const uint32_t row = (tid >> 4) + 16u * it, sl = (tid >> 3) & 1u, vec = tid & 7u;
+                const long long vox = row_vox(row);
+                if (vox >= 0) *(u32x4*)((bf16_t*)a.h_out + (size_t)vox * 128 + sl * 64 + vec * 8) = *(const u32x4*)(smem + sl * (256 * 128) + tile_off(row, vec));
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            u32x4 xf[MI];
+#pragma unroll
+            for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(smem + (ks >> 1) * (256 * 128) + tile_off(wm * (MI * 16) + j * 16 + frow, (ks & 1) * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], w2[i][ks], xf[j]);
+        }
+    }
     fprop_epilogue_regs<MI, NI>(a, acc, wm, wn, frow, fq, n_base, row_vox);
 #endif
 }
@@ -999,20 +1047,20 @@ static bool halo256_eligible(const FpropArgs& a, int sz) {
     return eff >= 0.9 && (int64_t)g.N * g.Dm * hp * wp >= 256;
 }
 
-template <typename T>
+template <typename T, bool FUSE = false>
 static int launch_fprop_halo256(FpropArgs a, hipStream_t st) {
     a.HP = (uint32_t)(a.g.Ho + 15) / 16;
     a.WP = (uint32_t)(a.g.Wo + 15) / 16;
     a.nblk_m = (uint32_t)a.g.N * (uint32_t)a.g.Dm * a.HP * a.WP;
     const uint32_t nbn = (uint32_t)a.g.cout_valid / 128;
-    const size_t lds = 41 * 1024 + 2 * 128 * 128;
+    const size_t lds = 41 * 1024 + 2 * 128 * 128;   // 73 KiB (>= the 64 KiB hidden tile of the fused variant)
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)conv_fprop_halo256_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipFuncSetAttribute((const void*)conv_fprop_halo256_kernel<T, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_done = true;
     }
-    snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo256_kernel<%s>", tname<T>());
-    hipLaunchKernelGGL((conv_fprop_halo256_kernel<T>), dim3(a.nblk_m * nbn), dim3(256), lds, st, a);
+    snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo256_kernel<%s, %s>", tname<T>(), FUSE ? "true" : "false");
+    hipLaunchKernelGGL((conv_fprop_halo256_kernel<T, FUSE>), dim3(a.nblk_m * nbn), dim3(256), lds, st, a);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -1120,6 +1168,7 @@ extern "C" int sa_resblock_fprop(const sa_conv_geom* g, int dtype, const void* x
     a.bias1 = bias1;
     a.h_out = h_out;
     a.dbg = 0;
+    if (halo256_eligible(a, 2) && getenv("SA_NO_HALO256_FUSE") == nullptr) return launch_fprop_halo256<bf16_t, true>(a, (hipStream_t)stream);
     if (halo_eligible(a, 2)) return launch_fprop_halo<bf16_t, true>(a, (hipStream_t)stream);
     const size_t pipe = 2 * (128 + 128) * 128, epi = (size_t)128 * (128 + 4) * 4 + 128 * 8;
     snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma_kernel<unsigned short, 2, 2, 4, 4, true, true>");
