@@ -687,6 +687,8 @@ __global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradArgs a)
 // the activation halo tile [10 x 18][64 ci] (128-byte rows, 23 pieces) feed all NINE (kh, kw) taps.  8 waves: wave = (16-ci fragment,
 // 64-co half), 9 taps x 4 co fragments = 36 accumulators (144 VGPRs), 144 MFMAs per step and barrier (32 above).
 // Operand bytes per FLOP: 2.9 KB/MFLOP against 5.4 (three taps) and 15.6 (im2col order).
+// Measured dead end: touching the lines of step st+2 ahead of time (4-byte LDS-DMA lanes into a scratch slot, counted vmcnt) made it 10 %
+// slower -- the 40 % of wave time parked on the per-step wait is DMA throughput, not HBM latency.
 // 128-byte rows: 32-byte chunk c of row m sits at chunk c ^ ((m >> 1) & 3), which gives the transposing reads of 8 consecutive rows 8
 // distinct 32-byte bank groups (rows of equal parity share a 256-byte bank line).
 __device__ __forceinline__ uint32_t roff128(uint32_t m, uint32_t c) { return m * 128u + ((((c >> 4) ^ ((m >> 1) & 3u)) << 5) | ((c & 15u) << 1)); }
