@@ -85,6 +85,10 @@ _SIGS = {
                                 c_int, c_int, c_void_p, c_void_p]),
     "sa_favor_scan_b": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                 c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "sa_favor_scan_a_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                     c_void_p]),
+    "sa_favor_scan_b_cum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_int,
+                                    c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sa_cumsum_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sa_favor_den": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "sa_favor_dden": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -132,6 +136,9 @@ def lib():
             raise HipLibraryError("ABI version mismatch")
         _lib = l
     return _lib
+
+
+SA_EINVAL, SA_EUNSUPPORTED, SA_ENOGPU = -1, -2, -3   # include/synthanatomy_hip.h
 
 
 def check(rc: int, what: str = ""):

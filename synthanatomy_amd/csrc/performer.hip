@@ -316,8 +316,15 @@ struct ScanArgs {
     // segment parallelism: the N positions are cut into S segments scanned by independent blocks.
     // pass 0: one segment, no state buffer.  pass 1: accumulate only the segment's state sum into `state`.
     // (scan_state_prefix_kernel turns the sums into exclusive prefixes.)  pass 2: start from the prefix and emit y.
-    float* state;         // [B, G, S, LDF, dv]
+    float* state;         // [B, G, S, LDF, dv (+1 when zmode)]
     int32_t pass, S, seg_len;
+    // chunked MFMA path only: the running column sums z = sum_j a_j w_j ride along as one extra state column, which removes the separate
+    // cumsum / normaliser passes:  zmode 1: w = 1;   scan A: y_i /= c_i . (z_i + den_eps)  (inv written to inv_out);
+    //                                               scan B: y_i[m] += ex_scale_i * (z_i[m] + ex_const)
+    //                             zmode 2: w = ex_scale;  scan B: y_i[m] += z_i[m]
+    int32_t zmode;
+    float den_eps;
+    float* inv_out;
 };
 
 constexpr int SCAN_TB = 8;  // positions staged per barrier
@@ -467,10 +474,13 @@ __global__ __launch_bounds__(256) void favor_chunk_state_kernel(const ScanArgs s
     const int mlo = 64 * w + fr * 4;                       // this lane's 4 features
     const bool has4 = mlo + 3 < s.LDF, hast = 256 + fr < s.LDF;
     float4_t acc[4][4], acct = (float4_t){0.f, 0.f, 0.f, 0.f};
+    float4_t accz[4], acczt = (float4_t){0.f, 0.f, 0.f, 0.f};   // zmode: column 0 of an extra value fragment = sum_j a_j w_j
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < 4; ++e) {
+        accz[e] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int df = 0; df < 4; ++df) acc[e][df] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll 2
     for (int kk = 0; kk < 16; ++kk) {
         const int p = chunk * 64 + kk * 4 + g4;
@@ -492,8 +502,30 @@ __global__ __launch_bounds__(256) void favor_chunk_state_kernel(const ScanArgs s
 #pragma unroll
             for (int df = 0; df < 4; ++df) acc[e][df] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], bd[df], acc[e][df], 0, 0, 0);
         acct = __builtin_amdgcn_mfma_f32_16x16x4f32(at, bd[w], acct, 0, 0, 0);
+        if (s.zmode) {
+            const float wz = (ok && fr == 0) ? (s.zmode == 2 ? s.ex_scale[row] : 1.f) : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accz[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[e], wz, accz[e], 0, 0, 0);
+            acczt = __builtin_amdgcn_mfma_f32_16x16x4f32(at, wz, acczt, 0, 0, 0);
+        }
     }
-    float* st = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * s.LDF * s.dv;
+    const int64_t zs = (int64_t)s.LDF * s.dv + (s.zmode ? s.LDF : 0);
+    float* st = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * zs;
+    if (s.zmode && fr == 0) {
+        float* zp = st + (int64_t)s.LDF * s.dv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 64 * w + (g4 * 4 + r) * 4 + e;
+                if (m < s.LDF && m < 256) zp[m] = accz[e][r];
+            }
+        if (w == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (256 + g4 * 4 + r < s.LDF) zp[256 + g4 * 4 + r] = acczt[r];
+        }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -566,7 +598,26 @@ __global__ __launch_bounds__(256) void favor_chunk_out_a_kernel(const ScanArgs s
         for (int r = 0; r < 4; ++r)
             if (!vj || jf * 16 + g4 * 4 + r > w * 16 + fr) P[jf][r] = 0.f;
     }
-    const float* st = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * s.LDF * s.dv + (int64_t)g4 * span * s.dv + fr;
+    const int64_t zs = (int64_t)s.LDF * s.dv + (s.zmode ? s.LDF : 0);
+    const float* st0 = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * zs;
+    const float* st = st0 + (int64_t)g4 * span * s.dv + fr;
+    // zmode 1: normaliser  den_i = c_i . (z_prev + sum_{j <= i in chunk} a_j + den_eps)  from the masked pair products already in P
+    float inv_n = 1.f;
+    if (s.zmode == 1) {
+        const float4* zp = (const float4*)(st0 + (int64_t)s.LDF * s.dv + g4 * span);
+        float part = 0.f;
+#pragma unroll
+        for (int t = 0; t < 17; ++t) {
+            const float4 zv = zp[t < q4 ? t : 0];
+            part = fmaf(Creg[t * 4 + 0], zv.x + s.den_eps, fmaf(Creg[t * 4 + 1], zv.y + s.den_eps, fmaf(Creg[t * 4 + 2], zv.z + s.den_eps, fmaf(Creg[t * 4 + 3], zv.w + s.den_eps, part))));
+        }
+#pragma unroll
+        for (int jf = 0; jf < 4; ++jf) part += (P[jf][0] + P[jf][1]) + (P[jf][2] + P[jf][3]);
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        inv_n = 1.f / part;
+        if (vi && g4 == 0 && s.inv_out) s.inv_out[rowi] = inv_n;
+    }
     float4_t acc[4];
 #pragma unroll
     for (int df = 0; df < 4; ++df) acc[df] = (float4_t){0.f, 0.f, 0.f, 0.f};
@@ -585,7 +636,7 @@ __global__ __launch_bounds__(256) void favor_chunk_out_a_kernel(const ScanArgs s
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[df] = __builtin_amdgcn_mfma_f32_16x16x4f32(sB[jf * 16 + g4 * 4 + r][df * 16 + fr], P[jf][r], acc[df], 0, 0, 0);
     if (!vi) return;
-    const float ys = s.y_scale ? s.y_scale[rowi] : 1.f;
+    const float ys = s.zmode == 1 ? inv_n : (s.y_scale ? s.y_scale[rowi] : 1.f);
     float* yp = s.y + ri * s.y_stride + s.y_off + g * s.dv;
 #pragma unroll
     for (int df = 0; df < 4; ++df) {
@@ -631,11 +682,27 @@ __global__ __launch_bounds__(256) void favor_chunk_out_b_kernel(const ScanArgs s
             P[jf] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, Creg[t * 4 + 2], P[jf], 0, 0, 0);
             P[jf] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, Creg[t * 4 + 3], P[jf], 0, 0, 0);
         }
+        // zmode: the running column sums enter as an additive term of the pair products: y_i[m] = sum_{j <= i} a_j[m] (b_j . c_i + E[j][i]),
+        // E = ex_scale_i (mode 1: ex_scale_i * cumsum(a)_i) or ex_scale_j (mode 2: cumsum(a * ex_scale)_i)
+        if (s.zmode == 1) {
+            const float ev = vi ? s.ex_scale[rowi] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[jf][r] += ev;
+        } else if (s.zmode == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pj = chunk * 64 + jf * 16 + g4 * 4 + r;
+                const int64_t rj = ((int64_t)b * s.N + scan_pos(s, pj < s.N ? pj : 0)) * s.G + g;
+                P[jf][r] += pj < s.N ? s.ex_scale[rj] : 0.f;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (jf * 16 + g4 * 4 + r > w * 16 + fr) P[jf][r] = 0.f;
     }
-    const float* st = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * s.LDF * s.dv + g4 * 16;
+    const int64_t zs = (int64_t)s.LDF * s.dv + (s.zmode ? s.LDF : 0);
+    const float* st0 = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * zs;
+    const float* st = st0 + g4 * 16;
     // a rows of the 16 positions j = jf*16 + g4*4 + r this lane feeds as the MFMA k index (clamped; P is zero for j beyond N)
     const float* arow[16];
 #pragma unroll
@@ -646,8 +713,10 @@ __global__ __launch_bounds__(256) void favor_chunk_out_b_kernel(const ScanArgs s
             arow[jf * 4 + r] = s.a + (((int64_t)b * s.N + scan_pos(s, pj < s.N ? pj : 0)) * s.G + g) * s.LDF + fr;
             if (pj >= s.N) P[jf][r] = 0.f;
         }
-    const float exs = (vi && s.ex_vec) ? (s.ex_scale ? s.ex_scale[rowi] : 1.f) : 0.f;
+    const float exs = (vi && (s.ex_vec || s.zmode == 1)) ? (s.ex_scale ? s.ex_scale[rowi] : 1.f) : 0.f;
     const float* evp = s.ex_vec ? s.ex_vec + rowi * s.LDF + g4 * 4 : nullptr;
+    const float* zpp = s.zmode ? st0 + (int64_t)s.LDF * s.dv + g4 * 4 : nullptr;   // running sums of the chunks before this one
+    const float zf = s.zmode == 1 ? exs : 1.f;
     float* yp = s.y + rowi * s.LDF + g4 * 4;
     for (int mf = 0; mf < nmf; ++mf) {
         float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f};
@@ -672,6 +741,11 @@ __global__ __launch_bounds__(256) void favor_chunk_out_b_kernel(const ScanArgs s
             if (evp) {
                 const float4 ev = *(const float4*)(evp + mf * 16);
                 o.x += exs * (ev.x + s.ex_const); o.y += exs * (ev.y + s.ex_const); o.z += exs * (ev.z + s.ex_const); o.w += exs * (ev.w + s.ex_const);
+            }
+            if (zpp) {
+                const float4 zv = *(const float4*)(zpp + mf * 16);
+                const float cadd = s.zmode == 1 ? exs * s.ex_const : 0.f;
+                o.x += zf * zv.x + cadd; o.y += zf * zv.y + cadd; o.z += zf * zv.z + cadd; o.w += zf * zv.w + cadd;
             }
             *(float4*)(yp + mf * 16) = o;
         }
@@ -1280,7 +1354,7 @@ static void scan_segments(int N, int& S, int& seg_len, const void* ws) {
 }
 
 extern "C" int64_t sa_favor_scan_workspace_bytes(int B, int N, int G, int LDF, int dv) {
-    return (int64_t)B * G * ((N + 63) / 64) * LDF * dv * 4;  // one state per 64-position chunk
+    return (int64_t)B * G * ((N + 63) / 64) * LDF * (dv + 1) * 4;  // one state (+ its running column sums) per 64-position chunk
 }
 
 // which == 0: scan A, 1: scan B.  With a workspace: chunked MFMA path (3 launches); without: one VALU block per (b, g).
@@ -1294,8 +1368,12 @@ static int run_scan(K valu_kernel, int which, ScanArgs& s, unsigned base_blocks,
         return 0;
     }
     s.state = ws;
-    const int64_t elems = (int64_t)s.LDF * s.dv, bg = (int64_t)s.B * s.G;
-    if (!no_mfma && (s.LDF & 15) == 0 && s.LDF <= 272 && s.dv == 64) {
+    const int64_t bg = (int64_t)s.B * s.G;
+    int64_t elems = (int64_t)s.LDF * s.dv;
+    const bool mfma_ok = !no_mfma && (s.LDF & 15) == 0 && s.LDF <= 272 && s.dv == 64;
+    if (s.zmode && !mfma_ok) return SA_EUNSUPPORTED;   // the fused running sums exist on the chunked MFMA path only
+    if (mfma_ok) {
+        elems += s.zmode ? s.LDF : 0;
         s.S = (s.N + 63) / 64;
         s.seg_len = 64;
         const unsigned nblk = (unsigned)(bg * s.S);
@@ -1464,4 +1542,34 @@ extern "C" int sa_gemv_rows(const float* x, int x_stride, int in, int B, int nse
         SA_CHECK_LAUNCH();
     }
     return 0;
+}
+
+// scan A with the FAVOR+ normaliser fused: y_i = (sum_{j<=i} (c_i . a_j) b_j) / (c_i . (sum_{j<=i} a_j + den_eps)); inv_out[i] = 1 / that
+// denominator (kept for the backward pass).  Replaces sa_cumsum_rows + sa_favor_den + sa_favor_scan_a(y_scale = inv).  Chunked MFMA
+// path only (LDF % 16 == 0, LDF <= 272, dv == 64, workspace given): SA_EUNSUPPORTED otherwise.
+extern "C" int sa_favor_scan_a_norm(const float* a, const float* c, const float* b, int b_stride, int b_off, float* y, int y_stride, int y_off, float* inv_out,
+                                    float den_eps, int B, int N, int G, int LDF, int dv, float* state_ws, void* stream) {
+    if (!a || !c || !b || !y || !inv_out || !state_ws) return SA_EINVAL;
+    if (check_scan(B, N, G, LDF, dv)) return SA_EUNSUPPORTED;
+    ScanArgs s = {};
+    s.a = a; s.c_feat = c; s.b = b; s.y = y;
+    s.B = B; s.N = N; s.G = G; s.LDF = LDF; s.dv = dv; s.b_stride = b_stride; s.b_off = b_off; s.y_stride = y_stride; s.y_off = y_off;
+    s.zmode = 1; s.den_eps = den_eps; s.inv_out = inv_out;
+    return run_scan(favor_scan_a_kernel, 0, s, (unsigned)(B * G * (dv / 16)), state_ws, ST(stream));
+}
+
+// scan B with a cumulative extra term computed on the fly (no cumsum pass, no [B,N,G,LDF] operand):
+//   ex_mode 1: y_i[m] += ex_scale_i * (sum_{j<=i} a_j[m] + ex_const)      (gradient wrt the query features: ex_scale = d den)
+//   ex_mode 2: y_i[m] += sum_{j<=i} a_j[m] ex_scale_j                     (gradient wrt the key features, reversed scan)
+// (j <= i in scan order).  Chunked MFMA path only.
+extern "C" int sa_favor_scan_b_cum(const float* a, const float* b, int b_stride, int b_off, const float* b_scale, const float* c, int c_stride, int c_off,
+                                   const float* c_scale, float* y, const float* ex_scale, int ex_mode, float ex_const, int B, int N, int G, int LDF, int dv,
+                                   int reverse, float* state_ws, void* stream) {
+    if (!a || !b || !c || !y || !ex_scale || !state_ws || (ex_mode != 1 && ex_mode != 2)) return SA_EINVAL;
+    if (check_scan(B, N, G, LDF, dv)) return SA_EUNSUPPORTED;
+    ScanArgs s = {};
+    s.a = a; s.b = b; s.c_col = c; s.b_scale = b_scale; s.c_scale = c_scale; s.y = y; s.ex_scale = ex_scale; s.ex_vec = nullptr; s.ex_const = ex_const;
+    s.B = B; s.N = N; s.G = G; s.LDF = LDF; s.dv = dv; s.b_stride = b_stride; s.b_off = b_off; s.c_stride = c_stride; s.c_off = c_off; s.reverse = reverse;
+    s.zmode = ex_mode;
+    return run_scan(favor_scan_b_kernel, 1, s, (unsigned)(B * G * ((LDF + 63) / 64)), state_ws, ST(stream));
 }

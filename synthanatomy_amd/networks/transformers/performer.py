@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from enum import Enum
 from typing import List, Optional, Sequence, Tuple, Union
 
@@ -280,6 +281,7 @@ class _LayerEngine:
         self.ops = {n: _lin(getattr(sa, n), dtype) for n in ("to_q", "to_k", "to_v", "to_out")}
         self.ops["w1"], self.ops["w2"] = _lin(ff.w1, dtype), _lin(ff.w2, dtype)
         self._pscaled = None
+        self._fused_sums = os.environ.get("SA_NO_FUSED_SUMS") is None
         self._pop = None
         self._rot = None
         self._one = None
@@ -363,13 +365,20 @@ class _LayerEngine:
             gws = torch.zeros(2, dtype=torch.int64, device=dev)
             _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddq), _ffi.ptr(qg), G * dh, 0, G, dh, 1, _ffi.ptr(qf), None, R * G, m, LDF, st), "favor_features(q)")
             _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddk), _ffi.ptr(kg), G * dh, 0, G, dh, 0, _ffi.ptr(kf), _ffi.ptr(gws), R * G, m, LDF, st), "favor_features(k)")
-            Z = torch.empty_like(kf)
             ws = self._scan_ws(B, N, G, dev)
-            _ck(lib.sa_cumsum_rows(_ffi.ptr(kf), None, _ffi.ptr(Z), B, N, G, LDF, 0, _ffi.ptr(ws), st), "sa_cumsum_rows")
             inv = torch.empty(R * G, dtype=f32, device=dev)
-            _ck(lib.sa_favor_den(_ffi.ptr(qf), _ffi.ptr(Z), 1e-6, _ffi.ptr(inv), R * G, m, LDF, st), "sa_favor_den")
-            _ck(lib.sa_favor_scan_a(_ffi.ptr(kf), _ffi.ptr(qf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(attn), inner, 0, _ffi.ptr(inv), B, N, G, LDF, dh, 0, 0,
-                                    _ffi.ptr(ws), st), "sa_favor_scan_a")
+            Z = None
+            # normaliser fused into the scan (the running key sums ride along as an extra state column): no cumsum / den passes
+            rc = lib.sa_favor_scan_a_norm(_ffi.ptr(kf), _ffi.ptr(qf), _ffi.ptr(v), inner, 0, _ffi.ptr(attn), inner, 0, _ffi.ptr(inv), 1e-6, B, N, G, LDF, dh,
+                                          _ffi.ptr(ws), st) if self._fused_sums else _ffi.SA_EUNSUPPORTED
+            if rc == _ffi.SA_EUNSUPPORTED:
+                Z = torch.empty_like(kf)
+                _ck(lib.sa_cumsum_rows(_ffi.ptr(kf), None, _ffi.ptr(Z), B, N, G, LDF, 0, _ffi.ptr(ws), st), "sa_cumsum_rows")
+                _ck(lib.sa_favor_den(_ffi.ptr(qf), _ffi.ptr(Z), 1e-6, _ffi.ptr(inv), R * G, m, LDF, st), "sa_favor_den")
+                _ck(lib.sa_favor_scan_a(_ffi.ptr(kf), _ffi.ptr(qf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(attn), inner, 0, _ffi.ptr(inv), B, N, G, LDF, dh, 0, 0,
+                                        _ffi.ptr(ws), st), "sa_favor_scan_a")
+            else:
+                _ck(rc, "sa_favor_scan_a_norm")
             sv.update(qg=qg, kg=kg, ddq=ddq, ddk=ddk, qf=qf, kf=kf, gws=gws, Z=Z, inv=inv)
         if L > 0:
             cosb, sinb = self._rot_tables(N, dev)
@@ -529,13 +538,19 @@ class _LayerEngine:
             _ck(lib.sa_favor_dden(_ffi.ptr(dattn), _ffi.ptr(attn), inner, 0, G, dh, _ffi.ptr(inv), _ffi.ptr(dden), R * G, st), "sa_favor_dden")
             ws = self._scan_ws(B, N, G, dev)
             dqf = torch.empty_like(qf)
-            _ck(lib.sa_favor_scan_b(_ffi.ptr(kf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dqf), _ffi.ptr(dden), _ffi.ptr(Z),
-                                    1e-6, B, N, G, LDF, dh, 0, _ffi.ptr(ws), st), "sa_favor_scan_b(dq')")
-            rr = torch.empty_like(qf)
-            _ck(lib.sa_cumsum_rows(_ffi.ptr(qf), _ffi.ptr(dden), _ffi.ptr(rr), B, N, G, LDF, 1, _ffi.ptr(ws), st), "sa_cumsum_rows(rev)")
             dkf = torch.empty_like(kf)
-            _ck(lib.sa_favor_scan_b(_ffi.ptr(qf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dkf), None, _ffi.ptr(rr), 0.0,
-                                    B, N, G, LDF, dh, 1, _ffi.ptr(ws), st), "sa_favor_scan_b(dk')")
+            if Z is None:   # forward ran the fused form: the cumulative terms are rebuilt inside the scans as well
+                _ck(lib.sa_favor_scan_b_cum(_ffi.ptr(kf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dqf), _ffi.ptr(dden), 1, 1e-6,
+                                            B, N, G, LDF, dh, 0, _ffi.ptr(ws), st), "sa_favor_scan_b_cum(dq')")
+                _ck(lib.sa_favor_scan_b_cum(_ffi.ptr(qf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dkf), _ffi.ptr(dden), 2, 0.0,
+                                            B, N, G, LDF, dh, 1, _ffi.ptr(ws), st), "sa_favor_scan_b_cum(dk')")
+            else:
+                _ck(lib.sa_favor_scan_b(_ffi.ptr(kf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dqf), _ffi.ptr(dden), _ffi.ptr(Z),
+                                        1e-6, B, N, G, LDF, dh, 0, _ffi.ptr(ws), st), "sa_favor_scan_b(dq')")
+                rr = torch.empty_like(qf)
+                _ck(lib.sa_cumsum_rows(_ffi.ptr(qf), _ffi.ptr(dden), _ffi.ptr(rr), B, N, G, LDF, 1, _ffi.ptr(ws), st), "sa_cumsum_rows(rev)")
+                _ck(lib.sa_favor_scan_b(_ffi.ptr(qf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dkf), None, _ffi.ptr(rr), 0.0,
+                                        B, N, G, LDF, dh, 1, _ffi.ptr(ws), st), "sa_favor_scan_b(dk')")
             _ck(lib.sa_favor_scan_a(_ffi.ptr(qf), _ffi.ptr(kf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dv), inner, 0, None, B, N, G, LDF, dh, 1, 0,
                                     _ffi.ptr(ws), st), "sa_favor_scan_a(dv)")
             pop = self._proj_op()

@@ -152,6 +152,28 @@ def test_causal_scan_variants_against_einsum(N, reverse):
         assert _rel(ya.view(B, N, G, dv).cpu().double(), refA) < 1e-4
         assert _rel(yb[..., :m].cpu().double(), refB[..., :m]) < 1e-4
     assert _rel(outs[0][0], outs[1][0]) < 1e-4 and _rel(outs[0][1][..., :m], outs[1][1][..., :m]) < 1e-4
+    # ---- the fused running sums (chunked MFMA path): cumulative extra terms and the normaliser without cumsum / den passes
+    trif = tri
+    cum_a = torch.einsum("ij,bjgm->bigm", trif, a)                                   # sum_{j <= i (scan order)} a_j
+    cum_aw = torch.einsum("ij,bjgm->bigm", trif, a * bs[..., None])                  # ... weighted by ex_scale_j
+    base = torch.einsum("bjgm,bjgd,ij,bigd->bigm", a, bsc, trif, cc * ys[..., None])
+    y1 = torch.zeros(B, N, G, LDF, device="cuda")
+    _ffi.check(lib.sa_favor_scan_b_cum(_ffi.ptr(ad), _ffi.ptr(bd), G * dv, 0, _ffi.ptr(bsd), _ffi.ptr(ccd), G * dv, 0, _ffi.ptr(ysd), _ffi.ptr(y1), _ffi.ptr(bsd), 1, 0.25,
+                                       B, N, G, LDF, dv, reverse, _ffi.ptr(ws), st))
+    assert _rel(y1[..., :m].cpu().double(), (base + bs[..., None] * (cum_a + 0.25))[..., :m]) < 1e-4
+    y2 = torch.zeros(B, N, G, LDF, device="cuda")
+    _ffi.check(lib.sa_favor_scan_b_cum(_ffi.ptr(ad), _ffi.ptr(bd), G * dv, 0, _ffi.ptr(bsd), _ffi.ptr(ccd), G * dv, 0, _ffi.ptr(ysd), _ffi.ptr(y2), _ffi.ptr(bsd), 2, 0.0,
+                                       B, N, G, LDF, dv, reverse, _ffi.ptr(ws), st))
+    assert _rel(y2[..., :m].cpu().double(), (base + cum_aw)[..., :m]) < 1e-4
+    if not reverse:
+        num = torch.einsum("bigm,bjgm,ij,bjgd->bigd", c, a, trif, bb)
+        den = (c * (cum_a + 1e-6)).sum(-1, keepdim=True)
+        yn = torch.zeros(B * N, G * dv, device="cuda")
+        invn = torch.zeros(B * N * G, device="cuda")
+        _ffi.check(lib.sa_favor_scan_a_norm(_ffi.ptr(ad), _ffi.ptr(cd), _ffi.ptr(bd), G * dv, 0, _ffi.ptr(yn), G * dv, 0, _ffi.ptr(invn), 1e-6, B, N, G, LDF, dv,
+                                            _ffi.ptr(ws), st))
+        assert _rel(yn.view(B, N, G, dv).cpu().double(), num / den) < 1e-4
+        assert _rel(invn.view(B, N, G, 1).cpu().double(), 1.0 / den) < 1e-4
 
 
 @pytest.mark.parametrize("N,W", [(23, 5), (40, 8), (17, 32), (100, 420)])
