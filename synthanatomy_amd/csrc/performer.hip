@@ -162,20 +162,29 @@ __device__ __forceinline__ float unpack_max(unsigned long long p) {
 }
 
 __global__ void favor_global_max_kernel(const float* __restrict__ dd, int64_t rows, int m, int LDF, unsigned long long* __restrict__ out) {
+    // one wave per row, 16-byte loads (LDF % 4 == 0); the padding columns >= m are skipped
     unsigned long long best = 0ull;
-    const int64_t total = rows * m;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = e / m;
-        const int c = (int)(e - r * m);
-        const unsigned long long p = pack_max(dd[r * LDF + c], (uint32_t)(r * LDF + c));
-        best = p > best ? p : best;
+    const int lane = threadIdx.x & 63, nv = LDF >> 2;
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < rows; r += nw) {
+        const float4* rp = (const float4*)(dd + r * LDF);
+        for (int v = lane; v < nv; v += 64) {
+            const float4 x = rp[v];
+            const uint32_t i0 = (uint32_t)(r * LDF) + (uint32_t)v * 4u;
+            const int c = v * 4;
+            unsigned long long p;
+            if (c < m) { p = pack_max(x.x, i0); best = p > best ? p : best; }
+            if (c + 1 < m) { p = pack_max(x.y, i0 + 1); best = p > best ? p : best; }
+            if (c + 2 < m) { p = pack_max(x.z, i0 + 2); best = p > best ? p : best; }
+            if (c + 3 < m) { p = pack_max(x.w, i0 + 3); best = p > best ? p : best; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long ot = __shfl_xor(best, o, 64);
         best = ot > best ? ot : best;
     }
-    if ((threadIdx.x & 63) == 0) atomicMax(out, best);
+    if (lane == 0) atomicMax(out, best);
 }
 
 // one wave per row: feat = ratio * (exp(dd - |x|^2 c^2/2 - stab) + eps); stab = row max (query) or *gmax (key)

@@ -342,14 +342,17 @@ class _LayerEngine:
         return y, stats
 
     # ---------------------------------------------------------------------------------------------- forward
-    def fwd(self, x, B, N, tape):
+    def fwd(self, x, B, N, tape, x_lp=None):
+        """x_lp: the compute-dtype copy of x when the producer already wrote one (the previous block's ReZero kernel); the copy of this block's
+        output is left in ``self.out_lp`` for the next block (saves two cast launches per block on the ReZero path)."""
         self._sync()
         lib, st, dev, T = _ffi.lib(), _ffi.stream(), x.device, self.dtype
         R, H, G, L, dh, m, LDF = B * N, self.H, self.G, self.L, self.dh, self.m, self.LDF
         inner = H * dh
         f32 = torch.float32
+        lp = self.rezero and T != f32            # the residual kernel can emit the low-precision copy the next GEMM wants
         xa, st_a = self._pre(self.aw, x, R)
-        xaT = _cast(xa, T)
+        xaT = x_lp if (lp and x_lp is not None) else _cast(xa, T)
         q = self.ops["to_q"].fprop(_as5(xaT), out_dtype=f32).view(R, inner)
         k = self.ops["to_k"].fprop(_as5(xaT), out_dtype=f32).view(R, inner)
         v = self.ops["to_v"].fprop(_as5(xaT), out_dtype=f32).view(R, inner)
@@ -394,16 +397,21 @@ class _LayerEngine:
         Fa = self.ops["to_out"].fprop(_as5(attnT)).view(R, self.dim)
         x1 = torch.empty_like(x)
         ga = self._gate(self.aw, dev)
-        _ck(lib.sa_rezero_fwd(_ffi.ptr(x), _ffi.ptr(Fa), _ffi.dtype_id(Fa.dtype), _ffi.ptr(ga), _ffi.ptr(x1), None, 0, x.numel(), st), "sa_rezero_fwd")
+        x1T = torch.empty(x.shape, dtype=T, device=dev) if lp else None
+        _ck(lib.sa_rezero_fwd(_ffi.ptr(x), _ffi.ptr(Fa), _ffi.dtype_id(Fa.dtype), _ffi.ptr(ga), _ffi.ptr(x1), _ffi.ptr(x1T), _ffi.dtype_id(T) if lp else 0, x.numel(), st),
+            "sa_rezero_fwd")
         xf, st_f = self._pre(self.fw, x1, R)
-        xfT = _cast(xf, T)
+        xfT = x1T if lp else _cast(xf, T)
         u = self.ops["w1"].fprop(_as5(xfT)).view(R, -1)
         h = torch.empty_like(u)
         _ck(lib.sa_gelu(_ffi.ptr(u), _ffi.dtype_id(u.dtype), _ffi.ptr(h), _ffi.dtype_id(h.dtype), u.numel(), st), "sa_gelu")
         Ff = self.ops["w2"].fprop(_as5(h)).view(R, self.dim)
         x2 = torch.empty_like(x)
         gf = self._gate(self.fw, dev)
-        _ck(lib.sa_rezero_fwd(_ffi.ptr(x1), _ffi.ptr(Ff), _ffi.dtype_id(Ff.dtype), _ffi.ptr(gf), _ffi.ptr(x2), None, 0, x.numel(), st), "sa_rezero_fwd")
+        x2T = torch.empty(x.shape, dtype=T, device=dev) if lp else None
+        _ck(lib.sa_rezero_fwd(_ffi.ptr(x1), _ffi.ptr(Ff), _ffi.dtype_id(Ff.dtype), _ffi.ptr(gf), _ffi.ptr(x2), _ffi.ptr(x2T), _ffi.dtype_id(T) if lp else 0, x.numel(), st),
+            "sa_rezero_fwd")
+        self.out_lp = x2T
         if tape is not None:
             sv.update(attnT=attnT, Fa=Fa, x1=x1, xf=xf, xfT=xfT, st_f=st_f, u=u, h=h, Ff=Ff)
             tape.append(sv)
@@ -607,8 +615,10 @@ class _StackChain:
         B, N, D = x.shape
         x = x.reshape(B * N, D).float().contiguous()
         tape = [] if record else None
+        x_lp = None
         for l in self.layers:
-            x = l.fwd(x, B, N, tape)
+            x = l.fwd(x, B, N, tape, x_lp)
+            x_lp = l.out_lp
         return x.view(B, N, D), tape
 
     def backward(self, dy, tape):
