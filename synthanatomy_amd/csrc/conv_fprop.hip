@@ -1072,7 +1072,15 @@ static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
     if (halo_eligible(a, (int)sizeof(T))) return launch_fprop_halo<T, false>(a, st);
     // (measured and removed: a 3-stage ring with 8 waves and counted vmcnt = the 2-stage loop; an 8-wave ping-pong with staggered
     // barriers and s_setprio = -7 %: the L2 -> LDS operand stream bounds this loop, not the barrier structure.  DESIGN.md section 4.1)
-    if (cv > 64) return launch_fprop<T, 2, 2, 4, 4>(a, st);
+    if (cv > 64) {
+        // Small grids (the transformer's dense layers: 66 row tiles x N/128): 128 x 128 tiles at two blocks per CU leave the last round almost
+        // empty (528 blocks on 512 slots = two rounds).  128 x 64 tiles need 48 KiB of LDS -> three blocks per CU (768 slots) and half the
+        // work per block: N = 1024 takes ~1 unit instead of 2.  SA_NO_SMALL_TILES=1 keeps the wide tiles.
+        const uint64_t blocks128 = (uint64_t)a.nblk_m * (((uint32_t)cv + 127u) / 128u);
+        static const bool small_ok = getenv("SA_NO_SMALL_TILES") == nullptr;
+        if (small_ok && blocks128 < 2048 && a.in_bytes != 0) return launch_fprop<T, 4, 1, 2, 4>(a, st);
+        return launch_fprop<T, 2, 2, 4, 4>(a, st);
+    }
     if (cv > 32) return launch_fprop<T, 4, 1, 2, 4>(a, st);
     if (cv > 16) return launch_fprop<T, 4, 1, 2, 2>(a, st);
     return launch_fprop<T, 4, 1, 2, 1>(a, st);
