@@ -204,10 +204,16 @@ int sa_favor_scan_b(const float *a, const float *b, int b_stride, int b_off, con
  * sa_favor_scan_b_cum : ex_mode 1: y_i[m] += ex_scale_i * (sum_{j<=i} a_j[m] + ex_const);  ex_mode 2: y_i[m] += sum_{j<=i} a_j[m] ex_scale_j
  *                       (j <= i in scan order; = sa_cumsum_rows + sa_favor_scan_b with ex_vec). */
 int sa_favor_scan_a_norm(const float *a, const float *c, const float *b, int b_stride, int b_off, float *y, int y_stride, int y_off, float *inv_out,
-                         float den_eps, int B, int N, int G, int LDF, int dv, float *state_ws, void *stream);
+                         float den_eps, int B, int N, int G, int LDF, int dv, float *state_ws, int state_flags, void *stream);
 int sa_favor_scan_b_cum(const float *a, const float *b, int b_stride, int b_off, const float *b_scale, const float *c, int c_stride, int c_off,
                         const float *c_scale, float *y, const float *ex_scale, int ex_mode, float ex_const, int B, int N, int G, int LDF, int dv,
-                        int reverse, float *state_ws, void *stream);
+                        int reverse, float *state_ws, int state_flags, void *stream);
+/* state_flags bit 0: state_ws already holds the exclusive chunk prefixes of exactly this (a, b, b_scale, reverse) -- written by an earlier
+ * scan on the same operands -- so the state and prefix passes are skipped; bit 1 (sa_favor_scan_a_state): the buffer has the extra
+ * running-sum column.  Forward and dq' share one state set, dk' and dv another: two state passes per head instead of four. */
+int sa_favor_scan_a_state(const float *a, const float *c, const float *b, int b_stride, int b_off, const float *b_scale, float *y, int y_stride,
+                          int y_off, const float *y_scale, int B, int N, int G, int LDF, int dv, int reverse, int accumulate, float *state_ws,
+                          int state_flags, void *stream);
 int sa_cumsum_rows(const float *x, const float *scale, float *out, int B, int N, int G, int LDF, int reverse, float *seg_ws, void *stream);
 int sa_favor_den(const float *q, const float *z, float eps, float *inv, int64_t rows, int m, int LDF, void *stream);
 int sa_favor_dden(const float *dout, const float *out, int stride, int off, int G, int dv, const float *inv, float *dden, int64_t rows,

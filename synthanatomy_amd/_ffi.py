@@ -86,9 +86,11 @@ _SIGS = {
     "sa_favor_scan_b": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                 c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sa_favor_scan_a_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p,
-                                     c_void_p]),
+                                     c_int, c_void_p]),
     "sa_favor_scan_b_cum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_int,
-                                    c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+                                    c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "sa_favor_scan_a_state": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_int, c_void_p, c_int, c_void_p]),
     "sa_cumsum_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sa_favor_den": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "sa_favor_dden": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),

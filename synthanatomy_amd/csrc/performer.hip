@@ -332,6 +332,8 @@ struct ScanArgs {
     //                                               scan B: y_i[m] += ex_scale_i * (z_i[m] + ex_const)
     //                             zmode 2: w = ex_scale;  scan B: y_i[m] += z_i[m]
     int32_t zmode;
+    int32_t zcol;          // the state buffer has the extra column (stride LDF * dv + LDF); implied by zmode, may also be set alone to READ such a buffer
+    int32_t state_ready;   // host side: `state` already holds the exclusive chunk prefixes of exactly this (a, b, b_scale, reverse): skip both passes
     float den_eps;
     float* inv_out;
 };
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(256) void favor_chunk_state_kernel(const ScanArgs s
             acczt = __builtin_amdgcn_mfma_f32_16x16x4f32(at, wz, acczt, 0, 0, 0);
         }
     }
-    const int64_t zs = (int64_t)s.LDF * s.dv + (s.zmode ? s.LDF : 0);
+    const int64_t zs = (int64_t)s.LDF * s.dv + (s.zcol ? s.LDF : 0);
     float* st = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * zs;
     if (s.zmode && fr == 0) {
         float* zp = st + (int64_t)s.LDF * s.dv;
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(256) void favor_chunk_out_a_kernel(const ScanArgs s
         for (int r = 0; r < 4; ++r)
             if (!vj || jf * 16 + g4 * 4 + r > w * 16 + fr) P[jf][r] = 0.f;
     }
-    const int64_t zs = (int64_t)s.LDF * s.dv + (s.zmode ? s.LDF : 0);
+    const int64_t zs = (int64_t)s.LDF * s.dv + (s.zcol ? s.LDF : 0);
     const float* st0 = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * zs;
     const float* st = st0 + (int64_t)g4 * span * s.dv + fr;
     // zmode 1: normaliser  den_i = c_i . (z_prev + sum_{j <= i in chunk} a_j + den_eps)  from the masked pair products already in P
@@ -709,7 +711,7 @@ __global__ __launch_bounds__(256) void favor_chunk_out_b_kernel(const ScanArgs s
         for (int r = 0; r < 4; ++r)
             if (jf * 16 + g4 * 4 + r > w * 16 + fr) P[jf][r] = 0.f;
     }
-    const int64_t zs = (int64_t)s.LDF * s.dv + (s.zmode ? s.LDF : 0);
+    const int64_t zs = (int64_t)s.LDF * s.dv + (s.zcol ? s.LDF : 0);
     const float* st0 = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * zs;
     const float* st = st0 + g4 * 16;
     // a rows of the 16 positions j = jf*16 + g4*4 + r this lane feeds as the MFMA k index (clamped; P is zero for j beyond N)
@@ -1380,16 +1382,19 @@ static int run_scan(K valu_kernel, int which, ScanArgs& s, unsigned base_blocks,
     const int64_t bg = (int64_t)s.B * s.G;
     int64_t elems = (int64_t)s.LDF * s.dv;
     const bool mfma_ok = !no_mfma && (s.LDF & 15) == 0 && s.LDF <= 272 && s.dv == 64;
-    if (s.zmode && !mfma_ok) return SA_EUNSUPPORTED;   // the fused running sums exist on the chunked MFMA path only
+    if (s.zmode) s.zcol = 1;
+    if ((s.zcol || s.state_ready) && !mfma_ok) return SA_EUNSUPPORTED;   // the fused running sums / shared states exist on the chunked MFMA path only
     if (mfma_ok) {
-        elems += s.zmode ? s.LDF : 0;
+        elems += s.zcol ? s.LDF : 0;
         s.S = (s.N + 63) / 64;
         s.seg_len = 64;
         const unsigned nblk = (unsigned)(bg * s.S);
-        hipLaunchKernelGGL(favor_chunk_state_kernel, dim3(nblk), dim3(256), 0, st, s);
-        SA_CHECK_LAUNCH();
-        hipLaunchKernelGGL(scan_state_prefix_kernel, dim3((unsigned)((bg * elems + 255) / 256)), dim3(256), 0, st, ws, bg, s.S, elems);
-        SA_CHECK_LAUNCH();
+        if (!s.state_ready) {
+            hipLaunchKernelGGL(favor_chunk_state_kernel, dim3(nblk), dim3(256), 0, st, s);
+            SA_CHECK_LAUNCH();
+            hipLaunchKernelGGL(scan_state_prefix_kernel, dim3((unsigned)((bg * elems + 255) / 256)), dim3(256), 0, st, ws, bg, s.S, elems);
+            SA_CHECK_LAUNCH();
+        }
         if (which == 0) hipLaunchKernelGGL(favor_chunk_out_a_kernel, dim3(nblk), dim3(256), 0, st, s);
         else hipLaunchKernelGGL(favor_chunk_out_b_kernel, dim3(nblk), dim3(256), 0, st, s);
         SA_CHECK_LAUNCH();
@@ -1557,13 +1562,13 @@ extern "C" int sa_gemv_rows(const float* x, int x_stride, int in, int B, int nse
 // denominator (kept for the backward pass).  Replaces sa_cumsum_rows + sa_favor_den + sa_favor_scan_a(y_scale = inv).  Chunked MFMA
 // path only (LDF % 16 == 0, LDF <= 272, dv == 64, workspace given): SA_EUNSUPPORTED otherwise.
 extern "C" int sa_favor_scan_a_norm(const float* a, const float* c, const float* b, int b_stride, int b_off, float* y, int y_stride, int y_off, float* inv_out,
-                                    float den_eps, int B, int N, int G, int LDF, int dv, float* state_ws, void* stream) {
+                                    float den_eps, int B, int N, int G, int LDF, int dv, float* state_ws, int state_flags, void* stream) {
     if (!a || !c || !b || !y || !inv_out || !state_ws) return SA_EINVAL;
     if (check_scan(B, N, G, LDF, dv)) return SA_EUNSUPPORTED;
     ScanArgs s = {};
     s.a = a; s.c_feat = c; s.b = b; s.y = y;
     s.B = B; s.N = N; s.G = G; s.LDF = LDF; s.dv = dv; s.b_stride = b_stride; s.b_off = b_off; s.y_stride = y_stride; s.y_off = y_off;
-    s.zmode = 1; s.den_eps = den_eps; s.inv_out = inv_out;
+    s.zmode = 1; s.den_eps = den_eps; s.inv_out = inv_out; s.state_ready = state_flags & 1;
     return run_scan(favor_scan_a_kernel, 0, s, (unsigned)(B * G * (dv / 16)), state_ws, ST(stream));
 }
 
@@ -1573,12 +1578,29 @@ extern "C" int sa_favor_scan_a_norm(const float* a, const float* c, const float*
 // (j <= i in scan order).  Chunked MFMA path only.
 extern "C" int sa_favor_scan_b_cum(const float* a, const float* b, int b_stride, int b_off, const float* b_scale, const float* c, int c_stride, int c_off,
                                    const float* c_scale, float* y, const float* ex_scale, int ex_mode, float ex_const, int B, int N, int G, int LDF, int dv,
-                                   int reverse, float* state_ws, void* stream) {
+                                   int reverse, float* state_ws, int state_flags, void* stream) {
     if (!a || !b || !c || !y || !ex_scale || !state_ws || (ex_mode != 1 && ex_mode != 2)) return SA_EINVAL;
     if (check_scan(B, N, G, LDF, dv)) return SA_EUNSUPPORTED;
     ScanArgs s = {};
     s.a = a; s.b = b; s.c_col = c; s.b_scale = b_scale; s.c_scale = c_scale; s.y = y; s.ex_scale = ex_scale; s.ex_vec = nullptr; s.ex_const = ex_const;
     s.B = B; s.N = N; s.G = G; s.LDF = LDF; s.dv = dv; s.b_stride = b_stride; s.b_off = b_off; s.c_stride = c_stride; s.c_off = c_off; s.reverse = reverse;
-    s.zmode = ex_mode;
+    s.zmode = ex_mode; s.state_ready = state_flags & 1;
     return run_scan(favor_scan_b_kernel, 1, s, (unsigned)(B * G * ((LDF + 63) / 64)), state_ws, ST(stream));
+}
+
+// sa_favor_scan_a on a state buffer some other scan of the SAME (a, b, b_scale, reverse) already filled: state_flags bit 0 = the exclusive
+// chunk prefixes are in state_ws (skip the state and prefix passes), bit 1 = the buffer has the extra running-sum column (it was written
+// by sa_favor_scan_a_norm / sa_favor_scan_b_cum).  The three backward scans of a FAVOR+ head need two distinct state sets, not four.
+extern "C" int sa_favor_scan_a_state(const float* a, const float* c, const float* b, int b_stride, int b_off, const float* b_scale, float* y, int y_stride,
+                                     int y_off, const float* y_scale, int B, int N, int G, int LDF, int dv, int reverse, int accumulate, float* state_ws,
+                                     int state_flags, void* stream) {
+    if (!a || !c || !b || !y || !state_ws) return SA_EINVAL;
+    if (check_scan(B, N, G, LDF, dv)) return SA_EUNSUPPORTED;
+    ScanArgs s = {};
+    s.a = a; s.c_feat = c; s.b = b; s.b_scale = b_scale; s.y = y; s.y_scale = y_scale;
+    s.B = B; s.N = N; s.G = G; s.LDF = LDF; s.dv = dv; s.b_stride = b_stride; s.b_off = b_off; s.y_stride = y_stride; s.y_off = y_off;
+    s.reverse = reverse; s.accumulate = accumulate;
+    s.state_ready = state_flags & 1;
+    s.zcol = (state_flags >> 1) & 1;
+    return run_scan(favor_scan_a_kernel, 0, s, (unsigned)(B * G * (dv / 16)), state_ws, ST(stream));
 }

@@ -369,11 +369,13 @@ class _LayerEngine:
             _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddq), _ffi.ptr(qg), G * dh, 0, G, dh, 1, _ffi.ptr(qf), None, R * G, m, LDF, st), "favor_features(q)")
             _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddk), _ffi.ptr(kg), G * dh, 0, G, dh, 0, _ffi.ptr(kf), _ffi.ptr(gws), R * G, m, LDF, st), "favor_features(k)")
             ws = self._scan_ws(B, N, G, dev)
+            if tape is not None and self._fused_sums:   # training: the chunk states (sum k' (x) v, sum k') are kept for the dq' scan of the backward pass
+                ws = torch.empty_like(ws)
             inv = torch.empty(R * G, dtype=f32, device=dev)
             Z = None
             # normaliser fused into the scan (the running key sums ride along as an extra state column): no cumsum / den passes
             rc = lib.sa_favor_scan_a_norm(_ffi.ptr(kf), _ffi.ptr(qf), _ffi.ptr(v), inner, 0, _ffi.ptr(attn), inner, 0, _ffi.ptr(inv), 1e-6, B, N, G, LDF, dh,
-                                          _ffi.ptr(ws), st) if self._fused_sums else _ffi.SA_EUNSUPPORTED
+                                          _ffi.ptr(ws), 0, st) if self._fused_sums else _ffi.SA_EUNSUPPORTED
             if rc == _ffi.SA_EUNSUPPORTED:
                 Z = torch.empty_like(kf)
                 _ck(lib.sa_cumsum_rows(_ffi.ptr(kf), None, _ffi.ptr(Z), B, N, G, LDF, 0, _ffi.ptr(ws), st), "sa_cumsum_rows")
@@ -382,7 +384,7 @@ class _LayerEngine:
                                         _ffi.ptr(ws), st), "sa_favor_scan_a")
             else:
                 _ck(rc, "sa_favor_scan_a_norm")
-            sv.update(qg=qg, kg=kg, ddq=ddq, ddk=ddk, qf=qf, kf=kf, gws=gws, Z=Z, inv=inv)
+            sv.update(qg=qg, kg=kg, ddq=ddq, ddk=ddk, qf=qf, kf=kf, gws=gws, Z=Z, inv=inv, scan_state=ws if (Z is None and tape is not None) else None)
         if L > 0:
             cosb, sinb = self._rot_tables(N, dev)
             qr = torch.empty(R, L * dh, dtype=f32, device=dev)
@@ -547,11 +549,16 @@ class _LayerEngine:
             ws = self._scan_ws(B, N, G, dev)
             dqf = torch.empty_like(qf)
             dkf = torch.empty_like(kf)
+            shared_dv = False
             if Z is None:   # forward ran the fused form: the cumulative terms are rebuilt inside the scans as well
+                kept = sv.get("scan_state")   # the forward's chunk states: same (a = k', b = v) -> no state / prefix passes for dq'
                 _ck(lib.sa_favor_scan_b_cum(_ffi.ptr(kf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dqf), _ffi.ptr(dden), 1, 1e-6,
-                                            B, N, G, LDF, dh, 0, _ffi.ptr(ws), st), "sa_favor_scan_b_cum(dq')")
+                                            B, N, G, LDF, dh, 0, _ffi.ptr(kept if kept is not None else ws), 1 if kept is not None else 0, st),
+                    "sa_favor_scan_b_cum(dq')")
+                sv["scan_state"] = None
                 _ck(lib.sa_favor_scan_b_cum(_ffi.ptr(qf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dkf), _ffi.ptr(dden), 2, 0.0,
-                                            B, N, G, LDF, dh, 1, _ffi.ptr(ws), st), "sa_favor_scan_b_cum(dk')")
+                                            B, N, G, LDF, dh, 1, _ffi.ptr(ws), 0, st), "sa_favor_scan_b_cum(dk')")
+                shared_dv = True
             else:
                 _ck(lib.sa_favor_scan_b(_ffi.ptr(kf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dqf), _ffi.ptr(dden), _ffi.ptr(Z),
                                         1e-6, B, N, G, LDF, dh, 0, _ffi.ptr(ws), st), "sa_favor_scan_b(dq')")
@@ -559,8 +566,12 @@ class _LayerEngine:
                 _ck(lib.sa_cumsum_rows(_ffi.ptr(qf), _ffi.ptr(dden), _ffi.ptr(rr), B, N, G, LDF, 1, _ffi.ptr(ws), st), "sa_cumsum_rows(rev)")
                 _ck(lib.sa_favor_scan_b(_ffi.ptr(qf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dkf), None, _ffi.ptr(rr), 0.0,
                                         B, N, G, LDF, dh, 1, _ffi.ptr(ws), st), "sa_favor_scan_b(dk')")
-            _ck(lib.sa_favor_scan_a(_ffi.ptr(qf), _ffi.ptr(kf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dv), inner, 0, None, B, N, G, LDF, dh, 1, 0,
-                                    _ffi.ptr(ws), st), "sa_favor_scan_a(dv)")
+            if shared_dv:   # dv runs on the states the dk' scan just built (same a = q', b = d attn * inv, reversed)
+                _ck(lib.sa_favor_scan_a_state(_ffi.ptr(qf), _ffi.ptr(kf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dv), inner, 0, None, B, N, G, LDF, dh, 1, 0,
+                                              _ffi.ptr(ws), 3, st), "sa_favor_scan_a_state(dv)")
+            else:
+                _ck(lib.sa_favor_scan_a(_ffi.ptr(qf), _ffi.ptr(kf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dv), inner, 0, None, B, N, G, LDF, dh, 1, 0,
+                                        _ffi.ptr(ws), st), "sa_favor_scan_a(dv)")
             pop = self._proj_op()
             dqg = torch.zeros(R, G * dh, dtype=f32, device=dev)
             dkg = torch.zeros(R, G * dh, dtype=f32, device=dev)

@@ -159,11 +159,16 @@ def test_causal_scan_variants_against_einsum(N, reverse):
     base = torch.einsum("bjgm,bjgd,ij,bigd->bigm", a, bsc, trif, cc * ys[..., None])
     y1 = torch.zeros(B, N, G, LDF, device="cuda")
     _ffi.check(lib.sa_favor_scan_b_cum(_ffi.ptr(ad), _ffi.ptr(bd), G * dv, 0, _ffi.ptr(bsd), _ffi.ptr(ccd), G * dv, 0, _ffi.ptr(ysd), _ffi.ptr(y1), _ffi.ptr(bsd), 1, 0.25,
-                                       B, N, G, LDF, dv, reverse, _ffi.ptr(ws), st))
+                                       B, N, G, LDF, dv, reverse, _ffi.ptr(ws), 0, st))
     assert _rel(y1[..., :m].cpu().double(), (base + bs[..., None] * (cum_a + 0.25))[..., :m]) < 1e-4
     y2 = torch.zeros(B, N, G, LDF, device="cuda")
     _ffi.check(lib.sa_favor_scan_b_cum(_ffi.ptr(ad), _ffi.ptr(bd), G * dv, 0, _ffi.ptr(bsd), _ffi.ptr(ccd), G * dv, 0, _ffi.ptr(ysd), _ffi.ptr(y2), _ffi.ptr(bsd), 2, 0.0,
-                                       B, N, G, LDF, dv, reverse, _ffi.ptr(ws), st))
+                                       B, N, G, LDF, dv, reverse, _ffi.ptr(ws), 0, st))
+    # the same states serve a plain scan A on the same (a, b, b_scale, reverse): no state / prefix passes, extra-column layout
+    ya2 = f(y0.reshape(B * N, G * dv))
+    _ffi.check(lib.sa_favor_scan_a_state(_ffi.ptr(ad), _ffi.ptr(cd), _ffi.ptr(bd), G * dv, 0, _ffi.ptr(bsd), _ffi.ptr(ya2), G * dv, 0, _ffi.ptr(ysd), B, N, G, LDF, dv,
+                                         reverse, 1, _ffi.ptr(ws), 3, st))
+    assert _rel(ya2.view(B, N, G, dv).cpu().double(), refA) < 1e-4
     assert _rel(y2[..., :m].cpu().double(), (base + cum_aw)[..., :m]) < 1e-4
     if not reverse:
         num = torch.einsum("bigm,bjgm,ij,bjgd->bigd", c, a, trif, bb)
@@ -171,7 +176,7 @@ def test_causal_scan_variants_against_einsum(N, reverse):
         yn = torch.zeros(B * N, G * dv, device="cuda")
         invn = torch.zeros(B * N * G, device="cuda")
         _ffi.check(lib.sa_favor_scan_a_norm(_ffi.ptr(ad), _ffi.ptr(cd), _ffi.ptr(bd), G * dv, 0, _ffi.ptr(yn), G * dv, 0, _ffi.ptr(invn), 1e-6, B, N, G, LDF, dv,
-                                            _ffi.ptr(ws), st))
+                                            _ffi.ptr(ws), 0, st))
         assert _rel(yn.view(B, N, G, dv).cpu().double(), num / den) < 1e-4
         assert _rel(invn.view(B, N, G, 1).cpu().double(), 1.0 / den) < 1e-4
 
