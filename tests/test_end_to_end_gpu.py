@@ -42,3 +42,19 @@ def test_pipeline(tmp_path):
     run_vqvae.run(vq + ["--training_subjects=" + proj + "e2e/performer/outputs/*/*_sample.npy", "--validation_subjects=synthetic:1", "--mode=decoding"])
     dec = glob.glob(proj + "e2e/baseline_vqvae/outputs/*/*_sample_sample.npy")
     assert len(dec) == 2 and np.load(dec[0]).shape == (16, 24, 16)
+
+
+def test_adversarial_training_step(tmp_path):
+    """generator step with the least-square GAN term + discriminator step (run_vqvae.py --adversarial_component)."""
+    import torch
+
+    import run_vqvae
+    proj = str(tmp_path) + "/"
+    vq = ["--project_directory=" + proj, "--experiment_name=adv", "--no_levels=2", "--downsample_parameters=((4,2,1,1),(4,2,1,1))",
+          "--upsample_parameters=((4,2,1,0,1),(4,2,1,0,1))", "--no_channels=32", "--num_embeddings=(64,)", "--embedding_dim=(16,)", "--decay=(0.5,)",
+          "--roi=((0,32),(0,32),(0,32))", "--batch_size=2", "--eval_batch_size=2", "--loss=mse", "--learning_rate=1e-3", "--adversarial_component=True"]
+    run_vqvae.run(vq + ["--training_subjects=synthetic:4", "--validation_subjects=synthetic:2", "--mode=training", "--epochs=1"])
+    ck = glob.glob(proj + "adv/baseline_vqvae/checkpoints/checkpoint_epoch=*.pt")
+    assert len(ck) == 1
+    sd = torch.load(ck[0], map_location="cpu", weights_only=False)
+    assert "network" in sd and all(torch.isfinite(v).all() for v in sd["network"].values() if v.is_floating_point())
