@@ -412,7 +412,7 @@ __device__ __forceinline__ void la_block(const LAArgs& a, const uint16_t* order,
 
 // MODE 0: forward (o, lse)   MODE 1: backward wrt q (dq, D)
 template <int MODE>
-__global__ __launch_bounds__(256) void local_attn_q_split_kernel(const LAArgs a) {
+__global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void local_attn_q_split_kernel(const LAArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char sKh[LTB], sKl[LTB], sVh[LTB], sVl[LTB];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qi = lane & 15, g = lane >> 4;
@@ -485,64 +485,40 @@ __global__ __launch_bounds__(256) void local_attn_q_split_kernel(const LAArgs a)
         const int jb = kt * LT + g * 4;
         const bool unmasked = kt * LT >= free_lo && kt * LT + LT - 1 <= wq0;   // wave-uniform
         float4_t p[4];
+        if (!unmasked) {   // masked scores become -inf: exp() below turns them into exact zeros (the running max is floored at -1e30)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = jb + f * 16 + r;
+                    s[f][r] = (j >= lo_i && j <= j_hi) ? s[f][r] : -INFINITY;
+                }
+        }
         if (MODE == 0) {
             float mx = -1e30f;
-            if (unmasked) {
 #pragma unroll
-                for (int f = 0; f < 4; ++f) mx = fmaxf(fmaxf(mx, fmaxf(s[f][0], s[f][1])), fmaxf(s[f][2], s[f][3]));
-            } else {
-#pragma unroll
-                for (int f = 0; f < 4; ++f)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int j = jb + f * 16 + r;
-                        if (j >= lo_i && j <= j_hi) mx = fmaxf(mx, s[f][r]);
-                    }
-            }
+            for (int f = 0; f < 4; ++f) mx = fmaxf(fmaxf(mx, fmaxf(s[f][0], s[f][1])), fmaxf(s[f][2], s[f][3]));
             mx = group_max(mx);
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __expf(m_run - m_new);
             float ls = 0.f;
-            if (unmasked) {
 #pragma unroll
-                for (int f = 0; f < 4; ++f)
+            for (int f = 0; f < 4; ++f)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        p[f][r] = __expf(s[f][r] - m_new);
-                        ls += p[f][r];
-                    }
-            } else {
-#pragma unroll
-                for (int f = 0; f < 4; ++f)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int j = jb + f * 16 + r;
-                        const float pvv = (j >= lo_i && j <= j_hi) ? __expf(s[f][r] - m_new) : 0.f;
-                        p[f][r] = pvv;
-                        ls += pvv;
-                    }
-            }
+                for (int r = 0; r < 4; ++r) {
+                    p[f][r] = __expf(s[f][r] - m_new);
+                    ls += p[f][r];
+                }
             ls = group_sum(ls);
             l_run = l_run * alpha + ls;
             m_run = m_new;
 #pragma unroll
             for (int df = 0; df < 4; ++df) acc[df] *= alpha;
         } else {
-            if (unmasked) {
 #pragma unroll
-                for (int f = 0; f < 4; ++f)
+            for (int f = 0; f < 4; ++f)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) p[f][r] = __expf(s[f][r] - lse) * (dp[f][r] - Dv);
-            } else {
-#pragma unroll
-                for (int f = 0; f < 4; ++f)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int j = jb + f * 16 + r;
-                        const float pvv = (j >= lo_i && j <= j_hi) ? __expf(s[f][r] - lse) : 0.f;
-                        p[f][r] = pvv * (dp[f][r] - Dv);  // dS
-                    }
-            }
+                for (int r = 0; r < 4; ++r) p[f][r] = __expf(s[f][r] - lse) * (dp[f][r] - Dv);  // dS
         }
         short8_t Ph[2], Pl[2];
         la_acc_operand(Ph, Pl, p);
@@ -635,24 +611,23 @@ __global__ __launch_bounds__(256) void local_attn_kv_split_kernel(const LAArgs a
         // lane element (f, r) <-> query i = qt*64 + f*16 + g*4 + r, key kj
         const bool unmasked = qt * LT >= free_lo && qt * LT + LT - 1 <= free_hi;   // wave-uniform
         float4_t p[4], ds[4];
+        if (!unmasked) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = qt * LT + f * 16 + g * 4 + r;
+                    s[f][r] = (i >= i_lo && i <= i_hi) ? s[f][r] : -INFINITY;
+                }
+        }
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             const float4 l4 = *(const float4*)&sLse[f * 16 + g * 4], d4 = *(const float4*)&sD[f * 16 + g * 4];
             const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
-            if (unmasked) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    p[f][r] = __expf(s[f][r] - lv[r]);
-                    ds[f][r] = p[f][r] * (dp[f][r] - dv4[r]);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = qt * LT + f * 16 + g * 4 + r;
-                    const float pvv = (i >= i_lo && i <= i_hi) ? __expf(s[f][r] - lv[r]) : 0.f;
-                    p[f][r] = pvv;
-                    ds[f][r] = pvv * (dp[f][r] - dv4[r]);
-                }
+            for (int r = 0; r < 4; ++r) {
+                p[f][r] = __expf(s[f][r] - lv[r]);
+                ds[f][r] = p[f][r] * (dp[f][r] - dv4[r]);
             }
         }
         short8_t Ph[2], Pl[2];
