@@ -221,7 +221,9 @@ int sa_favor_dden(const float *dout, const float *out, int stride, int off, int 
 /* rotary embedding of the local heads (local-attention >= 1.2); transpose=1 applies the adjoint (backward) */
 int sa_rotary(const float *x, int stride, int off, int L, int dh, const float *cosb, const float *sinb, float *y, int y_stride, int y_off,
               int N, int64_t R, int transpose, int accumulate, void *stream);
-/* causal local-window attention (window W, look back one window): per query softmax over keys [max(0,(n/W-1)W), n] */
+/* causal local-window attention (window W, look back one window): per query softmax over keys [max(0,(n/W-1)W), n].
+ * fp32 in / out; products are evaluated as split-bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate; ~1e-5 relative) unless the environment
+ * has SA_LOCAL_ATTN_EXACT=1 (exact-fp32 MFMA).  N * max(stride) * 4 must stay below 2^31 (SA_EUNSUPPORTED otherwise). */
 int sa_local_attn_fwd(const float *q, int q_stride, int q_off, const float *k, int k_stride, int k_off, const float *v, int v_stride, int v_off,
                       float *o, int o_stride, int o_off, float *lse, int B, int N, int L, int W, int dh, void *stream);
 /* dq/dk/dv use the strides and offsets of q/k/v */

@@ -181,8 +181,15 @@ def test_causal_scan_variants_against_einsum(N, reverse):
         assert _rel(invn.view(B, N, G, 1).cpu().double(), 1.0 / den) < 1e-4
 
 
-@pytest.mark.parametrize("N,W", [(23, 5), (40, 8), (17, 32), (100, 420)])
-def test_local_attention_kernel_against_dense_band(N, W):
+@pytest.fixture(params=["split-bf16", "exact-fp32"])
+def la_path(request, monkeypatch):
+    """Both arithmetic paths of csrc/local_attn.hip (the library reads the variable at every launch)."""
+    monkeypatch.setenv("SA_LOCAL_ATTN_EXACT", "1" if request.param == "exact-fp32" else "0")
+    return request.param
+
+
+@pytest.mark.parametrize("N,W", [(23, 5), (40, 8), (17, 32), (100, 420), (333, 64)])
+def test_local_attention_kernel_against_dense_band(N, W, la_path):
     from synthanatomy_amd import _ffi
     lib, st = _ffi.lib(), _ffi.stream()
     torch.manual_seed(N)
@@ -275,8 +282,8 @@ def test_stateful_sampler_equals_the_quadratic_loop(rezero, shape, window, local
     assert int(smp.min()) >= 0 and int(smp.max()) <= 18
 
 
-@pytest.mark.parametrize("N,W", [(23, 5), (100, 420), (150, 64), (200, 70)])
-def test_local_attention_backward_kernels_against_autograd(N, W):
+@pytest.mark.parametrize("N,W", [(23, 5), (100, 420), (150, 64), (200, 70), (321, 128)])
+def test_local_attention_backward_kernels_against_autograd(N, W, la_path):
     from synthanatomy_amd import _ffi
     lib, st = _ffi.lib(), _ffi.stream()
     torch.manual_seed(N + W)
