@@ -27,7 +27,7 @@ def _sources():
 
 def _digest(path):
     h = hashlib.sha1()
-    for dep in [path, os.path.join(CSRC, "sa_common.h"), os.path.join(HERE, "..", "include", "synthanatomy_hip.h")]:
+    for dep in [path, os.path.join(CSRC, "sa_common.h"), os.path.join(CSRC, "split_bf16.h"), os.path.join(HERE, "..", "include", "synthanatomy_hip.h")]:
         with open(dep, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "sa_common.h"
+#include "split_bf16.h"
 
 namespace sa {
 
@@ -265,28 +266,9 @@ __global__ __launch_bounds__(256) void local_attn_kv_kernel(const LAArgs a) {
 // ------------------------------------------------------------------------------------------------------------------------------
 // split-bf16 path
 // ------------------------------------------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef short v4s_t __attribute__((ext_vector_type(4)));
-
 constexpr int LTB = 64 * 128;   // one [64 rows][64 bf16] tile, bytes
 
-// x = hi + lo (+ <= 2^-17 |x|): hi = bf16(x), lo = bf16(x - hi); two values per call, packed as bf16 pairs
-__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const f32x2_t v = {a, b};
-    const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
-    const f32x2_t r = v - __builtin_convertvector(h, f32x2_t);
-    const bf16x2_t l = __builtin_convertvector(r, bf16x2_t);
-    hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, l);
-}
-
-// byte offset of column c (bf16 index, multiple of 4) of row m in a [64][64] bf16 tile; 32-byte chunks XOR-swizzled with the row
-__device__ __forceinline__ uint32_t lroff(uint32_t m, uint32_t c) { return m * 128u + ((((c >> 4) ^ ((m >> 1) & 3u)) << 5) | ((c & 15u) << 1)); }
-
-__device__ __forceinline__ v4s_t la_tr16(const unsigned char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(p));
-}
+__device__ __forceinline__ v4s_t la_tr16(const unsigned char* p) { return lds_tr16_b64(p); }
 
 // One (batch, head-block) matrix [N rows][stride floats] behind a buffer descriptor: rows beyond N read as zeros (the range check is on
 // the per-lane offset), so tile loads need neither clamps nor masks and their addresses are one add per tile.
@@ -363,20 +345,6 @@ __device__ __forceinline__ void la_rows_gemm(float4_t (&acc)[4], const unsigned 
         for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], bh[h2], acc[f], 0, 0, 0);
 #pragma unroll
         for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bh[h2], acc[f], 0, 0, 0);
-    }
-}
-
-// accumulator fragments (f, r) <-> tile row f*16 + g*4 + r  ->  B operands of the transposed GEMM: k = 32-row block h, rows (2h + e/4)*16 + 4g + e%4
-__device__ __forceinline__ void la_acc_operand(short8_t (&hi)[2], short8_t (&lo)[2], const float4_t (&p)[4]) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        uint32_t a[4], b[4];
-        split_pair(p[2 * h][0], p[2 * h][1], a[0], b[0]);
-        split_pair(p[2 * h][2], p[2 * h][3], a[1], b[1]);
-        split_pair(p[2 * h + 1][0], p[2 * h + 1][1], a[2], b[2]);
-        split_pair(p[2 * h + 1][2], p[2 * h + 1][3], a[3], b[3]);
-        hi[h] = __builtin_bit_cast(short8_t, (u32x4){a[0], a[1], a[2], a[3]});
-        lo[h] = __builtin_bit_cast(short8_t, (u32x4){b[0], b[1], b[2], b[3]});
     }
 }
 
@@ -521,7 +489,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void local_attn_q_split_ker
                 for (int r = 0; r < 4; ++r) p[f][r] = __expf(s[f][r] - lse) * (dp[f][r] - Dv);  // dS
         }
         short8_t Ph[2], Pl[2];
-        la_acc_operand(Ph, Pl, p);
+        acc_to_operand(Ph, Pl, p);
         if (MODE == 0) la_cols_gemm(acc, sVh, sVl, Ph, Pl, lane);   // O^T += V^T P^T
         else la_cols_gemm(acc, sKh, sKl, Ph, Pl, lane);             // dQ^T += K^T dS^T
     }
@@ -631,9 +599,9 @@ __global__ __launch_bounds__(256) void local_attn_kv_split_kernel(const LAArgs a
             }
         }
         short8_t Ph[2], Pl[2];
-        la_acc_operand(Ph, Pl, p);
+        acc_to_operand(Ph, Pl, p);
         la_cols_gemm(dva, sGh, sGl, Ph, Pl, lane);   // dV^T += dO^T P
-        la_acc_operand(Ph, Pl, ds);
+        acc_to_operand(Ph, Pl, ds);
         la_cols_gemm(dka, sQh, sQl, Ph, Pl, lane);   // dK^T += Q^T dS
     }
     if (!vk) return;

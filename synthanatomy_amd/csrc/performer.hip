@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "sa_common.h"
+#include "split_bf16.h"
 
 namespace sa {
 
@@ -551,6 +552,139 @@ __global__ __launch_bounds__(256) void favor_chunk_state_kernel(const ScanArgs s
     for (int r = 0; r < 4; ++r) {
         const int m = 256 + g4 * 4 + r;
         if (m < s.LDF) st[m * s.dv + w * 16 + fr] = acct[r];
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ chunked scans on split-bf16 MFMA
+// Same three-launch scheme (chunk state sums -> exclusive prefix -> chunk outputs), with every product evaluated as hi*hi + hi*lo + lo*hi
+// on mfma_f32_16x16x32_bf16 (split_bf16.h) and every operand staged ONCE per block in LDS as bf16 hi / lo tiles: the fp32 kernels above feed
+// their MFMAs straight from global memory, each of the four waves re-reading the whole feature chunk.  Feature matrices are staged in slabs of
+// 144 features (9 MFMA fragments, 288-byte rows: the transposing reads of 16 rows land on all 64 banks exactly twice); value tiles use the
+// swizzled 128-byte rows of lroff().  Rows outside [0, N) come back as zeros from the buffer descriptor, in both scan directions.
+constexpr int SLAB = 144;
+constexpr int SLAB_RS = SLAB * 2;            // bytes per staged row
+constexpr int SLAB_BYTES = 64 * SLAB_RS;     // one of hi / lo, 64 positions
+constexpr int VT_BYTES = 64 * 128;           // [64 positions][64 values] bf16
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t scan_rsrc(const float* base, int64_t elems) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(elems * 4), 0x00020000);
+}
+__device__ __forceinline__ float scan_ld1(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); }
+__device__ __forceinline__ int scan_row(const ScanArgs& s, int p) { return s.reverse ? s.N - 1 - p : p; }   // may leave [0, N): reads zeros
+
+// features [slab0, slab0 + 144) of the 64 positions of a chunk of one (batch, head) -> hi / lo tiles (columns beyond LDF hold junk nobody reads)
+__device__ __forceinline__ void scan_stage_slab(unsigned char* hi, unsigned char* lo, __amdgpu_buffer_rsrc_t rs, const ScanArgs& s, int g, int chunk,
+                                                int slab0, int tid) {
+    u32x4 v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int idx = tid + 256 * t, j = idx / 36, c4 = idx - j * 36;
+        const int i = scan_row(s, chunk * 64 + j);
+        v[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)((i * s.G + g) * s.LDF + slab0 + c4 * 4) * 4u, 0, 0));
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int idx = tid + 256 * t, j = idx / 36, c4 = idx - j * 36;
+        uint2 h, l;
+        split_pair(__uint_as_float(v[t][0]), __uint_as_float(v[t][1]), h.x, l.x);
+        split_pair(__uint_as_float(v[t][2]), __uint_as_float(v[t][3]), h.y, l.y);
+        *(uint2*)(hi + j * SLAB_RS + c4 * 8) = h;
+        *(uint2*)(lo + j * SLAB_RS + c4 * 8) = l;
+    }
+}
+
+// value rows (column block at off) of the 64 positions of a chunk, times an optional per-position scale -> swizzled hi / lo tiles
+__device__ __forceinline__ void scan_stage_values(unsigned char* hi, unsigned char* lo, __amdgpu_buffer_rsrc_t rv, int stride, int off,
+                                                  const float* scale, __amdgpu_buffer_rsrc_t rsc, const ScanArgs& s, int g, int chunk, int tid) {
+    u32x4 v[4];
+    float sc[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int j = (tid >> 4) + 16 * it;
+        const int i = scan_row(s, chunk * 64 + j);
+        v[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, (uint32_t)(i * stride + off + (tid & 15) * 4) * 4u, 0, 0));
+        sc[it] = scale ? scan_ld1(rsc, (uint32_t)(i * s.G + g) * 4u) : 1.f;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const uint32_t o = lroff((tid >> 4) + 16 * it, (tid & 15) * 4);
+        uint2 h, l;
+        split_pair(__uint_as_float(v[it][0]) * sc[it], __uint_as_float(v[it][1]) * sc[it], h.x, l.x);
+        split_pair(__uint_as_float(v[it][2]) * sc[it], __uint_as_float(v[it][3]) * sc[it], h.y, l.y);
+        *(uint2*)(hi + o) = h;
+        *(uint2*)(lo + o) = l;
+    }
+}
+
+// one MFMA operand (reduction over the 32 tile rows of block ks) for tile columns col0 + lane&15, through the transposing read
+__device__ __forceinline__ short8_t scan_tr_operand(const unsigned char* t, uint32_t o0, uint32_t o1) {
+    return __builtin_shufflevector(lds_tr16_b64(t + o0), lds_tr16_b64(t + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// U_c[m][d] = sum_{j in chunk} a_j[m] (b_j[d] bs_j)   (+ the running-sum column z[m] = sum_j a_j[m] w_j)
+__global__ __launch_bounds__(256) void favor_chunk_state_split_kernel(const ScanArgs s) {
+    __shared__ __attribute__((aligned(16))) unsigned char sAh[SLAB_BYTES], sAl[SLAB_BYTES], sBh[VT_BYTES], sBl[VT_BYTES];
+    __shared__ float sW[64];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
+    const int chunk = blockIdx.x % s.S, g = (blockIdx.x / s.S) % s.G, b = blockIdx.x / (s.S * s.G);
+    const __amdgpu_buffer_rsrc_t ra = scan_rsrc(s.a + (int64_t)b * s.N * s.G * s.LDF, (int64_t)s.N * s.G * s.LDF);
+    const __amdgpu_buffer_rsrc_t rb = scan_rsrc(s.b + (int64_t)b * s.N * s.b_stride, (int64_t)s.N * s.b_stride);
+    const __amdgpu_buffer_rsrc_t rsc = scan_rsrc((s.b_scale ? s.b_scale : s.a) + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G);
+    scan_stage_values(sBh, sBl, rb, s.b_stride, s.b_off + g * s.dv, s.b_scale, rsc, s, g, chunk, tid);
+    if (s.zmode && tid < 64) {
+        const int p = chunk * 64 + tid, i = scan_row(s, p);
+        float wv = p < s.N ? 1.f : 0.f;
+        if (s.zmode == 2) {
+            const __amdgpu_buffer_rsrc_t rex = scan_rsrc(s.ex_scale + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G);
+            wv = scan_ld1(rex, (uint32_t)(i * s.G + g) * 4u);
+        }
+        sW[tid] = wv;
+    }
+    __syncthreads();
+    const uint32_t trow = (uint32_t)g4 * 4u + ((uint32_t)fr >> 2), tcol = (uint32_t)(fr & 3) * 4u;
+    short8_t bh[4][2], bl[4][2], wh[2], wl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+            const uint32_t o0 = lroff(ks * 32 + trow, df * 16 + tcol), o1 = lroff(ks * 32 + 16 + trow, df * 16 + tcol);
+            bh[df][ks] = scan_tr_operand(sBh, o0, o1);
+            bl[df][ks] = scan_tr_operand(sBl, o0, o1);
+        }
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (s.zmode && fr == 0) ? sW[ks * 32 + (e >> 2) * 16 + g4 * 4 + (e & 3)] : 0.f;
+        split8(x, wh[ks], wl[ks]);
+    }
+    const int64_t zs = (int64_t)s.LDF * s.dv + (s.zcol ? s.LDF : 0);
+    float* st = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * zs;
+    float* zp = st + (int64_t)s.LDF * s.dv;
+    for (int slab0 = 0; slab0 < s.LDF; slab0 += SLAB) {
+        if (slab0) __syncthreads();
+        scan_stage_slab(sAh, sAl, ra, s, g, chunk, slab0, tid);
+        __syncthreads();
+        const int nfr = min(SLAB, s.LDF - slab0) >> 4;
+        for (int f = w; f < nfr; f += 4) {
+            float4_t acc[4], accz = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int df = 0; df < 4; ++df) acc[df] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint32_t o0 = (ks * 32 + trow) * SLAB_RS + (f * 16 + tcol) * 2, o1 = o0 + 16 * SLAB_RS;
+                const short8_t ah = scan_tr_operand(sAh, o0, o1), al = scan_tr_operand(sAl, o0, o1);
+#pragma unroll
+                for (int df = 0; df < 4; ++df) acc[df] = mfma3(ah, al, bh[df][ks], bl[df][ks], acc[df]);
+                if (s.zmode) accz = mfma3(ah, al, wh[ks], wl[ks], accz);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = slab0 + f * 16 + g4 * 4 + r;
+#pragma unroll
+                for (int df = 0; df < 4; ++df) st[m * s.dv + df * 16 + fr] = acc[df][r];
+                if (s.zmode && fr == 0) zp[m] = accz[r];
+            }
+        }
     }
 }
 
@@ -1389,8 +1523,12 @@ static int run_scan(K valu_kernel, int which, ScanArgs& s, unsigned base_blocks,
         s.S = (s.N + 63) / 64;
         s.seg_len = 64;
         const unsigned nblk = (unsigned)(bg * s.S);
+        const char* ex = getenv("SA_SCAN_EXACT");
+        const int exact = ex ? atoi(ex) : 0;   // bit 0: state sums, bit 1: scan A outputs, bit 2: scan B outputs on the exact-fp32 MFMA kernels
+        const bool fits32 = (int64_t)s.N * s.G * s.LDF * 4 < ((int64_t)1 << 31) && (int64_t)s.N * std::max(s.b_stride, std::max(s.c_stride, s.y_stride)) * 4 < ((int64_t)1 << 31);
         if (!s.state_ready) {
-            hipLaunchKernelGGL(favor_chunk_state_kernel, dim3(nblk), dim3(256), 0, st, s);
+            if (!(exact & 1) && fits32) hipLaunchKernelGGL(favor_chunk_state_split_kernel, dim3(nblk), dim3(256), 0, st, s);
+            else hipLaunchKernelGGL(favor_chunk_state_kernel, dim3(nblk), dim3(256), 0, st, s);
             SA_CHECK_LAUNCH();
             hipLaunchKernelGGL(scan_state_prefix_kernel, dim3((unsigned)((bg * elems + 255) / 256)), dim3(256), 0, st, ws, bg, s.S, elems);
             SA_CHECK_LAUNCH();
