@@ -210,7 +210,10 @@ int sa_favor_scan_b_cum(const float *a, const float *b, int b_stride, int b_off,
                         int reverse, float *state_ws, int state_flags, void *stream);
 /* state_flags bit 0: state_ws already holds the exclusive chunk prefixes of exactly this (a, b, b_scale, reverse) -- written by an earlier
  * scan on the same operands -- so the state and prefix passes are skipped; bit 1 (sa_favor_scan_a_state): the buffer has the extra
- * running-sum column.  Forward and dq' share one state set, dk' and dv another: two state passes per head instead of four. */
+ * running-sum column.  Forward and dq' share one state set, dk' and dv another: two state passes per head instead of four.
+ * bit 2: evaluate every product on the exact-fp32 MFMA.  Default is split-bf16 (x = hi + lo in bf16, hi*hi + hi*lo + lo*hi with fp32
+ * accumulation, ~1e-5 relative): plenty next to bf16 dense layers, but the query-side gradients cancel to ~1e-3 of their terms, so the
+ * fp32 parity mode of the Python engine sets the bit.  (Environment SA_SCAN_EXACT=7 forces it for every entry point.) */
 int sa_favor_scan_a_state(const float *a, const float *c, const float *b, int b_stride, int b_off, const float *b_scale, float *y, int y_stride,
                           int y_off, const float *y_scale, int B, int N, int G, int LDF, int dv, int reverse, int accumulate, float *state_ws,
                           int state_flags, void *stream);

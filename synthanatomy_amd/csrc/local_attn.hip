@@ -268,8 +268,6 @@ __global__ __launch_bounds__(256) void local_attn_kv_kernel(const LAArgs a) {
 // ------------------------------------------------------------------------------------------------------------------------------
 constexpr int LTB = 64 * 128;   // one [64 rows][64 bf16] tile, bytes
 
-__device__ __forceinline__ v4s_t la_tr16(const unsigned char* p) { return lds_tr16_b64(p); }
-
 // One (batch, head-block) matrix [N rows][stride floats] behind a buffer descriptor: rows beyond N read as zeros (the range check is on
 // the per-lane offset), so tile loads need neither clamps nor masks and their addresses are one add per tile.
 struct LATile {
@@ -324,49 +322,6 @@ __device__ __forceinline__ void la_row_operand(short8_t (&hi)[2], short8_t (&lo)
         split_pair(x1.z * scale, x1.w * scale, h[3], l[3]);
         hi[h2] = __builtin_bit_cast(short8_t, (u32x4){h[0], h[1], h[2], h[3]});
         lo[h2] = __builtin_bit_cast(short8_t, (u32x4){l[0], l[1], l[2], l[3]});
-    }
-}
-
-// acc[f] (+)= A-tile rows (f*16 + lane&15) . B operand rows, three-term split product; tile fragments via ds_read_b128
-__device__ __forceinline__ void la_rows_gemm(float4_t (&acc)[4], const unsigned char* tHi, const unsigned char* tLo, const short8_t (&bh)[2],
-                                             const short8_t (&bl)[2], int i16, int g) {
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-        short8_t ah[4], al[4];
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const uint32_t o = lroff(f * 16 + i16, h2 * 32 + g * 8);
-            ah[f] = *(const short8_t*)(tHi + o);
-            al[f] = *(const short8_t*)(tLo + o);
-        }
-#pragma unroll
-        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bl[h2], acc[f], 0, 0, 0);
-#pragma unroll
-        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], bh[h2], acc[f], 0, 0, 0);
-#pragma unroll
-        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bh[h2], acc[f], 0, 0, 0);
-    }
-}
-
-// acc[df][.] (+)= tile^T (columns df*16 + lane&15) . B operand (rows of the tile on the reduction axis); fragments via the transposing read
-__device__ __forceinline__ void la_cols_gemm(float4_t (&acc)[4], const unsigned char* tHi, const unsigned char* tLo, const short8_t (&bh)[2],
-                                             const short8_t (&bl)[2], int lane) {
-    const uint32_t trow = (uint32_t)(lane >> 4) * 4u + ((uint32_t)(lane & 15) >> 2), tcol = (uint32_t)(lane & 3) * 4u;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        short8_t ah[4], al[4];
-#pragma unroll
-        for (int df = 0; df < 4; ++df) {
-            const uint32_t o0 = lroff(h * 32 + trow, df * 16 + tcol), o1 = lroff(h * 32 + 16 + trow, df * 16 + tcol);
-            ah[df] = __builtin_shufflevector(la_tr16(tHi + o0), la_tr16(tHi + o1), 0, 1, 2, 3, 4, 5, 6, 7);
-            al[df] = __builtin_shufflevector(la_tr16(tLo + o0), la_tr16(tLo + o1), 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-#pragma unroll
-        for (int df = 0; df < 4; ++df) acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[df], bl[h], acc[df], 0, 0, 0);
-#pragma unroll
-        for (int df = 0; df < 4; ++df) acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[df], bh[h], acc[df], 0, 0, 0);
-#pragma unroll
-        for (int df = 0; df < 4; ++df) acc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[df], bh[h], acc[df], 0, 0, 0);
     }
 }
 
@@ -447,8 +402,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void local_attn_q_split_ker
             s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
             dp[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
         }
-        la_rows_gemm(s, sKh, sKl, Qh, Ql, qi, g);                       // S^T = K Q^T
-        if (MODE == 1) la_rows_gemm(dp, sVh, sVl, Gh, Gl, qi, g);       // dP^T = V dO^T
+        tile_rows_gemm(s, sKh, sKl, Qh, Ql, qi, g);                       // S^T = K Q^T
+        if (MODE == 1) tile_rows_gemm(dp, sVh, sVl, Gh, Gl, qi, g);       // dP^T = V dO^T
         // lane element (f, r) <-> key j = kt*64 + f*16 + g*4 + r, query iq
         const int jb = kt * LT + g * 4;
         const bool unmasked = kt * LT >= free_lo && kt * LT + LT - 1 <= wq0;   // wave-uniform
@@ -490,8 +445,8 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void local_attn_q_split_ker
         }
         short8_t Ph[2], Pl[2];
         acc_to_operand(Ph, Pl, p);
-        if (MODE == 0) la_cols_gemm(acc, sVh, sVl, Ph, Pl, lane);   // O^T += V^T P^T
-        else la_cols_gemm(acc, sKh, sKl, Ph, Pl, lane);             // dQ^T += K^T dS^T
+        if (MODE == 0) tile_cols_gemm(acc, sVh, sVl, Ph, Pl, lane);   // O^T += V^T P^T
+        else tile_cols_gemm(acc, sKh, sKl, Ph, Pl, lane);             // dQ^T += K^T dS^T
     }
     if (!vq) return;
     if (MODE == 0) {
@@ -574,8 +529,8 @@ __global__ __launch_bounds__(256) void local_attn_kv_split_kernel(const LAArgs a
             s[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
             dp[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
         }
-        la_rows_gemm(s, sQh, sQl, Kh, Kl, kc, g);    // S = Q K^T
-        la_rows_gemm(dp, sGh, sGl, Vh, Vl, kc, g);   // dP = dO V^T
+        tile_rows_gemm(s, sQh, sQl, Kh, Kl, kc, g);    // S = Q K^T
+        tile_rows_gemm(dp, sGh, sGl, Vh, Vl, kc, g);   // dP = dO V^T
         // lane element (f, r) <-> query i = qt*64 + f*16 + g*4 + r, key kj
         const bool unmasked = qt * LT >= free_lo && qt * LT + LT - 1 <= free_hi;   // wave-uniform
         float4_t p[4], ds[4];
@@ -600,9 +555,9 @@ __global__ __launch_bounds__(256) void local_attn_kv_split_kernel(const LAArgs a
         }
         short8_t Ph[2], Pl[2];
         acc_to_operand(Ph, Pl, p);
-        la_cols_gemm(dva, sGh, sGl, Ph, Pl, lane);   // dV^T += dO^T P
+        tile_cols_gemm(dva, sGh, sGl, Ph, Pl, lane);   // dV^T += dO^T P
         acc_to_operand(Ph, Pl, ds);
-        la_cols_gemm(dka, sQh, sQl, Ph, Pl, lane);   // dK^T += Q^T dS
+        tile_cols_gemm(dka, sQh, sQl, Ph, Pl, lane);   // dK^T += Q^T dS
     }
     if (!vk) return;
 #pragma unroll

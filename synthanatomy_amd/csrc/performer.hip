@@ -337,6 +337,7 @@ struct ScanArgs {
     int32_t state_ready;   // host side: `state` already holds the exclusive chunk prefixes of exactly this (a, b, b_scale, reverse): skip both passes
     float den_eps;
     float* inv_out;
+    int32_t exact;         // host side: exact-fp32 MFMA kernels instead of the split-bf16 ones (state_flags bit 2)
 };
 
 constexpr int SCAN_TB = 8;  // positions staged per barrier
@@ -685,6 +686,220 @@ __global__ __launch_bounds__(256) void favor_chunk_state_split_kernel(const Scan
                 if (s.zmode && fr == 0) zp[m] = accz[r];
             }
         }
+    }
+}
+
+
+// One 64-wide slab of the chunk's operands, loaded a slab ahead into registers: A = features [slab0, +64) of the 64 positions (rows = positions),
+// T = rows [slab0, +64) of the chunk's exclusive-prefix state (64 value columns); both read zeros outside their matrices.
+struct ScanSlabRegs {
+    u32x4 a[4], t[4];
+};
+__device__ __forceinline__ void scan_slab_load(ScanSlabRegs& r, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rt, const ScanArgs& s, int g, int chunk,
+                                               int slab0, int tid, bool zero_cols) {
+    const int col = slab0 + (tid & 15) * 4;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int j = (tid >> 4) + 16 * it;
+        const int i = scan_row(s, chunk * 64 + j);
+        // feature columns beyond LDF belong to the next row: forced out of range when they take part in a reduction (zero_cols)
+        const uint32_t oa = (zero_cols && col >= s.LDF) ? 0xfffffff0u : (uint32_t)((i * s.G + g) * s.LDF + col) * 4u;
+        r.a[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, oa, 0, 0));
+        r.t[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rt, (uint32_t)((slab0 + j) * s.dv + (tid & 15) * 4) * 4u, 0, 0));
+    }
+}
+
+// scan B outputs:  y_i[m] = sum_d T_prev[m][d] c_i[d] + sum_{j <= i} a_j[m] (b_j . c_i + E[j][i])  (+ the extra terms of ScanArgs)
+__global__ __launch_bounds__(256, 3) void favor_chunk_out_b_split_kernel(const ScanArgs s) {
+    __shared__ __attribute__((aligned(16))) unsigned char sBh[VT_BYTES], sBl[VT_BYTES], sAh[VT_BYTES], sAl[VT_BYTES];
+    unsigned char* const sTh = sBh;   // the value tile is dead once the pair products exist: the state slabs take its place
+    unsigned char* const sTl = sBl;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
+    const int chunk = blockIdx.x % s.S, g = (blockIdx.x / s.S) % s.G, b = blockIdx.x / (s.S * s.G);
+    const __amdgpu_buffer_rsrc_t ra = scan_rsrc(s.a + (int64_t)b * s.N * s.G * s.LDF, (int64_t)s.N * s.G * s.LDF);
+    const __amdgpu_buffer_rsrc_t rb = scan_rsrc(s.b + (int64_t)b * s.N * s.b_stride, (int64_t)s.N * s.b_stride);
+    const __amdgpu_buffer_rsrc_t rc = scan_rsrc(s.c_col + (int64_t)b * s.N * s.c_stride, (int64_t)s.N * s.c_stride);
+    const __amdgpu_buffer_rsrc_t rsc = scan_rsrc((s.b_scale ? s.b_scale : s.a) + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G);
+    const __amdgpu_buffer_rsrc_t rcs = scan_rsrc((s.c_scale ? s.c_scale : s.a) + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G);
+    const __amdgpu_buffer_rsrc_t rex = scan_rsrc((s.ex_scale ? s.ex_scale : s.a) + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G);
+    const int64_t zs = (int64_t)s.LDF * s.dv + (s.zcol ? s.LDF : 0);
+    const float* st0 = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * zs;
+    const __amdgpu_buffer_rsrc_t rt = scan_rsrc(st0, (int64_t)s.LDF * s.dv);
+    ScanSlabRegs pre;
+    scan_slab_load(pre, ra, rt, s, g, chunk, 0, tid, false);
+    scan_stage_values(sBh, sBl, rb, s.b_stride, s.b_off + g * s.dv, s.b_scale, rsc, s, g, chunk, tid);
+
+    const int pi = chunk * 64 + w * 16 + fr;
+    const bool vi = pi < s.N;
+    const int ri = scan_row(s, pi);
+    const int64_t rowi = ((int64_t)b * s.N + (vi ? ri : 0)) * s.G + g;
+    short8_t Ch[2], Cl[2];   // c_i (times c_scale) as B operand, natural order d = ks*32 + g4*8 + e
+    {
+        const float cs = s.c_scale ? scan_ld1(rcs, (uint32_t)(ri * s.G + g) * 4u) : 1.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float x[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, (uint32_t)(ri * s.c_stride + s.c_off + g * s.dv + ks * 32 + g4 * 8 + q * 4) * 4u, 0, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[q * 4 + e] = __uint_as_float(v[e]) * cs;
+            }
+            split8(x, Ch[ks], Cl[ks]);
+        }
+    }
+    const float exs = (vi && (s.ex_vec || s.zmode == 1)) ? (s.ex_scale ? s.ex_scale[rowi] : 1.f) : 0.f;
+    __syncthreads();
+    float4_t P[4];   // P[j][i] = b_j . c_i (+ E), masked to j <= i; rows beyond N are zero in sB but E is not
+#pragma unroll
+    for (int jf = 0; jf < 4; ++jf) P[jf] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    tile_rows_gemm(P, sBh, sBl, Ch, Cl, fr, g4);
+#pragma unroll
+    for (int jf = 0; jf < 4; ++jf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jl = jf * 16 + g4 * 4 + r, pj = chunk * 64 + jl;
+            float e = 0.f;
+            if (s.zmode == 1) e = vi ? exs : 0.f;
+            else if (s.zmode == 2) e = scan_ld1(rex, (uint32_t)(scan_row(s, pj) * s.G + g) * 4u);
+            P[jf][r] = (jl > w * 16 + fr || pj >= s.N) ? 0.f : P[jf][r] + e;
+        }
+    short8_t Ph[2], Pl[2];
+    acc_to_operand(Ph, Pl, P);
+
+    const float* evp = s.ex_vec ? s.ex_vec + rowi * s.LDF + g4 * 4 : nullptr;
+    const float* zpp = s.zmode ? st0 + (int64_t)s.LDF * s.dv + g4 * 4 : nullptr;   // running sums of the chunks before this one
+    const float zf = s.zmode == 1 ? exs : 1.f;
+    const float cadd = s.zmode == 1 ? exs * s.ex_const : 0.f;
+    float* yp = s.y + rowi * s.LDF + g4 * 4;
+    for (int slab0 = 0; slab0 < s.LDF; slab0 += 64) {
+        __syncthreads();   // previous slab consumed (first pass: the pair products have read the value tile)
+        tile_stage(sAh, sAl, pre.a, tid);
+        tile_stage(sTh, sTl, pre.t, tid);
+        __syncthreads();
+        if (slab0 + 64 < s.LDF) scan_slab_load(pre, ra, rt, s, g, chunk, slab0 + 64, tid, false);
+        float4_t acc[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        tile_rows_gemm(acc, sTh, sTl, Ch, Cl, fr, g4);   // inter-chunk: T_prev c_i
+        tile_cols_gemm(acc, sAh, sAl, Ph, Pl, lane);     // intra-chunk: sum_j a_j[m] P[j][i]
+        if (vi) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int m0 = slab0 + f * 16;   // + g4*4 folded into the pointers
+                if (m0 < s.LDF) {
+                    float4 o = make_float4(acc[f][0], acc[f][1], acc[f][2], acc[f][3]);
+                    if (evp) {
+                        const float4 ev = *(const float4*)(evp + m0);
+                        o.x += exs * (ev.x + s.ex_const); o.y += exs * (ev.y + s.ex_const); o.z += exs * (ev.z + s.ex_const); o.w += exs * (ev.w + s.ex_const);
+                    }
+                    if (zpp) {
+                        const float4 zv = *(const float4*)(zpp + m0);
+                        o.x += zf * zv.x + cadd; o.y += zf * zv.y + cadd; o.z += zf * zv.z + cadd; o.w += zf * zv.w + cadd;
+                    }
+                    *(float4*)(yp + m0) = o;
+                }
+            }
+        }
+    }
+}
+
+// scan A outputs:  y_i[d] = sum_m T_prev[m][d] c_i[m] + sum_{j <= i} b_j[d] (a_j . c_i)   (zmode 1: divided by c_i . (z_i + eps))
+__global__ __launch_bounds__(256, 2) void favor_chunk_out_a_split_kernel(const ScanArgs s) {
+    __shared__ __attribute__((aligned(16))) unsigned char sBh[VT_BYTES], sBl[VT_BYTES], sAh[VT_BYTES], sAl[VT_BYTES], sTh[VT_BYTES], sTl[VT_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
+    const int chunk = blockIdx.x % s.S, g = (blockIdx.x / s.S) % s.G, b = blockIdx.x / (s.S * s.G);
+    const __amdgpu_buffer_rsrc_t ra = scan_rsrc(s.a + (int64_t)b * s.N * s.G * s.LDF, (int64_t)s.N * s.G * s.LDF);
+    const __amdgpu_buffer_rsrc_t rcf = scan_rsrc(s.c_feat + (int64_t)b * s.N * s.G * s.LDF, (int64_t)s.N * s.G * s.LDF);
+    const __amdgpu_buffer_rsrc_t rb = scan_rsrc(s.b + (int64_t)b * s.N * s.b_stride, (int64_t)s.N * s.b_stride);
+    const __amdgpu_buffer_rsrc_t rsc = scan_rsrc((s.b_scale ? s.b_scale : s.a) + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G);
+    const int64_t zs = (int64_t)s.LDF * s.dv + (s.zcol ? s.LDF : 0);
+    const float* st0 = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * zs;
+    const __amdgpu_buffer_rsrc_t rt = scan_rsrc(st0, (int64_t)s.LDF * s.dv);
+    const __amdgpu_buffer_rsrc_t rz = scan_rsrc(st0 + (int64_t)s.LDF * s.dv, s.zmode == 1 ? s.LDF : 0);
+    const int pi = chunk * 64 + w * 16 + fr;
+    const bool vi = pi < s.N;
+    const int ri = scan_row(s, pi);
+    const int64_t rowi = ((int64_t)b * s.N + (vi ? ri : 0)) * s.G + g;
+    // this lane's c_i in accumulator-row order: word e of reduction block ks is feature slab0 + ks*32 + (e/4)*16 + 4 g4 + e%4
+    const uint32_t cbase = (uint32_t)((ri * s.G + g) * s.LDF) * 4u;
+    u32x4 pc[4], pz[4];
+    auto load_c = [&](int slab0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = slab0 + q * 16 + g4 * 4;
+            const bool in = m < s.LDF;
+            pc[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rcf, in ? cbase + (uint32_t)m * 4u : 0xfffffff0u, 0, 0));
+            pz[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, (uint32_t)m * 4u, 0, 0));
+        }
+    };
+    ScanSlabRegs pre;
+    scan_slab_load(pre, ra, rt, s, g, chunk, 0, tid, true);
+    load_c(0);
+    scan_stage_values(sBh, sBl, rb, s.b_stride, s.b_off + g * s.dv, s.b_scale, rsc, s, g, chunk, tid);
+
+    float4_t P[4], acc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        P[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        acc[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    float den = 0.f;
+    for (int slab0 = 0; slab0 < s.LDF; slab0 += 64) {
+        if (slab0) __syncthreads();
+        tile_stage(sAh, sAl, pre.a, tid);
+        tile_stage(sTh, sTl, pre.t, tid);
+        short8_t Ch[2], Cl[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                x[e] = __uint_as_float(pc[ks * 2 + (e >> 2)][e & 3]);
+                den = fmaf(x[e], __uint_as_float(pz[ks * 2 + (e >> 2)][e & 3]) + s.den_eps, den);
+            }
+            split8(x, Ch[ks], Cl[ks]);
+        }
+        __syncthreads();
+        const int nks = (min(64, s.LDF - slab0) + 31) >> 5;
+        if (slab0 + 64 < s.LDF) {
+            scan_slab_load(pre, ra, rt, s, g, chunk, slab0 + 64, tid, true);
+            load_c(slab0 + 64);
+        }
+        tile_rows_gemm_perm(P, sAh, sAl, Ch, Cl, fr, g4, nks);   // pair products a_j . c_i
+        tile_cols_gemm(acc, sTh, sTl, Ch, Cl, lane, nks);        // inter-chunk: T_prev^T c_i
+    }
+    // mask to j <= i (positions beyond N carry zero features)
+#pragma unroll
+    for (int jf = 0; jf < 4; ++jf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (jf * 16 + g4 * 4 + r > w * 16 + fr) P[jf][r] = 0.f;
+    float inv_n = 1.f;
+    if (s.zmode == 1) {   // den_i = c_i . (z_prev + eps) + sum_{j <= i in chunk} a_j . c_i
+        float part = den;
+#pragma unroll
+        for (int jf = 0; jf < 4; ++jf) part += (P[jf][0] + P[jf][1]) + (P[jf][2] + P[jf][3]);
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        inv_n = 1.f / part;
+        if (vi && g4 == 0 && s.inv_out) s.inv_out[rowi] = inv_n;
+    }
+    short8_t Ph[2], Pl[2];
+    acc_to_operand(Ph, Pl, P);
+    tile_cols_gemm(acc, sBh, sBl, Ph, Pl, lane);   // intra-chunk: sum_j b_j[d] P[j][i]
+    if (!vi) return;
+    const float ys = s.zmode == 1 ? inv_n : (s.y_scale ? s.y_scale[rowi] : 1.f);
+    float* yp = s.y + ((int64_t)b * s.N + ri) * s.y_stride + s.y_off + g * s.dv;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+        float4 o = make_float4(acc[df][0] * ys, acc[df][1] * ys, acc[df][2] * ys, acc[df][3] * ys);
+        float4* d4 = (float4*)(yp + df * 16 + g4 * 4);
+        if (s.accumulate) {
+            const float4 old = *d4;
+            o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *d4 = o;
     }
 }
 
@@ -1524,7 +1739,7 @@ static int run_scan(K valu_kernel, int which, ScanArgs& s, unsigned base_blocks,
         s.seg_len = 64;
         const unsigned nblk = (unsigned)(bg * s.S);
         const char* ex = getenv("SA_SCAN_EXACT");
-        const int exact = ex ? atoi(ex) : 0;   // bit 0: state sums, bit 1: scan A outputs, bit 2: scan B outputs on the exact-fp32 MFMA kernels
+        const int exact = (ex ? atoi(ex) : 0) | (s.exact ? 7 : 0);   // bit 0: state sums, bit 1: scan A outputs, bit 2: scan B outputs on the exact-fp32 MFMA kernels
         const bool fits32 = (int64_t)s.N * s.G * s.LDF * 4 < ((int64_t)1 << 31) && (int64_t)s.N * std::max(s.b_stride, std::max(s.c_stride, s.y_stride)) * 4 < ((int64_t)1 << 31);
         if (!s.state_ready) {
             if (!(exact & 1) && fits32) hipLaunchKernelGGL(favor_chunk_state_split_kernel, dim3(nblk), dim3(256), 0, st, s);
@@ -1533,8 +1748,13 @@ static int run_scan(K valu_kernel, int which, ScanArgs& s, unsigned base_blocks,
             hipLaunchKernelGGL(scan_state_prefix_kernel, dim3((unsigned)((bg * elems + 255) / 256)), dim3(256), 0, st, ws, bg, s.S, elems);
             SA_CHECK_LAUNCH();
         }
-        if (which == 0) hipLaunchKernelGGL(favor_chunk_out_a_kernel, dim3(nblk), dim3(256), 0, st, s);
-        else hipLaunchKernelGGL(favor_chunk_out_b_kernel, dim3(nblk), dim3(256), 0, st, s);
+        if (which == 0) {
+            if (!(exact & 2) && fits32) hipLaunchKernelGGL(favor_chunk_out_a_split_kernel, dim3(nblk), dim3(256), 0, st, s);
+            else hipLaunchKernelGGL(favor_chunk_out_a_kernel, dim3(nblk), dim3(256), 0, st, s);
+        } else {
+            if (!(exact & 4) && fits32) hipLaunchKernelGGL(favor_chunk_out_b_split_kernel, dim3(nblk), dim3(256), 0, st, s);
+            else hipLaunchKernelGGL(favor_chunk_out_b_kernel, dim3(nblk), dim3(256), 0, st, s);
+        }
         SA_CHECK_LAUNCH();
         return 0;
     }
@@ -1706,7 +1926,7 @@ extern "C" int sa_favor_scan_a_norm(const float* a, const float* c, const float*
     ScanArgs s = {};
     s.a = a; s.c_feat = c; s.b = b; s.y = y;
     s.B = B; s.N = N; s.G = G; s.LDF = LDF; s.dv = dv; s.b_stride = b_stride; s.b_off = b_off; s.y_stride = y_stride; s.y_off = y_off;
-    s.zmode = 1; s.den_eps = den_eps; s.inv_out = inv_out; s.state_ready = state_flags & 1;
+    s.zmode = 1; s.den_eps = den_eps; s.inv_out = inv_out; s.state_ready = state_flags & 1; s.exact = (state_flags >> 2) & 1;
     return run_scan(favor_scan_a_kernel, 0, s, (unsigned)(B * G * (dv / 16)), state_ws, ST(stream));
 }
 
@@ -1722,7 +1942,7 @@ extern "C" int sa_favor_scan_b_cum(const float* a, const float* b, int b_stride,
     ScanArgs s = {};
     s.a = a; s.b = b; s.c_col = c; s.b_scale = b_scale; s.c_scale = c_scale; s.y = y; s.ex_scale = ex_scale; s.ex_vec = nullptr; s.ex_const = ex_const;
     s.B = B; s.N = N; s.G = G; s.LDF = LDF; s.dv = dv; s.b_stride = b_stride; s.b_off = b_off; s.c_stride = c_stride; s.c_off = c_off; s.reverse = reverse;
-    s.zmode = ex_mode; s.state_ready = state_flags & 1;
+    s.zmode = ex_mode; s.state_ready = state_flags & 1; s.exact = (state_flags >> 2) & 1;
     return run_scan(favor_scan_b_kernel, 1, s, (unsigned)(B * G * ((LDF + 63) / 64)), state_ws, ST(stream));
 }
 
@@ -1740,5 +1960,6 @@ extern "C" int sa_favor_scan_a_state(const float* a, const float* c, const float
     s.reverse = reverse; s.accumulate = accumulate;
     s.state_ready = state_flags & 1;
     s.zcol = (state_flags >> 1) & 1;
+    s.exact = (state_flags >> 2) & 1;
     return run_scan(favor_scan_a_kernel, 0, s, (unsigned)(B * G * (dv / 16)), state_ws, ST(stream));
 }

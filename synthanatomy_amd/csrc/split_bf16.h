@@ -57,4 +57,87 @@ __device__ __forceinline__ void acc_to_operand(short8_t (&hi)[2], short8_t (&lo)
     }
 }
 
+// ---- GEMM steps over one [64 rows][64 bf16] hi / lo tile pair in the lroff() layout; four accumulator fragments per call ----
+
+// acc[f] += rows (f*16 + lane&15) of the tile . B operand; reduction over the 64 tile columns in natural order: B operand word e of lane
+// (n, g) is column ks*32 + g*8 + e.  Fragments via ds_read_b128.
+__device__ __forceinline__ void tile_rows_gemm(float4_t (&acc)[4], const unsigned char* tHi, const unsigned char* tLo, const short8_t (&bh)[2],
+                                               const short8_t (&bl)[2], int i16, int g) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        short8_t ah[4], al[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const uint32_t o = lroff(f * 16 + i16, ks * 32 + g * 8);
+            ah[f] = *(const short8_t*)(tHi + o);
+            al[f] = *(const short8_t*)(tLo + o);
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bl[ks], acc[f], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], bh[ks], acc[f], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bh[ks], acc[f], 0, 0, 0);
+    }
+}
+
+// same product with the reduction index in accumulator-row order: word e of lane (n, g) is column ks*32 + (e/4)*16 + 4g + e%4
+// (two ds_read_b64 per fragment), so one B operand can serve this GEMM and a tile_cols_gemm over the same index
+__device__ __forceinline__ void tile_rows_gemm_perm(float4_t (&acc)[4], const unsigned char* tHi, const unsigned char* tLo, const short8_t (&bh)[2],
+                                                    const short8_t (&bl)[2], int i16, int g, int nks = 2) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        if (ks >= nks) break;
+        short8_t ah[4], al[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const uint32_t o0 = lroff(f * 16 + i16, ks * 32 + g * 4), o1 = lroff(f * 16 + i16, ks * 32 + 16 + g * 4);
+            ah[f] = __builtin_shufflevector(*(const v4s_t*)(tHi + o0), *(const v4s_t*)(tHi + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+            al[f] = __builtin_shufflevector(*(const v4s_t*)(tLo + o0), *(const v4s_t*)(tLo + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bl[ks], acc[f], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], bh[ks], acc[f], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bh[ks], acc[f], 0, 0, 0);
+    }
+}
+
+// acc[f] += tile^T (tile columns f*16 + lane&15) . B operand; reduction over the 64 tile ROWS in accumulator-row order (transposing reads)
+__device__ __forceinline__ void tile_cols_gemm(float4_t (&acc)[4], const unsigned char* tHi, const unsigned char* tLo, const short8_t (&bh)[2],
+                                               const short8_t (&bl)[2], int lane, int nks = 2) {
+    const uint32_t trow = (uint32_t)(lane >> 4) * 4u + ((uint32_t)(lane & 15) >> 2), tcol = (uint32_t)(lane & 3) * 4u;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        if (ks >= nks) break;
+        short8_t ah[4], al[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const uint32_t o0 = lroff(ks * 32 + trow, f * 16 + tcol), o1 = lroff(ks * 32 + 16 + trow, f * 16 + tcol);
+            ah[f] = __builtin_shufflevector(lds_tr16_b64(tHi + o0), lds_tr16_b64(tHi + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+            al[f] = __builtin_shufflevector(lds_tr16_b64(tLo + o0), lds_tr16_b64(tLo + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bl[ks], acc[f], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], bh[ks], acc[f], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bh[ks], acc[f], 0, 0, 0);
+    }
+}
+
+// four 16-byte pieces per thread of a [64][64] fp32 tile (thread = row tid/16 + 16 it, columns 4 (tid%16)..+3) -> hi / lo tiles
+__device__ __forceinline__ void tile_stage(unsigned char* hi, unsigned char* lo, const u32x4 (&v)[4], int tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const uint32_t o = lroff((tid >> 4) + 16 * it, (tid & 15) * 4);
+        uint2 h, l;
+        split_pair(__uint_as_float(v[it][0]), __uint_as_float(v[it][1]), h.x, l.x);
+        split_pair(__uint_as_float(v[it][2]), __uint_as_float(v[it][3]), h.y, l.y);
+        *(uint2*)(hi + o) = h;
+        *(uint2*)(lo + o) = l;
+    }
+}
+
 }  // namespace sa

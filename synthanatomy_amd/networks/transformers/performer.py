@@ -282,6 +282,9 @@ class _LayerEngine:
         self.ops["w1"], self.ops["w2"] = _lin(ff.w1, dtype), _lin(ff.w2, dtype)
         self._pscaled = None
         self._fused_sums = os.environ.get("SA_NO_FUSED_SUMS") is None
+        # state_flags bit 2 of the fused scans: fp32 (parity) mode keeps every product on the exact-fp32 MFMA; the bf16 throughput mode uses the
+        # split-bf16 kernels (~1e-5 relative, far below the rounding of its dense layers)
+        self._xf = 4 if dtype == torch.float32 else 0
         self._pop = None
         self._rot = None
         self._one = None
@@ -375,7 +378,7 @@ class _LayerEngine:
             Z = None
             # normaliser fused into the scan (the running key sums ride along as an extra state column): no cumsum / den passes
             rc = lib.sa_favor_scan_a_norm(_ffi.ptr(kf), _ffi.ptr(qf), _ffi.ptr(v), inner, 0, _ffi.ptr(attn), inner, 0, _ffi.ptr(inv), 1e-6, B, N, G, LDF, dh,
-                                          _ffi.ptr(ws), 0, st) if self._fused_sums else _ffi.SA_EUNSUPPORTED
+                                          _ffi.ptr(ws), self._xf, st) if self._fused_sums else _ffi.SA_EUNSUPPORTED
             if rc == _ffi.SA_EUNSUPPORTED:
                 Z = torch.empty_like(kf)
                 _ck(lib.sa_cumsum_rows(_ffi.ptr(kf), None, _ffi.ptr(Z), B, N, G, LDF, 0, _ffi.ptr(ws), st), "sa_cumsum_rows")
@@ -553,11 +556,11 @@ class _LayerEngine:
             if Z is None:   # forward ran the fused form: the cumulative terms are rebuilt inside the scans as well
                 kept = sv.get("scan_state")   # the forward's chunk states: same (a = k', b = v) -> no state / prefix passes for dq'
                 _ck(lib.sa_favor_scan_b_cum(_ffi.ptr(kf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dqf), _ffi.ptr(dden), 1, 1e-6,
-                                            B, N, G, LDF, dh, 0, _ffi.ptr(kept if kept is not None else ws), 1 if kept is not None else 0, st),
+                                            B, N, G, LDF, dh, 0, _ffi.ptr(kept if kept is not None else ws), (1 if kept is not None else 0) | self._xf, st),
                     "sa_favor_scan_b_cum(dq')")
                 sv["scan_state"] = None
                 _ck(lib.sa_favor_scan_b_cum(_ffi.ptr(qf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dkf), _ffi.ptr(dden), 2, 0.0,
-                                            B, N, G, LDF, dh, 1, _ffi.ptr(ws), 0, st), "sa_favor_scan_b_cum(dk')")
+                                            B, N, G, LDF, dh, 1, _ffi.ptr(ws), self._xf, st), "sa_favor_scan_b_cum(dk')")
                 shared_dv = True
             else:
                 _ck(lib.sa_favor_scan_b(_ffi.ptr(kf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dqf), _ffi.ptr(dden), _ffi.ptr(Z),
@@ -568,7 +571,7 @@ class _LayerEngine:
                                         B, N, G, LDF, dh, 1, _ffi.ptr(ws), st), "sa_favor_scan_b(dk')")
             if shared_dv:   # dv runs on the states the dk' scan just built (same a = q', b = d attn * inv, reversed)
                 _ck(lib.sa_favor_scan_a_state(_ffi.ptr(qf), _ffi.ptr(kf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dv), inner, 0, None, B, N, G, LDF, dh, 1, 0,
-                                              _ffi.ptr(ws), 3, st), "sa_favor_scan_a_state(dv)")
+                                              _ffi.ptr(ws), 3 | self._xf, st), "sa_favor_scan_a_state(dv)")
             else:
                 _ck(lib.sa_favor_scan_a(_ffi.ptr(qf), _ffi.ptr(kf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dv), inner, 0, None, B, N, G, LDF, dh, 1, 0,
                                         _ffi.ptr(ws), st), "sa_favor_scan_a(dv)")

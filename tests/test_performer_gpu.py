@@ -86,6 +86,68 @@ def test_bf16_projections_close_to_fp32_oracle():
     assert _rel(out, P.forward(st, cfg, tok, seqs)) < 3e-2
 
 
+def test_bf16_mode_gradients_follow_fp32_oracle():
+    """Throughput mode end to end (bf16 dense layers, split-bf16 scans and local attention): parameter gradients against the fp32 oracle.
+    The bound is the bf16 rounding of the dense layers; the ill-conditioned query-side gradients are compared in aggregate norm."""
+    shape = (2, 4, 4)
+    n = 32
+    cfg = P.PerformerConfig(num_tokens=33, max_seq_len=n, dim=64, depth=2, heads=4, dim_head=64, local_attn_heads=2, local_window_size=8, spatial_shape=shape)
+    st = P.init_state(cfg, seed=9)
+    for k in st:
+        if k.endswith(".g"):
+            st[k] = torch.tensor(0.4)
+    net, o = _build(cfg, st, dtype=torch.bfloat16)
+    net.train()
+    seqs = P.spatial_index_sequences(shape, o.get_sequence_ordering())
+    torch.manual_seed(3)
+    tok = torch.randint(0, 33, (2, n))
+    tgt = torch.randint(0, 32, (2, n))
+    leaf = {k: v.clone().requires_grad_(True) for k, v in st.items() if "projection_matrix" not in k}
+    stt = dict(st)
+    stt.update(leaf)
+    P.ce_loss(P.forward(stt, cfg, tok, seqs), tgt).backward()
+    from synthanatomy_amd.losses.transformer import CELoss
+    loss = CELoss()(net(tok.cuda()).transpose(1, 2), tgt.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    params = dict(net.named_parameters())
+    num = den = 0.0
+    for k, p in leaf.items():
+        if p.grad is None:
+            continue
+        g = params[k].grad.cpu().double()
+        num += float((g - p.grad.double()).pow(2).sum())
+        den += float(p.grad.double().pow(2).sum())
+        if not any(t in k for t in ("to_q", "to_k")):
+            assert _rel(g, p.grad) < 5e-2, k
+    assert (num / den) ** 0.5 < 2e-2
+
+
+def test_scan_exact_flag_selects_fp32_products():
+    """state_flags bit 2 of the fused scans: exact-fp32 MFMA products; both paths agree to the split-bf16 error (~1e-5) and differ bitwise."""
+    from synthanatomy_amd import _ffi
+    lib, st = _ffi.lib(), _ffi.stream()
+    torch.manual_seed(11)
+    B, N, G, m, LDF, dv = 2, 150, 2, 266, 272, 64
+    a = torch.zeros(B, N, G, LDF, device="cuda")
+    c = torch.zeros(B, N, G, LDF, device="cuda")
+    a[..., :m] = torch.rand(B, N, G, m, device="cuda") + 0.01
+    c[..., :m] = torch.rand(B, N, G, m, device="cuda") + 0.01
+    bb = torch.randn(B * N, G * dv, device="cuda")
+    ws = torch.empty(lib.sa_favor_scan_workspace_bytes(B, N, G, LDF, dv) // 4, device="cuda")
+    outs = []
+    for flags in (0, 4):
+        y = torch.zeros(B * N, G * dv, device="cuda")
+        inv = torch.zeros(B * N * G, device="cuda")
+        _ffi.check(lib.sa_favor_scan_a_norm(_ffi.ptr(a), _ffi.ptr(c), _ffi.ptr(bb), G * dv, 0, _ffi.ptr(y), G * dv, 0, _ffi.ptr(inv), 1e-6, B, N, G, LDF, dv,
+                                            _ffi.ptr(ws), flags, st))
+        outs.append((y, inv))
+    ref = torch.einsum("bigm,bjgm,ij,bjgd->bigd", c.double(), a.double(), torch.tril(torch.ones(N, N, dtype=torch.float64, device="cuda")), bb.view(B, N, G, dv).double())
+    ref = ref / torch.einsum("bigm,bigm->big", c.double(), a.double().cumsum(1) + 1e-6)[..., None]
+    e_split, e_exact = _rel(outs[0][0].view(B, N, G, dv), ref), _rel(outs[1][0].view(B, N, G, dv), ref)
+    assert e_exact < 2e-6 and e_split < 5e-5 and not torch.equal(outs[0][0], outs[1][0])
+
+
 @pytest.mark.parametrize("N,segmented", [(37, False), (37, True), (300, True), (1400, True)])
 def test_causal_scan_kernels_against_quadratic_form(N, segmented):
     from synthanatomy_amd import _ffi
