@@ -162,22 +162,32 @@ __device__ __forceinline__ float unpack_max(unsigned long long p) {
     return __uint_as_float(u);
 }
 
-__global__ void favor_global_max_kernel(const float* __restrict__ dd, int64_t rows, int m, int LDF, unsigned long long* __restrict__ out) {
-    // one wave per row, 16-byte loads (LDF % 4 == 0); the padding columns >= m are skipped
+__global__ __launch_bounds__(256) void favor_global_max_kernel(const float* __restrict__ dd, int64_t rows, int m, int LDF, unsigned long long* __restrict__ out) {
+    // one wave per group of four rows, 16-byte loads (LDF % 4 == 0), the four rows' loads in flight together; the padding columns >= m are
+    // skipped; one atomic per block
+    __shared__ unsigned long long sbest[4];
     unsigned long long best = 0ull;
     const int lane = threadIdx.x & 63, nv = LDF >> 2;
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
-    for (int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < rows; r += nw) {
-        const float4* rp = (const float4*)(dd + r * LDF);
+    for (int64_t r0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4; r0 < rows; r0 += nw * 4) {
         for (int v = lane; v < nv; v += 64) {
-            const float4 x = rp[v];
-            const uint32_t i0 = (uint32_t)(r * LDF) + (uint32_t)v * 4u;
+            float4 x[4];
+            int64_t rr[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rr[q] = r0 + q < rows ? r0 + q : rows - 1;   // a repeated row repeats (value, index) pairs: harmless for the maximum
+                x[q] = ((const float4*)(dd + rr[q] * LDF))[v];
+            }
             const int c = v * 4;
-            unsigned long long p;
-            if (c < m) { p = pack_max(x.x, i0); best = p > best ? p : best; }
-            if (c + 1 < m) { p = pack_max(x.y, i0 + 1); best = p > best ? p : best; }
-            if (c + 2 < m) { p = pack_max(x.z, i0 + 2); best = p > best ? p : best; }
-            if (c + 3 < m) { p = pack_max(x.w, i0 + 3); best = p > best ? p : best; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t i0 = (uint32_t)(rr[q] * LDF) + (uint32_t)c;
+                unsigned long long p;
+                if (c < m) { p = pack_max(x[q].x, i0); best = p > best ? p : best; }
+                if (c + 1 < m) { p = pack_max(x[q].y, i0 + 1); best = p > best ? p : best; }
+                if (c + 2 < m) { p = pack_max(x[q].z, i0 + 2); best = p > best ? p : best; }
+                if (c + 3 < m) { p = pack_max(x[q].w, i0 + 3); best = p > best ? p : best; }
+            }
         }
     }
 #pragma unroll
@@ -185,7 +195,13 @@ __global__ void favor_global_max_kernel(const float* __restrict__ dd, int64_t ro
         const unsigned long long ot = __shfl_xor(best, o, 64);
         best = ot > best ? ot : best;
     }
-    if (lane == 0) atomicMax(out, best);
+    if (lane == 0) sbest[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 1; q < 4; ++q) best = sbest[q] > best ? sbest[q] : best;
+        atomicMax(out, best);
+    }
 }
 
 // one wave per row: feat = ratio * (exp(dd - |x|^2 c^2/2 - stab) + eps); stab = row max (query) or *gmax (key)
@@ -1672,7 +1688,7 @@ extern "C" int sa_favor_features_fwd(const float* dd, const float* src, int src_
     if (!is_query) {
         gm = (unsigned long long*)gmax_ws;
         hipMemsetAsync(gm, 0, 8, ST(stream));
-        hipLaunchKernelGGL(favor_global_max_kernel, dim3(grid1d(rows * m, 256, 2048)), dim3(256), 0, ST(stream), dd, rows, m, LDF, gm);
+        hipLaunchKernelGGL(favor_global_max_kernel, dim3(grid1d(rows * 16, 256, 2048)), dim3(256), 0, ST(stream), dd, rows, m, LDF, gm);
         SA_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(favor_feat_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), dd, src, src_stride, h0, G, dh, gm, feat, rows, m,
