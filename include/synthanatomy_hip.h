@@ -70,6 +70,18 @@ const char *sa_last_conv_kernel(void);
  * (baseline.py:283): s_row=T, s_red=Co*T.  Swapping the two gives the data-gradient operand. */
 int sa_pack_weights(const float *w, void *wpk, int dtype, int rows, int red, int ntaps, const int32_t *tap_lut_host,
                     int64_t s_row, int64_t s_red, int rows_pad, int red_stride, int Kpad, void *stream);
+/* The same for many operands in ONE launch (a training step re-packs every layer's forward and data-gradient operand after the optimizer
+ * step: ~300 launches of a few microseconds each otherwise).  `table` is a DEVICE array of n descriptors and `block_first` a DEVICE array of
+ * n + 1 ints: descriptor i is packed by blocks [block_first[i], block_first[i+1]); the caller uploads both once -- parameters and packed
+ * operands keep their addresses across steps.  tap_lut holds ntaps entries (identity: 0, 1, 2, ...). */
+typedef struct sa_pack_desc {
+  const float *w;
+  void *wpk;
+  int32_t tap_lut[SA_MAX_TAPS];
+  int64_t s_row, s_red;
+  int32_t dtype, rows, red, ntaps, rows_pad, red_stride, Kpad, reserved;
+} sa_pack_desc;
+int sa_pack_weights_batch(const sa_pack_desc *table, const int32_t *block_first, int n, int total_blocks, void *stream);
 
 /* ---- convolution forward / data gradient (implicit GEMM on MFMA) -- replaces cuDNN behind nn.Conv3d /
  * nn.ConvTranspose3d / nn.Linear at baseline.py:153-160,218-244,258-293; discriminator/baseline.py:41-80;

@@ -32,6 +32,12 @@ class ConvGeom(Structure):
     ]
 
 
+class PackDesc(Structure):
+    """sa_pack_desc (include/synthanatomy_hip.h)."""
+    _fields_ = [("w", c_void_p), ("wpk", c_void_p), ("tap_lut", c_int32 * 64), ("s_row", c_int64), ("s_red", c_int64), ("dtype", c_int32), ("rows", c_int32),
+                ("red", c_int32), ("ntaps", c_int32), ("rows_pad", c_int32), ("red_stride", c_int32), ("Kpad", c_int32), ("reserved", c_int32)]
+
+
 class Epilogue(Structure):
     _fields_ = [
         ("bias", c_void_p), ("addend", c_void_p), ("mask", c_void_p), ("alpha", c_void_p),
@@ -45,6 +51,7 @@ _SIGS = {
     "sa_abi_version": (c_int, []),
     "sa_last_error": (c_char_p, []),
     "sa_last_conv_kernel": (c_char_p, []),
+    "sa_pack_weights_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "sa_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int32), c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "sa_conv_fprop": (c_int, [POINTER(ConvGeom), c_int, c_void_p, c_void_p, c_void_p, POINTER(Epilogue), c_void_p]),
     "sa_resblock_fprop": (c_int, [POINTER(ConvGeom), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Epilogue), c_void_p]),

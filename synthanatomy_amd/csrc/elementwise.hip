@@ -28,6 +28,33 @@ __global__ void pack_weights_kernel(const PackArgs a) {
     }
 }
 
+// many packs in one launch: block -> descriptor by binary search in block_first
+__global__ void pack_weights_batch_kernel(const sa_pack_desc* __restrict__ table, const int32_t* __restrict__ block_first, int n) {
+    __shared__ int s_desc;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (block_first[mid] <= (int)blockIdx.x) lo = mid;
+            else hi = mid - 1;
+        }
+        s_desc = lo;
+    }
+    __syncthreads();
+    const sa_pack_desc& a = table[s_desc];
+    const int b0 = block_first[s_desc], nb = block_first[s_desc + 1] - b0;
+    const int64_t total = (int64_t)a.rows_pad * a.Kpad;
+    for (int64_t e = (int64_t)(blockIdx.x - b0) * blockDim.x + threadIdx.x; e < total; e += (int64_t)nb * blockDim.x) {
+        const int r = (int)(e / a.Kpad);
+        const int k = (int)(e - (int64_t)r * a.Kpad);
+        const int t = k / a.red_stride;
+        const int c = k - t * a.red_stride;
+        float v = 0.f;
+        if (r < a.rows && t < a.ntaps && c < a.red) v = a.w[r * a.s_row + c * a.s_red + a.tap_lut[t]];
+        store_from_f32(a.wpk, a.dtype, e, v);
+    }
+}
+
 __global__ void cast_pad_kernel(const void* src, int src_dtype, int src_c, void* dst, int dst_dtype, int dst_stride, int64_t rows) {
     const int64_t total = rows * dst_stride;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -103,6 +130,14 @@ extern "C" int sa_pack_weights(const float* w, void* wpk, int dtype, int rows, i
     a.red_stride = red_stride;
     a.Kpad = Kpad;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for((int64_t)rows_pad * Kpad)), dim3(256), 0, (hipStream_t)stream, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_pack_weights_batch(const sa_pack_desc* table, const int32_t* block_first, int n, int total_blocks, void* stream) {
+    using namespace sa;
+    if (!table || !block_first || n <= 0 || total_blocks < n) return SA_EINVAL;
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table, block_first, n);
     SA_CHECK_LAUNCH();
     return 0;
 }

@@ -214,8 +214,11 @@ class ConvOp:
         """Call after the weights changed through a raw pointer (our Adam kernel): packed operands are rebuilt lazily."""
         self._epoch += 1
 
+    def _pack_version(self):
+        return (self.weight._version, self.weight.data_ptr(), self._epoch)
+
     def _ensure_packed(self, plans: Sequence[_Plan]):
-        ver = (self.weight._version, self.weight.data_ptr(), self._epoch)
+        ver = self._pack_version()
         for pl in plans:
             self._pack(pl, ver)
 
@@ -304,6 +307,50 @@ class ConvOp:
                         lib.sa_conv_wgrad(ctypes.byref(pl.geom), did, _ffi.ptr(x), _ffi.ptr(g), _ffi.ptr(dw), _ffi.ptr(db), pl.lut_c, pl.s_row, pl.s_red, _ffi.ptr(ws),
                                           nbytes, st),
                         "sa_conv_wgrad"))
+
+
+class PackSet:
+    """Re-packs the GEMM operands of many ConvOps in ONE launch (sa_pack_weights_batch) after the parameters changed.
+
+    The descriptor table lives on the device and is rebuilt only when the set of (parameter, packed operand) addresses changes: parameters sit in
+    the flat optimizer buffer and packed operands are allocated once per layout, so in steady state a training step pays one launch instead of
+    one per layer and direction.  Operands whose layout first appears later are packed lazily by their op and join the table at the next call."""
+
+    def __init__(self):
+        self._sig = None
+        self._table = None
+        self._first = None
+        self._n = 0
+        self._blocks = 0
+
+    def repack(self, ops: Sequence["ConvOp"]):
+        if os.environ.get("SA_NO_BATCHED_PACK") is not None:
+            return
+        items = [(op, key, ent) for op in ops for key, ent in op._packs.items() if ent[0].device == op.weight.device]
+        if not items:
+            return
+        sig = tuple((op.weight.data_ptr(), ent[0].data_ptr(), key) for op, key, ent in items)
+        if sig != self._sig:
+            table = (_ffi.PackDesc * len(items))()
+            first = [0]
+            for d, (op, key, ent) in zip(table, items):
+                rows, red, ntaps, lut, s_row, s_red, rows_pad, red_stride, kpad = key
+                d.w, d.wpk = op.weight.data_ptr(), ent[0].data_ptr()
+                for t in range(ntaps):
+                    d.tap_lut[t] = lut[t] if lut is not None else t
+                d.s_row, d.s_red, d.dtype, d.rows, d.red, d.ntaps = s_row, s_red, _ffi.dtype_id(op.dtype), rows, red, ntaps
+                d.rows_pad, d.red_stride, d.Kpad = rows_pad, red_stride, kpad
+                first.append(first[-1] + max(1, min(64, (rows_pad * kpad + 2047) // 2048)))
+            dev = items[0][0].weight.device
+            raw = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8)
+            self._table = raw.to(dev)
+            self._first = torch.tensor(first, dtype=torch.int32).to(dev)
+            self._n, self._blocks, self._sig = len(items), first[-1], sig
+        _launch("pack_weights_batch", 0.0,
+                lambda: _ffi.check(_ffi.lib().sa_pack_weights_batch(_ffi.ptr(self._table), _ffi.ptr(self._first), self._n, self._blocks, _ffi.stream()),
+                                   "sa_pack_weights_batch"))
+        for op, key, ent in items:
+            ent[1] = op._pack_version()
 
 
 def conv1x1_backward(op: "ConvOp", x: torch.Tensor, g: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor]) -> Optional[torch.Tensor]:

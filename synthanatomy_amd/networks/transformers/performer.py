@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from ... import _ffi
 from ..._ffi import MASK_GELU
-from ...engine import ConvOp
+from ...engine import ConvOp, PackSet
 from .img2seq_ordering import Ordering
 from .transformer import TransformerBase
 
@@ -835,6 +835,10 @@ class Performer(TransformerBase):
     def invalidate_packed_weights(self):
         self._chain.invalidate()
         self._out_op.invalidate()
+        # every dense layer's forward / data-gradient operand again, in one launch
+        if getattr(self, "_packset", None) is None:
+            self._packset = PackSet()
+        self._packset.repack([op for l in self._chain.layers for op in l.ops.values()] + [self._out_op])
 
     # ------------------------------------------------------------------------------------------------ sampling
     @torch.no_grad()

@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from ... import _ffi
 from ..._ffi import ACT_NONE, ACT_RELU, MASK_NONE, MASK_POS
-from ...engine import ConvOp, cast_pad, vec_of
+from ...engine import ConvOp, PackSet, cast_pad, vec_of
 from .vqvae import VQVAEBase
 
 
@@ -386,11 +386,14 @@ class _Chain:
     def params(self) -> List[nn.Parameter]:
         return [p for s in self.stages for p in s.params()]
 
+    def ops(self):
+        return [op for s in self.stages
+                for op in (getattr(s, "op", None), getattr(s, "c3", None), getattr(s, "c1", None), getattr(s, "taps_fwd", None), getattr(s, "taps_bwd", None))
+                if op is not None]
+
     def invalidate(self):
-        for s in self.stages:
-            for op in (getattr(s, "op", None), getattr(s, "c3", None), getattr(s, "c1", None), getattr(s, "taps_fwd", None), getattr(s, "taps_bwd", None)):
-                if op is not None:
-                    op.invalidate()
+        for op in self.ops():
+            op.invalidate()
 
     def forward(self, x_ncdhw: torch.Tensor, record: bool):
         """x [B,C,D,H,W] fp32 (any strides) -> y channels-last [B,D,H,W,C'] (+ tape)."""
@@ -547,6 +550,9 @@ class BaselineVQVAE(VQVAEBase, nn.Module):
         """Tell the launch chains that parameters were modified through raw pointers (fused Adam kernel)."""
         self._enc_chain.invalidate()
         self._dec_chain.invalidate()
+        if getattr(self, "_packset", None) is None:
+            self._packset = PackSet()
+        self._packset.repack(self._enc_chain.ops() + self._dec_chain.ops())   # all packed operands again, in one launch
 
     # ---------------------------------------------------------------- accessors (baseline.py:301-327)
     def get_ema_decay(self) -> Sequence[float]:
