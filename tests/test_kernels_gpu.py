@@ -180,6 +180,48 @@ def test_linear_as_one_tap_conv():
         _close(y.cpu().view(M, Nn), F.gelu(_rt(x, dtype) @ _rt(w, dtype).t() + b), dtype, "linear+gelu")
 
 
+def test_batched_weight_repack_matches_single_launches():
+    """engine.PackSet (sa_pack_weights_batch: all operands of a network in one launch after the optimizer step) writes exactly what the per-operand
+    sa_pack_weights launches write: conv / transposed conv / linear, forward and data-gradient layouts, bf16 and fp32."""
+    _ffi, engine = _ops()
+    torch.manual_seed(6)
+    mk = lambda *shp: (torch.randn(*shp) * 0.1).cuda()
+    specs = [("conv", 16, 24, 3, 1, 1, torch.bfloat16), ("conv", 8, 136, 4, 2, 1, torch.float32), ("convT", 24, 16, 4, 2, 1, torch.bfloat16),
+             ("conv", 512, 96, 1, 1, 0, torch.bfloat16)]
+    ops = []
+    for kind, cin, cout, k, st, pad, dt in specs:
+        w = mk(cout, cin, k, k, k) if kind == "conv" else mk(cin, cout, k, k, k)
+        op = engine.ConvOp(kind, cin, cout, k, st, pad, w, mk(cout), dt)
+        dims = (1, 1, 40) if k == 1 else (8, 8, 8)
+        x = torch.randn(1, *dims, op.cs_in(), device="cuda").to(dt)
+        y = op.fprop(x)                                     # lazy single-launch packs: forward ...
+        op.dgrad(torch.randn_like(y), dims)                 # ... and data-gradient operands
+        ops.append(op)
+    ref = []
+    for op in ops:
+        op.weight = op.weight * 1.5 + 0.01                  # "optimizer step"
+        op.invalidate()
+    for op in ops:                                          # reference: what the lazy path packs for the new weights
+        for plans in op._plans.values():
+            op._ensure_packed(plans["fwd"]); op._ensure_packed(plans["dgrad"])
+        ref.append({k: e[0].clone() for k, e in op._packs.items()})
+        for e in op._packs.values():
+            e[0].zero_(); e[1] = None
+    ps = engine.PackSet()
+    ps.repack(ops)
+    torch.cuda.synchronize()
+    n = 0
+    for op, r in zip(ops, ref):
+        for k, e in op._packs.items():
+            assert e[1] == op._pack_version()
+            assert torch.equal(e[0].view(torch.uint8), r[k].view(torch.uint8)), (op.kind, k[:3])
+            n += 1
+    assert n >= 8
+    ps.repack(ops)   # second call reuses the device table
+    torch.cuda.synchronize()
+    assert all(torch.equal(e[0].view(torch.uint8), r[k].view(torch.uint8)) for op, r in zip(ops, ref) for k, e in op._packs.items())
+
+
 # ----------------------------------------------------------------------------------------------- quantizer
 def _vq_run(x_rows, cb, decay=None, N=None, avg=None):
     _ffi, _ = _ops()
