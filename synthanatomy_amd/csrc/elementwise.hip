@@ -28,9 +28,12 @@ __global__ void pack_weights_kernel(const PackArgs a) {
     }
 }
 
-// many packs in one launch: block -> descriptor by binary search in block_first
-__global__ void pack_weights_batch_kernel(const sa_pack_desc* __restrict__ table, const int32_t* __restrict__ block_first, int n) {
+// many packs in one launch: block -> descriptor by binary search in block_first.  Each block walks 64 x 64 tiles of the packed operand through
+// LDS so that BOTH sides are coalesced: the data-gradient operand of a Linear is the transpose of the parameter (s_row = 1), which a direct
+// gather reads 4 bytes per 2 KiB stride.
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const sa_pack_desc* __restrict__ table, const int32_t* __restrict__ block_first, int n) {
     __shared__ int s_desc;
+    __shared__ float tile[64][65];
     if (threadIdx.x == 0) {
         int lo = 0, hi = n - 1;
         while (lo < hi) {
@@ -43,15 +46,27 @@ __global__ void pack_weights_batch_kernel(const sa_pack_desc* __restrict__ table
     __syncthreads();
     const sa_pack_desc& a = table[s_desc];
     const int b0 = block_first[s_desc], nb = block_first[s_desc + 1] - b0;
-    const int64_t total = (int64_t)a.rows_pad * a.Kpad;
-    for (int64_t e = (int64_t)(blockIdx.x - b0) * blockDim.x + threadIdx.x; e < total; e += (int64_t)nb * blockDim.x) {
-        const int r = (int)(e / a.Kpad);
-        const int k = (int)(e - (int64_t)r * a.Kpad);
-        const int t = k / a.red_stride;
-        const int c = k - t * a.red_stride;
-        float v = 0.f;
-        if (r < a.rows && t < a.ntaps && c < a.red) v = a.w[r * a.s_row + c * a.s_red + a.tap_lut[t]];
-        store_from_f32(a.wpk, a.dtype, e, v);
+    const int tr = (a.rows_pad + 63) >> 6, tk = (a.Kpad + 63) >> 6;
+    const bool row_fast = a.s_row < a.s_red;   // consecutive rows are adjacent in the parameter: read with the row index on the lanes
+    const int lo6 = threadIdx.x & 63, hi2 = threadIdx.x >> 6;
+    for (int t = (int)blockIdx.x - b0; t < tr * tk; t += nb) {
+        const int r0 = (t / tk) << 6, k0 = (t % tk) << 6;
+        __syncthreads();
+#pragma unroll 4
+        for (int p = 0; p < 16; ++p) {
+            const int rl = row_fast ? lo6 : hi2 + 4 * p, kl = row_fast ? hi2 + 4 * p : lo6;
+            const int r = r0 + rl, k = k0 + kl;
+            const int tp = k / a.red_stride, c = k - tp * a.red_stride;
+            float v = 0.f;
+            if (r < a.rows && k < a.Kpad && tp < a.ntaps && c < a.red) v = a.w[r * a.s_row + c * a.s_red + a.tap_lut[tp]];
+            tile[rl][kl] = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int p = 0; p < 16; ++p) {
+            const int rl = hi2 + 4 * p, r = r0 + rl, k = k0 + lo6;
+            if (r < a.rows_pad && k < a.Kpad) store_from_f32(a.wpk, a.dtype, (int64_t)r * a.Kpad + k, tile[rl][lo6]);
+        }
     }
 }
 

@@ -340,7 +340,7 @@ class PackSet:
                     d.tap_lut[t] = lut[t] if lut is not None else t
                 d.s_row, d.s_red, d.dtype, d.rows, d.red, d.ntaps = s_row, s_red, _ffi.dtype_id(op.dtype), rows, red, ntaps
                 d.rows_pad, d.red_stride, d.Kpad = rows_pad, red_stride, kpad
-                first.append(first[-1] + max(1, min(64, (rows_pad * kpad + 2047) // 2048)))
+                first.append(first[-1] + max(1, min(256, ((rows_pad + 63) // 64) * ((kpad + 63) // 64))))   # one block per 64 x 64 tile, capped
             dev = items[0][0].weight.device
             raw = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8)
             self._table = raw.to(dev)
