@@ -472,6 +472,9 @@ __device__ __forceinline__ void resblock_second_gemm(const FpropArgs& a, float4_
 // lane l of an 8-row x 128-byte piece fetches 16-byte vector (l&7) ^ (l>>3) of row (l>>3).  When a 128-byte K-slab never
 // straddles two taps (Cin*sizeof(T) % 128 == 0, UNIFORM) the tap decode is scalar (SALU) work.
 // Needs every operand < 4 GiB (32-bit buffer offsets); the register-staged kernel above is the fallback.
+// Measured dead end for the narrow tiles (128 x 64, the dense layers of the Performer: 8 slabs of 16 MFMAs per wave): a three-buffer ring with
+// two slabs in flight (counted s_waitcnt vmcnt + raw barrier) was 25-35 % SLOWER (512 -> 512 layer 25 -> 33 us, Performer step +10 %): the
+// third buffer costs a resident block per CU (72 KiB against 48 KiB), and co-resident blocks hide the DMA round trip better than depth does.
 constexpr uint32_t OOB_OFF = 0xfffffff0u;
 
 template <typename T, int WM, int WN, int MI, int NI, bool UNIFORM, bool FUSE = false>
