@@ -229,6 +229,13 @@ int sa_favor_scan_b_cum(const float *a, const float *b, int b_stride, int b_off,
 int sa_favor_scan_a_state(const float *a, const float *c, const float *b, int b_stride, int b_off, const float *b_scale, float *y, int y_stride,
                           int y_off, const float *y_scale, int B, int N, int G, int LDF, int dv, int reverse, int accumulate, float *state_ws,
                           int state_flags, void *stream);
+/* FAVOR+ random-feature projection (performer_pytorch softmax_kernel: data_dash = data_normalizer * data @ projection^T) and its adjoint as
+ * HBM-bound kernels; proj [m][dh] already carries the data normalizer.  dd [rows][LDF] (columns >= m are written as zeros);
+ * dx [rows][dx_stride] = ddd @ proj (+ addend, same stride).  dh = 64, LDF % 16 == 0, LDF <= 272.  Products are split-bf16 (~1e-5 relative);
+ * the exact alternative is sa_conv_fprop on the same operands as a 1x1x1 convolution. */
+int sa_favor_project(const float *x, int x_stride, const float *proj, float *dd, int64_t rows, int m, int LDF, int dh, void *stream);
+int sa_favor_project_bwd(const float *ddd, const float *proj, const float *addend, float *dx, int dx_stride, int64_t rows, int m, int LDF, int dh,
+                         void *stream);
 int sa_cumsum_rows(const float *x, const float *scale, float *out, int B, int N, int G, int LDF, int reverse, float *seg_ws, void *stream);
 int sa_favor_den(const float *q, const float *z, float eps, float *inv, int64_t rows, int m, int LDF, void *stream);
 int sa_favor_dden(const float *dout, const float *out, int stride, int off, int G, int dv, const float *inv, float *dden, int64_t rows,

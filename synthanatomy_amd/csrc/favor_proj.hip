@@ -1,0 +1,169 @@
+// Random-feature projection of FAVOR+ (performer_pytorch.softmax_kernel: data_dash = data_normalizer * data @ projection^T, and its adjoint)
+// as HBM-bound kernels: dd[r][f] = sum_d x[r][d] P[f][d] with d = 64, f < m <= 272.  The generic implicit-GEMM kernel spends its time in
+// per-tile prologues / epilogues on this shape (K = 64: two slabs); here a block stages the whole projection matrix ONCE in LDS as split-bf16
+// hi / lo tiles (split_bf16.h: hi*hi + hi*lo + lo*hi on mfma_f32_16x16x32_bf16, fp32 accumulate, ~1e-5 relative), streams rows straight from
+// global memory into MFMA operands and writes 16-byte pieces of the result rows from the accumulators.  Traffic = read x, write dd (forward);
+// read ddd (+ addend), write dx (adjoint).  The fp32 parity mode of the engine keeps the exact-fp32 GEMM.
+#include "sa_common.h"
+#include "split_bf16.h"
+
+namespace sa {
+
+struct ProjArgs {
+    const float* x;        // forward: [rows][x_stride] (first 64 floats of each row)
+    const float* proj;     // [m][64]
+    float* out;            // forward: dd [rows][LDF];  adjoint: dx [rows][o_stride]
+    const float* g;        // adjoint: ddd [rows][LDF]
+    const float* addend;   // adjoint, optional: [rows][o_stride]
+    int64_t rows;
+    int32_t m, LDF, x_stride, o_stride;
+};
+
+// projection rows [0, nrows) -> hi / lo tiles [nrows][64] bf16 in the lroff() layout (rows >= m are zero)
+__device__ __forceinline__ void proj_stage(unsigned char* hi, unsigned char* lo, const float* proj, int m, int nrows, int tid) {
+    for (int idx = tid; idx < nrows * 16; idx += 256) {
+        const int f = idx >> 4, c4 = idx & 15;
+        const float4 v = *(const float4*)(proj + (int64_t)min(f, m - 1) * 64 + c4 * 4);
+        const float k = f < m ? 1.f : 0.f;
+        uint2 h, l;
+        split_pair(v.x * k, v.y * k, h.x, l.x);
+        split_pair(v.z * k, v.w * k, h.y, l.y);
+        const uint32_t o = lroff(f, c4 * 4);
+        *(uint2*)(hi + o) = h;
+        *(uint2*)(lo + o) = l;
+    }
+}
+
+__device__ __forceinline__ float4 proj_keep(float4 x, bool keep) {
+    const uint32_t mk = keep ? 0xffffffffu : 0u;
+    return make_float4(__uint_as_float(__float_as_uint(x.x) & mk), __uint_as_float(__float_as_uint(x.y) & mk), __uint_as_float(__float_as_uint(x.z) & mk),
+                       __uint_as_float(__float_as_uint(x.w) & mk));
+}
+
+// forward: block = 128 rows, wave = 32 rows (two MFMA column sets); D[i = feature][j = row]
+__global__ __launch_bounds__(256, 2) void favor_project_fwd_kernel(const ProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nfr = a.LDF >> 4;
+    unsigned char* const sPh = smem;
+    unsigned char* const sPl = smem + nfr * 16 * 128;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), qi = lane & 15, g = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * 128 + w * 32;
+    short8_t xh[2][2], xl[2][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const int64_t r = r0 + st * 16 + qi;
+        const bool ok = r < a.rows;
+        const float* xr = a.x + (ok ? r : a.rows - 1) * a.x_stride;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float4 v0 = proj_keep(*(const float4*)(xr + ks * 32 + g * 8), ok), v1 = proj_keep(*(const float4*)(xr + ks * 32 + g * 8 + 4), ok);
+            const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            split8(xs, xh[st][ks], xl[st][ks]);
+        }
+    }
+    proj_stage(sPh, sPl, a.proj, a.m, nfr * 16, tid);
+    __syncthreads();
+    float* o0 = a.out + (r0 + qi) * a.LDF + g * 4;
+    float* o1 = o0 + (int64_t)16 * a.LDF;
+    const bool ok0 = r0 + qi < a.rows, ok1 = r0 + 16 + qi < a.rows;
+    for (int f = 0; f < nfr; ++f) {
+        short8_t ah[2], al[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint32_t o = lroff(f * 16 + qi, ks * 32 + g * 8);
+            ah[ks] = *(const short8_t*)(sPh + o);
+            al[ks] = *(const short8_t*)(sPl + o);
+        }
+        float4_t c0 = (float4_t){0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            c0 = mfma3(ah[ks], al[ks], xh[0][ks], xl[0][ks], c0);
+            c1 = mfma3(ah[ks], al[ks], xh[1][ks], xl[1][ks], c1);
+        }
+        if (ok0) *(float4*)(o0 + f * 16) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+        if (ok1) *(float4*)(o1 + f * 16) = make_float4(c1[0], c1[1], c1[2], c1[3]);
+    }
+}
+
+// adjoint: dx[r][d] = sum_f g[r][f] P[f][d] (+ addend); block = 128 rows, wave = 2 x 16 rows; D[i = d][j = row], reduction over the
+// projection rows in accumulator-row order (transposing reads of the staged tile)
+__global__ __launch_bounds__(256, 2) void favor_project_bwd_kernel(const ProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nks = (a.LDF + 31) >> 5;
+    unsigned char* const sPh = smem;
+    unsigned char* const sPl = smem + nks * 32 * 128;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), qi = lane & 15, g = lane >> 4;
+    proj_stage(sPh, sPl, a.proj, a.m, nks * 32, tid);
+    __syncthreads();
+    const uint32_t trow = (uint32_t)g * 4u + ((uint32_t)qi >> 2), tcol = (uint32_t)(qi & 3) * 4u;
+    for (int it = 0; it < 2; ++it) {
+        const int64_t r = (int64_t)blockIdx.x * 128 + w * 32 + it * 16 + qi;
+        const bool ok = r < a.rows;
+        const float* gr = a.g + (ok ? r : a.rows - 1) * a.LDF;
+        float4_t acc[4];
+#pragma unroll
+        for (int df = 0; df < 4; ++df) acc[df] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        float4 v[9][2];   // the whole gradient row of this lane's quarter, in flight together (LDF <= 272: nine 32-feature blocks)
+#pragma unroll
+        for (int ks = 0; ks < 9; ++ks) {
+            const int c0 = ks * 32 + g * 4, c1 = c0 + 16;
+            v[ks][0] = proj_keep(*(const float4*)(gr + min(c0, a.LDF - 4)), ok && c0 < a.LDF);
+            v[ks][1] = proj_keep(*(const float4*)(gr + min(c1, a.LDF - 4)), ok && c1 < a.LDF);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 9; ++ks) {
+            if (ks < nks) {
+                const float xs[8] = {v[ks][0].x, v[ks][0].y, v[ks][0].z, v[ks][0].w, v[ks][1].x, v[ks][1].y, v[ks][1].z, v[ks][1].w};
+                short8_t bh, bl;
+                split8(xs, bh, bl);
+#pragma unroll
+                for (int df = 0; df < 4; ++df) {
+                    const uint32_t o0 = lroff(ks * 32 + trow, df * 16 + tcol), o1 = lroff(ks * 32 + 16 + trow, df * 16 + tcol);
+                    const short8_t ah = __builtin_shufflevector(lds_tr16_b64(sPh + o0), lds_tr16_b64(sPh + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+                    const short8_t al = __builtin_shufflevector(lds_tr16_b64(sPl + o0), lds_tr16_b64(sPl + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[df] = mfma3(ah, al, bh, bl, acc[df]);
+                }
+            }
+        }
+        if (ok) {
+#pragma unroll
+            for (int df = 0; df < 4; ++df) {
+                float4 o = make_float4(acc[df][0], acc[df][1], acc[df][2], acc[df][3]);
+                if (a.addend) {
+                    const float4 ad = *(const float4*)(a.addend + r * a.o_stride + df * 16 + g * 4);
+                    o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+                }
+                *(float4*)(a.out + r * a.o_stride + df * 16 + g * 4) = o;
+            }
+        }
+    }
+}
+
+}  // namespace sa
+
+using namespace sa;
+
+extern "C" int sa_favor_project(const float* x, int x_stride, const float* proj, float* dd, int64_t rows, int m, int LDF, int dh, void* stream) {
+    if (!x || !proj || !dd || rows <= 0 || m <= 0) return SA_EINVAL;
+    if (dh != 64 || (LDF & 15) || LDF < m || LDF > 272 || (x_stride & 3) || x_stride < dh) return SA_EUNSUPPORTED;
+    ProjArgs a = {};
+    a.x = x; a.proj = proj; a.out = dd; a.rows = rows; a.m = m; a.LDF = LDF; a.x_stride = x_stride;
+    const size_t lds = (size_t)2 * LDF * 128;
+    hipFuncSetAttribute((const void*)favor_project_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(favor_project_fwd_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_favor_project_bwd(const float* ddd, const float* proj, const float* addend, float* dx, int dx_stride, int64_t rows, int m, int LDF, int dh,
+                                    void* stream) {
+    if (!ddd || !proj || !dx || rows <= 0 || m <= 0) return SA_EINVAL;
+    if (dh != 64 || (LDF & 15) || LDF < m || LDF > 272 || (dx_stride & 3) || dx_stride < dh) return SA_EUNSUPPORTED;
+    ProjArgs a = {};
+    a.g = ddd; a.proj = proj; a.addend = addend; a.out = dx; a.rows = rows; a.m = m; a.LDF = LDF; a.o_stride = dx_stride;
+    const size_t lds = (size_t)2 * ((LDF + 31) / 32) * 32 * 128;
+    hipFuncSetAttribute((const void*)favor_project_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(favor_project_bwd_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}

@@ -365,8 +365,15 @@ class _LayerEngine:
             pop = self._proj_op()
             qg = q[:, : G * dh].contiguous()
             kg = k[:, : G * dh].contiguous()
-            ddq = pop.fprop(qg.view(1, 1, 1, R * G, dh), out_channels_stride=LDF, use_bias=False).view(R * G, LDF)
-            ddk = pop.fprop(kg.view(1, 1, 1, R * G, dh), out_channels_stride=LDF, use_bias=False).view(R * G, LDF)
+            if self._xf:   # fp32 parity mode: exact-fp32 GEMM
+                ddq = pop.fprop(qg.view(1, 1, 1, R * G, dh), out_channels_stride=LDF, use_bias=False).view(R * G, LDF)
+                ddk = pop.fprop(kg.view(1, 1, 1, R * G, dh), out_channels_stride=LDF, use_bias=False).view(R * G, LDF)
+            else:          # throughput mode: HBM-bound split-bf16 projection kernels (the matrix is staged once per block)
+                ps = self._pop[2]
+                ddq = torch.empty(R * G, LDF, dtype=f32, device=dev)
+                ddk = torch.empty(R * G, LDF, dtype=f32, device=dev)
+                _ck(lib.sa_favor_project(_ffi.ptr(qg), dh, _ffi.ptr(ps), _ffi.ptr(ddq), R * G, m, LDF, dh, st), "sa_favor_project(q)")
+                _ck(lib.sa_favor_project(_ffi.ptr(kg), dh, _ffi.ptr(ps), _ffi.ptr(ddk), R * G, m, LDF, dh, st), "sa_favor_project(k)")
             qf, kf = torch.empty_like(ddq), torch.empty_like(ddk)
             gws = torch.zeros(2, dtype=torch.int64, device=dev)
             _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddq), _ffi.ptr(qg), G * dh, 0, G, dh, 1, _ffi.ptr(qf), None, R * G, m, LDF, st), "favor_features(q)")
@@ -585,8 +592,13 @@ class _LayerEngine:
             _ck(lib.sa_favor_features_bwd(_ffi.ptr(dkf), _ffi.ptr(kf), _ffi.ptr(sv["ddk"]), _ffi.ptr(sv["kg"]), G * dh, 0, G, dh, 0, _ffi.ptr(dddk), _ffi.ptr(dkg),
                                           _ffi.ptr(sv["gws"]), _ffi.ptr(tsum), R * G, m, LDF, st), "favor_features_bwd(k)")
             rg = (1, 1, R * G)
-            dqg = pop.dgrad(dddq.view(1, 1, 1, R * G, LDF), rg, addend=dqg.view(1, 1, 1, R * G, dh), fwd_out_stride=LDF).view(R, G * dh)
-            dkg = pop.dgrad(dddk.view(1, 1, 1, R * G, LDF), rg, addend=dkg.view(1, 1, 1, R * G, dh), fwd_out_stride=LDF).view(R, G * dh)
+            if self._xf:
+                dqg = pop.dgrad(dddq.view(1, 1, 1, R * G, LDF), rg, addend=dqg.view(1, 1, 1, R * G, dh), fwd_out_stride=LDF).view(R, G * dh)
+                dkg = pop.dgrad(dddk.view(1, 1, 1, R * G, LDF), rg, addend=dkg.view(1, 1, 1, R * G, dh), fwd_out_stride=LDF).view(R, G * dh)
+            else:
+                ps = self._pop[2]
+                _ck(lib.sa_favor_project_bwd(_ffi.ptr(dddq), _ffi.ptr(ps), _ffi.ptr(dqg), _ffi.ptr(dqg), dh, R * G, m, LDF, dh, st), "sa_favor_project_bwd(q)")
+                _ck(lib.sa_favor_project_bwd(_ffi.ptr(dddk), _ffi.ptr(ps), _ffi.ptr(dkg), _ffi.ptr(dkg), dh, R * G, m, LDF, dh, st), "sa_favor_project_bwd(k)")
             dq[:, : G * dh] = dqg
             dk[:, : G * dh] = dkg
         if L > 0:

@@ -148,6 +148,32 @@ def test_scan_exact_flag_selects_fp32_products():
     assert e_exact < 2e-6 and e_split < 5e-5 and not torch.equal(outs[0][0], outs[1][0])
 
 
+@pytest.mark.parametrize("rows,m,LDF", [(1, 266, 272), (130, 266, 272), (1000, 100, 112), (67200, 266, 272), (77, 256, 256)])
+def test_projection_kernels_against_matmul(rows, m, LDF):
+    """sa_favor_project / sa_favor_project_bwd (split-bf16, projection matrix staged once per block) against fp64 matmuls: ragged row counts,
+    padded feature columns written as zeros, strided input rows, addend."""
+    from synthanatomy_amd import _ffi
+    lib, st = _ffi.lib(), _ffi.stream()
+    torch.manual_seed(rows + m)
+    xs = 96                                               # rows live in a wider matrix
+    x = torch.randn(rows, xs, device="cuda")
+    P_ = torch.randn(m, 64, device="cuda") * 0.35
+    dd = torch.full((rows, LDF), float("nan"), device="cuda")
+    _ffi.check(lib.sa_favor_project(_ffi.ptr(x), xs, _ffi.ptr(P_), _ffi.ptr(dd), rows, m, LDF, 64, st))
+    ref = x[:, :64].double() @ P_.double().t()
+    assert _rel(dd[:, :m], ref) < 2e-5
+    assert float(dd[:, m:].abs().max()) == 0.0 if LDF > m else True
+    g = torch.randn(rows, LDF, device="cuda")
+    g[:, m:] = 7.0                                        # padded gradient columns must not leak (the staged projection rows are zero)
+    add = torch.randn(rows, 64, device="cuda")
+    dx = torch.full((rows, 64), float("nan"), device="cuda")
+    _ffi.check(lib.sa_favor_project_bwd(_ffi.ptr(g), _ffi.ptr(P_), _ffi.ptr(add), _ffi.ptr(dx), 64, rows, m, LDF, 64, st))
+    refb = g[:, :m].double() @ P_.double() + add.double()
+    assert _rel(dx, refb) < 2e-5
+    _ffi.check(lib.sa_favor_project_bwd(_ffi.ptr(g), _ffi.ptr(P_), None, _ffi.ptr(dx), 64, rows, m, LDF, 64, st))
+    assert _rel(dx, g[:, :m].double() @ P_.double()) < 2e-5
+
+
 @pytest.mark.parametrize("N,segmented", [(37, False), (37, True), (300, True), (1400, True)])
 def test_causal_scan_kernels_against_quadratic_form(N, segmented):
     from synthanatomy_amd import _ffi
