@@ -282,6 +282,7 @@ class _LayerEngine:
         self.ops["w1"], self.ops["w2"] = _lin(ff.w1, dtype), _lin(ff.w2, dtype)
         self._pscaled = None
         self._fused_sums = os.environ.get("SA_NO_FUSED_SUMS") is None
+        self._no_fused_qkv = os.environ.get("SA_NO_FUSED_QKV") is not None
         # state_flags bit 2 of the fused scans: fp32 (parity) mode keeps every product on the exact-fp32 MFMA; the bf16 throughput mode uses the
         # split-bf16 kernels (~1e-5 relative, far below the rounding of its dense layers)
         self._xf = 4 if dtype == torch.float32 else 0
@@ -294,10 +295,35 @@ class _LayerEngine:
         for op in self.ops.values():
             op.invalidate()
 
+    @staticmethod
+    def _stacked(ts):
+        """One [sum rows, cols] view over equally shaped 2-D tensors that sit back to back in memory (the flat parameter / gradient buffers of
+        runtime.optim.FlatParams), or None."""
+        t0 = ts[0]
+        if any(t is None or t.shape != t0.shape or t.dtype != t0.dtype or not t.is_contiguous() for t in ts):
+            return None
+        nb = t0.numel() * t0.element_size()
+        if any(t.data_ptr() != t0.data_ptr() + i * nb for i, t in enumerate(ts)):
+            return None
+        if t0.storage_offset() + len(ts) * t0.numel() > t0.untyped_storage().nbytes() // t0.element_size():
+            return None
+        return torch.as_strided(t0, (len(ts) * t0.shape[0], t0.shape[1]), (t0.shape[1], 1))
+
     def _sync(self):
         sa, ff = self.sa, self.ff
         for n in ("to_q", "to_k", "to_v", "to_out"):
             self.ops[n].weight, self.ops[n].bias = getattr(sa, n).weight, getattr(sa, n).bias
+        # to_q / to_k / to_v as ONE dense layer (one forward, one data-gradient and one weight-gradient launch instead of three each) when the
+        # three bias-free weights are adjacent in memory
+        wqkv = None
+        if not self._no_fused_qkv and sa.to_q.bias is None and sa.to_k.bias is None and sa.to_v.bias is None:
+            wqkv = self._stacked([sa.to_q.weight.detach(), sa.to_k.weight.detach(), sa.to_v.weight.detach()])
+        if wqkv is None:
+            self.ops.pop("to_qkv", None)
+        elif "to_qkv" not in self.ops:
+            self.ops["to_qkv"] = ConvOp("conv", wqkv.shape[1], wqkv.shape[0], 1, 1, 0, wqkv.view(*wqkv.shape, 1, 1, 1), None, self.dtype)
+        else:
+            self.ops["to_qkv"].weight = wqkv.view(*wqkv.shape, 1, 1, 1)
         self.ops["w1"].weight, self.ops["w1"].bias = ff.w1.weight, ff.w1.bias
         self.ops["w2"].weight, self.ops["w2"].bias = ff.w2.weight, ff.w2.bias
 
@@ -356,9 +382,14 @@ class _LayerEngine:
         lp = self.rezero and T != f32            # the residual kernel can emit the low-precision copy the next GEMM wants
         xa, st_a = self._pre(self.aw, x, R)
         xaT = x_lp if (lp and x_lp is not None) else _cast(xa, T)
-        q = self.ops["to_q"].fprop(_as5(xaT), out_dtype=f32).view(R, inner)
-        k = self.ops["to_k"].fprop(_as5(xaT), out_dtype=f32).view(R, inner)
-        v = self.ops["to_v"].fprop(_as5(xaT), out_dtype=f32).view(R, inner)
+        if "to_qkv" in self.ops:
+            qkv = self.ops["to_qkv"].fprop(_as5(xaT), out_dtype=f32).view(R, 3 * inner)
+            q, k, v = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
+        else:
+            q = self.ops["to_q"].fprop(_as5(xaT), out_dtype=f32).view(R, inner)
+            k = self.ops["to_k"].fprop(_as5(xaT), out_dtype=f32).view(R, inner)
+            v = self.ops["to_v"].fprop(_as5(xaT), out_dtype=f32).view(R, inner)
+        qs = q.stride(0)   # row stride of q / k / v (3 * inner when they are column blocks of one matrix)
         attn = torch.empty(R, inner, dtype=f32, device=dev)
         sv = dict(x=x, xa=xa, xaT=xaT, st_a=st_a, q=q, k=k, v=v, attn=attn)
         if G > 0:
@@ -384,13 +415,13 @@ class _LayerEngine:
             inv = torch.empty(R * G, dtype=f32, device=dev)
             Z = None
             # normaliser fused into the scan (the running key sums ride along as an extra state column): no cumsum / den passes
-            rc = lib.sa_favor_scan_a_norm(_ffi.ptr(kf), _ffi.ptr(qf), _ffi.ptr(v), inner, 0, _ffi.ptr(attn), inner, 0, _ffi.ptr(inv), 1e-6, B, N, G, LDF, dh,
+            rc = lib.sa_favor_scan_a_norm(_ffi.ptr(kf), _ffi.ptr(qf), _ffi.ptr(v), qs, 0, _ffi.ptr(attn), inner, 0, _ffi.ptr(inv), 1e-6, B, N, G, LDF, dh,
                                           _ffi.ptr(ws), self._xf, st) if self._fused_sums else _ffi.SA_EUNSUPPORTED
             if rc == _ffi.SA_EUNSUPPORTED:
                 Z = torch.empty_like(kf)
                 _ck(lib.sa_cumsum_rows(_ffi.ptr(kf), None, _ffi.ptr(Z), B, N, G, LDF, 0, _ffi.ptr(ws), st), "sa_cumsum_rows")
                 _ck(lib.sa_favor_den(_ffi.ptr(qf), _ffi.ptr(Z), 1e-6, _ffi.ptr(inv), R * G, m, LDF, st), "sa_favor_den")
-                _ck(lib.sa_favor_scan_a(_ffi.ptr(kf), _ffi.ptr(qf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(attn), inner, 0, _ffi.ptr(inv), B, N, G, LDF, dh, 0, 0,
+                _ck(lib.sa_favor_scan_a(_ffi.ptr(kf), _ffi.ptr(qf), _ffi.ptr(v), qs, 0, None, _ffi.ptr(attn), inner, 0, _ffi.ptr(inv), B, N, G, LDF, dh, 0, 0,
                                         _ffi.ptr(ws), st), "sa_favor_scan_a")
             else:
                 _ck(rc, "sa_favor_scan_a_norm")
@@ -399,10 +430,10 @@ class _LayerEngine:
             cosb, sinb = self._rot_tables(N, dev)
             qr = torch.empty(R, L * dh, dtype=f32, device=dev)
             kr = torch.empty(R, L * dh, dtype=f32, device=dev)
-            _ck(lib.sa_rotary(_ffi.ptr(q), inner, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(qr), L * dh, 0, N, R, 0, 0, st), "sa_rotary(q)")
-            _ck(lib.sa_rotary(_ffi.ptr(k), inner, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(kr), L * dh, 0, N, R, 0, 0, st), "sa_rotary(k)")
+            _ck(lib.sa_rotary(_ffi.ptr(q), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(qr), L * dh, 0, N, R, 0, 0, st), "sa_rotary(q)")
+            _ck(lib.sa_rotary(_ffi.ptr(k), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(kr), L * dh, 0, N, R, 0, 0, st), "sa_rotary(k)")
             lse = torch.empty(R * L, dtype=f32, device=dev)
-            _ck(lib.sa_local_attn_fwd(_ffi.ptr(qr), L * dh, 0, _ffi.ptr(kr), L * dh, 0, _ffi.ptr(v), inner, G * dh, _ffi.ptr(attn), inner, G * dh, _ffi.ptr(lse),
+            _ck(lib.sa_local_attn_fwd(_ffi.ptr(qr), L * dh, 0, _ffi.ptr(kr), L * dh, 0, _ffi.ptr(v), qs, G * dh, _ffi.ptr(attn), inner, G * dh, _ffi.ptr(lse),
                                       B, N, L, self.W, dh, st), "sa_local_attn_fwd")
             sv.update(qr=qr, kr=kr, lse=lse)
         attnT = _cast(attn, T)
@@ -549,9 +580,16 @@ class _LayerEngine:
         gc.done(sa.to_out.weight, sa.to_out.bias)
         dattn = ops["to_out"].dgrad(_as5(dFa), r5, out_dtype=f32).view(R, inner)
         q, k, v, attn = sv["q"], sv["k"], sv["v"], sv["attn"]
-        dq = torch.empty(R, inner, dtype=f32, device=dev)
-        dk = torch.empty(R, inner, dtype=f32, device=dev)
-        dv = torch.empty(R, inner, dtype=f32, device=dev)
+        fused_qkv = "to_qkv" in ops and q.stride(0) == 3 * inner
+        if fused_qkv:   # gradients as column blocks of one matrix, like q / k / v themselves: one cast, one wgrad, one dgrad below
+            dqkv = torch.empty(R, 3 * inner, dtype=f32, device=dev)
+            dq, dk, dv = dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:]
+        else:
+            dq = torch.empty(R, inner, dtype=f32, device=dev)
+            dk = torch.empty(R, inner, dtype=f32, device=dev)
+            dv = torch.empty(R, inner, dtype=f32, device=dev)
+        qs = dq.stride(0)   # == q.stride(0): the kernels below address v / dv (and dq / dk) with one row stride
+        assert qs == q.stride(0) == v.stride(0)
         if G > 0:
             qf, kf, Z, inv = sv["qf"], sv["kf"], sv["Z"], sv["inv"]
             dden = torch.empty(R * G, dtype=f32, device=dev)
@@ -562,25 +600,25 @@ class _LayerEngine:
             shared_dv = False
             if Z is None:   # forward ran the fused form: the cumulative terms are rebuilt inside the scans as well
                 kept = sv.get("scan_state")   # the forward's chunk states: same (a = k', b = v) -> no state / prefix passes for dq'
-                _ck(lib.sa_favor_scan_b_cum(_ffi.ptr(kf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dqf), _ffi.ptr(dden), 1, 1e-6,
+                _ck(lib.sa_favor_scan_b_cum(_ffi.ptr(kf), _ffi.ptr(v), qs, 0, None, _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dqf), _ffi.ptr(dden), 1, 1e-6,
                                             B, N, G, LDF, dh, 0, _ffi.ptr(kept if kept is not None else ws), (1 if kept is not None else 0) | self._xf, st),
                     "sa_favor_scan_b_cum(dq')")
                 sv["scan_state"] = None
-                _ck(lib.sa_favor_scan_b_cum(_ffi.ptr(qf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dkf), _ffi.ptr(dden), 2, 0.0,
+                _ck(lib.sa_favor_scan_b_cum(_ffi.ptr(qf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(v), qs, 0, None, _ffi.ptr(dkf), _ffi.ptr(dden), 2, 0.0,
                                             B, N, G, LDF, dh, 1, _ffi.ptr(ws), self._xf, st), "sa_favor_scan_b_cum(dk')")
                 shared_dv = True
             else:
-                _ck(lib.sa_favor_scan_b(_ffi.ptr(kf), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dqf), _ffi.ptr(dden), _ffi.ptr(Z),
+                _ck(lib.sa_favor_scan_b(_ffi.ptr(kf), _ffi.ptr(v), qs, 0, None, _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dqf), _ffi.ptr(dden), _ffi.ptr(Z),
                                         1e-6, B, N, G, LDF, dh, 0, _ffi.ptr(ws), st), "sa_favor_scan_b(dq')")
                 rr = torch.empty_like(qf)
                 _ck(lib.sa_cumsum_rows(_ffi.ptr(qf), _ffi.ptr(dden), _ffi.ptr(rr), B, N, G, LDF, 1, _ffi.ptr(ws), st), "sa_cumsum_rows(rev)")
-                _ck(lib.sa_favor_scan_b(_ffi.ptr(qf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(v), inner, 0, None, _ffi.ptr(dkf), None, _ffi.ptr(rr), 0.0,
+                _ck(lib.sa_favor_scan_b(_ffi.ptr(qf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(v), qs, 0, None, _ffi.ptr(dkf), None, _ffi.ptr(rr), 0.0,
                                         B, N, G, LDF, dh, 1, _ffi.ptr(ws), st), "sa_favor_scan_b(dk')")
             if shared_dv:   # dv runs on the states the dk' scan just built (same a = q', b = d attn * inv, reversed)
-                _ck(lib.sa_favor_scan_a_state(_ffi.ptr(qf), _ffi.ptr(kf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dv), inner, 0, None, B, N, G, LDF, dh, 1, 0,
+                _ck(lib.sa_favor_scan_a_state(_ffi.ptr(qf), _ffi.ptr(kf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dv), qs, 0, None, B, N, G, LDF, dh, 1, 0,
                                               _ffi.ptr(ws), 3 | self._xf, st), "sa_favor_scan_a_state(dv)")
             else:
-                _ck(lib.sa_favor_scan_a(_ffi.ptr(qf), _ffi.ptr(kf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dv), inner, 0, None, B, N, G, LDF, dh, 1, 0,
+                _ck(lib.sa_favor_scan_a(_ffi.ptr(qf), _ffi.ptr(kf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dv), qs, 0, None, B, N, G, LDF, dh, 1, 0,
                                         _ffi.ptr(ws), st), "sa_favor_scan_a(dv)")
             pop = self._proj_op()
             dqg = torch.zeros(R, G * dh, dtype=f32, device=dev)
@@ -606,21 +644,35 @@ class _LayerEngine:
             dqr = torch.empty(R, L * dh, dtype=f32, device=dev)
             dkr = torch.empty(R, L * dh, dtype=f32, device=dev)
             Db = torch.empty(R * L, dtype=f32, device=dev)
-            _ck(lib.sa_local_attn_bwd(_ffi.ptr(sv["qr"]), L * dh, 0, _ffi.ptr(sv["kr"]), L * dh, 0, _ffi.ptr(v), inner, G * dh, _ffi.ptr(attn), _ffi.ptr(dattn),
+            _ck(lib.sa_local_attn_bwd(_ffi.ptr(sv["qr"]), L * dh, 0, _ffi.ptr(sv["kr"]), L * dh, 0, _ffi.ptr(v), qs, G * dh, _ffi.ptr(attn), _ffi.ptr(dattn),
                                       inner, G * dh, _ffi.ptr(sv["lse"]), _ffi.ptr(dqr), _ffi.ptr(dkr), _ffi.ptr(dv), _ffi.ptr(Db), B, N, L, self.W, dh, st),
                 "sa_local_attn_bwd")
-            _ck(lib.sa_rotary(_ffi.ptr(dqr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dq), inner, G * dh, N, R, 1, 0, st), "sa_rotary^T(q)")
-            _ck(lib.sa_rotary(_ffi.ptr(dkr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dk), inner, G * dh, N, R, 1, 0, st), "sa_rotary^T(k)")
+            _ck(lib.sa_rotary(_ffi.ptr(dqr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dq), qs, G * dh, N, R, 1, 0, st), "sa_rotary^T(q)")
+            _ck(lib.sa_rotary(_ffi.ptr(dkr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dk), qs, G * dh, N, R, 1, 0, st), "sa_rotary^T(k)")
         xaT = _as5(sv["xaT"])
-        dqT, dkT, dvT = (_as5(_cast(t, T)) for t in (dq, dk, dv))
-        for nm, g_ in (("to_q", dqT), ("to_k", dkT), ("to_v", dvT)):
-            mod = getattr(sa, nm)
-            ops[nm].wgrad(xaT, g_, gc.buf(mod.weight), gc.buf(mod.bias))
-            gc.done(mod.weight, mod.bias)
         base = _as5(dx1) if self.rezero else None
-        dxa = ops["to_q"].dgrad(dqT, r5, addend=base, out_dtype=f32)
-        dxa = ops["to_k"].dgrad(dkT, r5, addend=dxa, out_dtype=f32)
-        dxa = ops["to_v"].dgrad(dvT, r5, addend=dxa, out_dtype=f32).view(R, self.dim)
+        if fused_qkv:
+            dqkvT = _as5(_cast(dqkv, T))
+            gbufs = [gc.buf(sa.to_q.weight), gc.buf(sa.to_k.weight), gc.buf(sa.to_v.weight)]
+            gw = self._stacked([t.view(inner, self.dim) for t in gbufs])
+            if gw is not None:
+                ops["to_qkv"].wgrad(xaT, dqkvT, gw.view(3 * inner, self.dim, 1, 1, 1), None)
+            else:   # gradient buffers are not adjacent: through a scratch matrix
+                tmp = torch.zeros(3 * inner, self.dim, 1, 1, 1, dtype=f32, device=dev)
+                ops["to_qkv"].wgrad(xaT, dqkvT, tmp, None)
+                for i, t in enumerate(gbufs):
+                    t.view(inner, self.dim).add_(tmp.view(3 * inner, self.dim)[i * inner:(i + 1) * inner])
+            gc.done(sa.to_q.weight, sa.to_k.weight, sa.to_v.weight)
+            dxa = ops["to_qkv"].dgrad(dqkvT, r5, addend=base, out_dtype=f32).view(R, self.dim)
+        else:
+            dqT, dkT, dvT = (_as5(_cast(t, T)) for t in (dq, dk, dv))
+            for nm, g_ in (("to_q", dqT), ("to_k", dkT), ("to_v", dvT)):
+                mod = getattr(sa, nm)
+                ops[nm].wgrad(xaT, g_, gc.buf(mod.weight), gc.buf(mod.bias))
+                gc.done(mod.weight, mod.bias)
+            dxa = ops["to_q"].dgrad(dqT, r5, addend=base, out_dtype=f32)
+            dxa = ops["to_k"].dgrad(dkT, r5, addend=dxa, out_dtype=f32)
+            dxa = ops["to_v"].dgrad(dvT, r5, addend=dxa, out_dtype=f32).view(R, self.dim)
         return self._pre_bwd(self.aw, dxa, dx1, sv["x"], sv["st_a"], R, gc)
 
 

@@ -174,6 +174,43 @@ def test_projection_kernels_against_matmul(rows, m, LDF):
     assert _rel(dx, g[:, :m].double() @ P_.double()) < 2e-5
 
 
+@pytest.mark.parametrize("with_sink", [False, True])
+def test_fused_qkv_projection_matches_separate_layers(with_sink, monkeypatch):
+    """to_q / to_k / to_v run as ONE dense layer when their weights sit back to back in the flat parameter buffer (runtime.optim.FlatParams):
+    same logits and gradients as the three separate layers, with the gradient buffers adjacent (sink) or not (scratch matrix)."""
+    from synthanatomy_amd.losses.transformer import CELoss
+    from synthanatomy_amd.runtime.ddp import GradReducer
+    from synthanatomy_amd.runtime.optim import FlatParams
+    shape, n = (2, 4, 5), 40
+    cfg = P.PerformerConfig(num_tokens=33, max_seq_len=n, dim=64, depth=2, heads=4, dim_head=64, local_attn_heads=2, local_window_size=8, spatial_shape=shape)
+    st = P.init_state(cfg, seed=4)
+    for k in st:
+        if k.endswith(".g"):
+            st[k] = torch.tensor(0.3)
+    torch.manual_seed(7)
+    tok = torch.randint(0, 33, (2, n)).cuda()
+    tgt = torch.randint(0, 32, (2, n)).cuda()
+    res = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("SA_NO_FUSED_QKV", raising=False)
+        else:
+            monkeypatch.setenv("SA_NO_FUSED_QKV", "1")
+        net, _ = _build(cfg, st, dtype=torch.bfloat16)
+        net.train()
+        flat = FlatParams(net.parameters())
+        if with_sink:
+            net.set_grad_sink(GradReducer(flat))
+        out = net(tok)
+        CELoss()(out.transpose(1, 2), tgt).backward()
+        torch.cuda.synchronize()
+        eng = net._chain.layers[0]
+        assert ("to_qkv" in eng.ops) == fused
+        res.append((out.detach().float().clone(), flat.grad.clone()))
+    assert _rel(res[0][0], res[1][0]) < 2e-3
+    assert _rel(res[0][1], res[1][1]) < 5e-3 and float(res[0][1].abs().max()) > 0
+
+
 @pytest.mark.parametrize("N,segmented", [(37, False), (37, True), (300, True), (1400, True)])
 def test_causal_scan_kernels_against_quadratic_form(N, segmented):
     from synthanatomy_amd import _ffi
