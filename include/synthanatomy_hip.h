@@ -192,6 +192,8 @@ int sa_axpy(float *y, const float *x, float alpha, int64_t n, void *stream);
  * feat = m^-1/2 (exp(dd - |x|^2 d^-1/2 / 2 - stab) + 1e-4), stab = row max (is_query) or the GLOBAL max (keys; gmax_ws = 8 bytes). */
 int sa_favor_features_fwd(const float *dd, const float *src, int src_stride, int h0, int G, int dh, int is_query, float *feat, void *gmax_ws,
                           int64_t rows, int m, int LDF, void *stream);
+/* backward: ddd = d loss / d dd; dsrc (same stride / head offset as src) is OVERWRITTEN with the gradient through the -|x|^2 term, the
+ * projection adjoint (sa_favor_project_bwd with addend = dx, or a dgrad GEMM with an addend) adds the rest */
 int sa_favor_features_bwd(const float *dfeat, const float *feat, const float *dd, const float *src, int src_stride, int h0, int G, int dh,
                           int is_query, float *ddd, float *dsrc, const void *gmax_ws, float *tsum_ws /* [rows] */, int64_t rows, int m, int LDF,
                           void *stream);
@@ -230,12 +232,13 @@ int sa_favor_scan_a_state(const float *a, const float *c, const float *b, int b_
                           int y_off, const float *y_scale, int B, int N, int G, int LDF, int dv, int reverse, int accumulate, float *state_ws,
                           int state_flags, void *stream);
 /* FAVOR+ random-feature projection (performer_pytorch softmax_kernel: data_dash = data_normalizer * data @ projection^T) and its adjoint as
- * HBM-bound kernels; proj [m][dh] already carries the data normalizer.  dd [rows][LDF] (columns >= m are written as zeros);
- * dx [rows][dx_stride] = ddd @ proj (+ addend, same stride).  dh = 64, LDF % 16 == 0, LDF <= 272.  Products are split-bf16 (~1e-5 relative);
- * the exact alternative is sa_conv_fprop on the same operands as a 1x1x1 convolution. */
-int sa_favor_project(const float *x, int x_stride, const float *proj, float *dd, int64_t rows, int m, int LDF, int dh, void *stream);
-int sa_favor_project_bwd(const float *ddd, const float *proj, const float *addend, float *dx, int dx_stride, int64_t rows, int m, int LDF, int dh,
-                         void *stream);
+ * HBM-bound kernels; proj [m][dh] already carries the data normalizer.  Row r of x / dx is head block r % heads of the wider row r / heads:
+ * it starts at (r / heads) * stride + (r % heads) * dh floats (heads = 1: plain rows).  dd [rows][LDF] (columns >= m are written as zeros);
+ * dx = ddd @ proj (+ addend, laid out like dx; addend == dx is allowed).  dh = 64, LDF % 16 == 0, LDF <= 272.  Products are split-bf16 (~1e-5 relative); the exact
+ * alternative is sa_conv_fprop on the same operands as a 1x1x1 convolution. */
+int sa_favor_project(const float *x, int x_stride, int heads, const float *proj, float *dd, int64_t rows, int m, int LDF, int dh, void *stream);
+int sa_favor_project_bwd(const float *ddd, const float *proj, const float *addend, float *dx, int dx_stride, int heads, int64_t rows, int m, int LDF,
+                         int dh, void *stream);
 int sa_cumsum_rows(const float *x, const float *scale, float *out, int B, int N, int G, int LDF, int reverse, float *seg_ws, void *stream);
 int sa_favor_den(const float *q, const float *z, float eps, float *inv, int64_t rows, int m, int LDF, void *stream);
 int sa_favor_dden(const float *dout, const float *out, int stride, int off, int G, int dv, const float *inv, float *dden, int64_t rows,

@@ -10,14 +10,17 @@
 namespace sa {
 
 struct ProjArgs {
-    const float* x;        // forward: [rows][x_stride] (first 64 floats of each row)
+    const float* x;        // forward: rows of 64 floats, see heads
     const float* proj;     // [m][64]
     float* out;            // forward: dd [rows][LDF];  adjoint: dx [rows][o_stride]
     const float* g;        // adjoint: ddd [rows][LDF]
-    const float* addend;   // adjoint, optional: [rows][o_stride]
+    const float* addend;   // adjoint, optional: laid out like out (may be out itself)
     int64_t rows;
     int32_t m, LDF, x_stride, o_stride;
+    int32_t heads;         // x / out rows are head blocks of wider rows: row r lives at (r / heads) * stride + (r % heads) * 64
 };
+
+__device__ __forceinline__ int64_t proj_row_off(int64_t r, int heads, int stride) { return (r / heads) * stride + (r % heads) * 64; }
 
 // projection rows [0, nrows) -> hi / lo tiles [nrows][64] bf16 in the lroff() layout (rows >= m are zero)
 __device__ __forceinline__ void proj_stage(unsigned char* hi, unsigned char* lo, const float* proj, int m, int nrows, int tid) {
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void favor_project_fwd_kernel(const ProjArg
     for (int st = 0; st < 2; ++st) {
         const int64_t r = r0 + st * 16 + qi;
         const bool ok = r < a.rows;
-        const float* xr = a.x + (ok ? r : a.rows - 1) * a.x_stride;
+        const float* xr = a.x + proj_row_off(ok ? r : a.rows - 1, a.heads, a.x_stride);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const float4 v0 = proj_keep(*(const float4*)(xr + ks * 32 + g * 8), ok), v1 = proj_keep(*(const float4*)(xr + ks * 32 + g * 8 + 4), ok);
@@ -130,10 +133,10 @@ __global__ __launch_bounds__(256, 2) void favor_project_bwd_kernel(const ProjArg
             for (int df = 0; df < 4; ++df) {
                 float4 o = make_float4(acc[df][0], acc[df][1], acc[df][2], acc[df][3]);
                 if (a.addend) {
-                    const float4 ad = *(const float4*)(a.addend + r * a.o_stride + df * 16 + g * 4);
+                    const float4 ad = *(const float4*)(a.addend + proj_row_off(r, a.heads, a.o_stride) + df * 16 + g * 4);
                     o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
                 }
-                *(float4*)(a.out + r * a.o_stride + df * 16 + g * 4) = o;
+                *(float4*)(a.out + proj_row_off(r, a.heads, a.o_stride) + df * 16 + g * 4) = o;
             }
         }
     }
@@ -143,11 +146,11 @@ __global__ __launch_bounds__(256, 2) void favor_project_bwd_kernel(const ProjArg
 
 using namespace sa;
 
-extern "C" int sa_favor_project(const float* x, int x_stride, const float* proj, float* dd, int64_t rows, int m, int LDF, int dh, void* stream) {
-    if (!x || !proj || !dd || rows <= 0 || m <= 0) return SA_EINVAL;
-    if (dh != 64 || (LDF & 15) || LDF < m || LDF > 272 || (x_stride & 3) || x_stride < dh) return SA_EUNSUPPORTED;
+extern "C" int sa_favor_project(const float* x, int x_stride, int heads, const float* proj, float* dd, int64_t rows, int m, int LDF, int dh, void* stream) {
+    if (!x || !proj || !dd || rows <= 0 || m <= 0 || heads <= 0) return SA_EINVAL;
+    if (dh != 64 || (LDF & 15) || LDF < m || LDF > 272 || (x_stride & 3) || x_stride < dh * heads) return SA_EUNSUPPORTED;
     ProjArgs a = {};
-    a.x = x; a.proj = proj; a.out = dd; a.rows = rows; a.m = m; a.LDF = LDF; a.x_stride = x_stride;
+    a.x = x; a.proj = proj; a.out = dd; a.rows = rows; a.m = m; a.LDF = LDF; a.x_stride = x_stride; a.heads = heads;
     const size_t lds = (size_t)2 * LDF * 128;
     hipFuncSetAttribute((const void*)favor_project_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(favor_project_fwd_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);
@@ -155,12 +158,12 @@ extern "C" int sa_favor_project(const float* x, int x_stride, const float* proj,
     return 0;
 }
 
-extern "C" int sa_favor_project_bwd(const float* ddd, const float* proj, const float* addend, float* dx, int dx_stride, int64_t rows, int m, int LDF, int dh,
-                                    void* stream) {
-    if (!ddd || !proj || !dx || rows <= 0 || m <= 0) return SA_EINVAL;
-    if (dh != 64 || (LDF & 15) || LDF < m || LDF > 272 || (dx_stride & 3) || dx_stride < dh) return SA_EUNSUPPORTED;
+extern "C" int sa_favor_project_bwd(const float* ddd, const float* proj, const float* addend, float* dx, int dx_stride, int heads, int64_t rows, int m, int LDF,
+                                    int dh, void* stream) {
+    if (!ddd || !proj || !dx || rows <= 0 || m <= 0 || heads <= 0) return SA_EINVAL;
+    if (dh != 64 || (LDF & 15) || LDF < m || LDF > 272 || (dx_stride & 3) || dx_stride < dh * heads) return SA_EUNSUPPORTED;
     ProjArgs a = {};
-    a.g = ddd; a.proj = proj; a.addend = addend; a.out = dx; a.rows = rows; a.m = m; a.LDF = LDF; a.o_stride = dx_stride;
+    a.g = ddd; a.proj = proj; a.addend = addend; a.out = dx; a.rows = rows; a.m = m; a.LDF = LDF; a.o_stride = dx_stride; a.heads = heads;
     const size_t lds = (size_t)2 * ((LDF + 31) / 32) * 32 * 128;
     hipFuncSetAttribute((const void*)favor_project_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(favor_project_bwd_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);

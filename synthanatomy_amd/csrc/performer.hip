@@ -231,7 +231,7 @@ __global__ void favor_feat_fwd_kernel(const float* __restrict__ dd, const float*
     for (int c = lane; c < LDF; c += 64) feat[rp * LDF + c] = c < m ? ratio * (expf(dr[c] - diag - stab) + eps) : 0.f;
 }
 
-// backward of the feature map: ddd = e*g (minus the stabiliser path), dsrc[head slice] += -(sum e*g) * c^2 * x
+// backward of the feature map: ddd = e*g (minus the stabiliser path), dsrc[head slice] = -(sum e*g) * c^2 * x
 __global__ void favor_feat_bwd_kernel(const float* __restrict__ dfeat, const float* __restrict__ feat, const float* __restrict__ dd,
                                       const float* __restrict__ src, int src_stride, int h0, int G, int dh, int is_query, float* __restrict__ ddd,
                                       float* __restrict__ dsrc, float* __restrict__ tsum, int64_t rows, int m, int LDF, float c2, float ratio_eps) {
@@ -274,7 +274,7 @@ __global__ void favor_feat_bwd_kernel(const float* __restrict__ dfeat, const flo
     }
     const float* x = src + r * src_stride + (h0 + h) * dh;
     float* dx = dsrc + r * src_stride + (h0 + h) * dh;
-    for (int d = lane; d < dh; d += 64) dx[d] += -t * c2 * x[d];
+    for (int d = lane; d < dh; d += 64) dx[d] = -t * c2 * x[d];   // overwritten: the projection adjoint adds its part to this
 }
 
 // the global-max element receives -sum_rows t (d feat / d stab = -e for every element of the key tensor)

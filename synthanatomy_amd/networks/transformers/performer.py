@@ -394,21 +394,23 @@ class _LayerEngine:
         sv = dict(x=x, xa=xa, xaT=xaT, st_a=st_a, q=q, k=k, v=v, attn=attn)
         if G > 0:
             pop = self._proj_op()
-            qg = q[:, : G * dh].contiguous()
-            kg = k[:, : G * dh].contiguous()
-            if self._xf:   # fp32 parity mode: exact-fp32 GEMM
+            if self._xf:   # fp32 parity mode: exact-fp32 GEMM on contiguous copies of the global-head columns
+                qg = q[:, : G * dh].contiguous()
+                kg = k[:, : G * dh].contiguous()
+                sst = G * dh
                 ddq = pop.fprop(qg.view(1, 1, 1, R * G, dh), out_channels_stride=LDF, use_bias=False).view(R * G, LDF)
                 ddk = pop.fprop(kg.view(1, 1, 1, R * G, dh), out_channels_stride=LDF, use_bias=False).view(R * G, LDF)
-            else:          # throughput mode: HBM-bound split-bf16 projection kernels (the matrix is staged once per block)
+            else:          # throughput mode: HBM-bound split-bf16 projection kernels reading the head blocks of q / k in place
+                qg, kg, sst = q, k, qs
                 ps = self._pop[2]
                 ddq = torch.empty(R * G, LDF, dtype=f32, device=dev)
                 ddk = torch.empty(R * G, LDF, dtype=f32, device=dev)
-                _ck(lib.sa_favor_project(_ffi.ptr(qg), dh, _ffi.ptr(ps), _ffi.ptr(ddq), R * G, m, LDF, dh, st), "sa_favor_project(q)")
-                _ck(lib.sa_favor_project(_ffi.ptr(kg), dh, _ffi.ptr(ps), _ffi.ptr(ddk), R * G, m, LDF, dh, st), "sa_favor_project(k)")
+                _ck(lib.sa_favor_project(_ffi.ptr(q), qs, G, _ffi.ptr(ps), _ffi.ptr(ddq), R * G, m, LDF, dh, st), "sa_favor_project(q)")
+                _ck(lib.sa_favor_project(_ffi.ptr(k), qs, G, _ffi.ptr(ps), _ffi.ptr(ddk), R * G, m, LDF, dh, st), "sa_favor_project(k)")
             qf, kf = torch.empty_like(ddq), torch.empty_like(ddk)
             gws = torch.zeros(2, dtype=torch.int64, device=dev)
-            _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddq), _ffi.ptr(qg), G * dh, 0, G, dh, 1, _ffi.ptr(qf), None, R * G, m, LDF, st), "favor_features(q)")
-            _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddk), _ffi.ptr(kg), G * dh, 0, G, dh, 0, _ffi.ptr(kf), _ffi.ptr(gws), R * G, m, LDF, st), "favor_features(k)")
+            _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddq), _ffi.ptr(qg), sst, 0, G, dh, 1, _ffi.ptr(qf), None, R * G, m, LDF, st), "favor_features(q)")
+            _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddk), _ffi.ptr(kg), sst, 0, G, dh, 0, _ffi.ptr(kf), _ffi.ptr(gws), R * G, m, LDF, st), "favor_features(k)")
             ws = self._scan_ws(B, N, G, dev)
             if tape is not None and self._fused_sums:   # training: the chunk states (sum k' (x) v, sum k') are kept for the dq' scan of the backward pass
                 ws = torch.empty_like(ws)
@@ -621,24 +623,28 @@ class _LayerEngine:
                 _ck(lib.sa_favor_scan_a(_ffi.ptr(qf), _ffi.ptr(kf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dv), qs, 0, None, B, N, G, LDF, dh, 1, 0,
                                         _ffi.ptr(ws), st), "sa_favor_scan_a(dv)")
             pop = self._proj_op()
-            dqg = torch.zeros(R, G * dh, dtype=f32, device=dev)
-            dkg = torch.zeros(R, G * dh, dtype=f32, device=dev)
             dddq, dddk = torch.empty_like(qf), torch.empty_like(kf)
             tsum = torch.empty(R * G, dtype=f32, device=dev)
-            _ck(lib.sa_favor_features_bwd(_ffi.ptr(dqf), _ffi.ptr(qf), _ffi.ptr(sv["ddq"]), _ffi.ptr(sv["qg"]), G * dh, 0, G, dh, 1, _ffi.ptr(dddq), _ffi.ptr(dqg),
-                                          None, None, R * G, m, LDF, st), "favor_features_bwd(q)")
-            _ck(lib.sa_favor_features_bwd(_ffi.ptr(dkf), _ffi.ptr(kf), _ffi.ptr(sv["ddk"]), _ffi.ptr(sv["kg"]), G * dh, 0, G, dh, 0, _ffi.ptr(dddk), _ffi.ptr(dkg),
-                                          _ffi.ptr(sv["gws"]), _ffi.ptr(tsum), R * G, m, LDF, st), "favor_features_bwd(k)")
-            rg = (1, 1, R * G)
             if self._xf:
+                dqg = torch.empty(R, G * dh, dtype=f32, device=dev)
+                dkg = torch.empty(R, G * dh, dtype=f32, device=dev)
+                dqs, dks, sst = dqg, dkg, G * dh
+            else:   # straight into the global-head columns of dq / dk (same row stride as q / k)
+                dqs, dks, sst = dq, dk, qs
+            _ck(lib.sa_favor_features_bwd(_ffi.ptr(dqf), _ffi.ptr(qf), _ffi.ptr(sv["ddq"]), _ffi.ptr(sv["qg"]), sst, 0, G, dh, 1, _ffi.ptr(dddq), _ffi.ptr(dqs),
+                                          None, None, R * G, m, LDF, st), "favor_features_bwd(q)")
+            _ck(lib.sa_favor_features_bwd(_ffi.ptr(dkf), _ffi.ptr(kf), _ffi.ptr(sv["ddk"]), _ffi.ptr(sv["kg"]), sst, 0, G, dh, 0, _ffi.ptr(dddk), _ffi.ptr(dks),
+                                          _ffi.ptr(sv["gws"]), _ffi.ptr(tsum), R * G, m, LDF, st), "favor_features_bwd(k)")
+            if self._xf:
+                rg = (1, 1, R * G)
                 dqg = pop.dgrad(dddq.view(1, 1, 1, R * G, LDF), rg, addend=dqg.view(1, 1, 1, R * G, dh), fwd_out_stride=LDF).view(R, G * dh)
                 dkg = pop.dgrad(dddk.view(1, 1, 1, R * G, LDF), rg, addend=dkg.view(1, 1, 1, R * G, dh), fwd_out_stride=LDF).view(R, G * dh)
+                dq[:, : G * dh] = dqg
+                dk[:, : G * dh] = dkg
             else:
                 ps = self._pop[2]
-                _ck(lib.sa_favor_project_bwd(_ffi.ptr(dddq), _ffi.ptr(ps), _ffi.ptr(dqg), _ffi.ptr(dqg), dh, R * G, m, LDF, dh, st), "sa_favor_project_bwd(q)")
-                _ck(lib.sa_favor_project_bwd(_ffi.ptr(dddk), _ffi.ptr(ps), _ffi.ptr(dkg), _ffi.ptr(dkg), dh, R * G, m, LDF, dh, st), "sa_favor_project_bwd(k)")
-            dq[:, : G * dh] = dqg
-            dk[:, : G * dh] = dkg
+                _ck(lib.sa_favor_project_bwd(_ffi.ptr(dddq), _ffi.ptr(ps), _ffi.ptr(dq), _ffi.ptr(dq), qs, G, R * G, m, LDF, dh, st), "sa_favor_project_bwd(q)")
+                _ck(lib.sa_favor_project_bwd(_ffi.ptr(dddk), _ffi.ptr(ps), _ffi.ptr(dk), _ffi.ptr(dk), qs, G, R * G, m, LDF, dh, st), "sa_favor_project_bwd(k)")
         if L > 0:
             cosb, sinb = self._rot_tables(N, dev)
             dqr = torch.empty(R, L * dh, dtype=f32, device=dev)

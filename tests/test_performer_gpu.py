@@ -148,30 +148,33 @@ def test_scan_exact_flag_selects_fp32_products():
     assert e_exact < 2e-6 and e_split < 5e-5 and not torch.equal(outs[0][0], outs[1][0])
 
 
-@pytest.mark.parametrize("rows,m,LDF", [(1, 266, 272), (130, 266, 272), (1000, 100, 112), (67200, 266, 272), (77, 256, 256)])
-def test_projection_kernels_against_matmul(rows, m, LDF):
+@pytest.mark.parametrize("rows,m,LDF,heads", [(1, 266, 272, 1), (130, 266, 272, 2), (1000, 100, 112, 1), (67200, 266, 272, 8), (77, 256, 256, 1)])
+def test_projection_kernels_against_matmul(rows, m, LDF, heads):
     """sa_favor_project / sa_favor_project_bwd (split-bf16, projection matrix staged once per block) against fp64 matmuls: ragged row counts,
-    padded feature columns written as zeros, strided input rows, addend."""
+    padded feature columns written as zeros, rows that are head blocks of wider rows, addend."""
     from synthanatomy_amd import _ffi
     lib, st = _ffi.lib(), _ffi.stream()
     torch.manual_seed(rows + m)
-    xs = 96                                               # rows live in a wider matrix
-    x = torch.randn(rows, xs, device="cuda")
+    wide = heads * 64 + 32                               # head blocks live in a wider matrix
+    xw = torch.randn(rows // heads, wide, device="cuda")
+    x = xw[:, :heads * 64].reshape(rows, 64)
     P_ = torch.randn(m, 64, device="cuda") * 0.35
     dd = torch.full((rows, LDF), float("nan"), device="cuda")
-    _ffi.check(lib.sa_favor_project(_ffi.ptr(x), xs, _ffi.ptr(P_), _ffi.ptr(dd), rows, m, LDF, 64, st))
-    ref = x[:, :64].double() @ P_.double().t()
+    _ffi.check(lib.sa_favor_project(_ffi.ptr(xw), wide, heads, _ffi.ptr(P_), _ffi.ptr(dd), rows, m, LDF, 64, st))
+    ref = x.double() @ P_.double().t()
     assert _rel(dd[:, :m], ref) < 2e-5
-    assert float(dd[:, m:].abs().max()) == 0.0 if LDF > m else True
+    assert LDF == m or float(dd[:, m:].abs().max()) == 0.0
     g = torch.randn(rows, LDF, device="cuda")
     g[:, m:] = 7.0                                        # padded gradient columns must not leak (the staged projection rows are zero)
-    add = torch.randn(rows, 64, device="cuda")
-    dx = torch.full((rows, 64), float("nan"), device="cuda")
-    _ffi.check(lib.sa_favor_project_bwd(_ffi.ptr(g), _ffi.ptr(P_), _ffi.ptr(add), _ffi.ptr(dx), 64, rows, m, LDF, 64, st))
+    dxw = torch.full((rows // heads, wide), float("nan"), device="cuda")
+    dxw[:, :heads * 64] = torch.randn(rows // heads, heads * 64, device="cuda")   # addend in place (what the feature-map backward left there)
+    add = dxw[:, :heads * 64].reshape(rows, 64).clone()
+    _ffi.check(lib.sa_favor_project_bwd(_ffi.ptr(g), _ffi.ptr(P_), _ffi.ptr(dxw), _ffi.ptr(dxw), wide, heads, rows, m, LDF, 64, st))
     refb = g[:, :m].double() @ P_.double() + add.double()
-    assert _rel(dx, refb) < 2e-5
-    _ffi.check(lib.sa_favor_project_bwd(_ffi.ptr(g), _ffi.ptr(P_), None, _ffi.ptr(dx), 64, rows, m, LDF, 64, st))
-    assert _rel(dx, g[:, :m].double() @ P_.double()) < 2e-5
+    assert _rel(dxw[:, :heads * 64].reshape(rows, 64), refb) < 2e-5
+    assert bool(torch.isnan(dxw[:, heads * 64:]).all())   # nothing outside the head blocks is touched
+    _ffi.check(lib.sa_favor_project_bwd(_ffi.ptr(g), _ffi.ptr(P_), None, _ffi.ptr(dxw), wide, heads, rows, m, LDF, 64, st))
+    assert _rel(dxw[:, :heads * 64].reshape(rows, 64), g[:, :m].double() @ P_.double()) < 2e-5
 
 
 @pytest.mark.parametrize("with_sink", [False, True])
