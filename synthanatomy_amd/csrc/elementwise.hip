@@ -80,6 +80,18 @@ __global__ void cast_pad_kernel(const void* src, int src_dtype, int src_c, void*
     }
 }
 
+__global__ void cast_f32_bf16_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, int64_t n8) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n8; e += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = src[2 * e], b = src[2 * e + 1];
+        uint4 o;
+        o.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
+        o.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
+        o.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
+        o.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+        dst[e] = o;
+    }
+}
+
 __global__ void mse_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* __restrict__ loss_sum, float* __restrict__ grad,
                            float gcoef) {
     float s = 0.f;
@@ -160,6 +172,13 @@ extern "C" int sa_pack_weights_batch(const sa_pack_desc* table, const int32_t* b
 extern "C" int sa_cast_pad(const void* src, int src_dtype, int src_c, void* dst, int dst_dtype, int dst_stride, int64_t rows, void* stream) {
     using namespace sa;
     if (!src || !dst || src_c <= 0 || dst_stride <= 0 || rows <= 0) return SA_EINVAL;
+    const int64_t n = rows * dst_stride;
+    if (src_c == dst_stride && src_dtype == SA_F32 && dst_dtype == SA_BF16 && (n & 7) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        // no padding: a flat fp32 -> bf16 conversion, 32 bytes in / 16 bytes out per thread and step
+        hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (uint4*)dst, n / 8);
+        SA_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(cast_pad_kernel, dim3(grid_for(rows * dst_stride)), dim3(256), 0, (hipStream_t)stream, src, src_dtype, src_c, dst, dst_dtype,
                        dst_stride, rows);
     SA_CHECK_LAUNCH();

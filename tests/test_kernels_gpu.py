@@ -344,6 +344,14 @@ def test_elementwise_kernels():
     x = torch.randn(37, 3)
     y = engine.cast_pad(x.cuda(), torch.bfloat16, 8)
     assert y.shape == (37, 8) and torch.equal(y[:, :3].float().cpu(), x.bfloat16().float()) and float(y[:, 3:].abs().max()) == 0.0
+    # no padding: the flat vectorised conversion (round to nearest even, like torch), including specials
+    x = torch.randn(1001, 24)
+    x[0, :4] = torch.tensor([float("inf"), float("-inf"), 0.0, -0.0])
+    x[1, 0] = float("nan")
+    y = engine.cast_pad(x.cuda(), torch.bfloat16, 24).cpu()
+    ref = x.bfloat16()
+    ok = torch.isnan(ref) & torch.isnan(y) | (y.view(torch.int16) == ref.view(torch.int16))
+    assert bool(ok.all())
 
 
 def test_abi_rejects_bad_arguments():
