@@ -214,6 +214,45 @@ def test_fused_qkv_projection_matches_separate_layers(with_sink, monkeypatch):
     assert _rel(res[0][1], res[1][1]) < 5e-3 and float(res[0][1].abs().max()) > 0
 
 
+@pytest.mark.parametrize("m,LDF,N", [(120, 128, 100), (256, 256, 130), (16, 16, 70), (200, 208, 64), (266, 272, 257)])
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_split_scans_other_feature_counts(m, LDF, N, reverse):
+    """The split-bf16 chunk kernels stage features in slabs (144 wide for the state sums, 64 wide for the outputs): feature counts that end inside a
+    slab / a 32-step reduction block, against the exact-fp32 kernels (state_flags bit 2) on every fused entry point."""
+    from synthanatomy_amd import _ffi
+    lib, st = _ffi.lib(), _ffi.stream()
+    torch.manual_seed(m + N)
+    B, G, dv = 2, 2, 64
+    a = torch.zeros(B, N, G, LDF, device="cuda")
+    c = torch.zeros(B, N, G, LDF, device="cuda")
+    a[..., :m] = torch.rand(B, N, G, m, device="cuda") + 0.01
+    c[..., :m] = torch.rand(B, N, G, m, device="cuda") + 0.01
+    bb = torch.randn(B * N, G * dv, device="cuda")
+    cc = torch.randn(B * N, G * dv, device="cuda")
+    bs = torch.rand(B, N, G, device="cuda") + 0.5
+    ws = torch.empty(lib.sa_favor_scan_workspace_bytes(B, N, G, LDF, dv) // 4, device="cuda")
+    outs = []
+    for xf in (0, 4):
+        yn = torch.zeros(B * N, G * dv, device="cuda")
+        inv = torch.zeros(B * N * G, device="cuda")
+        if not reverse:
+            _ffi.check(lib.sa_favor_scan_a_norm(_ffi.ptr(a), _ffi.ptr(c), _ffi.ptr(bb), G * dv, 0, _ffi.ptr(yn), G * dv, 0, _ffi.ptr(inv), 1e-6, B, N, G, LDF, dv,
+                                                _ffi.ptr(ws), xf, st))
+        y1 = torch.zeros(B, N, G, LDF, device="cuda")
+        _ffi.check(lib.sa_favor_scan_b_cum(_ffi.ptr(a), _ffi.ptr(bb), G * dv, 0, _ffi.ptr(bs), _ffi.ptr(cc), G * dv, 0, None, _ffi.ptr(y1), _ffi.ptr(bs), 1, 0.25,
+                                           B, N, G, LDF, dv, reverse, _ffi.ptr(ws), xf, st))
+        y2 = torch.zeros(B, N, G, LDF, device="cuda")
+        _ffi.check(lib.sa_favor_scan_b_cum(_ffi.ptr(a), _ffi.ptr(bb), G * dv, 0, _ffi.ptr(bs), _ffi.ptr(cc), G * dv, 0, None, _ffi.ptr(y2), _ffi.ptr(bs), 2, 0.0,
+                                           B, N, G, LDF, dv, reverse, _ffi.ptr(ws), xf, st))
+        y3 = torch.zeros(B * N, G * dv, device="cuda")
+        _ffi.check(lib.sa_favor_scan_a_state(_ffi.ptr(a), _ffi.ptr(c), _ffi.ptr(bb), G * dv, 0, _ffi.ptr(bs), _ffi.ptr(y3), G * dv, 0, None, B, N, G, LDF, dv,
+                                             reverse, 0, _ffi.ptr(ws), 3 | xf, st))
+        outs.append((yn, inv, y1[..., :m], y2[..., :m], y3))
+    for s_, e_ in zip(*outs):
+        assert bool(torch.isfinite(s_).all())
+        assert _rel(s_, e_) < 5e-5
+
+
 @pytest.mark.parametrize("N,segmented", [(37, False), (37, True), (300, True), (1400, True)])
 def test_causal_scan_kernels_against_quadratic_form(N, segmented):
     from synthanatomy_amd import _ffi
