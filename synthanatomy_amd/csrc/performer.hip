@@ -145,6 +145,27 @@ __global__ void rezero_bwd_kernel(const float* __restrict__ dy, const void* F, i
     if (threadIdx.x == 0) unsafeAtomicAdd(dg, red[0] + red[1] + red[2] + red[3]);
 }
 
+// the same for bf16 F / dF, four elements per thread and step (16 + 8 bytes in, 8 bytes out)
+__global__ void rezero_bwd_bf16x4_kernel(const float4* __restrict__ dy, const uint2* __restrict__ F, const float* __restrict__ g, uint2* __restrict__ dF,
+                                         float* __restrict__ dg, int64_t n4) {
+    const float gv = g[0];
+    float s = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+        const float4 d = dy[e];
+        const uint2 f = F[e];
+        s += d.x * __uint_as_float(f.x << 16) + d.y * __uint_as_float(f.x & 0xffff0000u) + d.z * __uint_as_float(f.y << 16) + d.w * __uint_as_float(f.y & 0xffff0000u);
+        uint2 o;
+        o.x = (uint32_t)f32_to_bf16(gv * d.x) | ((uint32_t)f32_to_bf16(gv * d.y) << 16);
+        o.y = (uint32_t)f32_to_bf16(gv * d.z) | ((uint32_t)f32_to_bf16(gv * d.w) << 16);
+        dF[e] = o;
+    }
+    s = wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(dg, red[0] + red[1] + red[2] + red[3]);
+}
+
 __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, int64_t n) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) y[e] += alpha * x[e];
 }
@@ -1196,30 +1217,38 @@ __global__ void favor_dden_kernel(const float* __restrict__ dout, const float* _
 
 // ------------------------------------------------------------------------------------------------ rotary (local heads)
 // x [R, stride] head block at off + h*dh; table [N, dh] (cos | sin).  mode 0: y = x cos + rot(x) sin ; mode 1: transpose
+// thread = four consecutive dimensions of the first half of one head row and their partners in the second half (16-byte accesses)
 __global__ void rotary_kernel(const float* __restrict__ x, int stride, int off, int L, int dh, const float* __restrict__ cosb,
                               const float* __restrict__ sinb, float* __restrict__ y, int y_stride, int y_off, int N, int64_t R, int mode,
                               int accumulate) {
-    const int half = dh / 2;
-    const int64_t total = R * L * dh;
+    const int half = dh / 2, q4 = half / 4;
+    const int64_t total = R * L * q4;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int d = (int)(e % dh);
-        const int h = (int)((e / dh) % L);
-        const int64_t r = e / ((int64_t)dh * L);
-        const int n = (int)(r % N);
+        const int j = (int)(e % q4);
+        const int64_t rh = e / q4;
+        const int h = (int)(rh % L);
+        const int64_t r = rh / L;
+        const int n = (int)(r % N), d = j * 4;
         const float* xr = x + r * stride + off + h * dh;
-        const float cs = cosb[n * dh + d];
-        float o;
-        if (mode == 0) {
-            const float rot = d < half ? -xr[d + half] : xr[d - half];
-            o = xr[d] * cs + rot * sinb[n * dh + d];
-        } else {
-            // y_d = g_d cos_d + (rot^T (g sin))_d ;  rot^T(u)_d = u_{d+half} for d < half, -u_{d-half} otherwise
-            const float rt = d < half ? xr[d + half] * sinb[n * dh + d + half] : -xr[d - half] * sinb[n * dh + d - half];
-            o = xr[d] * cs + rt;
+        const float4 xl = *(const float4*)(xr + d), xh = *(const float4*)(xr + d + half);
+        const float4 cl = *(const float4*)(cosb + n * dh + d), ch = *(const float4*)(cosb + n * dh + d + half);
+        const float4 sl = *(const float4*)(sinb + n * dh + d), sh = *(const float4*)(sinb + n * dh + d + half);
+        float4 ol, oh;
+        if (mode == 0) {   // y = x cos + rot(x) sin,  rot(x)_d = -x_{d+half} (d < half), x_{d-half} otherwise
+            ol = make_float4(xl.x * cl.x - xh.x * sl.x, xl.y * cl.y - xh.y * sl.y, xl.z * cl.z - xh.z * sl.z, xl.w * cl.w - xh.w * sl.w);
+            oh = make_float4(xh.x * ch.x + xl.x * sh.x, xh.y * ch.y + xl.y * sh.y, xh.z * ch.z + xl.z * sh.z, xh.w * ch.w + xl.w * sh.w);
+        } else {           // adjoint: y_d = g_d cos_d + (rot^T (g sin))_d ;  rot^T(u)_d = u_{d+half} for d < half, -u_{d-half} otherwise
+            ol = make_float4(xl.x * cl.x + xh.x * sh.x, xl.y * cl.y + xh.y * sh.y, xl.z * cl.z + xh.z * sh.z, xl.w * cl.w + xh.w * sh.w);
+            oh = make_float4(xh.x * ch.x - xl.x * sl.x, xh.y * ch.y - xl.y * sl.y, xh.z * ch.z - xl.z * sl.z, xh.w * ch.w - xl.w * sl.w);
         }
         float* yp = y + r * y_stride + y_off + h * dh + d;
-        if (accumulate) *yp += o;
-        else *yp = o;
+        if (accumulate) {
+            const float4 a = *(const float4*)yp, b = *(const float4*)(yp + half);
+            ol.x += a.x; ol.y += a.y; ol.z += a.z; ol.w += a.w;
+            oh.x += b.x; oh.y += b.y; oh.z += b.z; oh.w += b.w;
+        }
+        *(float4*)yp = ol;
+        *(float4*)(yp + half) = oh;
     }
 }
 
@@ -1668,6 +1697,12 @@ extern "C" int sa_rezero_fwd(const float* x, const void* F, int f_dtype, const f
 
 extern "C" int sa_rezero_bwd(const float* dy, const void* F, int f_dtype, const float* g, void* dF, int df_dtype, float* dg, int64_t n, void* stream) {
     if (!dy || !F || !g || !dF || !dg || n <= 0) return SA_EINVAL;
+    if (f_dtype == SA_BF16 && df_dtype == SA_BF16 && (n & 3) == 0 && (((uintptr_t)dy | (uintptr_t)F | (uintptr_t)dF) & 15) == 0) {
+        hipLaunchKernelGGL(rezero_bwd_bf16x4_kernel, dim3(grid1d(n / 4, 256, 1024)), dim3(256), 0, ST(stream), (const float4*)dy, (const uint2*)F, g, (uint2*)dF, dg,
+                           n / 4);
+        SA_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(rezero_bwd_kernel, dim3(grid1d(n, 256, 1024)), dim3(256), 0, ST(stream), dy, F, f_dtype, g, dF, df_dtype, dg, n);
     SA_CHECK_LAUNCH();
     return 0;
@@ -1842,7 +1877,8 @@ extern "C" int sa_favor_dden(const float* dout, const float* out, int stride, in
 extern "C" int sa_rotary(const float* x, int stride, int off, int L, int dh, const float* cosb, const float* sinb, float* y, int y_stride, int y_off,
                          int N, int64_t R, int transpose, int accumulate, void* stream) {
     if (!x || !cosb || !sinb || !y || L <= 0 || dh <= 0 || (dh & 1) || R <= 0) return SA_EINVAL;
-    hipLaunchKernelGGL(rotary_kernel, dim3(grid1d(R * L * dh)), dim3(256), 0, ST(stream), x, stride, off, L, dh, cosb, sinb, y, y_stride, y_off, N, R,
+    if ((dh & 7) || ((stride | off | y_stride | y_off) & 3)) return SA_EUNSUPPORTED;   // 16-byte accesses on both halves of a head row
+    hipLaunchKernelGGL(rotary_kernel, dim3(grid1d(R * L * dh / 8)), dim3(256), 0, ST(stream), x, stride, off, L, dh, cosb, sinb, y, y_stride, y_off, N, R,
                        transpose, accumulate);
     SA_CHECK_LAUNCH();
     return 0;

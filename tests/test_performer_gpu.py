@@ -253,6 +253,47 @@ def test_split_scans_other_feature_counts(m, LDF, N, reverse):
         assert _rel(s_, e_) < 5e-5
 
 
+def test_rotary_and_rezero_backward_kernels():
+    """sa_rotary (forward, adjoint, accumulate; head blocks of wider rows) against the rotate-half formula, and the 4-wide bf16 path of
+    sa_rezero_bwd against torch."""
+    from synthanatomy_amd import _ffi
+    lib, st = _ffi.lib(), _ffi.stream()
+    torch.manual_seed(21)
+    B, N, L, dh, wide = 2, 37, 3, 64, 288
+    R = B * N
+    x = torch.randn(R, wide, device="cuda")
+    fr = torch.einsum("i,j->ij", torch.arange(N, device="cuda", dtype=torch.float32), 1.0 / (10000 ** (torch.arange(0, dh, 2, device="cuda").float() / dh)))
+    fr = torch.cat((fr, fr), -1)
+    cosb, sinb = fr.cos().contiguous(), fr.sin().contiguous()
+    xs = x[:, 64:64 + L * dh].reshape(B, N, L, dh)
+    rot = lambda t: torch.cat((-t[..., dh // 2:], t[..., :dh // 2]), -1)
+    ref = xs * cosb[None, :, None, :] + rot(xs) * sinb[None, :, None, :]
+    y = torch.zeros(R, L * dh, device="cuda")
+    _ffi.check(lib.sa_rotary(_ffi.ptr(x), wide, 64, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(y), L * dh, 0, N, R, 0, 0, st))
+    assert _rel(y.view(B, N, L, dh), ref) < 1e-6
+    # adjoint: <rot(x), g> == <x, rot^T(g)>, written into a wider matrix, then accumulated once more
+    g = torch.randn(R, L * dh, device="cuda")
+    gx = torch.zeros(R, wide, device="cuda")
+    _ffi.check(lib.sa_rotary(_ffi.ptr(g), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(gx), wide, 64, N, R, 1, 0, st))
+    lhs = float((y.double() * g.double()).sum())
+    rhs = float((x[:, 64:64 + L * dh].double() * gx[:, 64:64 + L * dh].double()).sum())
+    assert abs(lhs - rhs) < 1e-6 * abs(lhs) + 1e-6
+    assert float(gx[:, :64].abs().max()) == 0.0 and float(gx[:, 64 + L * dh:].abs().max()) == 0.0
+    once = gx.clone()
+    _ffi.check(lib.sa_rotary(_ffi.ptr(g), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(gx), wide, 64, N, R, 1, 1, st))
+    assert _rel(gx, 2 * once) < 1e-6
+    # ReZero backward, bf16 F / dF
+    n = 4096 * 3
+    dy = torch.randn(n, device="cuda")
+    F_ = torch.randn(n, device="cuda").bfloat16()
+    gate = torch.tensor([0.37], device="cuda")
+    dF = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    dg = torch.zeros(1, device="cuda")
+    _ffi.check(lib.sa_rezero_bwd(_ffi.ptr(dy), _ffi.ptr(F_), _ffi.dtype_id(torch.bfloat16), _ffi.ptr(gate), _ffi.ptr(dF), _ffi.dtype_id(torch.bfloat16), _ffi.ptr(dg), n, st))
+    assert torch.equal(dF, (dy * 0.37).bfloat16())
+    assert abs(float(dg) - float((dy.double() * F_.double()).sum())) < 1e-3
+
+
 @pytest.mark.parametrize("N,segmented", [(37, False), (37, True), (300, True), (1400, True)])
 def test_causal_scan_kernels_against_quadratic_form(N, segmented):
     from synthanatomy_amd import _ffi
