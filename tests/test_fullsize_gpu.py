@@ -84,3 +84,52 @@ def test_full_size_halo_kernels_agree_with_im2col_order_kernels(net):
     assert gr_h.keys() == gr_r.keys() and len(gr_h) >= 100
     worst = max((_rel(gr_h[n], gr_r[n]), n) for n in gr_h)
     assert worst[0] < 3e-2, worst
+
+
+# ------------------------------------------------------------------------------------------------------------------ Performer, README size
+PERF = dict(vocab=2048, dim=512, depth=24, heads=16, local_heads=8, window=420)
+SPATIAL = (10, 14, 10)
+
+
+@pytest.fixture(scope="module")
+def performer():
+    from synthanatomy_amd.networks.transformers.img2seq_ordering import Ordering
+    from synthanatomy_amd.networks.transformers.performer import Performer
+    torch.manual_seed(4)
+    order = Ordering("raster_scan", 3, (1,) + SPATIAL, (False, False, False), ((2, 0, 1),), ((0, 1),), ("rotate_90", "transpose"))
+    net = Performer(num_tokens=PERF["vocab"] + 1, max_seq_len=int(np.prod(SPATIAL)), dim=PERF["dim"], depth=PERF["depth"], heads=PERF["heads"], ordering=order,
+                    local_attn_heads=PERF["local_heads"], local_window_size=PERF["window"], feature_redraw_interval=None, use_rezero=True,
+                    spatial_position_emb="absolute", spatial_shape=SPATIAL, compute_dtype=torch.bfloat16).cuda().eval()
+    with torch.no_grad():
+        for n_, p in net.named_parameters():
+            if n_.endswith(".g"):
+                p.fill_(0.2)          # the 1e-3 ReZero init would hide the attention path behind the residual
+    return net
+
+
+def test_performer_full_size_properties(performer, monkeypatch):
+    """24 layers, N = 1 400, bf16 throughput mode (split-bf16 attention / scans / projections): determinism, causality up to the global key
+    stabiliser, and agreement with the same network run on the exact-fp32 MFMA kernels."""
+    net = performer
+    torch.manual_seed(0)
+    N = int(np.prod(SPATIAL))
+    tok = torch.randint(0, PERF["vocab"], (2, N), device="cuda")
+    with torch.no_grad():
+        a = net(tok).float()
+        b = net(tok).float()
+        assert torch.isfinite(a).all() and torch.equal(a, b)                      # no atomics-order dependence in the forward
+        tok2 = tok.clone()
+        tok2[:, 1300:] = (tok2[:, 1300:] + 7) % PERF["vocab"]
+        c = net(tok2).float()
+        # positions before the edit move only through the keys' global stabiliser (a scalar shift that cancels in the normaliser up to the +eps term)
+        early = _rel(c[:, :1300], a[:, :1300])
+        late = _rel(c[:, 1300:], a[:, 1300:])
+        assert early < 2e-2 and late > 10 * early, (early, late)
+        monkeypatch.setenv("SA_SCAN_EXACT", "7")
+        monkeypatch.setenv("SA_LOCAL_ATTN_EXACT", "1")
+        e = net(tok).float()
+        monkeypatch.delenv("SA_SCAN_EXACT")
+        monkeypatch.delenv("SA_LOCAL_ATTN_EXACT")
+        assert not torch.equal(e, a)
+        d = (e - a).double().norm() / e.double().norm()
+        assert float(d) < 2e-3, float(d)                                          # bf16 rounding of the dense layers amplifies 1e-5 differences
