@@ -229,6 +229,62 @@ class _ConvStage:
         return self.op.dgrad(G, tuple(x.shape[1:4]), mask=x if self.in_act else None, mask_mode=MASK_POS)
 
 
+class _Conv1Stage:
+    """First encoder layer Conv3d(1 -> C, k4 s2 p1) (+ReLU; baseline.py:218-226).  With ONE input channel the implicit GEMM pads the reduction
+    8x (channels travel in 16-byte vectors) and spends 2.1 ms per launch at 160x224x160 / batch 8 plus 0.8 ms padding the volume.  Here the 64
+    taps become the channels of a 1x1x1 convolution: sa_convt1_im2col gathers Xc[cell][tap] = x[2 cell - 1 + tap] straight from the fp32
+    volume (the same gather the last decoder layer's backward uses), the dense kernels do Xc . W^T (+bias, ReLU) and, in the backward pass,
+    the weight / bias gradient from the saved Xc.  No data gradient: this is the network input.  Odd extents or tiny volumes take the
+    generic stage."""
+
+    GEMM_MIN_CELLS = 4096
+
+    def __init__(self, mod: nn.Conv3d, act, dtype):
+        self.mod, self.act, self.dtype = mod, act, dtype
+        self.op = ConvOp("conv", 64, mod.out_channels, 1, 1, 0, mod.weight.view(mod.out_channels, 64, 1, 1, 1), mod.bias, dtype)
+        self.fallback = _ConvStage(mod, "conv", act, in_act=False, dtype=dtype, need_dx=False)
+        self.fallback_op = self.fallback.op
+
+    @staticmethod
+    def applicable(mod) -> bool:
+        return (isinstance(mod, nn.Conv3d) and mod.in_channels == 1 and mod.kernel_size == (4, 4, 4) and mod.stride == (2, 2, 2)
+                and mod.padding == (1, 1, 1) and mod.dilation == (1, 1, 1) and mod.out_channels % 8 == 0)
+
+    def params(self):
+        return [self.mod.weight, self.mod.bias]
+
+    def _sync(self):
+        self.op.weight, self.op.bias = self.mod.weight.view(self.mod.out_channels, 64, 1, 1, 1), self.mod.bias
+
+    def fwd(self, x, tape):
+        """x: the raw fp32 volume [N, D, H, W]."""
+        N, D, H, W = x.shape
+        if D % 2 or H % 2 or W % 2 or N * (D // 2) * (H // 2) * (W // 2) < self.GEMM_MIN_CELLS or os.environ.get("SA_NO_CONV1_GEMM") is not None:
+            vec = vec_of(self.dtype)
+            return self.fallback.fwd(cast_pad(x.unsqueeze(-1), self.dtype, vec), tape)
+        self._sync()
+        Xc = torch.empty((N, D // 2, H // 2, W // 2, 64), dtype=self.dtype, device=x.device)
+        _ffi.check(_ffi.lib().sa_convt1_im2col(_ffi.ptr(x), _ffi.dtype_id(self.dtype), _ffi.ptr(Xc), None, N, D // 2, H // 2, W // 2, _ffi.stream()),
+                   "sa_convt1_im2col")
+        y = self.op.fprop(Xc, act=self.act, out_dtype=self.dtype, out_channels_stride=self.op.cout)
+        if tape is not None:
+            tape.append((Xc, True))
+        return y
+
+    def bwd(self, G, saved, grads):
+        if len(saved) == 1:
+            return self.fallback.bwd(G, saved, grads)
+        Xc = saved[0]
+        self._sync()
+        vec = vec_of(self.dtype)
+        if G.shape[-1] % vec or G.dtype != self.dtype:
+            G = cast_pad(G, self.dtype, (G.shape[-1] + vec - 1) // vec * vec)
+        dw, db = grads.buf(self.mod.weight), grads.buf(self.mod.bias)
+        self.op.wgrad(Xc, G, dw.view(self.mod.out_channels, 64, 1, 1, 1), db)
+        grads.done(self.mod.weight, self.mod.bias)
+        return None
+
+
 class _ConvT1Stage:
     """Final ConvTranspose3d(128 -> 1, k4 s2 p1) (csrc/convt1.hip).  At scale the 64 taps become the channels of a 1x1x1 convolution on
     the MFMA kernels (P = x . w per cell, then a gather onto the output grid; backward: im2col of the gradient, then the 1x1x1 dgrad /
@@ -388,7 +444,8 @@ class _Chain:
 
     def ops(self):
         return [op for s in self.stages
-                for op in (getattr(s, "op", None), getattr(s, "c3", None), getattr(s, "c1", None), getattr(s, "taps_fwd", None), getattr(s, "taps_bwd", None))
+                for op in (getattr(s, "op", None), getattr(s, "c3", None), getattr(s, "c1", None), getattr(s, "taps_fwd", None), getattr(s, "taps_bwd", None),
+                           getattr(s, "fallback_op", None))
                 if op is not None]
 
     def invalidate(self):
@@ -399,8 +456,11 @@ class _Chain:
         """x [B,C,D,H,W] fp32 (any strides) -> y channels-last [B,D,H,W,C'] (+ tape)."""
         _ffi.require_gpu()
         vec = vec_of(self.dtype)
-        x = x_ncdhw.float().permute(0, 2, 3, 4, 1).contiguous()
-        x = cast_pad(x, self.dtype, (self.in_channels + vec - 1) // vec * vec)
+        if isinstance(self.stages[0], _Conv1Stage) and x_ncdhw.shape[1] == 1:
+            x = x_ncdhw.float().contiguous().view(x_ncdhw.shape[0], *x_ncdhw.shape[2:])   # the first stage reads the fp32 volume itself
+        else:
+            x = x_ncdhw.float().permute(0, 2, 3, 4, 1).contiguous()
+            x = cast_pad(x, self.dtype, (self.in_channels + vec - 1) // vec * vec)
         tape = [] if record else None
         for s in self.stages:
             x = s.fwd(x, tape)
@@ -519,7 +579,10 @@ class BaselineVQVAE(VQVAEBase, nn.Module):
         stages = []
         for lvl in range(self.n_levels):
             conv, res = mods[3 * lvl], mods[3 * lvl + 2]
-            stages.append(_ConvStage(conv, "conv", ACT_RELU, in_act=lvl > 0, dtype=dt, need_dx=lvl > 0))
+            if lvl == 0 and _Conv1Stage.applicable(conv):
+                stages.append(_Conv1Stage(conv, ACT_RELU, dt))
+            else:
+                stages.append(_ConvStage(conv, "conv", ACT_RELU, in_act=lvl > 0, dtype=dt, need_dx=lvl > 0))
             stages += [_ResStage(r, in_act=True, dtype=dt) for r in res]
         stages.append(_ConvStage(mods[3 * self.n_levels], "conv", ACT_NONE, in_act=True, dtype=dt, out_f32=True))
         return _Chain(stages, dt, in_channels=1)

@@ -72,18 +72,36 @@ def test_full_size_halo_kernels_agree_with_im2col_order_kernels(net):
     the same products in a different order)."""
     g = torch.Generator(device="cuda").manual_seed(5)
     x = torch.rand(1, 1, *VOL, generator=g, device="cuda")
+
+    def codes():
+        net.eval()
+        with torch.no_grad():
+            return net.index_quantize(x)[0].clone()
+
+    idx_h = codes()
     loss_h, gr_h = _grads(net, x)
     os.environ["SA_NO_HALO"] = "1"
     os.environ["SA_NO_FUSED_1X1_BWD"] = "1"     # ... and the two-launch 1x1x1 backward instead of sa_conv1x1_backward
     try:
+        idx_r = codes()
         loss_r, gr_r = _grads(net, x)
     finally:
         del os.environ["SA_NO_HALO"]
         del os.environ["SA_NO_FUSED_1X1_BWD"]
+    # bf16 activations: a different summation order moves a few of the 1 400 encoder outputs across a code boundary (4-8 measured), and every
+    # flipped code changes the decoder's input at one voxel outright -- the gradient bound below is per flip (measured 0.4-0.8 % each)
+    flips = int((idx_h != idx_r).sum())
+    assert flips <= idx_h.numel() // 100, flips
     assert np.isfinite(loss_h) and abs(loss_h - loss_r) <= 2e-3 * abs(loss_r)
     assert gr_h.keys() == gr_r.keys() and len(gr_h) >= 100
+    bound = 1e-2 + 8e-3 * flips
     worst = max((_rel(gr_h[n], gr_r[n]), n) for n in gr_h)
-    assert worst[0] < 3e-2, worst
+    assert worst[0] < bound, (worst, flips)
+    fro = max((float((gr_h[n].double() - gr_r[n].double()).norm() / (gr_r[n].double().norm() + 1e-30)), n) for n in gr_h)
+    assert fro[0] < bound, (fro, flips)
+    # the encoder side (everything before the codes) does not see the flips
+    enc = max((float((gr_h[n].double() - gr_r[n].double()).norm() / (gr_r[n].double().norm() + 1e-30)), n) for n in gr_h if n.startswith("encoder"))
+    assert enc[0] < bound, enc
 
 
 # ------------------------------------------------------------------------------------------------------------------ Performer, README size
