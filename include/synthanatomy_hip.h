@@ -269,6 +269,15 @@ int sa_bn_backward(const void *x, const void *g, int dtype, int64_t M, int C, co
 /* g = dy * (y > 0 ? 1 : slope) */
 int sa_lrelu_mask(const void *dy, const void *y, int dtype, void *g, int64_t n, float slope, void *stream);
 
+/* ==== first encoder layer nn.Conv3d(1 -> 128, k4 s2 p1) (+ReLU) (baseline.py:218-226, level 0), bf16: the taps are gathered straight from
+ * the fp32 volume x [N,2D,2H,2W] into LDS (no channel padding, no im2col matrix in HBM).  (N, D, H, W) is the OUTPUT grid.
+ * sa_conv1_fwd  : y [N,D,H,W,128] bf16 = act(bias + W x);  wpk = the layer's weight [128][64 taps] as bf16 (sa_pack_weights with rows = 128,
+ *                 red = 64, one tap);  act = SA_ACT_NONE / SA_ACT_RELU.
+ * sa_conv1_wgrad: dw [128][64] += g^T x_taps, db [128] += sum g  (g [N,D,H,W,128] bf16; accumulated with fp32 atomics: zero them first).
+ * cout != 128 -> SA_EUNSUPPORTED: use sa_convt1_im2col + sa_conv_fprop / sa_conv_wgrad on the [cells][64] matrix. */
+int sa_conv1_fwd(const float *x, const void *wpk, const float *bias, void *y, int N, int D, int H, int W, int cout, int act, void *stream);
+int sa_conv1_wgrad(const float *x, const void *g, float *dw, float *db, int N, int D, int H, int W, int cout, void *stream);
+
 /* ==== final decoder layer nn.ConvTranspose3d(128 -> 1, k4 s2 p1) (baseline.py:283-293, last level): HBM-bound direct kernels ====
  * x [N,D,H,W,128] (dtype), w [128][64] fp32 (the reference weight [Cin,1,4,4,4]), out / g [N,2D,2H,2W] fp32.
  * sa_convt1_bwd: dx = dgrad * (relu_mask > 0) (dx may be NULL), dw += wgrad, db += sum g. */

@@ -1,0 +1,245 @@
+// First encoder layer nn.Conv3d(1 -> 128, k4 s2 p1) (+ReLU) of the VQ-VAE (reference src/networks/vqvae/baseline.py:218-226, level 0) and its
+// weight / bias gradient, bf16, as kernels of their own.  With ONE input channel the 64 taps are the whole reduction: y[cell][co] =
+// sum_t W[co][t] x[2 cell - 1 + t].  The generic implicit GEMM pads that reduction 8x (channels travel in 16-byte vectors); routing it
+// through an explicit [cells][64] im2col matrix costs a 734 MB write plus a one-slab GEMM whose blocks are all prologue and epilogue
+// (0.66 + 1.49 ms at 160x224x160, batch 8).  Here a block gathers the taps of 256 (forward) / 128 (gradient) consecutive cells of one
+// output plane straight from the fp32 volume into an LDS tile ([cell][64 taps] bf16, 128-byte rows, lroff() swizzle) and feeds the MFMA from
+// it; the weights (16 KiB) are register-resident MFMA operands, outputs leave through the quarter transpose as 32-byte pieces.
+// HBM traffic = the output (forward) / the gradient (backward) once; the volume itself is 4 bytes per voxel and is re-read from L2.
+#include "sa_common.h"
+#include "split_bf16.h"
+
+namespace sa {
+
+struct C1Args {
+    const float* x;        // [N, 2D, 2H, 2W] fp32
+    const bf16_t* wpk;     // forward: [128][64] bf16 (sa_pack_weights operand of the layer as a 1x1x1 convolution over 64 tap channels)
+    const float* bias;     // forward: [128] or NULL
+    bf16_t* y;             // forward: [cells][128]
+    const bf16_t* g;       // backward: [cells][128]
+    float* dw;             // backward: [128][64] fp32, accumulated
+    float* db;             // backward: [128] or NULL, accumulated
+    int32_t N, D, H, W;    // OUTPUT grid
+    int32_t act;
+    uint32_t cells;        // N*D*H*W
+    FastDiv dW_, dH_, dD_;
+};
+
+typedef float float4u_t __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment (global_load_dwordx4)
+
+// taps (kd, kh, kw = 0..3) of NCELL consecutive cells starting at cell0 -> tile[cell][64] bf16; cells >= a.cells give zero rows.
+// Lanes run along the cells (thread = one cell, 256 / NCELL threads share its 16 (kd, kh) rows): consecutive lanes read overlapping 16-byte
+// windows 8 bytes apart of the same input row, i.e. a wave reads one contiguous 0.5 KiB stretch per (kd, kh).
+template <int NCELL>
+__device__ __forceinline__ void c1_gather(unsigned char* tile, const C1Args& a, uint32_t cell0, int tid) {
+    constexpr int PARTS = 256 / NCELL, PER = 16 / PARTS;
+    const uint32_t cl = (uint32_t)tid % NCELL, part = (uint32_t)tid / NCELL;
+    const uint32_t cell = cell0 + cl;
+    const uint32_t cc = min(cell, a.cells - 1u);
+    const uint32_t q = fdiv(cc, a.dW_);                  // cc = ((n*D + d)*H + h)*W + w
+    const int w = (int)(cc - q * (uint32_t)a.W);
+    const uint32_t hq = fdiv(q, a.dH_);
+    const int h = (int)(q - hq * (uint32_t)a.H);
+    const uint32_t n = fdiv(hq, a.dD_);
+    const int d = (int)(hq - n * (uint32_t)a.D);
+    const bool inner = w > 0 && w < a.W - 1;             // all four kw taps inside the row
+    const int iw0 = 2 * w - 1;
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+        const uint32_t kk = part * PER + it, kd = kk >> 2, kh = kk & 3u;
+        const int id = 2 * d - 1 + (int)kd, ih = 2 * h - 1 + (int)kh;
+        const bool ok = cell < a.cells && (unsigned)id < (unsigned)(2 * a.D) && (unsigned)ih < (unsigned)(2 * a.H);
+        const int cd = min(max(id, 0), 2 * a.D - 1), chh = min(max(ih, 0), 2 * a.H - 1);
+        const float* row = a.x + (((int64_t)n * 2 * a.D + cd) * 2 * a.H + chh) * 2 * a.W;
+        float v[4];
+        if (inner) {
+            const float4u_t t = *(const float4u_t*)(row + iw0);
+            v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+        } else {
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int iw = iw0 + kw;
+                const float xv = row[min(max(iw, 0), 2 * a.W - 1)];
+                v[kw] = (unsigned)iw < (unsigned)(2 * a.W) ? xv : 0.f;
+            }
+        }
+        uint2 pk;
+        pk.x = ok ? (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16) : 0u;
+        pk.y = ok ? (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16) : 0u;
+        *(uint2*)(tile + lroff(cl, kk * 4u)) = pk;
+    }
+}
+
+// forward: block = 256 consecutive cells, wave = 64 of them (four MFMA column sets); D[i = channel][j = cell]
+__global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const C1Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char sX[256 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g = lane >> 4;
+    const uint32_t cell0 = blockIdx.x * 256u;   // (a persistent variant that fetches the weight operands once per block measured 7 % slower)
+    short8_t wf[8][2];   // W[co = f*16 + fr][taps ks*32 + g*8 .. +7]
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wf[f][ks] = *(const short8_t*)(a.wpk + (f * 16 + fr) * 64 + ks * 32 + g * 8);
+    c1_gather<256>(sX, a, cell0, tid);
+    __syncthreads();
+#pragma unroll 1
+    for (int cf = 0; cf < 4; ++cf) {
+        const uint32_t cl = (uint32_t)w * 64u + cf * 16u + fr;   // this lane's cell (MFMA column, and the output row after the transpose)
+        short8_t xb[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) xb[ks] = *(const short8_t*)(sX + lroff(cl, ks * 32 + g * 8));
+        float4_t acc[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            acc[f] = a.bias ? *(const float4_t*)(a.bias + f * 16 + g * 4) : (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f][ks], xb[ks], acc[f], 0, 0, 0);
+        }
+        const uint32_t cell = cell0 + cl;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {   // channels half*64 + g*16 .. +15 of this lane's cell
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t0 = acc[half * 4 + 0][r], t1 = acc[half * 4 + 1][r], t2 = acc[half * 4 + 2][r], t3 = acc[half * 4 + 3][r];
+                quarter_transpose(t0, t1, t2, t3);   // t[i'] = channel half*64 + g*16 + i'*4 + r
+                v[r] = t0; v[4 + r] = t1; v[8 + r] = t2; v[12 + r] = t3;
+            }
+            if (cell < a.cells) {
+                uint32_t pk[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x0 = v[2 * e], x1 = v[2 * e + 1];
+                    if (a.act == SA_ACT_RELU) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+                    pk[e] = (uint32_t)f32_to_bf16(x0) | ((uint32_t)f32_to_bf16(x1) << 16);
+                }
+                u32x4* o = (u32x4*)(a.y + (int64_t)cell * 128 + half * 64 + g * 16);
+                o[0] = (u32x4){pk[0], pk[1], pk[2], pk[3]};
+                o[1] = (u32x4){pk[4], pk[5], pk[6], pk[7]};
+            }
+        }
+    }
+}
+
+// gradient tile [128 cells][128 channels] bf16, 256-byte rows; 32-byte chunks XOR-swizzled with the row for the transposing reads
+__device__ __forceinline__ uint32_t c1_goff(uint32_t m, uint32_t c) { return m * 256u + ((((c >> 4) ^ (m & 7u)) << 5) | ((c & 15u) << 1)); }
+
+// dW[co][t] += sum_cells g[cell][co] x[2 cell - 1 + t],  db[co] += sum_cells g[cell][co].  Persistent blocks walk 128-cell tiles; wave w owns
+// channels [32 w, 32 w + 32) x all 64 taps in registers for the whole walk and adds them to dw once at the end.
+__global__ __launch_bounds__(256, 3) void conv1_wgrad_kernel(const C1Args a, uint32_t ntiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char sX[128 * 128], sG[128 * 256];
+    __shared__ float sDb[16][8];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g = lane >> 4;
+    const uint32_t trow = (uint32_t)g * 4u + ((uint32_t)fr >> 2), tcol = (uint32_t)(fr & 3) * 4u;
+    float4_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint32_t cell0 = t * 128u;
+        u32x4 gv[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {   // piece = 8 channels of one cell; this thread's channel octet is tid & 15 throughout
+            const uint32_t p = (uint32_t)tid + 256u * it, cl = p >> 4;
+            const uint32_t cell = cell0 + cl;
+            const u32x4 v = *(const u32x4*)(a.g + (int64_t)min(cell, a.cells - 1u) * 128 + (p & 15u) * 8u);
+            const uint32_t mk = cell < a.cells ? 0xffffffffu : 0u;
+            gv[it] = (u32x4){v[0] & mk, v[1] & mk, v[2] & mk, v[3] & mk};
+        }
+        __syncthreads();   // the previous tile has been consumed
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const uint32_t p = (uint32_t)tid + 256u * it, cl = p >> 4;
+            *(u32x4*)(sG + c1_goff(cl, (p & 15u) * 8u)) = gv[it];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bsum[2 * e] += __uint_as_float(gv[it][e] << 16);
+                bsum[2 * e + 1] += __uint_as_float(gv[it][e] & 0xffff0000u);
+            }
+        }
+        c1_gather<128>(sX, a, cell0, tid);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            short8_t ga[2], xb[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t c = (uint32_t)(w * 32 + i * 16) + tcol;
+                ga[i] = __builtin_shufflevector(lds_tr16_b64(sG + c1_goff(ks * 32 + trow, c)), lds_tr16_b64(sG + c1_goff(ks * 32 + 16 + trow, c)), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                xb[j] = __builtin_shufflevector(lds_tr16_b64(sX + lroff(ks * 32 + trow, j * 16 + tcol)), lds_tr16_b64(sX + lroff(ks * 32 + 16 + trow, j * 16 + tcol)),
+                                                0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[i], xb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // D[i = channel][j = tap]: lane (tap fr, g) holds channels 4g .. 4g+3 of each fragment
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) unsafeAtomicAdd(a.dw + (w * 32 + i * 16 + g * 4 + r) * 64 + j * 16 + fr, acc[i][j][r]);
+    if (a.db) {
+        // threads with equal tid & 15 summed the same channel octet: lanes l, l^16, l^32 of a wave, then the four waves
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bsum[e] += __shfl_xor(bsum[e], 16, 64);
+            bsum[e] += __shfl_xor(bsum[e], 32, 64);
+        }
+        __syncthreads();
+        if (tid < 128) ((float*)sDb)[tid] = 0.f;
+        __syncthreads();
+        if (lane < 16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(&sDb[lane][e], bsum[e]);
+        }
+        __syncthreads();
+        if (tid < 128) unsafeAtomicAdd(a.db + tid, ((float*)sDb)[tid]);
+    }
+}
+
+static int c1_fill(C1Args& a, int N, int D, int H, int W, int cout) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return SA_EINVAL;
+    if (cout != 128 || (int64_t)N * D * H * W >= ((int64_t)1 << 31) - 256) return SA_EUNSUPPORTED;
+    a.N = N; a.D = D; a.H = H; a.W = W;
+    a.cells = (uint32_t)((int64_t)N * D * H * W);
+    a.dW_ = make_fastdiv((uint32_t)W);
+    a.dH_ = make_fastdiv((uint32_t)H);
+    a.dD_ = make_fastdiv((uint32_t)D);
+    return 0;
+}
+
+}  // namespace sa
+
+using namespace sa;
+
+extern "C" int sa_conv1_fwd(const float* x, const void* wpk, const float* bias, void* y, int N, int D, int H, int W, int cout, int act, void* stream) {
+    if (!x || !wpk || !y) return SA_EINVAL;
+    if (act != SA_ACT_NONE && act != SA_ACT_RELU) return SA_EUNSUPPORTED;
+    C1Args a = {};
+    const int rc = c1_fill(a, N, D, H, W, cout);
+    if (rc) return rc;
+    a.x = x; a.wpk = (const bf16_t*)wpk; a.bias = bias; a.y = (bf16_t*)y; a.act = act;
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((a.cells + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_conv1_wgrad(const float* x, const void* g, float* dw, float* db, int N, int D, int H, int W, int cout, void* stream) {
+    if (!x || !g || !dw) return SA_EINVAL;
+    C1Args a = {};
+    const int rc = c1_fill(a, N, D, H, W, cout);
+    if (rc) return rc;
+    a.x = x; a.g = (const bf16_t*)g; a.dw = dw; a.db = db;
+    const uint32_t ntiles = (a.cells + 127u) / 128u;
+    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(ntiles < 768u ? ntiles : 768u), dim3(256), 0, (hipStream_t)stream, a, ntiles);
+    SA_CHECK_LAUNCH();
+    return 0;
+}

@@ -222,6 +222,13 @@ class ConvOp:
         for pl in plans:
             self._pack(pl, ver)
 
+    def packed_fwd_operand(self, N: int, idims: Tuple[int, int, int]) -> torch.Tensor:
+        """The forward GEMM operand [CoutPad][Kpad] (compute dtype) for this launch geometry, packed and current -- for kernels outside the
+        generic launchers that consume the same layout (csrc/conv1.hip)."""
+        plans = self._get_plans(N, idims, self.cout, _ru(self.cout, self.vec))
+        self._ensure_packed(plans["fwd"])
+        return plans["fwd"][0].wpk
+
     def _bias_padded(self):
         if self.bias is None:
             return None

@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from ... import _ffi
 from ..._ffi import ACT_NONE, ACT_RELU, MASK_NONE, MASK_POS
-from ...engine import ConvOp, PackSet, cast_pad, vec_of
+from ...engine import ConvOp, PackSet, _launch, cast_pad, vec_of
 from .vqvae import VQVAEBase
 
 
@@ -232,10 +232,11 @@ class _ConvStage:
 class _Conv1Stage:
     """First encoder layer Conv3d(1 -> C, k4 s2 p1) (+ReLU; baseline.py:218-226).  With ONE input channel the implicit GEMM pads the reduction
     8x (channels travel in 16-byte vectors) and spends 2.1 ms per launch at 160x224x160 / batch 8 plus 0.8 ms padding the volume.  Here the 64
-    taps become the channels of a 1x1x1 convolution: sa_convt1_im2col gathers Xc[cell][tap] = x[2 cell - 1 + tap] straight from the fp32
-    volume (the same gather the last decoder layer's backward uses), the dense kernels do Xc . W^T (+bias, ReLU) and, in the backward pass,
-    the weight / bias gradient from the saved Xc.  No data gradient: this is the network input.  Odd extents or tiny volumes take the
-    generic stage."""
+    taps are the whole reduction.  bf16, 128 channels: csrc/conv1.hip gathers the taps of a tile of cells from the fp32 volume into LDS and
+    runs the MFMA from there, forward (+bias, ReLU) and weight / bias gradient -- only the output / the incoming gradient touch HBM.
+    Other widths / fp32: sa_convt1_im2col writes Xc[cell][tap] = x[2 cell - 1 + tap] (the gather the last decoder layer's backward uses)
+    and the dense kernels treat the taps as the channels of a 1x1x1 convolution.  No data gradient: this is the network input.  Odd extents
+    or tiny volumes take the generic stage."""
 
     GEMM_MIN_CELLS = 4096
 
@@ -259,28 +260,45 @@ class _Conv1Stage:
     def fwd(self, x, tape):
         """x: the raw fp32 volume [N, D, H, W]."""
         N, D, H, W = x.shape
-        if D % 2 or H % 2 or W % 2 or N * (D // 2) * (H // 2) * (W // 2) < self.GEMM_MIN_CELLS or os.environ.get("SA_NO_CONV1_GEMM") is not None:
+        if D % 2 or H % 2 or W % 2 or N * (D // 2) * (H // 2) * (W // 2) < self.GEMM_MIN_CELLS or os.environ.get("SA_NO_CONV1_GEMM") is not None:   # generic stage
             vec = vec_of(self.dtype)
             return self.fallback.fwd(cast_pad(x.unsqueeze(-1), self.dtype, vec), tape)
         self._sync()
-        Xc = torch.empty((N, D // 2, H // 2, W // 2, 64), dtype=self.dtype, device=x.device)
-        _ffi.check(_ffi.lib().sa_convt1_im2col(_ffi.ptr(x), _ffi.dtype_id(self.dtype), _ffi.ptr(Xc), None, N, D // 2, H // 2, W // 2, _ffi.stream()),
-                   "sa_convt1_im2col")
-        y = self.op.fprop(Xc, act=self.act, out_dtype=self.dtype, out_channels_stride=self.op.cout)
+        lib, st = _ffi.lib(), _ffi.stream()
+        Do, Ho, Wo, cout = D // 2, H // 2, W // 2, self.op.cout
+        if self.dtype == torch.bfloat16 and cout == 128 and os.environ.get("SA_NO_CONV1_FUSED") is None:
+            # csrc/conv1.hip: taps gathered into LDS straight from the volume; nothing but the output touches HBM
+            wpk = self.op.packed_fwd_operand(N, (Do, Ho, Wo))
+            y = torch.empty((N, Do, Ho, Wo, cout), dtype=self.dtype, device=x.device)
+            _launch("conv1_fwd_kernel", 2.0 * y.numel() * 64,
+                    lambda: _ffi.check(lib.sa_conv1_fwd(_ffi.ptr(x), _ffi.ptr(wpk), _ffi.ptr(self.mod.bias), _ffi.ptr(y), N, Do, Ho, Wo, cout, self.act, st),
+                                       "sa_conv1_fwd"))
+            if tape is not None:
+                tape.append((x, "fused"))
+            return y
+        Xc = torch.empty((N, Do, Ho, Wo, 64), dtype=self.dtype, device=x.device)
+        _ffi.check(lib.sa_convt1_im2col(_ffi.ptr(x), _ffi.dtype_id(self.dtype), _ffi.ptr(Xc), None, N, Do, Ho, Wo, st), "sa_convt1_im2col")
+        y = self.op.fprop(Xc, act=self.act, out_dtype=self.dtype, out_channels_stride=cout)
         if tape is not None:
-            tape.append((Xc, True))
+            tape.append((Xc, "im2col"))
         return y
 
     def bwd(self, G, saved, grads):
         if len(saved) == 1:
             return self.fallback.bwd(G, saved, grads)
-        Xc = saved[0]
         self._sync()
         vec = vec_of(self.dtype)
         if G.shape[-1] % vec or G.dtype != self.dtype:
             G = cast_pad(G, self.dtype, (G.shape[-1] + vec - 1) // vec * vec)
         dw, db = grads.buf(self.mod.weight), grads.buf(self.mod.bias)
-        self.op.wgrad(Xc, G, dw.view(self.mod.out_channels, 64, 1, 1, 1), db)
+        if saved[1] == "fused":
+            x = saved[0]
+            N, D, H, W = x.shape
+            _launch("conv1_wgrad_kernel", 2.0 * G.numel() * 64,
+                    lambda: _ffi.check(_ffi.lib().sa_conv1_wgrad(_ffi.ptr(x), _ffi.ptr(G), _ffi.ptr(dw), _ffi.ptr(db), N, D // 2, H // 2, W // 2, self.op.cout,
+                                                                 _ffi.stream()), "sa_conv1_wgrad"))
+        else:
+            self.op.wgrad(saved[0], G, dw.view(self.mod.out_channels, 64, 1, 1, 1), db)
         grads.done(self.mod.weight, self.mod.bias)
         return None
 

@@ -222,6 +222,43 @@ def test_batched_weight_repack_matches_single_launches():
     assert all(torch.equal(e[0].view(torch.uint8), r[k].view(torch.uint8)) for op, r in zip(ops, ref) for k, e in op._packs.items())
 
 
+@pytest.mark.parametrize("N,dims", [(1, (8, 8, 8)), (2, (6, 10, 12)), (1, (10, 14, 20)), (3, (4, 6, 50))])
+def test_first_layer_kernels(N, dims):
+    """sa_conv1_fwd / sa_conv1_wgrad (Conv3d(1 -> 128, k4 s2 p1) + ReLU with the taps gathered from the fp32 volume) against torch on bf16-rounded
+    operands: ragged tile tails (cell counts that are not multiples of 128 / 256), every border."""
+    _ffi, engine = _ops()
+    lib, st = _ffi.lib(), _ffi.stream()
+    torch.manual_seed(N + dims[2])
+    D, H, W = dims
+    x = torch.randn(N, 1, 2 * D, 2 * H, 2 * W)
+    w = torch.randn(128, 1, 4, 4, 4) * 0.2
+    b = torch.randn(128) * 0.1
+    xr, wr = _rt(x, torch.bfloat16), _rt(w, torch.bfloat16)
+    ref = F.relu(F.conv3d(xr.double(), wr.double(), b.double(), stride=2, padding=1)).permute(0, 2, 3, 4, 1)
+    wpk = wr.view(128, 64).bfloat16().cuda().contiguous()
+    y = torch.empty(N, D, H, W, 128, dtype=torch.bfloat16, device="cuda")
+    xd, bd = x.cuda().contiguous(), b.cuda()
+    _ffi.check(lib.sa_conv1_fwd(_ffi.ptr(xd), _ffi.ptr(wpk), _ffi.ptr(bd), _ffi.ptr(y), N, D, H, W, 128, _ffi.ACT_RELU, st))
+    _close(y.float().cpu(), ref.float(), torch.bfloat16, "conv1 fwd")
+    y0 = torch.empty_like(y)
+    _ffi.check(lib.sa_conv1_fwd(_ffi.ptr(xd), _ffi.ptr(wpk), None, _ffi.ptr(y0), N, D, H, W, 128, _ffi.ACT_NONE, st))
+    _close(y0.float().cpu(), F.conv3d(xr.double(), wr.double(), None, stride=2, padding=1).permute(0, 2, 3, 4, 1).float(), torch.bfloat16, "conv1 fwd (no bias / act)")
+    # weight / bias gradient
+    g = torch.randn(N, D, H, W, 128)
+    gr = _rt(g, torch.bfloat16)
+    wl = wr.double().clone().requires_grad_(True)
+    bl = b.double().clone().requires_grad_(True)
+    (F.conv3d(xr.double(), wl, bl, stride=2, padding=1).permute(0, 2, 3, 4, 1) * gr.double()).sum().backward()
+    dw = torch.zeros(128, 64, device="cuda")
+    db = torch.zeros(128, device="cuda")
+    gd = gr.bfloat16().cuda().contiguous()
+    _ffi.check(lib.sa_conv1_wgrad(_ffi.ptr(xd), _ffi.ptr(gd), _ffi.ptr(dw), _ffi.ptr(db), N, D, H, W, 128, st))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dw.cpu().numpy(), wl.grad.view(128, 64).float().numpy(), rtol=2e-3, atol=2e-3 * float(wl.grad.abs().max()))
+    np.testing.assert_allclose(db.cpu().numpy(), bl.grad.float().numpy(), rtol=2e-3, atol=2e-3 * float(bl.grad.abs().max()))
+    assert lib.sa_conv1_fwd(_ffi.ptr(xd), _ffi.ptr(wpk), None, _ffi.ptr(y0), N, D, H, W, 64, _ffi.ACT_NONE, st) == _ffi.SA_EUNSUPPORTED
+
+
 # ----------------------------------------------------------------------------------------------- quantizer
 def _vq_run(x_rows, cb, decay=None, N=None, avg=None):
     _ffi, _ = _ops()
