@@ -31,7 +31,7 @@ typedef float float4u_t __attribute__((ext_vector_type(4), aligned(4)));   // 16
 // Lanes run along the cells (thread = one cell, 256 / NCELL threads share its 16 (kd, kh) rows): consecutive lanes read overlapping 16-byte
 // windows 8 bytes apart of the same input row, i.e. a wave reads one contiguous 0.5 KiB stretch per (kd, kh).
 template <int NCELL>
-__device__ __forceinline__ void c1_gather(unsigned char* tile, const C1Args& a, uint32_t cell0, int tid) {
+__device__ __forceinline__ void c1_gather(unsigned char* tile, const C1Args& a, uint32_t cell0, int tid, float* centre_sum = nullptr) {
     constexpr int PARTS = 256 / NCELL, PER = 16 / PARTS;
     const uint32_t cl = (uint32_t)tid % NCELL, part = (uint32_t)tid / NCELL;
     const uint32_t cell = cell0 + cl;
@@ -63,6 +63,8 @@ __device__ __forceinline__ void c1_gather(unsigned char* tile, const C1Args& a, 
                 v[kw] = (unsigned)iw < (unsigned)(2 * a.W) ? xv : 0.f;
             }
         }
+        // every input voxel is covered exactly once by the taps {1,2}^3 of its cell
+        if (centre_sum && ok && (kd == 1u || kd == 2u) && (kh == 1u || kh == 2u)) *centre_sum += v[1] + v[2];
         uint2 pk;
         pk.x = ok ? (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16) : 0u;
         pk.y = ok ? (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16) : 0u;
@@ -203,6 +205,42 @@ __global__ __launch_bounds__(256, 3) void conv1_wgrad_kernel(const C1Args a, uin
         __syncthreads();
         if (tid < 128) unsafeAtomicAdd(a.db + tid, ((float*)sDb)[tid]);
     }
+}
+
+// Xc[cell][tap] (bf16) to HBM for the layers that still want the explicit matrix: the same gather, then the tile leaves LDS as linear 16-byte
+// pieces (the direct form wrote 8 bytes per thread at 128-byte stride from lanes that each read a different input row)
+__global__ __launch_bounds__(256, 3) void conv1_im2col_kernel(const C1Args a, bf16_t* __restrict__ gc, float* __restrict__ sum_out) {
+    __shared__ __attribute__((aligned(16))) unsigned char sX[256 * 128];
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const uint32_t cell0 = blockIdx.x * 256u;
+    float csum = 0.f;
+    c1_gather<256>(sX, a, cell0, tid, sum_out ? &csum : nullptr);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const uint32_t p = (uint32_t)tid + 256u * it, cl = p >> 3, piece = p & 7u;   // 8 pieces of 16 bytes per cell
+        if (cell0 + cl < a.cells) *(u32x4*)(gc + ((int64_t)(cell0 + cl) * 64 + piece * 8)) = *(const u32x4*)(sX + lroff(cl, piece * 8u));
+    }
+    if (sum_out) {
+        csum = wave_sum(csum);
+        if ((tid & 63) == 0) red[tid >> 6] = csum;
+        __syncthreads();
+        if (tid == 0) unsafeAtomicAdd(sum_out, red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+static int c1_fill(C1Args& a, int N, int D, int H, int W, int cout);
+
+// bf16 form of sa_convt1_im2col (csrc/convt1.hip dispatches here)
+int conv1_im2col_bf16(const float* g, void* gc, float* db, int N, int D, int H, int W, hipStream_t stream) {
+    C1Args a = {};
+    const int rc = c1_fill(a, N, D, H, W, 128);
+    if (rc) return rc;
+    a.x = g;
+    hipLaunchKernelGGL(conv1_im2col_kernel, dim3((a.cells + 255u) / 256u), dim3(256), 0, stream, a, (bf16_t*)gc, db);
+    SA_CHECK_LAUNCH();
+    return 0;
 }
 
 static int c1_fill(C1Args& a, int N, int D, int H, int W, int cout) {

@@ -8,6 +8,8 @@
 //   dgrad : dx[i][c] = sum_k g[2i-1+k] w[c][k]  (* relu mask)
 //   wgrad : dw[c][k] += sum_i x[i][c] g[2i-1+k],  db += sum g
 // out[o] = b + sum_{i,k : 2i-1+k = o} x[i] . w[:,k]   per dimension (k = 0..3).
+#include <stdlib.h>
+
 #include "sa_common.h"
 
 namespace sa {
@@ -333,6 +335,8 @@ static int fill_map(CT1Map& a, int N, int D, int H, int W) {
     return 0;
 }
 
+int conv1_im2col_bf16(const float* g, void* gc, float* db, int N, int D, int H, int W, hipStream_t stream);   // csrc/conv1.hip
+
 }  // namespace sa
 
 using namespace sa;
@@ -390,6 +394,10 @@ extern "C" int sa_convt1_im2col(const float* g, int dtype, void* gc, float* db, 
     a.g = g; a.gc = gc; a.db = db;
     unsigned blocks = (unsigned)(((uint64_t)a.cells * 16u + 255u) / 256u);
     if (blocks > 4096u) blocks = 4096u;   // one atomic per block for db
+    if (dtype == SA_BF16 && getenv("SA_IM2COL_DIRECT") == nullptr) {   // gather through an LDS tile, coalesced on both sides (csrc/conv1.hip)
+        const int rc = conv1_im2col_bf16(g, gc, db, N, D, H, W, (hipStream_t)stream);
+        if (rc != SA_EUNSUPPORTED) return rc;
+    }
     if (dtype == SA_F32) hipLaunchKernelGGL(convt1_im2col_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(convt1_im2col_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
