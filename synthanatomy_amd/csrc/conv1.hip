@@ -66,8 +66,8 @@ __device__ __forceinline__ void c1_gather(unsigned char* tile, const C1Args& a, 
         // every input voxel is covered exactly once by the taps {1,2}^3 of its cell
         if (centre_sum && ok && (kd == 1u || kd == 2u) && (kh == 1u || kh == 2u)) *centre_sum += v[1] + v[2];
         uint2 pk;
-        pk.x = ok ? (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16) : 0u;
-        pk.y = ok ? (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16) : 0u;
+        pk.x = ok ? pack_bf16x2(v[0], v[1]) : 0u;
+        pk.y = ok ? pack_bf16x2(v[2], v[3]) : 0u;
         *(uint2*)(tile + lroff(cl, kk * 4u)) = pk;
     }
 }
@@ -82,9 +82,12 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const C1Args a) {
     for (int f = 0; f < 8; ++f)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) wf[f][ks] = *(const short8_t*)(a.wpk + (f * 16 + fr) * 64 + ks * 32 + g * 8);
+    float4_t bv[8];      // bias of this lane's accumulator rows
+#pragma unroll
+    for (int f = 0; f < 8; ++f) bv[f] = a.bias ? *(const float4_t*)(a.bias + f * 16 + g * 4) : (float4_t){0.f, 0.f, 0.f, 0.f};
     c1_gather<256>(sX, a, cell0, tid);
     __syncthreads();
-#pragma unroll 1
+#pragma unroll 2
     for (int cf = 0; cf < 4; ++cf) {
         const uint32_t cl = (uint32_t)w * 64u + cf * 16u + fr;   // this lane's cell (MFMA column, and the output row after the transpose)
         short8_t xb[2];
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const C1Args a) {
         float4_t acc[8];
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
-            acc[f] = a.bias ? *(const float4_t*)(a.bias + f * 16 + g * 4) : (float4_t){0.f, 0.f, 0.f, 0.f};
+            acc[f] = bv[f];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f][ks], xb[ks], acc[f], 0, 0, 0);
         }
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const C1Args a) {
                 for (int e = 0; e < 8; ++e) {
                     float x0 = v[2 * e], x1 = v[2 * e + 1];
                     if (a.act == SA_ACT_RELU) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
-                    pk[e] = (uint32_t)f32_to_bf16(x0) | ((uint32_t)f32_to_bf16(x1) << 16);
+                    pk[e] = pack_bf16x2(x0, x1);
                 }
                 u32x4* o = (u32x4*)(a.y + (int64_t)cell * 128 + half * 64 + g * 16);
                 o[0] = (u32x4){pk[0], pk[1], pk[2], pk[3]};

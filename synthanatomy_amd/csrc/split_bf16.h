@@ -11,6 +11,13 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 
+// two fp32 -> one word of two bf16 (round to nearest even) with the gfx950 conversion instruction (v_cvt_pk_bf16_f32): one VALU op where the
+// bit-twiddling f32_to_bf16() of sa_common.h costs ~6 per value
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
 // two values per call, packed as bf16 pairs
 __device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
     const f32x2_t v = {a, b};
