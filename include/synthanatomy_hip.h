@@ -239,6 +239,10 @@ int sa_favor_scan_a_state(const float *a, const float *c, const float *b, int b_
 int sa_favor_project(const float *x, int x_stride, int heads, const float *proj, float *dd, int64_t rows, int m, int LDF, int dh, void *stream);
 int sa_favor_project_bwd(const float *ddd, const float *proj, const float *addend, float *dx, int dx_stride, int heads, int64_t rows, int m, int LDF,
                          int dh, void *stream);
+/* sa_favor_features_bwd + sa_favor_project_bwd in one launch (+ one fix-up launch for keys): the intermediate d loss / d dd is never written.
+ * src / dsrc rows are head blocks as for sa_favor_project (stride, heads); proj carries the data normalizer; dsrc is overwritten. */
+int sa_favor_features_project_bwd(const float *dfeat, const float *feat, const float *dd, const float *src, int src_stride, int heads, const float *proj,
+                                  int is_query, float *dsrc, const void *gmax_ws, float *tsum_ws, int64_t rows, int m, int LDF, int dh, void *stream);
 int sa_cumsum_rows(const float *x, const float *scale, float *out, int B, int N, int G, int LDF, int reverse, float *seg_ws, void *stream);
 int sa_favor_den(const float *q, const float *z, float eps, float *inv, int64_t rows, int m, int LDF, void *stream);
 int sa_favor_dden(const float *dout, const float *out, int stride, int off, int G, int dv, const float *inv, float *dden, int64_t rows,

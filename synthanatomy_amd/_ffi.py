@@ -53,6 +53,8 @@ _SIGS = {
     "sa_last_conv_kernel": (c_char_p, []),
     "sa_conv1_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "sa_conv1_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "sa_favor_features_project_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                              c_int, c_int, c_void_p]),
     "sa_favor_project": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "sa_favor_project_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
     "sa_pack_weights_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -142,9 +142,168 @@ __global__ __launch_bounds__(256, 2) void favor_project_bwd_kernel(const ProjArg
     }
 }
 
+// Feature-map backward fused with the projection adjoint (throughput mode): the intermediate ddd = d loss / d dd [rows][LDF] is never written.
+//   v_f = (feat_f - ratio eps) dfeat_f  (f < m),   t = sum_f v_f,   dx = sum_f v_f P[f] - [query] t P[argmax_f dd] - t c^2 x
+// (query rows are stabilised by their own maximum, which takes -t; key rows by the GLOBAL maximum: they report t and one fix-up launch applies
+// -(sum of all t) P[f*] to the row that holds it).  Same block shape as the adjoint above; the three feature rows stream through in groups of
+// three 32-feature blocks (18 loads of 16 bytes in flight per lane).
+struct FeatProjArgs {
+    const float *dfeat, *feat, *dd, *x, *proj;
+    float* dx;
+    float* tsum;           // keys: [rows]
+    int64_t rows;
+    int32_t m, LDF, x_stride, heads, is_query;
+    float c2, ratio_eps;
+};
+
+__global__ __launch_bounds__(256, 2) void favor_feat_proj_bwd_kernel(const FeatProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nks = (a.LDF + 31) >> 5;
+    unsigned char* const sPh = smem;
+    unsigned char* const sPl = smem + nks * 32 * 128;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), qi = lane & 15, g = lane >> 4;
+    proj_stage(sPh, sPl, a.proj, a.m, nks * 32, tid);
+    __syncthreads();
+    const uint32_t trow = (uint32_t)g * 4u + ((uint32_t)qi >> 2), tcol = (uint32_t)(qi & 3) * 4u;
+    for (int it = 0; it < 2; ++it) {
+        const int64_t r = (int64_t)blockIdx.x * 128 + w * 32 + it * 16 + qi;
+        const bool ok = r < a.rows;
+        const int64_t rc = ok ? r : a.rows - 1;
+        const float* pf = a.feat + rc * a.LDF;
+        const float* pg = a.dfeat + rc * a.LDF;
+        const float* pd = a.dd + rc * a.LDF;
+        float4_t acc[4];
+#pragma unroll
+        for (int df = 0; df < 4; ++df) acc[df] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        float tp = 0.f, mx = -INFINITY;
+        int am = 0x7fffffff;
+#pragma unroll
+        for (int grp = 0; grp < 3; ++grp) {
+            float4 vf[3][2], vg[3][2], vd[3][2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int c = min((grp * 3 + k) * 32 + q * 16 + g * 4, a.LDF - 4);
+                    vf[k][q] = *(const float4*)(pf + c);
+                    vg[k][q] = *(const float4*)(pg + c);
+                    vd[k][q] = *(const float4*)(pd + c);
+                }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int ks = grp * 3 + k;
+                if (ks < nks) {
+                    float xs[8];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int c0 = ks * 32 + q * 16 + g * 4;
+                        const float f4[4] = {vf[k][q].x, vf[k][q].y, vf[k][q].z, vf[k][q].w}, g4[4] = {vg[k][q].x, vg[k][q].y, vg[k][q].z, vg[k][q].w};
+                        const float d4[4] = {vd[k][q].x, vd[k][q].y, vd[k][q].z, vd[k][q].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int col = c0 + e;
+                            const bool valid = ok && col < a.m;
+                            const float v = valid ? (f4[e] - a.ratio_eps) * g4[e] : 0.f;
+                            tp += v;
+                            if (valid && (d4[e] > mx || (d4[e] == mx && col < am))) {   // first maximum, like torch.max
+                                mx = d4[e];
+                                am = col;
+                            }
+                            xs[q * 4 + e] = v;
+                        }
+                    }
+                    short8_t bh, bl;
+                    split8(xs, bh, bl);
+#pragma unroll
+                    for (int df = 0; df < 4; ++df) {
+                        const uint32_t o0 = lroff(ks * 32 + trow, df * 16 + tcol), o1 = lroff(ks * 32 + 16 + trow, df * 16 + tcol);
+                        const short8_t ah = __builtin_shufflevector(lds_tr16_b64(sPh + o0), lds_tr16_b64(sPh + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+                        const short8_t al = __builtin_shufflevector(lds_tr16_b64(sPl + o0), lds_tr16_b64(sPl + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[df] = mfma3(ah, al, bh, bl, acc[df]);
+                    }
+                }
+            }
+        }
+        // the row lives in the four lanes qi, qi + 16, qi + 32, qi + 48
+        float t = tp;
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float om = __shfl_xor(mx, o, 64);
+            const int oa = __shfl_xor(am, o, 64);
+            if (om > mx || (om == mx && oa < am)) {
+                mx = om;
+                am = oa;
+            }
+        }
+        if (ok) {
+            const float* xr = a.x + proj_row_off(r, a.heads, a.x_stride);
+            float* dxr = a.dx + proj_row_off(r, a.heads, a.x_stride);
+            const float* pa = a.proj + (int64_t)min(am, a.m - 1) * 64;
+            const float ts = a.is_query ? t : 0.f;
+#pragma unroll
+            for (int df = 0; df < 4; ++df) {
+                const int d0 = df * 16 + g * 4;
+                const float4 xv = *(const float4*)(xr + d0), pv = *(const float4*)(pa + d0);
+                const float tc = t * a.c2;
+                *(float4*)(dxr + d0) = make_float4(acc[df][0] - ts * pv.x - tc * xv.x, acc[df][1] - ts * pv.y - tc * xv.y, acc[df][2] - ts * pv.z - tc * xv.z,
+                                                   acc[df][3] - ts * pv.w - tc * xv.w);
+            }
+            if (!a.is_query && g == 0) a.tsum[r] = t;
+        }
+    }
+}
+
+// keys: the global-max element (row*, f*) of dd takes -(sum_rows t): dx[row*] -= T P[f*]
+__global__ __launch_bounds__(1024) void favor_key_stab_dx_kernel(float* __restrict__ dx, int x_stride, int heads, const unsigned long long* __restrict__ gmax,
+                                                                 const float* __restrict__ trow, int64_t rows, const float* __restrict__ proj, int LDF) {
+    __shared__ float red[16];
+    __shared__ float total;
+    float s = 0.f;
+    for (int64_t r = threadIdx.x; r < rows; r += 1024) s += trow[r];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        total = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const uint32_t idx = 0xffffffffu - (uint32_t)(*gmax & 0xffffffffull);
+        const int64_t r = idx / (uint32_t)LDF;
+        const int f = (int)(idx % (uint32_t)LDF);
+        dx[proj_row_off(r, heads, x_stride) + threadIdx.x] -= total * proj[(int64_t)f * 64 + threadIdx.x];
+    }
+}
+
 }  // namespace sa
 
 using namespace sa;
+
+extern "C" int sa_favor_features_project_bwd(const float* dfeat, const float* feat, const float* dd, const float* src, int src_stride, int heads,
+                                             const float* proj, int is_query, float* dsrc, const void* gmax_ws, float* tsum_ws, int64_t rows, int m, int LDF,
+                                             int dh, void* stream) {
+    if (!dfeat || !feat || !dd || !src || !proj || !dsrc || rows <= 0 || m <= 0 || heads <= 0 || (!is_query && (!gmax_ws || !tsum_ws))) return SA_EINVAL;
+    if (dh != 64 || (LDF & 15) || LDF < m || LDF > 272 || (src_stride & 3) || src_stride < dh * heads) return SA_EUNSUPPORTED;
+    FeatProjArgs a = {};
+    a.dfeat = dfeat; a.feat = feat; a.dd = dd; a.x = src; a.proj = proj; a.dx = dsrc; a.tsum = tsum_ws; a.rows = rows; a.m = m; a.LDF = LDF;
+    a.x_stride = src_stride; a.heads = heads; a.is_query = is_query;
+    const float c = powf((float)dh, -0.25f), ratio = 1.f / sqrtf((float)m);
+    a.c2 = c * c; a.ratio_eps = ratio * 1e-4f;
+    const size_t lds = (size_t)2 * ((LDF + 31) / 32) * 32 * 128;
+    hipFuncSetAttribute((const void*)favor_feat_proj_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(favor_feat_proj_bwd_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);
+    SA_CHECK_LAUNCH();
+    if (!is_query) {
+        hipLaunchKernelGGL(favor_key_stab_dx_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dsrc, src_stride, heads, (const unsigned long long*)gmax_ws, tsum_ws,
+                           rows, proj, LDF);
+        SA_CHECK_LAUNCH();
+    }
+    return 0;
+}
 
 extern "C" int sa_favor_project(const float* x, int x_stride, int heads, const float* proj, float* dd, int64_t rows, int m, int LDF, int dh, void* stream) {
     if (!x || !proj || !dd || rows <= 0 || m <= 0 || heads <= 0) return SA_EINVAL;

@@ -623,28 +623,26 @@ class _LayerEngine:
                 _ck(lib.sa_favor_scan_a(_ffi.ptr(qf), _ffi.ptr(kf), _ffi.ptr(dattn), inner, 0, _ffi.ptr(inv), _ffi.ptr(dv), qs, 0, None, B, N, G, LDF, dh, 1, 0,
                                         _ffi.ptr(ws), st), "sa_favor_scan_a(dv)")
             pop = self._proj_op()
-            dddq, dddk = torch.empty_like(qf), torch.empty_like(kf)
             tsum = torch.empty(R * G, dtype=f32, device=dev)
-            if self._xf:
+            if self._xf:   # fp32 parity mode: feature-map backward, then the exact-fp32 dgrad GEMM with the -|x|^2 part as addend
+                dddq, dddk = torch.empty_like(qf), torch.empty_like(kf)
                 dqg = torch.empty(R, G * dh, dtype=f32, device=dev)
                 dkg = torch.empty(R, G * dh, dtype=f32, device=dev)
-                dqs, dks, sst = dqg, dkg, G * dh
-            else:   # straight into the global-head columns of dq / dk (same row stride as q / k)
-                dqs, dks, sst = dq, dk, qs
-            _ck(lib.sa_favor_features_bwd(_ffi.ptr(dqf), _ffi.ptr(qf), _ffi.ptr(sv["ddq"]), _ffi.ptr(sv["qg"]), sst, 0, G, dh, 1, _ffi.ptr(dddq), _ffi.ptr(dqs),
-                                          None, None, R * G, m, LDF, st), "favor_features_bwd(q)")
-            _ck(lib.sa_favor_features_bwd(_ffi.ptr(dkf), _ffi.ptr(kf), _ffi.ptr(sv["ddk"]), _ffi.ptr(sv["kg"]), sst, 0, G, dh, 0, _ffi.ptr(dddk), _ffi.ptr(dks),
-                                          _ffi.ptr(sv["gws"]), _ffi.ptr(tsum), R * G, m, LDF, st), "favor_features_bwd(k)")
-            if self._xf:
+                _ck(lib.sa_favor_features_bwd(_ffi.ptr(dqf), _ffi.ptr(qf), _ffi.ptr(sv["ddq"]), _ffi.ptr(sv["qg"]), G * dh, 0, G, dh, 1, _ffi.ptr(dddq), _ffi.ptr(dqg),
+                                              None, None, R * G, m, LDF, st), "favor_features_bwd(q)")
+                _ck(lib.sa_favor_features_bwd(_ffi.ptr(dkf), _ffi.ptr(kf), _ffi.ptr(sv["ddk"]), _ffi.ptr(sv["kg"]), G * dh, 0, G, dh, 0, _ffi.ptr(dddk), _ffi.ptr(dkg),
+                                              _ffi.ptr(sv["gws"]), _ffi.ptr(tsum), R * G, m, LDF, st), "favor_features_bwd(k)")
                 rg = (1, 1, R * G)
                 dqg = pop.dgrad(dddq.view(1, 1, 1, R * G, LDF), rg, addend=dqg.view(1, 1, 1, R * G, dh), fwd_out_stride=LDF).view(R, G * dh)
                 dkg = pop.dgrad(dddk.view(1, 1, 1, R * G, LDF), rg, addend=dkg.view(1, 1, 1, R * G, dh), fwd_out_stride=LDF).view(R, G * dh)
                 dq[:, : G * dh] = dqg
                 dk[:, : G * dh] = dkg
-            else:
+            else:          # throughput mode: one launch per side straight into the global-head columns of dq / dk (d loss / d dd never exists)
                 ps = self._pop[2]
-                _ck(lib.sa_favor_project_bwd(_ffi.ptr(dddq), _ffi.ptr(ps), _ffi.ptr(dq), _ffi.ptr(dq), qs, G, R * G, m, LDF, dh, st), "sa_favor_project_bwd(q)")
-                _ck(lib.sa_favor_project_bwd(_ffi.ptr(dddk), _ffi.ptr(ps), _ffi.ptr(dk), _ffi.ptr(dk), qs, G, R * G, m, LDF, dh, st), "sa_favor_project_bwd(k)")
+                _ck(lib.sa_favor_features_project_bwd(_ffi.ptr(dqf), _ffi.ptr(qf), _ffi.ptr(sv["ddq"]), _ffi.ptr(sv["qg"]), qs, G, _ffi.ptr(ps), 1, _ffi.ptr(dq),
+                                                      None, None, R * G, m, LDF, dh, st), "sa_favor_features_project_bwd(q)")
+                _ck(lib.sa_favor_features_project_bwd(_ffi.ptr(dkf), _ffi.ptr(kf), _ffi.ptr(sv["ddk"]), _ffi.ptr(sv["kg"]), qs, G, _ffi.ptr(ps), 0, _ffi.ptr(dk),
+                                                      _ffi.ptr(sv["gws"]), _ffi.ptr(tsum), R * G, m, LDF, dh, st), "sa_favor_features_project_bwd(k)")
         if L > 0:
             cosb, sinb = self._rot_tables(N, dev)
             dqr = torch.empty(R, L * dh, dtype=f32, device=dev)

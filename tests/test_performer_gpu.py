@@ -294,6 +294,40 @@ def test_rotary_and_rezero_backward_kernels():
     assert abs(float(dg) - float((dy.double() * F_.double()).sum())) < 1e-3
 
 
+@pytest.mark.parametrize("R,G,m,LDF", [(37, 2, 266, 272), (1400, 8, 266, 272), (65, 1, 100, 112)])
+@pytest.mark.parametrize("is_query", [1, 0])
+def test_fused_feature_projection_backward(R, G, m, LDF, is_query):
+    """sa_favor_features_project_bwd (d loss / d dd never written) against sa_favor_features_bwd + sa_favor_project_bwd: query rows (own maximum)
+    and key rows (global maximum, fix-up launch), head blocks of wider rows."""
+    from synthanatomy_amd import _ffi
+    lib, st = _ffi.lib(), _ffi.stream()
+    torch.manual_seed(R + m + is_query)
+    rows, wide = R * G, G * 64 + 64
+    xw = torch.randn(R, wide, device="cuda") * 0.7
+    P_ = torch.randn(m, 64, device="cuda") * 0.35
+    dd = torch.empty(rows, LDF, device="cuda")
+    _ffi.check(lib.sa_favor_project(_ffi.ptr(xw), wide, G, _ffi.ptr(P_), _ffi.ptr(dd), rows, m, LDF, 64, st))
+    feat = torch.empty_like(dd)
+    gws = torch.zeros(2, dtype=torch.int64, device="cuda")
+    _ffi.check(lib.sa_favor_features_fwd(_ffi.ptr(dd), _ffi.ptr(xw), wide, 0, G, 64, is_query, _ffi.ptr(feat), None if is_query else _ffi.ptr(gws), rows, m, LDF, st))
+    dfeat = torch.randn(rows, LDF, device="cuda")
+    # two-launch reference
+    ddd = torch.empty_like(dd)
+    ref = torch.full((R, wide), float("nan"), device="cuda")
+    tsum = torch.empty(rows, device="cuda")
+    _ffi.check(lib.sa_favor_features_bwd(_ffi.ptr(dfeat), _ffi.ptr(feat), _ffi.ptr(dd), _ffi.ptr(xw), wide, 0, G, 64, is_query, _ffi.ptr(ddd), _ffi.ptr(ref),
+                                         None if is_query else _ffi.ptr(gws), None if is_query else _ffi.ptr(tsum), rows, m, LDF, st))
+    _ffi.check(lib.sa_favor_project_bwd(_ffi.ptr(ddd), _ffi.ptr(P_), _ffi.ptr(ref), _ffi.ptr(ref), wide, G, rows, m, LDF, 64, st))
+    got = torch.full((R, wide), float("nan"), device="cuda")
+    tsum2 = torch.empty(rows, device="cuda")
+    _ffi.check(lib.sa_favor_features_project_bwd(_ffi.ptr(dfeat), _ffi.ptr(feat), _ffi.ptr(dd), _ffi.ptr(xw), wide, G, _ffi.ptr(P_), is_query, _ffi.ptr(got),
+                                                 None if is_query else _ffi.ptr(gws), None if is_query else _ffi.ptr(tsum2), rows, m, LDF, 64, st))
+    assert _rel(got[:, :G * 64], ref[:, :G * 64]) < 3e-5
+    assert bool(torch.isnan(got[:, G * 64:]).all())
+    if not is_query:
+        assert _rel(tsum2, tsum) < 1e-5
+
+
 @pytest.mark.parametrize("N,segmented", [(37, False), (37, True), (300, True), (1400, True)])
 def test_causal_scan_kernels_against_quadratic_form(N, segmented):
     from synthanatomy_amd import _ffi
