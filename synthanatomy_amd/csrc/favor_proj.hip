@@ -23,17 +23,33 @@ struct ProjArgs {
 __device__ __forceinline__ int64_t proj_row_off(int64_t r, int heads, int stride) { return (r / heads) * stride + (r % heads) * 64; }
 
 // projection rows [0, nrows) -> hi / lo tiles [nrows][64] bf16 in the lroff() layout (rows >= m are zero)
+// PERM: tile row rho holds projection row pi(rho), pi(ks*32 + b*16 + 4g + r) = ks*32 + 8g + 4b + r.  The transposing reads hand lane group g the
+// tile rows {4g..4g+3, 16+4g..} of a 32-row block as its eight reduction steps; with pi those are the EIGHT CONSECUTIVE features ks*32 + 8g .. +7,
+// so the gradient rows that multiply them are read as 32 contiguous bytes per lane (a full 128-byte line per row and 32-feature block).
+template <bool PERM = false>
 __device__ __forceinline__ void proj_stage(unsigned char* hi, unsigned char* lo, const float* proj, int m, int nrows, int tid) {
-    for (int idx = tid; idx < nrows * 16; idx += 256) {
-        const int f = idx >> 4, c4 = idx & 15;
-        const float4 v = *(const float4*)(proj + (int64_t)min(f, m - 1) * 64 + c4 * 4);
-        const float k = f < m ? 1.f : 0.f;
-        uint2 h, l;
-        split_pair(v.x * k, v.y * k, h.x, l.x);
-        split_pair(v.z * k, v.w * k, h.y, l.y);
-        const uint32_t o = lroff(f, c4 * 4);
-        *(uint2*)(hi + o) = h;
-        *(uint2*)(lo + o) = l;
+    // all loads first (nrows <= 288: at most 18 pieces of 16 bytes per thread), then the splits: a load -> split -> store loop with a run-time
+    // trip count pays the L2 round trip once per iteration (18 us per block, measured as 2/3 of the adjoint kernel)
+    float4 v[18];
+#pragma unroll
+    for (int t = 0; t < 18; ++t) {
+        const int idx = tid + 256 * t, rho = min(idx >> 4, nrows - 1), c4 = idx & 15;
+        const int f = PERM ? (rho & ~31) | (((rho >> 2) & 3) << 3) | (((rho >> 4) & 1) << 2) | (rho & 3) : rho;
+        v[t] = *(const float4*)(proj + (int64_t)min(f, m - 1) * 64 + c4 * 4);
+    }
+#pragma unroll
+    for (int t = 0; t < 18; ++t) {
+        const int idx = tid + 256 * t, rho = idx >> 4, c4 = idx & 15;
+        if (rho < nrows) {
+            const int f = PERM ? (rho & ~31) | (((rho >> 2) & 3) << 3) | (((rho >> 4) & 1) << 2) | (rho & 3) : rho;
+            const float k = f < m ? 1.f : 0.f;
+            uint2 h, l;
+            split_pair(v[t].x * k, v[t].y * k, h.x, l.x);
+            split_pair(v[t].z * k, v[t].w * k, h.y, l.y);
+            const uint32_t o = lroff(rho, c4 * 4);
+            *(uint2*)(hi + o) = h;
+            *(uint2*)(lo + o) = l;
+        }
     }
 }
 
@@ -96,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void favor_project_bwd_kernel(const ProjArg
     unsigned char* const sPh = smem;
     unsigned char* const sPl = smem + nks * 32 * 128;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), qi = lane & 15, g = lane >> 4;
-    proj_stage(sPh, sPl, a.proj, a.m, nks * 32, tid);
+    proj_stage<true>(sPh, sPl, a.proj, a.m, nks * 32, tid);
     __syncthreads();
     const uint32_t trow = (uint32_t)g * 4u + ((uint32_t)qi >> 2), tcol = (uint32_t)(qi & 3) * 4u;
     for (int it = 0; it < 2; ++it) {
@@ -109,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void favor_project_bwd_kernel(const ProjArg
         float4 v[9][2];   // the whole gradient row of this lane's quarter, in flight together (LDF <= 272: nine 32-feature blocks)
 #pragma unroll
         for (int ks = 0; ks < 9; ++ks) {
-            const int c0 = ks * 32 + g * 4, c1 = c0 + 16;
+            const int c0 = ks * 32 + g * 8, c1 = c0 + 4;   // (permuted tile rows: see proj_stage)
             v[ks][0] = proj_keep(*(const float4*)(gr + min(c0, a.LDF - 4)), ok && c0 < a.LDF);
             v[ks][1] = proj_keep(*(const float4*)(gr + min(c1, a.LDF - 4)), ok && c1 < a.LDF);
         }
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void favor_feat_proj_bwd_kernel(const FeatP
     unsigned char* const sPh = smem;
     unsigned char* const sPl = smem + nks * 32 * 128;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), qi = lane & 15, g = lane >> 4;
-    proj_stage(sPh, sPl, a.proj, a.m, nks * 32, tid);
+    proj_stage<true>(sPh, sPl, a.proj, a.m, nks * 32, tid);
     __syncthreads();
     const uint32_t trow = (uint32_t)g * 4u + ((uint32_t)qi >> 2), tcol = (uint32_t)(qi & 3) * 4u;
     for (int it = 0; it < 2; ++it) {
@@ -177,18 +193,24 @@ __global__ __launch_bounds__(256, 2) void favor_feat_proj_bwd_kernel(const FeatP
         for (int df = 0; df < 4; ++df) acc[df] = (float4_t){0.f, 0.f, 0.f, 0.f};
         float tp = 0.f, mx = -INFINITY;
         int am = 0x7fffffff;
-#pragma unroll
-        for (int grp = 0; grp < 3; ++grp) {
-            float4 vf[3][2], vg[3][2], vd[3][2];
+        // group grp + 1 is in flight while group grp is consumed (two register sets)
+        float4 vf[2][3][2], vg[2][3][2], vd[2][3][2];
+        auto load_group = [&](int grp, int b) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const int c = min((grp * 3 + k) * 32 + q * 16 + g * 4, a.LDF - 4);
-                    vf[k][q] = *(const float4*)(pf + c);
-                    vg[k][q] = *(const float4*)(pg + c);
-                    vd[k][q] = *(const float4*)(pd + c);
+                    const int c = min((grp * 3 + k) * 32 + g * 8 + q * 4, a.LDF - 4);   // eight consecutive features per lane (permuted tile rows)
+                    vf[b][k][q] = *(const float4*)(pf + c);
+                    vg[b][k][q] = *(const float4*)(pg + c);
+                    vd[b][k][q] = *(const float4*)(pd + c);
                 }
+        };
+        load_group(0, 0);
+#pragma unroll
+        for (int grp = 0; grp < 3; ++grp) {
+            const int b = grp & 1;
+            if (grp < 2) load_group(grp + 1, b ^ 1);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int ks = grp * 3 + k;
@@ -196,19 +218,19 @@ __global__ __launch_bounds__(256, 2) void favor_feat_proj_bwd_kernel(const FeatP
                     float xs[8];
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        const int c0 = ks * 32 + q * 16 + g * 4;
-                        const float f4[4] = {vf[k][q].x, vf[k][q].y, vf[k][q].z, vf[k][q].w}, g4[4] = {vg[k][q].x, vg[k][q].y, vg[k][q].z, vg[k][q].w};
-                        const float d4[4] = {vd[k][q].x, vd[k][q].y, vd[k][q].z, vd[k][q].w};
+                        const int c0 = ks * 32 + g * 8 + q * 4;
+                        const float f4[4] = {vf[b][k][q].x, vf[b][k][q].y, vf[b][k][q].z, vf[b][k][q].w}, g4[4] = {vg[b][k][q].x, vg[b][k][q].y, vg[b][k][q].z, vg[b][k][q].w};
+                        const float d4[4] = {vd[b][k][q].x, vd[b][k][q].y, vd[b][k][q].z, vd[b][k][q].w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int col = c0 + e;
-                            const bool valid = ok && col < a.m;
+                            const bool valid = ok & (col < a.m);
                             const float v = valid ? (f4[e] - a.ratio_eps) * g4[e] : 0.f;
                             tp += v;
-                            if (valid && (d4[e] > mx || (d4[e] == mx && col < am))) {   // first maximum, like torch.max
-                                mx = d4[e];
-                                am = col;
-                            }
+                            // first maximum, like torch.max -- as selects (short-circuit && / || became 250 exec-mask branches)
+                            const bool take = valid & ((d4[e] > mx) | ((d4[e] == mx) & (col < am)));
+                            mx = take ? d4[e] : mx;
+                            am = take ? col : am;
                             xs[q * 4 + e] = v;
                         }
                     }
@@ -232,10 +254,9 @@ __global__ __launch_bounds__(256, 2) void favor_feat_proj_bwd_kernel(const FeatP
         for (int o = 16; o <= 32; o <<= 1) {
             const float om = __shfl_xor(mx, o, 64);
             const int oa = __shfl_xor(am, o, 64);
-            if (om > mx || (om == mx && oa < am)) {
-                mx = om;
-                am = oa;
-            }
+            const bool take = (om > mx) | ((om == mx) & (oa < am));
+            mx = take ? om : mx;
+            am = take ? oa : am;
         }
         if (ok) {
             const float* xr = a.x + proj_row_off(r, a.heads, a.x_stride);
