@@ -239,17 +239,34 @@ __global__ void favor_feat_fwd_kernel(const float* __restrict__ dd, const float*
     for (int d = lane; d < dh; d += 64) s += x[d] * x[d];
     const float diag = wave_sum(s) * c2half;
     const float* dr = dd + rp * LDF;
+    // the row as 16-byte pieces, both in flight before anything is reduced (LDF <= 512: lane l owns pieces l and 64 + l)
+    const int nv = LDF >> 2;
+    const bool has0 = lane < nv, has1 = 64 + lane < nv;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 r0 = has0 ? *(const float4*)(dr + lane * 4) : z4, r1 = has1 ? *(const float4*)(dr + 256 + lane * 4) : z4;
+    const float v0[4] = {r0.x, r0.y, r0.z, r0.w}, v1[4] = {r1.x, r1.y, r1.z, r1.w};
     float stab;
     if (gmax) {
         stab = unpack_max(*gmax);
     } else {
         float mx = -INFINITY;
-        for (int c = lane; c < m; c += 64) mx = fmaxf(mx, dr[c]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mx = (has0 && lane * 4 + e < m) ? fmaxf(mx, v0[e]) : mx;
+            mx = (has1 && 256 + lane * 4 + e < m) ? fmaxf(mx, v1[e]) : mx;
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
         stab = mx;
     }
-    for (int c = lane; c < LDF; c += 64) feat[rp * LDF + c] = c < m ? ratio * (expf(dr[c] - diag - stab) + eps) : 0.f;
+    float o0[4], o1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o0[e] = lane * 4 + e < m ? ratio * (expf(v0[e] - diag - stab) + eps) : 0.f;
+        o1[e] = 256 + lane * 4 + e < m ? ratio * (expf(v1[e] - diag - stab) + eps) : 0.f;
+    }
+    if (has0) *(float4*)(feat + rp * LDF + lane * 4) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+    if (has1) *(float4*)(feat + rp * LDF + 256 + lane * 4) = make_float4(o1[0], o1[1], o1[2], o1[3]);
 }
 
 // backward of the feature map: ddd = e*g (minus the stabiliser path), dsrc[head slice] = -(sum e*g) * c^2 * x
@@ -1718,6 +1735,7 @@ extern "C" int sa_axpy(float* y, const float* x, float alpha, int64_t n, void* s
 extern "C" int sa_favor_features_fwd(const float* dd, const float* src, int src_stride, int h0, int G, int dh, int is_query, float* feat, void* gmax_ws,
                                      int64_t rows, int m, int LDF, void* stream) {
     if (!dd || !src || !feat || rows <= 0 || m <= 0 || LDF < m || (!is_query && !gmax_ws)) return SA_EINVAL;
+    if ((LDF & 3) || LDF > 512) return SA_EUNSUPPORTED;   // rows are read as 16-byte pieces, two per lane
     const float c = powf((float)dh, -0.25f), ratio = 1.f / sqrtf((float)m);
     unsigned long long* gm = nullptr;
     if (!is_query) {
