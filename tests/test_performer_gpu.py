@@ -328,6 +328,31 @@ def test_fused_feature_projection_backward(R, G, m, LDF, is_query):
         assert _rel(tsum2, tsum) < 1e-5
 
 
+@pytest.mark.parametrize("R,C", [(37, 32), (8400, 512), (130, 200), (65, 640)])
+def test_layernorm_kernels(R, C):
+    """sa_layernorm_fwd / sa_layernorm_bwd against torch (the backward reduces dw / db per 32-row block for C <= 512, per element above)."""
+    from synthanatomy_amd import _ffi
+    lib, st = _ffi.lib(), _ffi.stream()
+    torch.manual_seed(R + C)
+    x = torch.randn(R, C, device="cuda") * 2 + 0.3
+    w = torch.randn(C, device="cuda")
+    b = torch.randn(C, device="cuda")
+    dy = torch.randn(R, C, device="cuda")
+    xr = x.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (C,), wr, br, 1e-5)
+    ref.backward(dy.double())
+    y = torch.empty_like(x)
+    stats = torch.empty(2 * R, device="cuda")
+    _ffi.check(lib.sa_layernorm_fwd(_ffi.ptr(x), _ffi.ptr(w), _ffi.ptr(b), _ffi.ptr(y), None, 0, _ffi.ptr(stats), R, C, 1e-5, st))
+    assert _rel(y, ref.detach()) < 1e-5
+    dx = torch.empty_like(x)
+    dw = torch.zeros(C, device="cuda")
+    db = torch.zeros(C, device="cuda")
+    _ffi.check(lib.sa_layernorm_bwd(_ffi.ptr(dy), _ffi.ptr(x), _ffi.ptr(w), _ffi.ptr(stats), _ffi.ptr(dx), _ffi.ptr(dw), _ffi.ptr(db), R, C, st))
+    assert _rel(dx, xr.grad) < 1e-5 and _rel(dw, wr.grad) < 1e-4 and _rel(db, br.grad) < 1e-4
+
+
 @pytest.mark.parametrize("N,segmented", [(37, False), (37, True), (300, True), (1400, True)])
 def test_causal_scan_kernels_against_quadratic_form(N, segmented):
     from synthanatomy_amd import _ffi
