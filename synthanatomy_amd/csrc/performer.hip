@@ -168,6 +168,38 @@ __global__ void gelu_kernel(const void* u, int u_dtype, void* h, int h_dtype, in
         store_from_f32(h, h_dtype, e, gelu_f(load_as_f32(u, u_dtype, e)));
 }
 
+// bf16 -> bf16, eight elements (16 bytes) per thread and step
+__global__ void gelu_bf16x8_kernel(const uint4* __restrict__ u, uint4* __restrict__ h, int64_t n8) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n8; e += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 v = u[e];
+        const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+        uint32_t out[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            out[i] = (uint32_t)f32_to_bf16(gelu_f(__uint_as_float(in[i] << 16))) | ((uint32_t)f32_to_bf16(gelu_f(__uint_as_float(in[i] & 0xffff0000u))) << 16);
+        h[e] = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+// ReZero forward for bf16 F and a bf16 copy of y, four elements per thread and step
+__global__ void rezero_fwd_bf16x4_kernel(const float4* __restrict__ x, const uint2* __restrict__ F, const float* __restrict__ g, float4* __restrict__ y,
+                                         uint2* __restrict__ y_lp, int64_t n4) {
+    const float gv = g[0];
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+        const float4 xv = x[e];
+        const uint2 f = F[e];
+        const float4 o = make_float4(xv.x + gv * __uint_as_float(f.x << 16), xv.y + gv * __uint_as_float(f.x & 0xffff0000u), xv.z + gv * __uint_as_float(f.y << 16),
+                                     xv.w + gv * __uint_as_float(f.y & 0xffff0000u));
+        y[e] = o;
+        if (y_lp) {
+            uint2 p;
+            p.x = (uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16);
+            p.y = (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16);
+            y_lp[e] = p;
+        }
+    }
+}
+
 // y = x + g * F   (ReZero, performer_pytorch.ReZero);  optional low-precision copy of y for the next GEMM
 __global__ void rezero_fwd_kernel(const float* __restrict__ x, const void* F, int f_dtype, const float* __restrict__ g, float* __restrict__ y, void* y_lp,
                                   int lp_dtype, int64_t n) {
@@ -1752,6 +1784,11 @@ extern "C" int sa_layernorm_bwd(const float* dy, const float* x, const float* w,
 
 extern "C" int sa_gelu(const void* u, int u_dtype, void* h, int h_dtype, int64_t n, void* stream) {
     if (!u || !h || n <= 0) return SA_EINVAL;
+    if (u_dtype == SA_BF16 && h_dtype == SA_BF16 && (n & 7) == 0 && (((uintptr_t)u | (uintptr_t)h) & 15) == 0) {
+        hipLaunchKernelGGL(gelu_bf16x8_kernel, dim3(grid1d(n / 8)), dim3(256), 0, ST(stream), (const uint4*)u, (uint4*)h, n / 8);
+        SA_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(gelu_kernel, dim3(grid1d(n)), dim3(256), 0, ST(stream), u, u_dtype, h, h_dtype, n);
     SA_CHECK_LAUNCH();
     return 0;
@@ -1759,6 +1796,11 @@ extern "C" int sa_gelu(const void* u, int u_dtype, void* h, int h_dtype, int64_t
 
 extern "C" int sa_rezero_fwd(const float* x, const void* F, int f_dtype, const float* g, float* y, void* y_lp, int lp_dtype, int64_t n, void* stream) {
     if (!x || !F || !g || !y || n <= 0) return SA_EINVAL;
+    if (f_dtype == SA_BF16 && (!y_lp || lp_dtype == SA_BF16) && (n & 3) == 0 && (((uintptr_t)x | (uintptr_t)F | (uintptr_t)y | (uintptr_t)y_lp) & 15) == 0) {
+        hipLaunchKernelGGL(rezero_fwd_bf16x4_kernel, dim3(grid1d(n / 4)), dim3(256), 0, ST(stream), (const float4*)x, (const uint2*)F, g, (float4*)y, (uint2*)y_lp, n / 4);
+        SA_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(rezero_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, ST(stream), x, F, f_dtype, g, y, y_lp, lp_dtype, n);
     SA_CHECK_LAUNCH();
     return 0;

@@ -292,6 +292,16 @@ def test_rotary_and_rezero_backward_kernels():
     _ffi.check(lib.sa_rezero_bwd(_ffi.ptr(dy), _ffi.ptr(F_), _ffi.dtype_id(torch.bfloat16), _ffi.ptr(gate), _ffi.ptr(dF), _ffi.dtype_id(torch.bfloat16), _ffi.ptr(dg), n, st))
     assert torch.equal(dF, (dy * 0.37).bfloat16())
     assert abs(float(dg) - float((dy.double() * F_.double()).sum())) < 1e-3
+    # ReZero forward (bf16 F, fp32 y + bf16 copy) and GELU (bf16 -> bf16), vector paths
+    y = torch.empty(n, device="cuda")
+    y_lp = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    bf = _ffi.dtype_id(torch.bfloat16)
+    _ffi.check(lib.sa_rezero_fwd(_ffi.ptr(dy), _ffi.ptr(F_), bf, _ffi.ptr(gate), _ffi.ptr(y), _ffi.ptr(y_lp), bf, n, st))
+    ref = dy + 0.37 * F_.float()
+    assert _rel(y, ref) < 1e-6 and torch.equal(y_lp, y.bfloat16())
+    h = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    _ffi.check(lib.sa_gelu(_ffi.ptr(F_), bf, _ffi.ptr(h), bf, n, st))
+    assert _rel(h.float(), torch.nn.functional.gelu(F_.float())) < 4e-3
 
 
 @pytest.mark.parametrize("R,G,m,LDF", [(37, 2, 266, 272), (1400, 8, 266, 272), (65, 1, 100, 112)])
