@@ -189,7 +189,8 @@ int sa_rezero_fwd(const float *x, const void *F, int f_dtype, const float *g, fl
 int sa_rezero_bwd(const float *dy, const void *F, int f_dtype, const float *g, void *dF, int df_dtype, float *dg, int64_t n, void *stream);
 int sa_axpy(float *y, const float *x, float alpha, int64_t n, void *stream);
 /* FAVOR+ softmax_kernel feature map on top of the projection GEMM output dd [rows, LDF] (rows = B*N*G):
- * feat = m^-1/2 (exp(dd - |x|^2 d^-1/2 / 2 - stab) + 1e-4), stab = row max (is_query) or the GLOBAL max (keys; gmax_ws = 8 bytes). */
+ * feat = m^-1/2 (exp(dd - |x|^2 d^-1/2 / 2 - stab) + 1e-4), stab = row max (is_query = 1) or the GLOBAL max (keys; gmax_ws = 8 bytes:
+ * is_query = 0 computes it here, is_query = 2 takes it as left there by sa_favor_project). */
 int sa_favor_features_fwd(const float *dd, const float *src, int src_stride, int h0, int G, int dh, int is_query, float *feat, void *gmax_ws,
                           int64_t rows, int m, int LDF, void *stream);
 /* backward: ddd = d loss / d dd; dsrc (same stride / head offset as src) is OVERWRITTEN with the gradient through the -|x|^2 term, the
@@ -234,9 +235,12 @@ int sa_favor_scan_a_state(const float *a, const float *c, const float *b, int b_
 /* FAVOR+ random-feature projection (performer_pytorch softmax_kernel: data_dash = data_normalizer * data @ projection^T) and its adjoint as
  * HBM-bound kernels; proj [m][dh] already carries the data normalizer.  Row r of x / dx is head block r % heads of the wider row r / heads:
  * it starts at (r / heads) * stride + (r % heads) * dh floats (heads = 1: plain rows).  dd [rows][LDF] (columns >= m are written as zeros);
+ * gmax_ws (8 bytes, optional): the global (value, index) maximum of dd that the key feature map needs, taken from the accumulators --
+ * pass it to sa_favor_features_fwd with is_query = 2 and the separate pass over dd is skipped;
  * dx = ddd @ proj (+ addend, laid out like dx; addend == dx is allowed).  dh = 64, LDF % 16 == 0, LDF <= 272.  Products are split-bf16 (~1e-5 relative); the exact
  * alternative is sa_conv_fprop on the same operands as a 1x1x1 convolution. */
-int sa_favor_project(const float *x, int x_stride, int heads, const float *proj, float *dd, int64_t rows, int m, int LDF, int dh, void *stream);
+int sa_favor_project(const float *x, int x_stride, int heads, const float *proj, float *dd, void *gmax_ws, int64_t rows, int m, int LDF, int dh,
+                     void *stream);
 int sa_favor_project_bwd(const float *ddd, const float *proj, const float *addend, float *dx, int dx_stride, int heads, int64_t rows, int m, int LDF,
                          int dh, void *stream);
 /* sa_favor_features_bwd + sa_favor_project_bwd in one launch (+ one fix-up launch for keys): the intermediate d loss / d dd is never written.

@@ -17,6 +17,7 @@ struct ProjArgs {
     const float* addend;   // adjoint, optional: laid out like out (may be out itself)
     int64_t rows;
     int32_t m, LDF, x_stride, o_stride;
+    unsigned long long* gmax;   // forward, optional: packed (value, index) maximum of dd over valid rows and columns < m
     int32_t heads;         // x / out rows are head blocks of wider rows: row r lives at (r / heads) * stride + (r % heads) * 64
 };
 
@@ -85,6 +86,9 @@ __global__ __launch_bounds__(256, 2) void favor_project_fwd_kernel(const ProjArg
     float* o0 = a.out + (r0 + qi) * a.LDF + g * 4;
     float* o1 = o0 + (int64_t)16 * a.LDF;
     const bool ok0 = r0 + qi < a.rows, ok1 = r0 + 16 + qi < a.rows;
+    float mx = -INFINITY;          // running maximum of this lane's results and its flat index (lowest index on ties)
+    uint32_t mi = 0xffffffffu;
+    const uint32_t i0 = (uint32_t)((r0 + qi) * a.LDF) + (uint32_t)g * 4u, i1 = i0 + 16u * (uint32_t)a.LDF;
     for (int f = 0; f < nfr; ++f) {
         short8_t ah[2], al[2];
 #pragma unroll
@@ -101,6 +105,35 @@ __global__ __launch_bounds__(256, 2) void favor_project_fwd_kernel(const ProjArg
         }
         if (ok0) *(float4*)(o0 + f * 16) = make_float4(c0[0], c0[1], c0[2], c0[3]);
         if (ok1) *(float4*)(o1 + f * 16) = make_float4(c1[0], c1[1], c1[2], c1[3]);
+        if (a.gmax) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool in = f * 16 + g * 4 + r < a.m;
+                const uint32_t j0 = i0 + (uint32_t)(f * 16 + r), j1 = i1 + (uint32_t)(f * 16 + r);
+                const bool t0 = ok0 & in & ((c0[r] > mx) | ((c0[r] == mx) & (j0 < mi)));
+                mx = t0 ? c0[r] : mx;
+                mi = t0 ? j0 : mi;
+                const bool t1 = ok1 & in & ((c1[r] > mx) | ((c1[r] == mx) & (j1 < mi)));
+                mx = t1 ? c1[r] : mx;
+                mi = t1 ? j1 : mi;
+            }
+        }
+    }
+    if (a.gmax) {   // one atomic per block
+        __shared__ unsigned long long sbest[4];
+        unsigned long long best = mi != 0xffffffffu ? pack_max(mx, mi) : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long ot = __shfl_xor(best, o, 64);
+            best = ot > best ? ot : best;
+        }
+        if (lane == 0) sbest[w] = best;
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int q = 1; q < 4; ++q) best = sbest[q] > best ? sbest[q] : best;
+            atomicMax(a.gmax, best);
+        }
     }
 }
 
@@ -326,11 +359,15 @@ extern "C" int sa_favor_features_project_bwd(const float* dfeat, const float* fe
     return 0;
 }
 
-extern "C" int sa_favor_project(const float* x, int x_stride, int heads, const float* proj, float* dd, int64_t rows, int m, int LDF, int dh, void* stream) {
+extern "C" int sa_favor_project(const float* x, int x_stride, int heads, const float* proj, float* dd, void* gmax_ws, int64_t rows, int m, int LDF, int dh,
+                                void* stream) {
     if (!x || !proj || !dd || rows <= 0 || m <= 0 || heads <= 0) return SA_EINVAL;
+    if (rows * LDF >= ((int64_t)1 << 32) - 1) return SA_EUNSUPPORTED;
     if (dh != 64 || (LDF & 15) || LDF < m || LDF > 272 || (x_stride & 3) || x_stride < dh * heads) return SA_EUNSUPPORTED;
     ProjArgs a = {};
     a.x = x; a.proj = proj; a.out = dd; a.rows = rows; a.m = m; a.LDF = LDF; a.x_stride = x_stride; a.heads = heads;
+    a.gmax = (unsigned long long*)gmax_ws;
+    if (gmax_ws) hipMemsetAsync(gmax_ws, 0, 8, (hipStream_t)stream);
     const size_t lds = (size_t)2 * LDF * 128;
     hipFuncSetAttribute((const void*)favor_project_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(favor_project_fwd_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);

@@ -255,17 +255,6 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
 
 // ------------------------------------------------------------------------------------------------ FAVOR+ feature map
 // rows r' = r*G + h (r = b*N + n).  dd [R*G, LDF] = x . (c P)^T from the projection GEMM; x = src[r, (h0+h)*dh .. +dh].
-__device__ __forceinline__ unsigned long long pack_max(float v, uint32_t idx) {
-    uint32_t u = __float_as_uint(v);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // order-preserving map float -> uint
-    return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - idx);  // ties: lowest index wins
-}
-__device__ __forceinline__ float unpack_max(unsigned long long p) {
-    uint32_t u = (uint32_t)(p >> 32);
-    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    return __uint_as_float(u);
-}
-
 __global__ __launch_bounds__(256) void favor_global_max_kernel(const float* __restrict__ dd, int64_t rows, int m, int LDF, unsigned long long* __restrict__ out) {
     // one wave per group of four rows, 16-byte loads (LDF % 4 == 0), the four rows' loads in flight together; the padding columns >= m are
     // skipped; one atomic per block
@@ -1828,11 +1817,13 @@ extern "C" int sa_axpy(float* y, const float* x, float alpha, int64_t n, void* s
 
 extern "C" int sa_favor_features_fwd(const float* dd, const float* src, int src_stride, int h0, int G, int dh, int is_query, float* feat, void* gmax_ws,
                                      int64_t rows, int m, int LDF, void* stream) {
-    if (!dd || !src || !feat || rows <= 0 || m <= 0 || LDF < m || (!is_query && !gmax_ws)) return SA_EINVAL;
+    if (!dd || !src || !feat || rows <= 0 || m <= 0 || LDF < m || (is_query != 1 && !gmax_ws)) return SA_EINVAL;
     if ((LDF & 3) || LDF > 512) return SA_EUNSUPPORTED;   // rows are read as 16-byte pieces, two per lane
     const float c = powf((float)dh, -0.25f), ratio = 1.f / sqrtf((float)m);
     unsigned long long* gm = nullptr;
-    if (!is_query) {
+    if (is_query == 2) {          // keys, global maximum already in gmax_ws (sa_favor_project computed it from its accumulators)
+        gm = (unsigned long long*)gmax_ws;
+    } else if (!is_query) {
         gm = (unsigned long long*)gmax_ws;
         hipMemsetAsync(gm, 0, 8, ST(stream));
         hipLaunchKernelGGL(favor_global_max_kernel, dim3(grid1d(rows * 16, 256, 2048)), dim3(256), 0, ST(stream), dd, rows, m, LDF, gm);

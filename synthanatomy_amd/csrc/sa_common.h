@@ -96,6 +96,18 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// (value, index) maximum as one 64-bit integer for atomicMax: order-preserving float bits above, inverted index below (ties: lowest index wins)
+__device__ __forceinline__ unsigned long long pack_max(float v, uint32_t idx) {
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - idx);
+}
+__device__ __forceinline__ float unpack_max(unsigned long long p) {
+    uint32_t u = (uint32_t)(p >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+
 // 4 x 4 transpose across the four 16-lane quarters of a wave (gfx950 v_permlane32_swap + v_permlane16_swap; semantics probed on MI355X):
 //   permlane32_swap(a, b) = {[a.q0 a.q1 b.q0 b.q1], [a.q2 a.q3 b.q2 b.q3]};  permlane16_swap(a, b) = {[a.q0 b.q0 a.q2 b.q2], [a.q1 b.q1 a.q3 b.q3]}
 // in: lane quarter q holds r_i = element (q, i);  out: lane quarter q holds r_i = element (i, q).

@@ -405,12 +405,15 @@ class _LayerEngine:
                 ps = self._pop[2]
                 ddq = torch.empty(R * G, LDF, dtype=f32, device=dev)
                 ddk = torch.empty(R * G, LDF, dtype=f32, device=dev)
-                _ck(lib.sa_favor_project(_ffi.ptr(q), qs, G, _ffi.ptr(ps), _ffi.ptr(ddq), R * G, m, LDF, dh, st), "sa_favor_project(q)")
-                _ck(lib.sa_favor_project(_ffi.ptr(k), qs, G, _ffi.ptr(ps), _ffi.ptr(ddk), R * G, m, LDF, dh, st), "sa_favor_project(k)")
             qf, kf = torch.empty_like(ddq), torch.empty_like(ddk)
-            gws = torch.zeros(2, dtype=torch.int64, device=dev)
+            gws = torch.empty(2, dtype=torch.int64, device=dev)
+            kmode = 0      # the keys' feature map finds the global maximum itself ...
+            if not self._xf:
+                _ck(lib.sa_favor_project(_ffi.ptr(q), qs, G, _ffi.ptr(ps), _ffi.ptr(ddq), None, R * G, m, LDF, dh, st), "sa_favor_project(q)")
+                _ck(lib.sa_favor_project(_ffi.ptr(k), qs, G, _ffi.ptr(ps), _ffi.ptr(ddk), _ffi.ptr(gws), R * G, m, LDF, dh, st), "sa_favor_project(k)")
+                kmode = 2  # ... unless the projection kernel already left it in gws (from its accumulators: no extra pass over ddk)
             _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddq), _ffi.ptr(qg), sst, 0, G, dh, 1, _ffi.ptr(qf), None, R * G, m, LDF, st), "favor_features(q)")
-            _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddk), _ffi.ptr(kg), sst, 0, G, dh, 0, _ffi.ptr(kf), _ffi.ptr(gws), R * G, m, LDF, st), "favor_features(k)")
+            _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddk), _ffi.ptr(kg), sst, 0, G, dh, kmode, _ffi.ptr(kf), _ffi.ptr(gws), R * G, m, LDF, st), "favor_features(k)")
             ws = self._scan_ws(B, N, G, dev)
             if tape is not None and self._fused_sums:   # training: the chunk states (sum k' (x) v, sum k') are kept for the dq' scan of the backward pass
                 ws = torch.empty_like(ws)

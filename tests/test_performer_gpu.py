@@ -160,10 +160,22 @@ def test_projection_kernels_against_matmul(rows, m, LDF, heads):
     x = xw[:, :heads * 64].reshape(rows, 64)
     P_ = torch.randn(m, 64, device="cuda") * 0.35
     dd = torch.full((rows, LDF), float("nan"), device="cuda")
-    _ffi.check(lib.sa_favor_project(_ffi.ptr(xw), wide, heads, _ffi.ptr(P_), _ffi.ptr(dd), rows, m, LDF, 64, st))
+    _ffi.check(lib.sa_favor_project(_ffi.ptr(xw), wide, heads, _ffi.ptr(P_), _ffi.ptr(dd), None, rows, m, LDF, 64, st))
     ref = x.double() @ P_.double().t()
     assert _rel(dd[:, :m], ref) < 2e-5
     assert LDF == m or float(dd[:, m:].abs().max()) == 0.0
+    # the global (value, index) maximum from the accumulators == the separate pass over dd (feature maps built from either agree bitwise)
+    gws = torch.empty(2, dtype=torch.int64, device="cuda")
+    dd2 = torch.empty_like(dd)
+    _ffi.check(lib.sa_favor_project(_ffi.ptr(xw), wide, heads, _ffi.ptr(P_), _ffi.ptr(dd2), _ffi.ptr(gws), rows, m, LDF, 64, st))
+    assert torch.equal(dd2, dd)
+    fa, fb = torch.empty_like(dd), torch.empty_like(dd)
+    gws0 = torch.zeros(2, dtype=torch.int64, device="cuda")
+    _ffi.check(lib.sa_favor_features_fwd(_ffi.ptr(dd), _ffi.ptr(xw), wide, 0, heads, 64, 0, _ffi.ptr(fa), _ffi.ptr(gws0), rows, m, LDF, st))
+    _ffi.check(lib.sa_favor_features_fwd(_ffi.ptr(dd), _ffi.ptr(xw), wide, 0, heads, 64, 2, _ffi.ptr(fb), _ffi.ptr(gws), rows, m, LDF, st))
+    assert int(gws[0]) == int(gws0[0]) and torch.equal(fa, fb)
+    flat = dd[:, :m].max()
+    assert float(flat) == float(dd.view(-1)[0xffffffff - (int(gws[0]) & 0xffffffff)])
     g = torch.randn(rows, LDF, device="cuda")
     g[:, m:] = 7.0                                        # padded gradient columns must not leak (the staged projection rows are zero)
     dxw = torch.full((rows // heads, wide), float("nan"), device="cuda")
@@ -316,7 +328,7 @@ def test_fused_feature_projection_backward(R, G, m, LDF, is_query):
     xw = torch.randn(R, wide, device="cuda") * 0.7
     P_ = torch.randn(m, 64, device="cuda") * 0.35
     dd = torch.empty(rows, LDF, device="cuda")
-    _ffi.check(lib.sa_favor_project(_ffi.ptr(xw), wide, G, _ffi.ptr(P_), _ffi.ptr(dd), rows, m, LDF, 64, st))
+    _ffi.check(lib.sa_favor_project(_ffi.ptr(xw), wide, G, _ffi.ptr(P_), _ffi.ptr(dd), None, rows, m, LDF, 64, st))
     feat = torch.empty_like(dd)
     gws = torch.zeros(2, dtype=torch.int64, device="cuda")
     _ffi.check(lib.sa_favor_features_fwd(_ffi.ptr(dd), _ffi.ptr(xw), wide, 0, G, 64, is_query, _ffi.ptr(feat), None if is_query else _ffi.ptr(gws), rows, m, LDF, st))
