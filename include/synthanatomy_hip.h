@@ -244,7 +244,8 @@ int sa_favor_project(const float *x, int x_stride, int heads, const float *proj,
 int sa_favor_project_bwd(const float *ddd, const float *proj, const float *addend, float *dx, int dx_stride, int heads, int64_t rows, int m, int LDF,
                          int dh, void *stream);
 /* sa_favor_features_bwd + sa_favor_project_bwd in one launch (+ one fix-up launch for keys): the intermediate d loss / d dd is never written.
- * src / dsrc rows are head blocks as for sa_favor_project (stride, heads); proj carries the data normalizer; dsrc is overwritten. */
+ * src / dsrc rows are head blocks as for sa_favor_project (stride, heads); proj carries the data normalizer; dsrc is overwritten.
+ * tsum_ws (keys): at least one float of scratch (tsum_ws[0] = sum over the rows of the stabiliser's share, for the fix-up launch). */
 int sa_favor_features_project_bwd(const float *dfeat, const float *feat, const float *dd, const float *src, int src_stride, int heads, const float *proj,
                                   int is_query, float *dsrc, const void *gmax_ws, float *tsum_ws, int64_t rows, int m, int LDF, int dh, void *stream);
 int sa_cumsum_rows(const float *x, const float *scale, float *out, int B, int N, int G, int LDF, int reverse, float *seg_ws, void *stream);

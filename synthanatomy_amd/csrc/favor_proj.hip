@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void favor_project_bwd_kernel(const ProjArg
 struct FeatProjArgs {
     const float *dfeat, *feat, *dd, *x, *proj;
     float* dx;
-    float* tsum;           // keys: [rows]
+    float* tsum;           // keys: one float, the sum of t over all rows (zeroed by the launcher)
     int64_t rows;
     int32_t m, LDF, x_stride, heads, is_query;
     float c2, ratio_eps;
@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256, 2) void favor_feat_proj_bwd_kernel(const FeatP
     proj_stage<true>(sPh, sPl, a.proj, a.m, nks * 32, tid);
     __syncthreads();
     const uint32_t trow = (uint32_t)g * 4u + ((uint32_t)qi >> 2), tcol = (uint32_t)(qi & 3) * 4u;
+    float tblock = 0.f;
     for (int it = 0; it < 2; ++it) {
         const int64_t r = (int64_t)blockIdx.x * 128 + w * 32 + it * 16 + qi;
         const bool ok = r < a.rows;
@@ -304,33 +305,25 @@ __global__ __launch_bounds__(256, 2) void favor_feat_proj_bwd_kernel(const FeatP
                 *(float4*)(dxr + d0) = make_float4(acc[df][0] - ts * pv.x - tc * xv.x, acc[df][1] - ts * pv.y - tc * xv.y, acc[df][2] - ts * pv.z - tc * xv.z,
                                                    acc[df][3] - ts * pv.w - tc * xv.w);
             }
-            if (!a.is_query && g == 0) a.tsum[r] = t;
         }
+        if (!a.is_query && ok && g == 0) tblock += t;
+    }
+    if (!a.is_query) {   // sum of t over the block's rows -> one atomic (the fix-up launch used to re-read one value per row)
+        __shared__ float sred[4];
+        tblock = wave_sum(tblock);
+        if (lane == 0) sred[w] = tblock;
+        __syncthreads();
+        if (tid == 0) unsafeAtomicAdd(a.tsum, (sred[0] + sred[1]) + (sred[2] + sred[3]));
     }
 }
 
-// keys: the global-max element (row*, f*) of dd takes -(sum_rows t): dx[row*] -= T P[f*]
-__global__ __launch_bounds__(1024) void favor_key_stab_dx_kernel(float* __restrict__ dx, int x_stride, int heads, const unsigned long long* __restrict__ gmax,
-                                                                 const float* __restrict__ trow, int64_t rows, const float* __restrict__ proj, int LDF) {
-    __shared__ float red[16];
-    __shared__ float total;
-    float s = 0.f;
-    for (int64_t r = threadIdx.x; r < rows; r += 1024) s += trow[r];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int i = 0; i < 16; ++i) t += red[i];
-        total = t;
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const uint32_t idx = 0xffffffffu - (uint32_t)(*gmax & 0xffffffffull);
-        const int64_t r = idx / (uint32_t)LDF;
-        const int f = (int)(idx % (uint32_t)LDF);
-        dx[proj_row_off(r, heads, x_stride) + threadIdx.x] -= total * proj[(int64_t)f * 64 + threadIdx.x];
-    }
+// keys: the global-max element (row*, f*) of dd takes -(sum_rows t): dx[row*] -= T P[f*]   (T = *total, accumulated by the kernel above)
+__global__ __launch_bounds__(64) void favor_key_stab_dx_kernel(float* __restrict__ dx, int x_stride, int heads, const unsigned long long* __restrict__ gmax,
+                                                               const float* __restrict__ total, const float* __restrict__ proj, int LDF) {
+    const uint32_t idx = 0xffffffffu - (uint32_t)(*gmax & 0xffffffffull);
+    const int64_t r = idx / (uint32_t)LDF;
+    const int f = (int)(idx % (uint32_t)LDF);
+    dx[proj_row_off(r, heads, x_stride) + threadIdx.x] -= total[0] * proj[(int64_t)f * 64 + threadIdx.x];
 }
 
 }  // namespace sa
@@ -349,11 +342,12 @@ extern "C" int sa_favor_features_project_bwd(const float* dfeat, const float* fe
     a.c2 = c * c; a.ratio_eps = ratio * 1e-4f;
     const size_t lds = (size_t)2 * ((LDF + 31) / 32) * 32 * 128;
     hipFuncSetAttribute((const void*)favor_feat_proj_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!is_query) hipMemsetAsync(tsum_ws, 0, 4, (hipStream_t)stream);   // tsum_ws[0] accumulates the sum over all rows
     hipLaunchKernelGGL(favor_feat_proj_bwd_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     if (!is_query) {
-        hipLaunchKernelGGL(favor_key_stab_dx_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dsrc, src_stride, heads, (const unsigned long long*)gmax_ws, tsum_ws,
-                           rows, proj, LDF);
+        hipLaunchKernelGGL(favor_key_stab_dx_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dsrc, src_stride, heads, (const unsigned long long*)gmax_ws, tsum_ws,
+                           proj, LDF);
         SA_CHECK_LAUNCH();
     }
     return 0;

@@ -347,7 +347,7 @@ def test_fused_feature_projection_backward(R, G, m, LDF, is_query):
     assert _rel(got[:, :G * 64], ref[:, :G * 64]) < 3e-5
     assert bool(torch.isnan(got[:, G * 64:]).all())
     if not is_query:
-        assert _rel(tsum2, tsum) < 1e-5
+        assert abs(float(tsum2[0]) - float(tsum.double().sum())) < 1e-4 * float(tsum.double().abs().sum())
 
 
 @pytest.mark.parametrize("R,C", [(37, 32), (8400, 512), (130, 200), (65, 640)])
