@@ -241,6 +241,9 @@ int sa_favor_scan_a_state(const float *a, const float *c, const float *b, int b_
  * alternative is sa_conv_fprop on the same operands as a 1x1x1 convolution. */
 int sa_favor_project(const float *x, int x_stride, int heads, const float *proj, float *dd, void *gmax_ws, int64_t rows, int m, int LDF, int dh,
                      void *stream);
+/* sa_favor_project + the QUERY feature map (sa_favor_features_fwd with is_query = 1) in one launch: dd and feat [rows][LDF] */
+int sa_favor_project_features(const float *x, int x_stride, int heads, const float *proj, float *dd, float *feat, int64_t rows, int m, int LDF, int dh,
+                              void *stream);
 int sa_favor_project_bwd(const float *ddd, const float *proj, const float *addend, float *dx, int dx_stride, int heads, int64_t rows, int m, int LDF,
                          int dh, void *stream);
 /* sa_favor_features_bwd + sa_favor_project_bwd in one launch (+ one fix-up launch for keys): the intermediate d loss / d dd is never written.

@@ -55,6 +55,7 @@ _SIGS = {
     "sa_conv1_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "sa_favor_features_project_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                               c_int, c_int, c_void_p]),
+    "sa_favor_project_features": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "sa_favor_project": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "sa_favor_project_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
     "sa_pack_weights_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

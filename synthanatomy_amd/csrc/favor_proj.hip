@@ -18,6 +18,8 @@ struct ProjArgs {
     int64_t rows;
     int32_t m, LDF, x_stride, o_stride;
     unsigned long long* gmax;   // forward, optional: packed (value, index) maximum of dd over valid rows and columns < m
+    float* feat;                // forward, QFEAT: query feature map [rows][LDF]
+    float c2half, ratio, eps;
     int32_t heads;         // x / out rows are head blocks of wider rows: row r lives at (r / heads) * stride + (r % heads) * 64
 };
 
@@ -61,6 +63,10 @@ __device__ __forceinline__ float4 proj_keep(float4 x, bool keep) {
 }
 
 // forward: block = 128 rows, wave = 32 rows (two MFMA column sets); D[i = feature][j = row]
+// QFEAT: the QUERY feature map phi = ratio (exp(dd - |x|^2 c^2 / 2 - rowmax) + eps) in the same launch: the row maximum is known after one walk over
+// the feature fragments, a second walk recomputes them (17 x 12 MFMAs: nothing next to the 2 x 73 MB of results) and writes phi -- the separate
+// feature-map launch and its read of dd disappear.
+template <bool QFEAT>
 __global__ __launch_bounds__(256, 2) void favor_project_fwd_kernel(const ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nfr = a.LDF >> 4;
@@ -69,6 +75,7 @@ __global__ __launch_bounds__(256, 2) void favor_project_fwd_kernel(const ProjArg
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), qi = lane & 15, g = lane >> 4;
     const int64_t r0 = (int64_t)blockIdx.x * 128 + w * 32;
     short8_t xh[2][2], xl[2][2];
+    float ss[2] = {0.f, 0.f};   // QFEAT: |x|^2 of this lane's quarter of the row
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
         const int64_t r = r0 + st * 16 + qi;
@@ -78,6 +85,10 @@ __global__ __launch_bounds__(256, 2) void favor_project_fwd_kernel(const ProjArg
         for (int ks = 0; ks < 2; ++ks) {
             const float4 v0 = proj_keep(*(const float4*)(xr + ks * 32 + g * 8), ok), v1 = proj_keep(*(const float4*)(xr + ks * 32 + g * 8 + 4), ok);
             const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if (QFEAT) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss[st] = fmaf(xs[e], xs[e], ss[st]);
+            }
             split8(xs, xh[st][ks], xl[st][ks]);
         }
     }
@@ -88,6 +99,7 @@ __global__ __launch_bounds__(256, 2) void favor_project_fwd_kernel(const ProjArg
     const bool ok0 = r0 + qi < a.rows, ok1 = r0 + 16 + qi < a.rows;
     float mx = -INFINITY;          // running maximum of this lane's results and its flat index (lowest index on ties)
     uint32_t mi = 0xffffffffu;
+    float rm0 = -INFINITY, rm1 = -INFINITY;   // QFEAT: row maxima over the valid features
     const uint32_t i0 = (uint32_t)((r0 + qi) * a.LDF) + (uint32_t)g * 4u, i1 = i0 + 16u * (uint32_t)a.LDF;
     for (int f = 0; f < nfr; ++f) {
         short8_t ah[2], al[2];
@@ -105,6 +117,14 @@ __global__ __launch_bounds__(256, 2) void favor_project_fwd_kernel(const ProjArg
         }
         if (ok0) *(float4*)(o0 + f * 16) = make_float4(c0[0], c0[1], c0[2], c0[3]);
         if (ok1) *(float4*)(o1 + f * 16) = make_float4(c1[0], c1[1], c1[2], c1[3]);
+        if (QFEAT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool in = f * 16 + g * 4 + r < a.m;
+                rm0 = in ? fmaxf(rm0, c0[r]) : rm0;
+                rm1 = in ? fmaxf(rm1, c1[r]) : rm1;
+            }
+        }
         if (a.gmax) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -133,6 +153,40 @@ __global__ __launch_bounds__(256, 2) void favor_project_fwd_kernel(const ProjArg
 #pragma unroll
             for (int q = 1; q < 4; ++q) best = sbest[q] > best ? sbest[q] : best;
             atomicMax(a.gmax, best);
+        }
+    }
+    if (QFEAT) {
+        // a row lives in the four lanes qi, qi + 16, qi + 32, qi + 48
+        rm0 = fmaxf(rm0, __shfl_xor(rm0, 16, 64)); rm0 = fmaxf(rm0, __shfl_xor(rm0, 32, 64));
+        rm1 = fmaxf(rm1, __shfl_xor(rm1, 16, 64)); rm1 = fmaxf(rm1, __shfl_xor(rm1, 32, 64));
+        ss[0] += __shfl_xor(ss[0], 16, 64); ss[0] += __shfl_xor(ss[0], 32, 64);
+        ss[1] += __shfl_xor(ss[1], 16, 64); ss[1] += __shfl_xor(ss[1], 32, 64);
+        const float sh0 = ss[0] * a.c2half + rm0, sh1 = ss[1] * a.c2half + rm1;
+        float* p0 = a.feat + (r0 + qi) * a.LDF + g * 4;
+        float* p1 = p0 + (int64_t)16 * a.LDF;
+        for (int f = 0; f < nfr; ++f) {
+            short8_t ah[2], al[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint32_t o = lroff(f * 16 + qi, ks * 32 + g * 8);
+                ah[ks] = *(const short8_t*)(sPh + o);
+                al[ks] = *(const short8_t*)(sPl + o);
+            }
+            float4_t c0 = (float4_t){0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                c0 = mfma3(ah[ks], al[ks], xh[0][ks], xl[0][ks], c0);
+                c1 = mfma3(ah[ks], al[ks], xh[1][ks], xl[1][ks], c1);
+            }
+            float e0[4], e1[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool in = f * 16 + g * 4 + r < a.m;
+                e0[r] = in ? a.ratio * (expf(c0[r] - sh0) + a.eps) : 0.f;
+                e1[r] = in ? a.ratio * (expf(c1[r] - sh1) + a.eps) : 0.f;
+            }
+            if (ok0) *(float4*)(p0 + f * 16) = make_float4(e0[0], e0[1], e0[2], e0[3]);
+            if (ok1) *(float4*)(p1 + f * 16) = make_float4(e1[0], e1[1], e1[2], e1[3]);
         }
     }
 }
@@ -363,8 +417,23 @@ extern "C" int sa_favor_project(const float* x, int x_stride, int heads, const f
     a.gmax = (unsigned long long*)gmax_ws;
     if (gmax_ws) hipMemsetAsync(gmax_ws, 0, 8, (hipStream_t)stream);
     const size_t lds = (size_t)2 * LDF * 128;
-    hipFuncSetAttribute((const void*)favor_project_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(favor_project_fwd_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);
+    hipFuncSetAttribute((const void*)favor_project_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(favor_project_fwd_kernel<false>, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_favor_project_features(const float* x, int x_stride, int heads, const float* proj, float* dd, float* feat, int64_t rows, int m, int LDF,
+                                         int dh, void* stream) {
+    if (!x || !proj || !dd || !feat || rows <= 0 || m <= 0 || heads <= 0) return SA_EINVAL;
+    if (dh != 64 || (LDF & 15) || LDF < m || LDF > 272 || (x_stride & 3) || x_stride < dh * heads) return SA_EUNSUPPORTED;
+    ProjArgs a = {};
+    a.x = x; a.proj = proj; a.out = dd; a.feat = feat; a.rows = rows; a.m = m; a.LDF = LDF; a.x_stride = x_stride; a.heads = heads;
+    const float c = powf((float)dh, -0.25f);
+    a.c2half = 0.5f * c * c; a.ratio = 1.f / sqrtf((float)m); a.eps = 1e-4f;
+    const size_t lds = (size_t)2 * LDF * 128;
+    hipFuncSetAttribute((const void*)favor_project_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(favor_project_fwd_kernel<true>, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     return 0;
 }

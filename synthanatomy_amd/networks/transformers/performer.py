@@ -409,10 +409,12 @@ class _LayerEngine:
             gws = torch.empty(2, dtype=torch.int64, device=dev)
             kmode = 0      # the keys' feature map finds the global maximum itself ...
             if not self._xf:
-                _ck(lib.sa_favor_project(_ffi.ptr(q), qs, G, _ffi.ptr(ps), _ffi.ptr(ddq), None, R * G, m, LDF, dh, st), "sa_favor_project(q)")
+                # queries: projection and feature map in one launch (the row maximum is local to the block)
+                _ck(lib.sa_favor_project_features(_ffi.ptr(q), qs, G, _ffi.ptr(ps), _ffi.ptr(ddq), _ffi.ptr(qf), R * G, m, LDF, dh, st), "sa_favor_project_features(q)")
                 _ck(lib.sa_favor_project(_ffi.ptr(k), qs, G, _ffi.ptr(ps), _ffi.ptr(ddk), _ffi.ptr(gws), R * G, m, LDF, dh, st), "sa_favor_project(k)")
                 kmode = 2  # ... unless the projection kernel already left it in gws (from its accumulators: no extra pass over ddk)
-            _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddq), _ffi.ptr(qg), sst, 0, G, dh, 1, _ffi.ptr(qf), None, R * G, m, LDF, st), "favor_features(q)")
+            else:
+                _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddq), _ffi.ptr(qg), sst, 0, G, dh, 1, _ffi.ptr(qf), None, R * G, m, LDF, st), "favor_features(q)")
             _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddk), _ffi.ptr(kg), sst, 0, G, dh, kmode, _ffi.ptr(kf), _ffi.ptr(gws), R * G, m, LDF, st), "favor_features(k)")
             ws = self._scan_ws(B, N, G, dev)
             if tape is not None and self._fused_sums:   # training: the chunk states (sum k' (x) v, sum k') are kept for the dq' scan of the backward pass

@@ -176,6 +176,13 @@ def test_projection_kernels_against_matmul(rows, m, LDF, heads):
     assert int(gws[0]) == int(gws0[0]) and torch.equal(fa, fb)
     flat = dd[:, :m].max()
     assert float(flat) == float(dd.view(-1)[0xffffffff - (int(gws[0]) & 0xffffffff)])
+    # projection + query feature map in one launch == the two launches
+    fq = torch.empty_like(dd)
+    _ffi.check(lib.sa_favor_features_fwd(_ffi.ptr(dd), _ffi.ptr(xw), wide, 0, heads, 64, 1, _ffi.ptr(fq), None, rows, m, LDF, st))
+    dd3, fq3 = torch.full_like(dd, float("nan")), torch.full_like(dd, float("nan"))
+    _ffi.check(lib.sa_favor_project_features(_ffi.ptr(xw), wide, heads, _ffi.ptr(P_), _ffi.ptr(dd3), _ffi.ptr(fq3), rows, m, LDF, 64, st))
+    assert torch.equal(dd3, dd) and _rel(fq3, fq) < 2e-6
+    assert LDF == m or float(fq3[:, m:].abs().max()) == 0.0
     g = torch.randn(rows, LDF, device="cuda")
     g[:, m:] = 7.0                                        # padded gradient columns must not leak (the staged projection rows are zero)
     dxw = torch.full((rows // heads, wide), float("nan"), device="cuda")
