@@ -232,9 +232,14 @@ class ConvOp:
     def _bias_padded(self):
         if self.bias is None:
             return None
+        if self.cout % 128 == 0 and self.bias.dtype == torch.float32 and self.bias.is_contiguous():
+            return self.bias.detach()   # nothing to pad: the kernels read the parameter itself (no per-step copy)
         ver = (self.bias._version, self.bias.data_ptr(), self._epoch)
         if self._bias_pad is None or self._bias_pad[0] != ver:
-            bp = torch.zeros(_ru(self.cout, 128), dtype=torch.float32, device=self.bias.device)
+            if self._bias_pad is None or self._bias_pad[1].device != self.bias.device:
+                bp = torch.zeros(_ru(self.cout, 128), dtype=torch.float32, device=self.bias.device)
+            else:
+                bp = self._bias_pad[1]      # the padding stays zero: one copy, no fill
             bp[: self.cout] = self.bias.detach()
             self._bias_pad = (ver, bp)
         return self._bias_pad[1]
