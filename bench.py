@@ -80,7 +80,7 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
     B = batch if batch is not None else args.performer_batch
     torch.manual_seed(4)
     order = Ordering("raster_scan", 3, (1,) + spatial, (False, False, False), ((2, 0, 1),), ((0, 1),), ("rotate_90", "transpose"))
-    net = Performer(num_tokens=PERF["vocab"] + 1, max_seq_len=N, dim=PERF["dim"], depth=PERF["depth"], heads=PERF["heads"], ordering=order,
+    net = Performer(num_tokens=PERF["vocab"] + 1, max_seq_len=N + 1, dim=PERF["dim"], depth=PERF["depth"], heads=PERF["heads"], ordering=order,
                     local_attn_heads=PERF["local_heads"], local_window_size=PERF["window"], feature_redraw_interval=1, use_rezero=True,
                     spatial_position_emb="absolute", spatial_shape=spatial, compute_dtype=dt).to(dev).train()
     flat = FlatParams(net.parameters())
@@ -167,6 +167,70 @@ def _pmc_traffic(kernel, args):
         return None
 
 
+def _respawn(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, the same command line under
+    torch.distributed.run) and pass their output through; rank 0 of the children prints the JSON line."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """Launch plumbing without a GPU (CPU, gloo): rendezvous, the bucketed gradient reducer over a flat host buffer, barrier-bracketed timing,
+    MAX over ranks and the one JSON line -- what `tests/test_bench_spawn_cpu.py` exercises.  No kernel runs, so the line says dry_run."""
+    from synthanatomy_amd.runtime.ddp import GradReducer, init_distributed
+    from synthanatomy_amd.runtime.optim import FlatParams
+
+    rank, local, world = init_distributed(backend="gloo")
+    assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    torch.manual_seed(4)
+    ps = [torch.nn.Parameter(torch.randn(256, 64)) for _ in range(6)]
+    flat = FlatParams(ps)
+    red = GradReducer(flat, bucket_bytes=128 << 10)
+
+    def step():
+        flat.zero_grad()
+        for p in reversed(ps):
+            red.buffer(p).add_(float(rank + 1))
+            red.ready(p)
+        return red.finish()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        scale = step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    want = world * (world + 1) / 2.0
+    assert abs(float(flat.grad[0]) - want) < 1e-6 and abs(scale - 1.0 / world) < 1e-12, (float(flat.grad[0]), want, scale)
+    if rank == 0:
+        print(json.dumps({"metric": "vqvae_train_volumes_per_sec", "value": None, "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "launch plumbing only (CPU, gloo): no kernel ran", "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,7 +245,12 @@ def main():
     ap.add_argument("--no-sampling", dest="sampling", action="store_false", help="skip the autoregressive sampling tokens/s measurement")
     ap.add_argument("--only-performer", action="store_true", help="dev/profiling: measure only the Performer workload")
     ap.add_argument("--performer-shape", default="10,14,10", help="latent grid of the Performer workload (20,28,25 = the 14 000-token variant)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: exercise the launch + reduction plumbing only (no GPU, no kernels)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # started without a launcher: spawn one process per GPU ourselves
+        sys.exit(_respawn(args))
+    if args.dry_run:
+        return dry_run(args)
 
     from synthanatomy_amd import engine
     from synthanatomy_amd.losses.vqvae import MSELoss
@@ -234,6 +303,7 @@ def main():
     if not args.no_kernel_timer:
         timer = engine.KernelTimer()
         engine.TIMER = timer
+    reducer.timing = world > 1
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -244,6 +314,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     engine.TIMER = None
+    reducer.timing = False
+    comm = reducer.comm_stats()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -289,6 +361,8 @@ def main():
             "tflops_per_gpu": round(value / world * STEP_TFLOP_PER_VOLUME, 2), "final_loss": round(final_loss, 6),
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         }
+        if comm is not None:
+            line["comm"] = comm   # gradient all-reduce on the side stream, rank 0: total / exposed after backward / hidden under backward
         if roof is not None:
             line["roofline"] = roof
         if roof_hbm is not None:

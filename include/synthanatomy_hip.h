@@ -64,6 +64,24 @@ const char *sa_last_error(void);
  * lets a profiler key its per-kernel timings exactly as the dispatcher decided, without mirroring the dispatch rules */
 const char *sa_last_conv_kernel(void);
 
+/* Developer switches that select an alternative kernel for the SAME result (A/B measurements and the cross-family parity tests).  The
+ * only process-wide state of the library: one atomic word, initialised ONCE at load time from the environment variables of the same names
+ * (SA_NO_HALO=1 ...), never re-read by a launch.  sa_set_debug_flags returns the previous value.  Launches read it without locking: set
+ * it while no other thread is inside the library. */
+#define SA_DBG_NO_HALO           (1u << 0)   /* 3x3x3 convs on the im2col-order kernels instead of the halo mainloops (fprop, dgrad, wgrad) */
+#define SA_DBG_NO_HALO256        (1u << 1)   /* 128-voxel halo tiles only */
+#define SA_DBG_NO_HALO256_FUSE   (1u << 2)   /* fused residual block on the 128-voxel halo kernel */
+#define SA_DBG_NO_DMA            (1u << 3)   /* register-staged mainloops instead of buffer_load ... lds */
+#define SA_DBG_NO_SMALL_TILES    (1u << 4)   /* keep 128x128 tiles for small dense grids */
+#define SA_DBG_NO_FUSED_DB       (1u << 5)   /* bias gradient by sa_colsum semantics inside wgrad disabled (separate pass) */
+#define SA_DBG_NO_WGRAD_HALO9    (1u << 6)   /* three-tap weight-gradient halo kernel instead of the nine-tap one */
+#define SA_DBG_IM2COL_DIRECT     (1u << 7)   /* sa_convt1_im2col without the LDS gather */
+#define SA_DBG_SCAN_VALU         (1u << 8)   /* FAVOR+ scans on the VALU segment kernels */
+#define SA_DBG_LOCAL_ATTN_EXACT  (1u << 9)   /* local attention on the exact-fp32 MFMA kernels */
+#define SA_DBG_SCAN_EXACT_SHIFT  10          /* 3 bits: chunk states | scan A outputs | scan B outputs on the exact-fp32 MFMA kernels */
+uint32_t sa_get_debug_flags(void);
+uint32_t sa_set_debug_flags(uint32_t flags);
+
 /* ---- weights: reference layout (fp32 nn.Parameter) -> packed [CoutPad][Kpad] GEMM operand ------------------------
  * element (row r, reduce channel c, tap t) is read at  w[r*s_row + c*s_red + tap_lut[t]]  (tap_lut NULL = identity).
  * Conv3d weight [Co,Ci,k,k,k] (baseline.py:218): s_row=Ci*T, s_red=T.  ConvTranspose3d weight [Ci,Co,k,k,k]

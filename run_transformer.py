@@ -48,7 +48,7 @@ def build(cfg, dims, dev):
     ordering = Ordering(ordering_type=cfg["ordering_type"], spatial_dims=len(dims), dimensions=(1,) + tuple(dims),
                         reflected_spatial_dims=cfg["reflected_spatial_dims"], transpositions_axes=cfg["transpositions_axes"],
                         rot90_axes=cfg["rot90_axes"], transformation_order=cfg["transformation_order"])
-    net = Performer(num_tokens=cfg["vocab_size"] + 1, max_seq_len=int(np.prod(dims)), dim=cfg["n_embd"], depth=cfg["n_layers"], heads=cfg["n_head"],
+    net = Performer(num_tokens=cfg["vocab_size"] + 1, max_seq_len=int(np.prod(dims)) + 1, dim=cfg["n_embd"], depth=cfg["n_layers"], heads=cfg["n_head"],
                     ordering=ordering, local_attn_heads=cfg["local_attn_heads"], local_window_size=cfg["local_window_size"],
                     feature_redraw_interval=cfg["feature_redraw_interval"], generalized_attention=cfg["generalized_attention"],
                     emb_dropout=cfg["emb_dropout"], ff_dropout=cfg["ff_dropout"], attn_dropout=cfg["attn_dropout"], use_rezero=cfg["use_rezero"],

@@ -1008,7 +1008,7 @@ static int launch_fprop(const FpropArgs& a, hipStream_t st) {
 // the halo mainloop applies to 3x3x3 / stride 1 / `same` geometry (forward, and the data gradient with the taps reversed)
 static bool halo_eligible(const FpropArgs& a, int sz) {
     const sa_conv_geom& g = a.g;
-    const bool off = getenv("SA_NO_HALO") != nullptr;  // (read per launch: the tests flip it)
+    const bool off = dbg(SA_DBG_NO_HALO);
     if (off || a.in_bytes == 0 || g.cout_valid <= 64 || ((size_t)g.Cin * sz) % 128 != 0) return false;
     for (int d = 0; d < 3; ++d) {
         if (g.KT[d] != 3 || g.in_mult[d] != 1 || g.out_mult[d] != 1 || g.out_off[d] != 0) return false;
@@ -1029,11 +1029,8 @@ static int launch_fprop_halo(FpropArgs a, hipStream_t st) {
     a.nblk_m = (uint32_t)a.g.N * (uint32_t)a.g.Dm * a.HP * a.WP;
     const uint32_t nbn_valid = ((uint32_t)a.g.cout_valid + 127) / 128;
     const size_t pipe = 2 * 23 * 1024 + 2 * 128 * 128, epi = (size_t)128 * (128 + 4) * 4 + 128 * 8;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)conv_fprop_halo_kernel<T, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};   // one bit per device (one static per template instance)
+    if (first_use_on_device(attr_done)) hipFuncSetAttribute((const void*)conv_fprop_halo_kernel<T, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo_kernel<%s, %s>", tname<T>(), FUSE ? "true" : "false");
     hipLaunchKernelGGL((conv_fprop_halo_kernel<T, FUSE>), dim3(a.nblk_m * nbn_valid), dim3(256), pipe > epi ? pipe : epi, st, a);
     SA_CHECK_LAUNCH();
@@ -1043,7 +1040,7 @@ static int launch_fprop_halo(FpropArgs a, hipStream_t st) {
 // the 256-voxel variant: register epilogue only (full, aligned 128-channel tiles), 16 x 16 patches that tile the plane well
 static bool halo256_eligible(const FpropArgs& a, int sz) {
     const sa_conv_geom& g = a.g;
-    if (getenv("SA_NO_HALO256") != nullptr || !halo_eligible(a, sz)) return false;
+    if (dbg(SA_DBG_NO_HALO256) || !halo_eligible(a, sz)) return false;
     if (g.cout_valid % 128 != 0 || (g.Cout & 7) != 0) return false;
     const int hp = (g.Ho + 15) / 16, wp = (g.Wo + 15) / 16;
     const double eff = (double)g.Ho * g.Wo / ((double)hp * 16 * wp * 16);
@@ -1057,11 +1054,8 @@ static int launch_fprop_halo256(FpropArgs a, hipStream_t st) {
     a.nblk_m = (uint32_t)a.g.N * (uint32_t)a.g.Dm * a.HP * a.WP;
     const uint32_t nbn = (uint32_t)a.g.cout_valid / 128;
     const size_t lds = 41 * 1024 + 2 * 128 * 128;   // 73 KiB (>= the 64 KiB hidden tile of the fused variant)
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)conv_fprop_halo256_kernel<T, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};   // one bit per device (one static per template instance)
+    if (first_use_on_device(attr_done)) hipFuncSetAttribute((const void*)conv_fprop_halo256_kernel<T, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo256_kernel<%s, %s>", tname<T>(), FUSE ? "true" : "false");
     hipLaunchKernelGGL((conv_fprop_halo256_kernel<T, FUSE>), dim3(a.nblk_m * nbn), dim3(256), lds, st, a);
     SA_CHECK_LAUNCH();
@@ -1080,7 +1074,7 @@ static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
         // empty (528 blocks on 512 slots = two rounds).  128 x 64 tiles need 48 KiB of LDS -> three blocks per CU (768 slots) and half the
         // work per block: N = 1024 takes ~1 unit instead of 2.  SA_NO_SMALL_TILES=1 keeps the wide tiles.
         const uint64_t blocks128 = (uint64_t)a.nblk_m * (((uint32_t)cv + 127u) / 128u);
-        static const bool small_ok = getenv("SA_NO_SMALL_TILES") == nullptr;
+        const bool small_ok = !dbg(SA_DBG_NO_SMALL_TILES);
         if (small_ok && blocks128 < 2048 && a.in_bytes != 0) return launch_fprop<T, 4, 1, 2, 4>(a, st);
         return launch_fprop<T, 2, 2, 4, 4>(a, st);
     }
@@ -1124,14 +1118,11 @@ extern "C" int sa_conv_fprop(const sa_conv_geom* g, int dtype, const void* in, c
     a.w2pk = nullptr;
     a.bias1 = nullptr;
     a.h_out = nullptr;
-    {
-        const char* d = getenv("SA_PP_DBG");
-        a.dbg = d ? (uint32_t)atoi(d) : 0u;
-    }
+    a.dbg = g_tunables.pp_dbg;
     {
         const int sz = dtype == SA_F32 ? 4 : 2;
         const uint64_t ib = (uint64_t)g->N * g->Di * g->Hi * g->Wi * g->Cin * sz, wb = (uint64_t)g->CoutPad * g->Kpad * sz;
-        const bool fits = ib < 0xfffffff0ull - 4096 && wb < 0xfffffff0ull && getenv("SA_NO_DMA") == nullptr;
+        const bool fits = ib < 0xfffffff0ull - 4096 && wb < 0xfffffff0ull && !dbg(SA_DBG_NO_DMA);
         a.in_bytes = fits ? (uint32_t)ib : 0u;
         a.w_bytes = fits ? (uint32_t)wb : 0u;
     }
@@ -1179,7 +1170,7 @@ extern "C" int sa_resblock_fprop(const sa_conv_geom* g, int dtype, const void* x
     a.bias1 = bias1;
     a.h_out = h_out;
     a.dbg = 0;
-    if (halo256_eligible(a, 2) && getenv("SA_NO_HALO256_FUSE") == nullptr) return launch_fprop_halo256<bf16_t, true>(a, (hipStream_t)stream);
+    if (halo256_eligible(a, 2) && !dbg(SA_DBG_NO_HALO256_FUSE)) return launch_fprop_halo256<bf16_t, true>(a, (hipStream_t)stream);
     if (halo_eligible(a, 2)) return launch_fprop_halo<bf16_t, true>(a, (hipStream_t)stream);
     const size_t pipe = 2 * (128 + 128) * 128, epi = (size_t)128 * (128 + 4) * 4 + 128 * 8;
     snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma_kernel<unsigned short, 2, 2, 4, 4, true, true>");

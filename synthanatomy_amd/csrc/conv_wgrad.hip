@@ -957,12 +957,12 @@ static int plan_wgrad(const sa_conv_geom* g, int dtype, WgradArgs& a, uint32_t& 
     a.ntiles = a.nkt * nct;
     // split so that one block streams ~10k voxels (SA_WGRAD_ROWS): short ranges keep the (tap, co) tiles sharing a range in lockstep
     // inside one XCD L2; at least ~1024 blocks to fill the chip, at most 2 GiB of partial tiles
-    static const int target_rows = getenv("SA_WGRAD_ROWS") ? atoi(getenv("SA_WGRAD_ROWS")) : 10240;
+    const int target_rows = g_tunables.wgrad_rows;
     const uint32_t want_cps = (uint32_t)(target_rows / mk) ? (uint32_t)(target_rows / mk) : 1u;
     splits = (a.nchunks + want_cps - 1) / want_cps;
     // dense layers (one tap: the Performer's M = 8 400 rows) do better with ~512 blocks of twice the range -- half the partial tiles to write
     // and reduce (measured 213 -> 191 us per layer over its four weight gradients); the convolutions measured better at 1024
-    static const uint32_t env_blocks = getenv("SA_WGRAD_MIN_BLOCKS") ? (uint32_t)atoi(getenv("SA_WGRAD_MIN_BLOCKS")) : 0u;
+    const uint32_t env_blocks = (uint32_t)g_tunables.wgrad_min_blocks;
     const uint32_t min_blocks = env_blocks ? env_blocks : ((ntaps == 1 && a.nchunks <= 1024u) ? 512u : 1024u);   // (long 1x1x1 reductions: 1024 again)
     const uint32_t min_splits = (min_blocks + a.ntiles - 1) / a.ntiles;
     if (splits < min_splits) splits = min_splits;
@@ -977,7 +977,7 @@ static int plan_wgrad(const sa_conv_geom* g, int dtype, WgradArgs& a, uint32_t& 
     // halo kernel: 3x3x3 / stride 1 / same, bf16, 128 input channels, both operands addressable with 32-bit offsets
     a.halo = 0;
     {
-        bool ok = dtype == SA_BF16 && g->Cin == 128 && g->cin_valid == 128 && g->Cout % 128 == 0 && getenv("SA_NO_HALO") == nullptr && getenv("SA_NO_DMA") == nullptr;
+        bool ok = dtype == SA_BF16 && g->Cin == 128 && g->cin_valid == 128 && g->Cout % 128 == 0 && !dbg(SA_DBG_NO_HALO) && !dbg(SA_DBG_NO_DMA);
         for (int d = 0; d < 3 && ok; ++d)
             ok = g->KT[d] == 3 && g->in_mult[d] == 1 && g->tap_step[d] == 1 && g->in_off[d] == -1 && g->out_mult[d] == 1 && g->out_off[d] == 0;
         ok = ok && g->Dm == g->Do && g->Hm == g->Ho && g->Wm == g->Wo && g->Di == g->Do && g->Hi == g->Ho && g->Wi == g->Wo;
@@ -985,7 +985,7 @@ static int plan_wgrad(const sa_conv_geom* g, int dtype, WgradArgs& a, uint32_t& 
         ok = ok && ib < 0xffffff00ull - (1u << 20) && gb < 0xffffff00ull - (1u << 20);
         if (ok) {
             // nine-tap kernel (steps of 8 x 16 voxels) by default; SA_WGRAD_HALO9=0 -> the three-tap kernel (steps of 4 x 16)
-            static const bool nine = !(getenv("SA_WGRAD_HALO9") && atoi(getenv("SA_WGRAD_HALO9")) == 0);
+            const bool nine = !dbg(SA_DBG_NO_WGRAD_HALO9);
             const uint32_t phs = nine ? 8u : 4u;
             const uint32_t hq = (uint32_t)(g->Ho + phs - 1) / phs, wp = (uint32_t)(g->Wo + 15) / 16;
             const double eff = (double)g->Ho * g->Wo / ((double)hq * phs * wp * 16);
@@ -997,7 +997,7 @@ static int plan_wgrad(const sa_conv_geom* g, int dtype, WgradArgs& a, uint32_t& 
                 a.nsteps = (uint32_t)nsteps;
                 a.dWP = make_fastdiv(wp);
                 a.dHQ = make_fastdiv(hq);
-                static const int want = getenv("SA_WGRAD_HALO_SPLITS") ? atoi(getenv("SA_WGRAD_HALO_SPLITS")) : (nine ? 128 : 256);
+                const int want = g_tunables.wgrad_halo_splits ? g_tunables.wgrad_halo_splits : (nine ? 128 : 256);
                 uint32_t sp = (uint32_t)want;
                 if (sp > a.nsteps / 16) sp = a.nsteps / 16;   // at least 16 steps per block
                 if (sp < 1) sp = 1;
@@ -1048,11 +1048,11 @@ static int conv_wgrad_impl(const sa_conv_geom* g, int dtype, const void* in, con
     {
         const int sz = dtype == SA_F32 ? 4 : 2;
         const uint64_t ib = (uint64_t)g->N * g->Di * g->Hi * g->Wi * g->Cin * sz, gb = (uint64_t)g->N * g->Do * g->Ho * g->Wo * g->Cout * sz;
-        const bool fits = ib < 0xffffff00ull && gb < 0xffffff00ull && getenv("SA_NO_DMA") == nullptr;
+        const bool fits = ib < 0xffffff00ull && gb < 0xffffff00ull && !dbg(SA_DBG_NO_DMA);
         a.in_bytes = fits ? (uint32_t)ib : 0u;
         a.g_bytes = fits ? (uint32_t)gb : 0u;
     }
-    const bool fuse_db = db && dtype == SA_BF16 && getenv("SA_NO_FUSED_DB") == nullptr;   // the bf16 LDS-DMA kernels sum the gradient tile they stage
+    const bool fuse_db = db && dtype == SA_BF16 && !dbg(SA_DBG_NO_FUSED_DB);   // the bf16 LDS-DMA kernels sum the gradient tile they stage
     a.dg_wpk = dg_wpk;
     a.dg_out = dg_out;
     if (dg_out) {  // fused 1x1x1 data gradient: only the bf16 LDS-DMA kernel, one (tap, co) tile, rows = voxels
@@ -1063,11 +1063,10 @@ static int conv_wgrad_impl(const sa_conv_geom* g, int dtype, const void* in, con
         hipLaunchKernelGGL((conv_wgrad_dma_kernel<bf16_t, true>), grid, dim3(256), lds, st, a);
     } else if (a.halo && a.ws) {
         if (fuse_db) a.db = db;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static std::atomic<uint64_t> attr_done{0};   // one bit per device
+        if (first_use_on_device(attr_done)) {
             hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024);
             hipFuncSetAttribute((const void*)conv_wgrad_halo9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 55 * 1024);
-            attr_done = true;
         }
         const uint32_t nct = a.ntiles / a.nkt, spx = (splits + 7u) / 8u;
         if (a.halo == 9) {

@@ -394,7 +394,7 @@ extern "C" int sa_convt1_im2col(const float* g, int dtype, void* gc, float* db, 
     a.g = g; a.gc = gc; a.db = db;
     unsigned blocks = (unsigned)(((uint64_t)a.cells * 16u + 255u) / 256u);
     if (blocks > 4096u) blocks = 4096u;   // one atomic per block for db
-    if (dtype == SA_BF16 && getenv("SA_IM2COL_DIRECT") == nullptr) {   // gather through an LDS tile, coalesced on both sides (csrc/conv1.hip)
+    if (dtype == SA_BF16 && !dbg(SA_DBG_IM2COL_DIRECT)) {   // gather through an LDS tile, coalesced on both sides (csrc/conv1.hip)
         const int rc = conv1_im2col_bf16(g, gc, db, N, D, H, W, (hipStream_t)stream);
         if (rc != SA_EUNSUPPORTED) return rc;
     }

@@ -6,6 +6,30 @@ namespace sa {
 thread_local hipError_t g_last_error = hipSuccess;
 thread_local char g_last_conv_kernel[128] = "";
 
+static uint32_t flags_from_env() {
+    auto on = [](const char* n) { return getenv(n) != nullptr; };
+    auto num = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+    uint32_t f = 0;
+    if (on("SA_NO_HALO")) f |= SA_DBG_NO_HALO;
+    if (on("SA_NO_HALO256")) f |= SA_DBG_NO_HALO256;
+    if (on("SA_NO_HALO256_FUSE")) f |= SA_DBG_NO_HALO256_FUSE;
+    if (on("SA_NO_DMA")) f |= SA_DBG_NO_DMA;
+    if (on("SA_NO_SMALL_TILES")) f |= SA_DBG_NO_SMALL_TILES;
+    if (on("SA_NO_FUSED_DB")) f |= SA_DBG_NO_FUSED_DB;
+    if (getenv("SA_WGRAD_HALO9") && num("SA_WGRAD_HALO9", 1) == 0) f |= SA_DBG_NO_WGRAD_HALO9;
+    if (on("SA_IM2COL_DIRECT")) f |= SA_DBG_IM2COL_DIRECT;
+    if (on("SA_SCAN_VALU")) f |= SA_DBG_SCAN_VALU;
+    if (num("SA_LOCAL_ATTN_EXACT", 0) == 1) f |= SA_DBG_LOCAL_ATTN_EXACT;
+    f |= ((uint32_t)num("SA_SCAN_EXACT", 0) & 7u) << SA_DBG_SCAN_EXACT_SHIFT;
+    return f;
+}
+static Tunables tunables_from_env() {
+    auto num = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+    return Tunables{num("SA_WGRAD_ROWS", 10240), num("SA_WGRAD_MIN_BLOCKS", 0), num("SA_WGRAD_HALO_SPLITS", 0), (uint32_t)num("SA_PP_DBG", 0)};
+}
+std::atomic<uint32_t> g_debug_flags{flags_from_env()};
+const Tunables g_tunables = tunables_from_env();
+
 struct PackArgs {
     const float* w;
     void* wpk;
@@ -135,6 +159,8 @@ static inline unsigned grid_for(int64_t n, int block = 256, unsigned cap = 4096)
 extern "C" int sa_abi_version(void) { return SA_ABI_VERSION; }
 extern "C" const char* sa_last_error(void) { return hipGetErrorString(sa::g_last_error); }
 extern "C" const char* sa_last_conv_kernel(void) { return sa::g_last_conv_kernel; }
+extern "C" uint32_t sa_get_debug_flags(void) { return sa::g_debug_flags.load(); }
+extern "C" uint32_t sa_set_debug_flags(uint32_t flags) { return sa::g_debug_flags.exchange(flags); }
 
 extern "C" int sa_pack_weights(const float* w, void* wpk, int dtype, int rows, int red, int ntaps, const int32_t* tap_lut_host, int64_t s_row,
                                int64_t s_red, int rows_pad, int red_stride, int Kpad, void* stream) {

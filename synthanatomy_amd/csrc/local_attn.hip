@@ -567,10 +567,7 @@ __global__ __launch_bounds__(256) void local_attn_kv_split_kernel(const LAArgs a
     }
 }
 
-static bool la_exact() {
-    const char* e = getenv("SA_LOCAL_ATTN_EXACT");
-    return e && e[0] == '1';
-}
+static bool la_exact() { return dbg(SA_DBG_LOCAL_ATTN_EXACT); }
 
 static int fill_la(LAArgs& a, int q_stride, int q_off, int k_stride, int k_off, int v_stride, int v_off, int o_stride, int o_off, int B, int N, int L, int W,
                    int dh) {

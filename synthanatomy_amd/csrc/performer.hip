@@ -1874,7 +1874,7 @@ extern "C" int64_t sa_favor_scan_workspace_bytes(int B, int N, int G, int LDF, i
 // which == 0: scan A, 1: scan B.  With a workspace: chunked MFMA path (3 launches); without: one VALU block per (b, g).
 template <typename K>
 static int run_scan(K valu_kernel, int which, ScanArgs& s, unsigned base_blocks, float* ws, hipStream_t st) {
-    static const bool no_mfma = getenv("SA_SCAN_VALU") != nullptr;
+    const bool no_mfma = dbg(SA_DBG_SCAN_VALU);
     if (!ws) {
         s.S = 1; s.seg_len = s.N; s.pass = 0; s.state = nullptr;
         hipLaunchKernelGGL(valu_kernel, dim3(base_blocks), dim3(256), 0, st, s);
@@ -1892,8 +1892,7 @@ static int run_scan(K valu_kernel, int which, ScanArgs& s, unsigned base_blocks,
         s.S = (s.N + 63) / 64;
         s.seg_len = 64;
         const unsigned nblk = (unsigned)(bg * s.S);
-        const char* ex = getenv("SA_SCAN_EXACT");
-        const int exact = (ex ? atoi(ex) : 0) | (s.exact ? 7 : 0);   // bit 0: state sums, bit 1: scan A outputs, bit 2: scan B outputs on the exact-fp32 MFMA kernels
+        const int exact = (int)((g_debug_flags.load(std::memory_order_relaxed) >> SA_DBG_SCAN_EXACT_SHIFT) & 7u) | (s.exact ? 7 : 0);   // bit 0: state sums, bit 1: scan A outputs, bit 2: scan B outputs on the exact-fp32 MFMA kernels
         const bool fits32 = (int64_t)s.N * s.G * s.LDF * 4 < ((int64_t)1 << 31) && (int64_t)s.N * std::max(s.b_stride, std::max(s.c_stride, s.y_stride)) * 4 < ((int64_t)1 << 31);
         if (!s.state_ready) {
             if (!(exact & 1) && fits32) hipLaunchKernelGGL(favor_chunk_state_split_kernel, dim3(nblk), dim3(256), 0, st, s);

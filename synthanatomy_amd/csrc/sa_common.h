@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/synthanatomy_hip.h"
 
 namespace sa {
@@ -13,6 +15,22 @@ typedef __attribute__((ext_vector_type(4))) float float4_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 extern thread_local hipError_t g_last_error;
+// Process-wide developer switches (SA_DBG_* bits of include/synthanatomy_hip.h).  Read ONCE from the environment when the library is
+// loaded; afterwards only sa_set_debug_flags() changes them.  No launch reads the environment.
+extern std::atomic<uint32_t> g_debug_flags;
+inline bool dbg(uint32_t bit) { return (g_debug_flags.load(std::memory_order_relaxed) & bit) != 0; }
+struct Tunables { int wgrad_rows, wgrad_min_blocks, wgrad_halo_splits; uint32_t pp_dbg; };
+extern const Tunables g_tunables;   // numeric developer knobs (SA_WGRAD_ROWS, SA_WGRAD_MIN_BLOCKS, SA_WGRAD_HALO_SPLITS, SA_PP_DBG), read once at load
+// hipFuncSetAttribute is per device: `mask` holds one bit per device ordinal that has been configured (setting twice is harmless, so the
+// race between two host threads is benign)
+inline bool first_use_on_device(std::atomic<uint64_t>& mask) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const uint64_t bit = 1ull << (d & 63);
+    if (mask.load(std::memory_order_acquire) & bit) return false;
+    mask.fetch_or(bit, std::memory_order_acq_rel);
+    return true;
+}
 // name of the convolution kernel instance the last sa_conv_fprop / sa_resblock_fprop / sa_conv_wgrad call launched (rocprofv3 spelling)
 extern thread_local char g_last_conv_kernel[128];
 template <typename T> inline const char* tname() { return sizeof(T) == 4 ? "float" : "unsigned short"; }

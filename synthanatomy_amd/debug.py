@@ -1,0 +1,54 @@
+"""Developer switches: alternative kernels / launch plans for the SAME result (A/B timing, cross-family parity tests).
+
+Two kinds, both read from the environment ONCE (library load / module import) and afterwards changed only through ``override``:
+
+* library flags -- the ``SA_DBG_*`` word of include/synthanatomy_hip.h (``sa_set_debug_flags``): which HIP kernel a launcher picks;
+* host switches -- which launch plan the Python chains pick (fused residual block vs two launches, ...).
+
+    with debug.override(no_halo=True, no_fused_res=True):
+        y_ref = stage.fwd(x, None)
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+
+LIB_FLAGS = dict(no_halo=1 << 0, no_halo256=1 << 1, no_halo256_fuse=1 << 2, no_dma=1 << 3, no_small_tiles=1 << 4, no_fused_db=1 << 5,
+                 no_wgrad_halo9=1 << 6, im2col_direct=1 << 7, scan_valu=1 << 8, local_attn_exact=1 << 9)
+SCAN_EXACT_SHIFT = 10   # scan_exact=0..7
+
+_HOST_ENV = dict(no_fused_res="SA_NO_FUSED_RES", no_fused_1x1_bwd="SA_NO_FUSED_1X1_BWD", no_conv1_gemm="SA_NO_CONV1_GEMM",
+                 no_conv1_fused="SA_NO_CONV1_FUSED", convt1_direct="SA_CONVT1_DIRECT", no_batched_pack="SA_NO_BATCHED_PACK",
+                 no_fused_sums="SA_NO_FUSED_SUMS", no_fused_qkv="SA_NO_FUSED_QKV", no_strided_halo="SA_NO_STRIDED_HALO",
+                 no_step_graph="SA_NO_STEP_GRAPH")
+_host = {k: os.environ.get(v) is not None for k, v in _HOST_ENV.items()}
+
+
+def host(name: str) -> bool:
+    return _host[name]
+
+
+@contextlib.contextmanager
+def override(**kw):
+    """Temporarily set switches (library flags, ``scan_exact=<0..7>`` and host switches) for the calling process."""
+    from . import _ffi
+    lib = _ffi.lib()
+    old_flags = lib.sa_get_debug_flags()
+    flags = old_flags
+    old_host = dict(_host)
+    for k, v in kw.items():
+        if k in LIB_FLAGS:
+            flags = (flags | LIB_FLAGS[k]) if v else (flags & ~LIB_FLAGS[k])
+        elif k == "scan_exact":
+            flags = (flags & ~(7 << SCAN_EXACT_SHIFT)) | ((int(v) & 7) << SCAN_EXACT_SHIFT)
+        elif k in _host:
+            _host[k] = bool(v)
+        else:
+            raise KeyError(f"unknown debug switch {k!r}")
+    lib.sa_set_debug_flags(flags)
+    try:
+        yield
+    finally:
+        lib.sa_set_debug_flags(old_flags)
+        _host.clear()
+        _host.update(old_host)

@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import torch
 
-from . import _ffi
+from . import _ffi, debug
 from ._ffi import ACT_NONE, MASK_NONE, ConvGeom, Epilogue
 
 
@@ -336,7 +336,7 @@ class PackSet:
         self._blocks = 0
 
     def repack(self, ops: Sequence["ConvOp"]):
-        if os.environ.get("SA_NO_BATCHED_PACK") is not None:
+        if debug.host("no_batched_pack"):
             return
         items = [(op, key, ent) for op in ops for key, ent in op._packs.items() if ent[0].device == op.weight.device]
         if not items:
@@ -369,7 +369,7 @@ def conv1x1_backward(op: "ConvOp", x: torch.Tensor, g: torch.Tensor, dw: torch.T
     """Weight, bias and (ReLU-masked) data gradient of a 1x1x1 128 -> 128 bf16 convolution in one launch (sa_conv1x1_backward); returns dx,
     or None when the layer is not of that shape (the caller then uses wgrad + dgrad)."""
     if not (op.kind == "conv" and op.k == 1 and op.cin == 128 and op.cout == 128 and op.dtype == torch.bfloat16 and op.w_strides is None
-            and os.environ.get("SA_NO_FUSED_1X1_BWD") is None and x.numel() * 2 < 0xffffff00 - (1 << 20)):
+            and not debug.host("no_fused_1x1_bwd") and x.numel() * 2 < 0xffffff00 - (1 << 20)):
         return None
     N, D, H, W, C = x.shape
     assert x.dtype == op.dtype and g.dtype == op.dtype and x.is_contiguous() and g.is_contiguous() and g.shape == x.shape

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ... import _ffi
+from ... import _ffi, debug
 from ..._ffi import MASK_GELU
 from ...engine import ConvOp, PackSet
 from .img2seq_ordering import Ordering
@@ -281,8 +281,8 @@ class _LayerEngine:
         self.ops = {n: _lin(getattr(sa, n), dtype) for n in ("to_q", "to_k", "to_v", "to_out")}
         self.ops["w1"], self.ops["w2"] = _lin(ff.w1, dtype), _lin(ff.w2, dtype)
         self._pscaled = None
-        self._fused_sums = os.environ.get("SA_NO_FUSED_SUMS") is None
-        self._no_fused_qkv = os.environ.get("SA_NO_FUSED_QKV") is not None
+        self._fused_sums = not debug.host("no_fused_sums")
+        self._no_fused_qkv = debug.host("no_fused_qkv")
         # state_flags bit 2 of the fused scans: fp32 (parity) mode keeps every product on the exact-fp32 MFMA; the bf16 throughput mode uses the
         # split-bf16 kernels (~1e-5 relative, far below the rounding of its dense layers)
         self._xf = 4 if dtype == torch.float32 else 0
@@ -903,7 +903,19 @@ class Performer(TransformerBase):
         self.performer.fix_projection_matrices_()
 
     def set_grad_sink(self, sink):
+        """Route weight gradients into a ``runtime.ddp.GradReducer``.  The layer stack reports each parameter as its gradient kernels are queued;
+        the parameters outside it (embeddings, final LayerNorm, vocabulary projection) get their gradients from autograd, which accumulates
+        them into the flat buffer, so they report from a post-accumulate hook -- otherwise the bucket holding the LAST parameters (the first
+        one backward completes) would only be reduced in ``finish()`` with nothing left to overlap."""
         self._chain.grad_sink = sink
+        for h in getattr(self, "_sink_hooks", []):
+            h.remove()
+        self._sink_hooks = []
+        if sink is not None:
+            in_chain = {id(p) for p in self._chain.params()}
+            for p in self.parameters():
+                if p.requires_grad and id(p) not in in_chain:
+                    self._sink_hooks.append(p.register_post_accumulate_grad_hook(lambda q, s=sink: s.ready(q)))
 
     def invalidate_packed_weights(self):
         self._chain.invalidate()

@@ -21,7 +21,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from ... import _ffi
+from ... import _ffi, debug
 from ..._ffi import ACT_NONE, ACT_RELU, MASK_NONE, MASK_POS
 from ...engine import ConvOp, PackSet, _launch, cast_pad, vec_of
 from .vqvae import VQVAEBase
@@ -112,7 +112,8 @@ class _VQFn(torch.autograd.Function):
             with torch.cuda.stream(q._side):
                 q._side.wait_event(ready)
                 if use_dist:
-                    dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=q.process_group)
+                    from ...runtime.ddp import all_reduce_sum
+                    all_reduce_sum(stats, q.process_group)
                 _ffi.check(lib.sa_vq_ema_update(_ffi.ptr(q.N), _ffi.ptr(q.embed_avg), _ffi.ptr(cb), _ffi.ptr(counts), _ffi.ptr(dw), K, D, decay, q.eps,
                                                 _ffi.stream()), "sa_vq_ema_update")
                 done = torch.cuda.Event()
@@ -260,13 +261,13 @@ class _Conv1Stage:
     def fwd(self, x, tape):
         """x: the raw fp32 volume [N, D, H, W]."""
         N, D, H, W = x.shape
-        if D % 2 or H % 2 or W % 2 or N * (D // 2) * (H // 2) * (W // 2) < self.GEMM_MIN_CELLS or os.environ.get("SA_NO_CONV1_GEMM") is not None:   # generic stage
+        if D % 2 or H % 2 or W % 2 or N * (D // 2) * (H // 2) * (W // 2) < self.GEMM_MIN_CELLS or debug.host("no_conv1_gemm"):   # generic stage
             vec = vec_of(self.dtype)
             return self.fallback.fwd(cast_pad(x.unsqueeze(-1), self.dtype, vec), tape)
         self._sync()
         lib, st = _ffi.lib(), _ffi.stream()
         Do, Ho, Wo, cout = D // 2, H // 2, W // 2, self.op.cout
-        if self.dtype == torch.bfloat16 and cout == 128 and os.environ.get("SA_NO_CONV1_FUSED") is None:
+        if self.dtype == torch.bfloat16 and cout == 128 and not debug.host("no_conv1_fused"):
             # csrc/conv1.hip: taps gathered into LDS straight from the volume; nothing but the output touches HBM
             wpk = self.op.packed_fwd_operand(N, (Do, Ho, Wo))
             y = torch.empty((N, Do, Ho, Wo, cout), dtype=self.dtype, device=x.device)
@@ -328,7 +329,7 @@ class _ConvT1Stage:
         self.taps_fwd.weight = self.taps_bwd.weight = self.mod.weight
 
     def _gemm(self, x):
-        return x.numel() // 128 >= self.GEMM_MIN_CELLS and os.environ.get("SA_CONVT1_DIRECT") is None
+        return x.numel() // 128 >= self.GEMM_MIN_CELLS and not debug.host("convt1_direct")
 
     def fwd(self, x, tape):
         N, D, H, W, C = x.shape
@@ -381,7 +382,7 @@ class _ResStage:
 
     def _fused_ok(self, x):
         return (self.dtype == torch.bfloat16 and self.c3.cin == 128 and self.c3.cout == 128 and self.c1.cout == 128
-                and x.numel() * 2 < 0xfffffff0 - 4096 and os.environ.get("SA_NO_FUSED_RES") is None)
+                and x.numel() * 2 < 0xfffffff0 - 4096 and not debug.host("no_fused_res"))
 
     def _fwd_fused(self, x, need_h):
         """3x3x3 conv + ReLU + 1x1x1 conv + residual + ReLU in one launch (csrc/conv_fprop.hip, FUSE=true)."""

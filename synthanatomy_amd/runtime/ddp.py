@@ -38,6 +38,33 @@ def init_distributed(backend: Optional[str] = None):
     return rank, local, world
 
 
+_HOST_STAGED = {}   # backend name -> True when collectives on device tensors must be staged through host memory
+
+
+def all_reduce_sum(t: torch.Tensor, group=None):
+    """SUM all-reduce of `t` in place on the CURRENT stream.  RCCL ("nccl") reduces device memory directly.  The gloo backend is only used
+    by the tests that run several ranks on ONE device (RCCL refuses duplicate devices): it reduces device tensors through its own pinned
+    staging when the build supports that, else through an explicit host copy here."""
+    if not t.is_cuda or dist.get_backend(group) != "gloo":
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return
+    staged = _HOST_STAGED.get("gloo")
+    if staged is None:
+        try:
+            probe = torch.zeros(1, device=t.device)
+            dist.all_reduce(probe, op=dist.ReduceOp.SUM, group=group)
+            staged = False
+        except RuntimeError:
+            staged = True
+        _HOST_STAGED["gloo"] = staged
+    if not staged:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return
+    h = t.detach().cpu()          # synchronises the current stream: everything queued before the collective has been produced
+    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+    t.copy_(h)
+
+
 class GradReducer:
     def __init__(self, flat: FlatParams, bucket_bytes: int = 32 << 20, process_group=None):
         self.flat, self.group = flat, process_group
@@ -61,6 +88,9 @@ class GradReducer:
         self._pending = None
         self._side = None
         self._works = []
+        self.timing = False      # bench.py: record HIP events around every bucket's collective and around the wait in finish()
+        self._ev = []            # per finished step: (bucket (start, end) events on the side stream, main-stream arrival, side-stream end)
+        self._bucket_ev = []
         self.reset()
 
     def reset(self):
@@ -94,7 +124,14 @@ class GradReducer:
             ev.record()
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ev)
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                if self.timing:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                all_reduce_sum(view, self.group)
+                if self.timing:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    self._bucket_ev.append((e0, e1))
         else:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -106,8 +143,28 @@ class GradReducer:
                 self._pending[b] = 0
                 self._launch(b)
         if self._side is not None:
+            if self.timing and self._bucket_ev:
+                arrive = torch.cuda.Event(enable_timing=True)
+                arrive.record()                      # the main stream has queued everything of backward and now has to wait
+                self._ev.append((self._bucket_ev, arrive, self._bucket_ev[-1][1]))
+                self._bucket_ev = []
             torch.cuda.current_stream().wait_stream(self._side)
         for w in self._works:
             w.wait()
         self.reset()
         return 1.0 / self.world
+
+    def comm_stats(self):
+        """After a device synchronisation: per-step averages of the collectives' time on the side stream (`comm_ms`), the part of it the main
+        stream had to wait for after backward had been queued (`exposed_ms`) and the rest (`hidden_ms`, overlapped with backward kernels)."""
+        if not self._ev:
+            return None
+        tot = exp = 0.0
+        for buckets, arrive, end in self._ev:
+            tot += sum(a.elapsed_time(b) for a, b in buckets)
+            exp += max(0.0, arrive.elapsed_time(end))
+        n = len(self._ev)
+        self._ev = []
+        exp = min(exp, tot)
+        return {"steps": n, "comm_ms": round(tot / n, 3), "exposed_ms": round(exp / n, 3), "hidden_ms": round((tot - exp) / n, 3),
+                "buckets": len(self.buckets), "bytes_per_step": int(self.flat.numel * 4)}

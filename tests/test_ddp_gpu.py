@@ -1,0 +1,173 @@
+"""GPU, world_size 2 on ONE MI355X: the PRODUCT's data-parallel path -- ``BaselineVQVAE`` / ``Performer`` training steps with
+``GradReducer`` as the gradient sink (wgrad kernels writing into the flat buffer while bucket collectives are in flight on the side
+stream) and the quantizer's side-stream statistics all-reduce followed by ``sa_vq_ema_update`` -- against the single-rank run on the
+full batch.  RCCL refuses two ranks on one device, so the process group is gloo over device tensors (``runtime.ddp.all_reduce_sum``);
+everything else is the code path `bench.py --gpus N` and the CLIs run.
+
+Reference behaviour matched: run_vqvae.py:71-77 (DDP wrap, gradient averaging), src/networks/vqvae/baseline.py:66-80 (statistics SUMMED
+over ranks before the EMA update), run_transformer.py:98-105 (projection matrices agree on every rank)."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+VQ = dict(n_levels=2, downsample_parameters=((4, 2, 1, 1),) * 2, upsample_parameters=((4, 2, 1, 0, 1),) * 2, n_embed=64, embed_dim=16, n_channels=32,
+          n_res_channels=32, n_res_layers=1)
+STEPS = 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _vqvae_steps(rank, world, dtype=torch.float32):
+    """STEPS training steps on this rank's slice of the seeded global batch; returns host copies of everything a rank must agree on."""
+    from oracle import vqvae_ref   # initial weights only (seeded init shared by all ranks); the arithmetic below is the HIP path
+    from synthanatomy_amd.losses.vqvae import MSELoss
+    from synthanatomy_amd.networks.vqvae.baseline import BaselineVQVAE
+    from synthanatomy_amd.runtime.ddp import GradReducer
+    from synthanatomy_amd.runtime.optim import FlatParams, FusedAdam
+
+    cfg = vqvae_ref.VQVAEConfig(**VQ)
+    st = vqvae_ref.init_state(cfg, seed=3)
+    net = BaselineVQVAE(**VQ, compute_dtype=dtype)
+    net.load_state_dict({k: v.clone() for k, v in st.items()})
+    net = net.cuda().train()
+    flat = FlatParams(net.parameters())
+    opt = FusedAdam(flat, lr=1e-3)
+    opt.on_step.append(net.invalidate_packed_weights)
+    red = GradReducer(flat, bucket_bytes=64 << 10)   # several buckets: collectives start while backward is still queueing kernels
+    red.timing = True
+    net.set_grad_sink(red)
+    g = torch.Generator().manual_seed(11)
+    xs = torch.rand(4, 1, 16, 16, 16, generator=g)
+    per = 4 // world
+    x = xs[rank * per:(rank + 1) * per].cuda()
+    loss_fn = MSELoss()
+    grads = []
+    for _ in range(STEPS):
+        flat.zero_grad()
+        out = net(x)
+        loss_fn(out, x).backward()
+        scale = red.finish()
+        torch.cuda.synchronize()
+        grads.append((flat.grad * scale).cpu())
+        opt.step(grad_scale=scale)
+    torch.cuda.synchronize()
+    sd = net.state_dict()
+    return dict(params=flat.data.cpu(), grads=grads, N=sd["quantizer.0.impl.N"].cpu(), embed_avg=sd["quantizer.0.impl.embed_avg"].cpu(),
+                weight=sd["quantizer.0.impl.weight"].cpu(), buckets=len(red.buckets), comm=red.comm_stats())
+
+
+def _performer_steps(rank, world):
+    from synthanatomy_amd.losses.transformer import CELoss
+    from synthanatomy_amd.networks.transformers.img2seq_ordering import Ordering
+    from synthanatomy_amd.networks.transformers.performer import FastAttention, Performer
+    from synthanatomy_amd.runtime.ddp import GradReducer
+    from synthanatomy_amd.runtime.optim import FlatParams, FusedAdam
+
+    shape = (2, 3, 4)
+    n = 24
+    torch.manual_seed(5)     # identical construction (weights, first projections, redraw base seed) on every rank
+    o = Ordering("raster_scan", 3, (1,) + shape, (False,) * 3, (), ())
+    net = Performer(num_tokens=33, max_seq_len=n + 1, dim=32, depth=2, heads=4, ordering=o, dim_head=64, local_attn_heads=2, local_window_size=6,
+                    use_rezero=True, spatial_position_emb="absolute", spatial_shape=shape, feature_redraw_interval=1, compute_dtype=torch.float32)
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if k.endswith(".g"):
+                p.fill_(0.4)     # the 1e-3 init would hide the layer stack behind the residual path
+    net = net.cuda().train()
+    flat = FlatParams(net.parameters())
+    opt = FusedAdam(flat, lr=1e-3)
+    opt.on_step.append(net.invalidate_packed_weights)
+    red = GradReducer(flat, bucket_bytes=32 << 10)
+    net.set_grad_sink(red)
+    g = torch.Generator().manual_seed(12)
+    tok = torch.randint(0, 33, (4, n), generator=g)
+    tgt = torch.randint(0, 32, (4, n), generator=g)
+    per = 4 // world
+    tok, tgt = tok[rank * per:(rank + 1) * per].cuda(), tgt[rank * per:(rank + 1) * per].cuda()
+    loss_fn = CELoss()
+    projs, grads = [], []
+    for _ in range(STEPS):       # feature_redraw_interval=1: projections are redrawn before the 2nd and 3rd forward
+        flat.zero_grad()
+        loss_fn(net(tok).transpose(1, 2), tgt).backward()
+        scale = red.finish()
+        torch.cuda.synchronize()
+        grads.append((flat.grad * scale).cpu())
+        projs.append(torch.stack([m.projection_matrix.cpu() for m in net.modules() if isinstance(m, FastAttention)]))
+        opt.step(grad_scale=scale)
+    torch.cuda.synchronize()
+    return dict(params=flat.data.cpu(), grads=grads, projs=projs, buckets=len(red.buckets))
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")   # both ranks on cuda:0
+    import torch.distributed as dist
+
+    from synthanatomy_amd.runtime.ddp import init_distributed
+    r, _l, w = init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    res = dict(vq=_vqvae_steps(rank, world), perf=_performer_steps(rank, world))
+    torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _close(a, b, rtol):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30)) <= rtol
+
+
+def test_two_ranks_equal_the_single_rank_full_batch_run():
+    assert torch.cuda.is_available()
+    # single rank, full batch, no process group: the result both ranks of the sharded run must reproduce
+    full_vq = _vqvae_steps(0, 1)
+    full_pf = _performer_steps(0, 1)
+    with tempfile.TemporaryDirectory() as d:
+        ctx = mp.get_context("spawn")
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, d)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=600)
+            assert p.exitcode == 0, p.exitcode
+        ranks = [torch.load(os.path.join(d, f"rank{r}.pt"), weights_only=False) for r in range(2)]
+
+    # ---- VQ-VAE: gradients of every step, Adam-updated parameters and the EMA codebook state
+    for r in ranks:
+        vq = r["vq"]
+        assert vq["buckets"] >= 3
+        for s in range(STEPS):
+            assert _close(vq["grads"][s], full_vq["grads"][s], 1e-5), ("grad", s)
+        for k in ("N", "embed_avg", "weight"):
+            assert _close(vq[k], full_vq[k], 1e-5), k
+        # Adam normalises the update (~lr whatever the gradient's size), so rounding-level gradient differences on near-zero entries
+        # can move a parameter by a fraction of lr: absolute gate of lr / 10 per step on top of the relative one
+        assert float((vq["params"] - full_vq["params"]).abs().max()) <= STEPS * 1e-4
+        assert vq["comm"] is not None and vq["comm"]["steps"] == STEPS and vq["comm"]["comm_ms"] > 0
+    # the two ranks hold bit-identical replicas (same reduced buffers, same update kernel)
+    for k in ("params", "N", "embed_avg", "weight"):
+        assert torch.equal(ranks[0]["vq"][k], ranks[1]["vq"][k]), k
+
+    # ---- Performer: redrawn projections identical on every rank AND equal to the single-rank draw; gradients / parameters as above
+    for r in ranks:
+        pf = r["perf"]
+        assert pf["buckets"] >= 3
+        for s in range(STEPS):
+            assert torch.equal(pf["projs"][s], full_pf["projs"][s]), ("projection", s)
+            assert _close(pf["grads"][s], full_pf["grads"][s], 2e-5), ("grad", s)
+        assert float((pf["params"] - full_pf["params"]).abs().max()) <= STEPS * 1e-4
+    assert not torch.equal(full_pf["projs"][0], full_pf["projs"][1]) and not torch.equal(full_pf["projs"][1], full_pf["projs"][2])   # they WERE redrawn
+    assert torch.equal(ranks[0]["perf"]["params"], ranks[1]["perf"]["params"])

@@ -80,14 +80,10 @@ def test_full_size_halo_kernels_agree_with_im2col_order_kernels(net):
 
     idx_h = codes()
     loss_h, gr_h = _grads(net, x)
-    os.environ["SA_NO_HALO"] = "1"
-    os.environ["SA_NO_FUSED_1X1_BWD"] = "1"     # ... and the two-launch 1x1x1 backward instead of sa_conv1x1_backward
-    try:
+    from synthanatomy_amd import debug
+    with debug.override(no_halo=True, no_fused_1x1_bwd=True, no_strided_halo=True):   # ... and the two-launch 1x1x1 backward instead of sa_conv1x1_backward
         idx_r = codes()
         loss_r, gr_r = _grads(net, x)
-    finally:
-        del os.environ["SA_NO_HALO"]
-        del os.environ["SA_NO_FUSED_1X1_BWD"]
     # bf16 activations: a different summation order moves a few of the 1 400 encoder outputs across a code boundary (4-8 measured), and every
     # flipped code changes the decoder's input at one voxel outright -- the gradient bound below is per flip (measured 0.4-0.8 % each)
     flips = int((idx_h != idx_r).sum())
@@ -104,50 +100,81 @@ def test_full_size_halo_kernels_agree_with_im2col_order_kernels(net):
     assert enc[0] < bound, enc
 
 
-# ------------------------------------------------------------------------------------------------------------------ Performer, README size
+# ------------------------------------------------------------------------------------------------------------------ Performer, full sizes
 PERF = dict(vocab=2048, dim=512, depth=24, heads=16, local_heads=8, window=420)
-SPATIAL = (10, 14, 10)
+# README latents (10x14x10 = 1 400 tokens, config 2's own grid) and BASELINE.json configs[3]'s "~14k-token" sequence (20x28x25 = 14 000)
+GRIDS = {"n1400": ((10, 14, 10), 2), "n14000": ((20, 28, 25), 1)}
 
 
-@pytest.fixture(scope="module")
-def performer():
+@pytest.fixture(scope="module", params=list(GRIDS))
+def performer(request):
     from synthanatomy_amd.networks.transformers.img2seq_ordering import Ordering
     from synthanatomy_amd.networks.transformers.performer import Performer
+    spatial, batch = GRIDS[request.param]
     torch.manual_seed(4)
-    order = Ordering("raster_scan", 3, (1,) + SPATIAL, (False, False, False), ((2, 0, 1),), ((0, 1),), ("rotate_90", "transpose"))
-    net = Performer(num_tokens=PERF["vocab"] + 1, max_seq_len=int(np.prod(SPATIAL)), dim=PERF["dim"], depth=PERF["depth"], heads=PERF["heads"], ordering=order,
+    order = Ordering("raster_scan", 3, (1,) + spatial, (False, False, False), ((2, 0, 1),), ((0, 1),), ("rotate_90", "transpose"))
+    net = Performer(num_tokens=PERF["vocab"] + 1, max_seq_len=int(np.prod(spatial)) + 1, dim=PERF["dim"], depth=PERF["depth"], heads=PERF["heads"], ordering=order,
                     local_attn_heads=PERF["local_heads"], local_window_size=PERF["window"], feature_redraw_interval=None, use_rezero=True,
-                    spatial_position_emb="absolute", spatial_shape=SPATIAL, compute_dtype=torch.bfloat16).cuda().eval()
+                    spatial_position_emb="absolute", spatial_shape=spatial, compute_dtype=torch.bfloat16).cuda().eval()
     with torch.no_grad():
         for n_, p in net.named_parameters():
             if n_.endswith(".g"):
                 p.fill_(0.2)          # the 1e-3 ReZero init would hide the attention path behind the residual
-    return net
+    yield net, spatial, batch
+    del net
+    torch.cuda.empty_cache()
 
 
-def test_performer_full_size_properties(performer, monkeypatch):
-    """24 layers, N = 1 400, bf16 throughput mode (split-bf16 attention / scans / projections): determinism, causality up to the global key
-    stabiliser, and agreement with the same network run on the exact-fp32 MFMA kernels."""
-    net = performer
+def test_performer_full_size_properties(performer):
+    """24 layers, N = 1 400 and N = 14 000, bf16 throughput mode (split-bf16 attention / scans / projections): determinism, causality up to the
+    global key stabiliser, and agreement with the same network run on the exact-fp32 MFMA kernels."""
+    net, spatial, batch = performer
     torch.manual_seed(0)
-    N = int(np.prod(SPATIAL))
-    tok = torch.randint(0, PERF["vocab"], (2, N), device="cuda")
+    N = int(np.prod(spatial))
+    cut = N - N // 14
+    tok = torch.randint(0, PERF["vocab"], (batch, N), device="cuda")
     with torch.no_grad():
         a = net(tok).float()
         b = net(tok).float()
+        assert a.shape == (batch, N, PERF["vocab"] + 1)
         assert torch.isfinite(a).all() and torch.equal(a, b)                      # no atomics-order dependence in the forward
         tok2 = tok.clone()
-        tok2[:, 1300:] = (tok2[:, 1300:] + 7) % PERF["vocab"]
+        tok2[:, cut:] = (tok2[:, cut:] + 7) % PERF["vocab"]
         c = net(tok2).float()
         # positions before the edit move only through the keys' global stabiliser (a scalar shift that cancels in the normaliser up to the +eps term)
-        early = _rel(c[:, :1300], a[:, :1300])
-        late = _rel(c[:, 1300:], a[:, 1300:])
+        early = _rel(c[:, :cut], a[:, :cut])
+        late = _rel(c[:, cut:], a[:, cut:])
         assert early < 2e-2 and late > 10 * early, (early, late)
-        monkeypatch.setenv("SA_SCAN_EXACT", "7")
-        monkeypatch.setenv("SA_LOCAL_ATTN_EXACT", "1")
-        e = net(tok).float()
-        monkeypatch.delenv("SA_SCAN_EXACT")
-        monkeypatch.delenv("SA_LOCAL_ATTN_EXACT")
+        from synthanatomy_amd import debug
+        with debug.override(scan_exact=7, local_attn_exact=True):
+            e = net(tok).float()
         assert not torch.equal(e, a)
         d = (e - a).double().norm() / e.double().norm()
         assert float(d) < 2e-3, float(d)                                          # bf16 rounding of the dense layers amplifies 1e-5 differences
+
+
+def test_performer_training_step_at_14k_tokens():
+    """One training step (fwd + CE + bwd) of the 24-layer network on the 14 000-token sequence: finite loss near ln(2049) at initialisation and a
+    finite, non-zero gradient for every parameter -- the configuration bench.py reports as `secondary_14k`."""
+    from synthanatomy_amd.losses.transformer import CELoss
+    from synthanatomy_amd.networks.transformers.img2seq_ordering import Ordering
+    from synthanatomy_amd.networks.transformers.performer import Performer
+    spatial = (20, 28, 25)
+    N = int(np.prod(spatial))
+    torch.manual_seed(4)
+    order = Ordering("raster_scan", 3, (1,) + spatial, (False, False, False), ((2, 0, 1),), ((0, 1),), ("rotate_90", "transpose"))
+    net = Performer(num_tokens=PERF["vocab"] + 1, max_seq_len=N + 1, dim=PERF["dim"], depth=PERF["depth"], heads=PERF["heads"], ordering=order,
+                    local_attn_heads=PERF["local_heads"], local_window_size=PERF["window"], feature_redraw_interval=1, use_rezero=True,
+                    spatial_position_emb="absolute", spatial_shape=spatial, compute_dtype=torch.bfloat16).cuda().train()
+    tok = torch.randint(0, PERF["vocab"], (1, N), device="cuda")
+    seq = torch.nn.functional.pad(tok, (1, 0), value=PERF["vocab"])
+    loss = CELoss()(net(seq[:, :-1]).transpose(1, 2), seq[:, 1:])
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - np.log(PERF["vocab"] + 1)) < 0.5, float(loss)
+    skip = ("conditioning",)
+    for k, p in net.named_parameters():
+        if any(s_ in k for s_ in skip):
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    assert float(net.to_out.weight.grad.abs().max()) > 0 and float(net.performer.net.layers[0][0].fn.to_q.weight.grad.abs().max()) > 0

@@ -197,7 +197,7 @@ def test_projection_kernels_against_matmul(rows, m, LDF, heads):
 
 
 @pytest.mark.parametrize("with_sink", [False, True])
-def test_fused_qkv_projection_matches_separate_layers(with_sink, monkeypatch):
+def test_fused_qkv_projection_matches_separate_layers(with_sink):
     """to_q / to_k / to_v run as ONE dense layer when their weights sit back to back in the flat parameter buffer (runtime.optim.FlatParams):
     same logits and gradients as the three separate layers, with the gradient buffers adjacent (sink) or not (scratch matrix)."""
     from synthanatomy_amd.losses.transformer import CELoss
@@ -213,12 +213,10 @@ def test_fused_qkv_projection_matches_separate_layers(with_sink, monkeypatch):
     tok = torch.randint(0, 33, (2, n)).cuda()
     tgt = torch.randint(0, 32, (2, n)).cuda()
     res = []
+    from synthanatomy_amd import debug
     for fused in (True, False):
-        if fused:
-            monkeypatch.delenv("SA_NO_FUSED_QKV", raising=False)
-        else:
-            monkeypatch.setenv("SA_NO_FUSED_QKV", "1")
-        net, _ = _build(cfg, st, dtype=torch.bfloat16)
+        with debug.override(no_fused_qkv=not fused):   # the layer engines read the switch when they are built
+            net, _ = _build(cfg, st, dtype=torch.bfloat16)
         net.train()
         flat = FlatParams(net.parameters())
         if with_sink:
@@ -478,10 +476,11 @@ def test_causal_scan_variants_against_einsum(N, reverse):
 
 
 @pytest.fixture(params=["split-bf16", "exact-fp32"])
-def la_path(request, monkeypatch):
-    """Both arithmetic paths of csrc/local_attn.hip (the library reads the variable at every launch)."""
-    monkeypatch.setenv("SA_LOCAL_ATTN_EXACT", "1" if request.param == "exact-fp32" else "0")
-    return request.param
+def la_path(request):
+    """Both arithmetic paths of csrc/local_attn.hip (SA_DBG_LOCAL_ATTN_EXACT of the library's debug word)."""
+    from synthanatomy_amd import debug
+    with debug.override(local_attn_exact=request.param == "exact-fp32"):
+        yield request.param
 
 
 @pytest.mark.parametrize("N,W", [(23, 5), (40, 8), (17, 32), (100, 420), (333, 64)])

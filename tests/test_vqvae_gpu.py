@@ -203,7 +203,6 @@ def test_discriminator_matches_reference_fixture(dtype):
 def test_fused_residual_block_matches_two_launch_path(shape):
     """sa_resblock_fprop (one launch) against the two-launch path of the same stage: y and the stored hidden activation.  The larger
     shape runs on the halo mainloop (8 x 16 patches, ragged in W); its reference path is forced onto the im2col-order kernels."""
-    import os
     from synthanatomy_amd.networks.vqvae.baseline import ResidualLayer, _ResStage
     torch.manual_seed(3)
     mod = ResidualLayer(128, 128, 0.0).cuda()
@@ -212,14 +211,10 @@ def test_fused_residual_block_matches_two_launch_path(shape):
     tape = []
     y_f = st.fwd(x, tape)
     h_f = tape[0][1]
-    os.environ["SA_NO_FUSED_RES"] = "1"
-    os.environ["SA_NO_HALO"] = "1"
-    try:
+    from synthanatomy_amd import debug
+    with debug.override(no_fused_res=True, no_halo=True):
         tape2 = []
         y_r = st.fwd(x, tape2)
-    finally:
-        del os.environ["SA_NO_FUSED_RES"]
-        del os.environ["SA_NO_HALO"]
     # same products, fp32 accumulation in a different K order on the halo path -> bf16 rounding may differ in the last bit
     assert _relerr(h_f.float().cpu().numpy(), tape2[0][1].float().cpu().numpy()) < 1e-2
     if shape[1] < 16:

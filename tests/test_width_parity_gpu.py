@@ -1,0 +1,153 @@
+"""GPU: the config-2 network (BASELINE.json configs[1]: no_levels=4, no_channels=256 -> 128-channel levels, K=2048, D=32) against the CPU
+oracle on a 64x96x64 crop, batch 2 -- a size the oracle finishes in seconds and at which the dispatcher selects the PRODUCTION kernels
+(16x16-patch halo mainloops, nine-tap halo weight gradient, the one-channel first / last layers), which the 16/32-channel fixtures never
+reach.  fp32 mode is the parity gate of `north_star` (indices exact, fp <= 1e-3); bf16 mode (the benchmarked one) is compared with the oracle
+run with bf16 storage rounding and its deviation is printed and gated."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NET = dict(n_levels=4, downsample_parameters=((4, 2, 1, 1),) * 4, upsample_parameters=((4, 2, 1, 0, 1),) * 4, n_embed=2048, embed_dim=32, n_channels=256,
+           n_res_channels=256, n_res_layers=3, p_dropout=0.0, commitment_cost=0.25, vq_decay=0.5)
+CROP, BATCH = (64, 96, 64), 2
+
+
+def _rel(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def _fro(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).norm() / (ref.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from oracle import vqvae_ref
+    cfg = vqvae_ref.VQVAEConfig(**NET)
+    st = vqvae_ref.init_state(cfg, seed=4)
+    torch.manual_seed(21)
+    x = torch.rand(BATCH, 1, *CROP)
+    return vqvae_ref, cfg, st, x
+
+
+def _product(st, dtype):
+    from synthanatomy_amd.networks.vqvae.baseline import BaselineVQVAE
+    net = BaselineVQVAE(**NET, compute_dtype=dtype)
+    net.load_state_dict({k: v.clone() for k, v in st.items()})
+    return net.cuda()
+
+
+def _oracle_step(vqvae_ref, cfg, st, x, rd):
+    leaf = {k: v.clone().requires_grad_(True) for k, v in st.items() if "quantizer" not in k}
+    stt = {k: v.clone() for k, v in st.items()}
+    stt.update(leaf)
+    with torch.no_grad():
+        ev = vqvae_ref.forward({k: v.clone() for k, v in st.items()}, cfg, x, training=False, round_dtype=rd)
+    ref = vqvae_ref.forward(stt, cfg, x, training=True, round_dtype=rd)
+    loss = vqvae_ref.mse_loss(ref, x)
+    loss.backward()
+    return ev, ref, float(loss), {k: v.grad for k, v in leaf.items()}, stt
+
+
+def _product_step(net, x):
+    from synthanatomy_amd import engine
+    xg = x.cuda()
+    net.eval()
+    with torch.no_grad():
+        z = net.encode(xg)[0].float().cpu()
+        idx = net.index_quantize(xg)[0].cpu()
+    net.train()
+    timer = engine.KernelTimer()
+    engine.TIMER = timer
+    try:
+        out = net(xg)
+        loss = torch.nn.functional.mse_loss(out["reconstruction"][0].float(), xg) + out["quantization_losses"][0]
+        loss.backward()
+    finally:
+        engine.TIMER = None
+    kernels = set(timer.collect())
+    return z, idx, out["reconstruction"][0].detach().float().cpu(), float(loss), {k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.grad is not None}, kernels
+
+
+def test_fp32_mode_meets_the_parity_bar_at_config2_widths(setup):
+    vqvae_ref, cfg, st, x = setup
+    ev, ref, ref_loss, ref_grads, stt = _oracle_step(vqvae_ref, cfg, st, x, None)
+    net = _product(st, torch.float32)
+    z, idx, rec, loss, grads, kernels = _product_step(net, x)
+    assert any(k.startswith("conv_fprop_halo256_kernel<float") for k in kernels), kernels      # same tiling family as production, exact-fp32 MFMA
+    assert _rel(z, ev["z"]) < 1e-3
+    # code indices: bit-exact wherever the oracle's own top-2 distance gap exceeds fp32 summation noise (a tie within 1e-5 relative is
+    # decided by the order of 128-term dot products, which differs between any two fp32 implementations)
+    flat = ev["z"].permute(0, 2, 3, 4, 1).reshape(-1, NET["embed_dim"])
+    d = vqvae_ref.vq_distances(flat, st["quantizer.0.impl.weight"])
+    top2 = torch.topk(-d, 2, dim=1)[0]
+    gap = (top2[:, 0] - top2[:, 1]) / d.abs().max(dim=1)[0]
+    clear = (gap > 1e-5).reshape(idx.shape)
+    assert float(clear.float().mean()) > 0.99
+    assert torch.equal(idx[clear], ev["indices"][clear])
+    assert int((idx != ev["indices"]).sum()) <= int((~clear).sum())
+    assert _rel(rec, ref["reconstruction"]) < 1e-3
+    assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss)
+    worst = max((_rel(grads[k], g), k) for k, g in ref_grads.items())
+    assert set(ref_grads) <= set(grads) and worst[0] < 2e-3, worst
+    sd = net.state_dict()
+    for nm in ("N", "embed_avg", "weight"):
+        assert _rel(sd["quantizer.0.impl." + nm], stt["quantizer.0.impl." + nm]) < 1e-4, nm
+
+
+def test_bf16_mode_runs_the_production_kernels_and_tracks_the_rounded_oracle(setup):
+    vqvae_ref, cfg, st, x = setup
+    ev, ref, ref_loss, ref_grads, _ = _oracle_step(vqvae_ref, cfg, st, x, torch.bfloat16)
+    net = _product(st, torch.bfloat16)
+    z, idx, rec, loss, grads, kernels = _product_step(net, x)
+    want = ["conv_fprop_halo256_kernel<unsigned short, true>",      # fused residual block (forward)
+            "conv_fprop_halo256_kernel<unsigned short, false>",     # its 3x3x3 data gradient
+            "conv_wgrad_halo9_kernel",                              # nine-tap weight gradient
+            "conv_wgrad_dma_kernel<unsigned short, true>",          # fused 1x1x1 backward
+            "conv1_fwd_kernel", "conv1_wgrad_kernel"]               # one-channel first layer
+    for w in want:
+        assert any(k.startswith(w) for k in kernels), (w, sorted(kernels))
+    agree = float((idx == ev["indices"]).float().mean())
+    zerr, rerr = _rel(z, ev["z"]), _rel(rec, ref["reconstruction"])
+    per_layer = {k: (_rel(grads[k], g), _fro(grads[k], g)) for k, g in ref_grads.items()}
+    worst_max = max((v[0], k) for k, v in per_layer.items())
+    worst_fro = max((v[1], k) for k, v in per_layer.items())
+    print(f"\\n[bf16 @ config-2 widths, {BATCH}x{CROP}] index agreement {agree:.4f}  z max-rel {zerr:.3e}  recon max-rel {rerr:.3e}  "
+          f"loss {loss:.6f} vs {ref_loss:.6f}  grad worst max-rel {worst_max}  worst fro-rel {worst_fro}")
+    assert zerr < 2e-2 and agree > 0.95, (zerr, agree)
+    assert rerr < 3e-2 + 0.5 * (1.0 - agree), rerr          # a flipped code changes the decoder input outright at that position
+    assert abs(loss - ref_loss) <= 2e-2 * abs(ref_loss)
+    assert worst_fro[0] < 8e-2 + (1.0 - agree), worst_fro
+
+
+def test_fused_residual_block_kernel_against_conv3d_chain():
+    """sa_resblock_fprop on the 16x16-patch halo kernel (the roofline kernel) directly against the definition
+    relu(x + conv1x1(relu(conv3x3(x) + b1)) + b2) (reference baseline.py:150-160) evaluated by torch-CPU in fp32 on the same bf16-rounded operands."""
+    import torch.nn.functional as F
+
+    from synthanatomy_amd import _ffi
+    from synthanatomy_amd.networks.vqvae.baseline import ResidualLayer, _ResStage
+    torch.manual_seed(8)
+    mod = ResidualLayer(128, 128, 0.0)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.copy_(p.to(torch.bfloat16).float() if p.dim() > 1 else p)    # weights as the kernel sees them; biases stay fp32
+    x = torch.relu(torch.randn(2, 22, 48, 32, 128)).to(torch.bfloat16)
+    xr = x.float().permute(0, 4, 1, 2, 3)
+    with torch.no_grad():
+        h_ref = torch.relu(F.conv3d(xr, mod[0].weight, mod[0].bias, padding=1))
+        h_rnd = h_ref.to(torch.bfloat16).float()                            # the kernel feeds the 1x1x1 GEMM with bf16 h
+        y_ref = torch.relu(xr + F.conv3d(h_rnd, mod[3].weight, mod[3].bias))
+    st = _ResStage(mod.cuda(), in_act=True, dtype=torch.bfloat16)
+    tape = []
+    y = st.fwd(x.cuda(), tape)
+    assert _ffi.lib().sa_last_conv_kernel().decode() == "conv_fprop_halo256_kernel<unsigned short, true>"
+    h = tape[0][1]
+    # bf16 outputs: half an ulp of rounding (2^-9 relative per element) on top of fp32 accumulation-order noise
+    assert _rel(h.float().permute(0, 4, 1, 2, 3), h_ref) < 6e-3
+    assert _rel(y.float().permute(0, 4, 1, 2, 3), y_ref) < 6e-3
+    assert _fro(y.float().permute(0, 4, 1, 2, 3), y_ref) < 3e-3

@@ -38,7 +38,7 @@ def main():
     unpack = lambda t: t.view(B, N, L, dh).permute(0, 2, 1, 3)
     qd, kd, vd, god = pack(q), pack(k), pack(v), pack(go)
     for exact in ("0", "1"):
-        os.environ["SA_LOCAL_ATTN_EXACT"] = exact
+        lib.sa_set_debug_flags((lib.sa_get_debug_flags() & ~(1 << 9)) | (int(exact) << 9))   # SA_DBG_LOCAL_ATTN_EXACT
         o = torch.empty_like(qd); lse = torch.empty(B * N * L, device="cuda")
         dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
         Db = torch.empty(B * N * L, device="cuda")

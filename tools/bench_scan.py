@@ -30,7 +30,7 @@ def main():
     ws = torch.empty(lib.sa_favor_scan_workspace_bytes(B, N, G, LDF, dv) // 4, device="cuda")
     res = {}
     for exact in ("0", "7"):
-        os.environ["SA_SCAN_EXACT"] = exact
+        lib.sa_set_debug_flags((lib.sa_get_debug_flags() & ~(7 << 10)) | (int(exact) << 10))   # SA_DBG_SCAN_EXACT bits
         yn = torch.zeros(B * N, G * dv, device="cuda"); inv = torch.zeros(B * N * G, device="cuda")
         fa = lambda: _ffi.check(lib.sa_favor_scan_a_norm(_ffi.ptr(a), _ffi.ptr(c), _ffi.ptr(bb), G * dv, 0, _ffi.ptr(yn), G * dv, 0, _ffi.ptr(inv), 1e-6,
                                                          B, N, G, LDF, dv, _ffi.ptr(ws), 0, st))
