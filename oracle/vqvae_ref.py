@@ -119,7 +119,7 @@ def residual_layer(x, w3, b3, w1, b1, round_dtype=None):
 
 def encode(st, cfg: VQVAEConfig, images: torch.Tensor, round_dtype=None) -> torch.Tensor:
     """baseline.py:213-246 / :329-330.  images [B,1,D,H,W] fp32 -> z [B,embed_dim,d,h,w]."""
-    x = _rd(images.float(), round_dtype)
+    x = _rd(images if images.dtype == torch.float64 else images.float(), round_dtype)   # fp64 in = fp64 throughout (error-floor checks)
     for i in range(cfg.n_levels):
         k, s, p, dil = cfg.downsample_parameters[i]
         p_ = f"encoder.0.{3 * i}"

@@ -81,8 +81,10 @@ class _Stage:
             tape.append((x, c, (mean, rstd), use_batch))
         return y
 
-    def bwd(self, G, saved, gc):
-        """G: gradient wrt this stage's pre-LeakyReLU output (the conv output, or the BatchNorm output)."""
+    def bwd(self, G, saved, gc, need_w=True, need_dx=True):
+        """G: gradient wrt this stage's pre-LeakyReLU output (the conv output, or the BatchNorm output).  ``need_w=False`` (generator step: the
+        discriminator is frozen) skips the weight / bias gradient launches; ``need_dx=False`` (discriminator step: the image needs no gradient)
+        skips the first stage's data gradient."""
         x, c, stats, use_batch = saved
         self.op.weight, self.op.bias = self.conv.weight, self.conv.bias
         lib, st = _ffi.lib(), _ffi.stream()
@@ -98,9 +100,10 @@ class _Stage:
                                           int(use_batch), _ffi.ptr(dc), _ffi.ptr(gc.buf(self.bn.weight)), _ffi.ptr(gc.buf(self.bn.bias)), _ffi.ptr(ws), st),
                        "sa_bn_backward")
             G = dc
-        self.op.wgrad(x, G, gc.buf(self.conv.weight), gc.buf(self.conv.bias))
+        if need_w:
+            self.op.wgrad(x, G, gc.buf(self.conv.weight), gc.buf(self.conv.bias))
         if self.first:
-            return self.op.dgrad(G, tuple(x.shape[1:4]), out_dtype=torch.float32)
+            return self.op.dgrad(G, tuple(x.shape[1:4]), out_dtype=torch.float32) if need_dx else None
         return self.op.dgrad(G, tuple(x.shape[1:4]), mask=x if self.in_lrelu else None, mask_mode=MASK_LRELU, slope=SLOPE)
 
 
@@ -122,8 +125,9 @@ class _DiscFn(torch.autograd.Function):
         net = ctx.net
         gc = _GradCtx()
         G = gy.permute(0, 2, 3, 4, 1).contiguous()
+        need_w = any(ctx.needs_input_grad[3:])
         for s, saved in zip(reversed(net._stages), reversed(ctx.tape)):
-            G = s.bwd(G, saved, gc)
+            G = s.bwd(G, saved, gc, need_w, ctx.need_dx)
         ctx.tape = None
         gx = G[..., : ctx.cin].permute(0, 4, 1, 2, 3) if ctx.need_dx else None
         return (None, None, gx, *[gc.grads.get(p) for p in net._params()])

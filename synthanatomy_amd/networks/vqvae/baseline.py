@@ -457,6 +457,7 @@ class _Chain:
     def __init__(self, stages, dtype, in_channels):
         self.stages, self.dtype, self.in_channels = stages, dtype, in_channels
         self.grad_sink = None
+        self.last_tape = None
 
     def params(self) -> List[nn.Parameter]:
         return [p for s in self.stages for p in s.params()]
@@ -483,7 +484,18 @@ class _Chain:
         tape = [] if record else None
         for s in self.stages:
             x = s.fwd(x, tape)
+        self.last_tape = tape     # for last_stage_wgrad (adaptive adversarial weight); dropped when the backward pass consumes the tape
         return x, tape
+
+    def last_stage_wgrad(self, G: torch.Tensor) -> torch.Tensor:
+        """Weight gradient of the LAST stage alone for an output gradient G [B, D, H, W, C] (channels-last), from the input the last recorded
+        forward saved.  Does not touch the gradient sink."""
+        if self.last_tape is None:
+            raise RuntimeError("last_stage_wgrad needs a recorded forward whose backward has not run yet")
+        st = self.stages[-1]
+        gc = _GradCtx(None)
+        st.bwd(G, self.last_tape[-1], gc)
+        return gc.grads[st.params()[0]]
 
     def backward(self, G: torch.Tensor, tape):
         gc = _GradCtx(self.grad_sink)
@@ -505,6 +517,8 @@ class _ChainFn(torch.autograd.Function):
         chain: _Chain = ctx.chain
         G = gy.permute(0, 2, 3, 4, 1).contiguous()
         Gin, grads = chain.backward(G, ctx.tape)
+        if chain.last_tape is ctx.tape:
+            chain.last_tape = None
         ctx.tape = None
         gx = None
         if ctx.x_needs and Gin is not None:
@@ -656,6 +670,12 @@ class BaselineVQVAE(VQVAEBase, nn.Module):
 
     def get_last_layer(self) -> nn.parameter.Parameter:
         return list(self.decoder.modules())[-1].weight
+
+    def last_layer_grad(self, d_recon: torch.Tensor) -> torch.Tensor:
+        """``torch.autograd.grad(loss, self.get_last_layer())`` of the reference's adaptive adversarial weight (src/engines/trainer.py:278-285)
+        for a loss that reaches the last layer through the reconstruction only, given ``d_recon = d loss / d reconstruction`` [B,1,D,H,W]:
+        the last decoder stage's weight-gradient launch on the input saved by the last recorded forward -- not a second decoder backward."""
+        return self._dec_chain.last_stage_wgrad(d_recon.permute(0, 2, 3, 4, 1).contiguous())
 
     # ---------------------------------------------------------------- hot path (baseline.py:329-362)
     @staticmethod

@@ -16,8 +16,13 @@ from .. import _ffi
 
 class FlatParams:
     def __init__(self, params: Iterable[torch.nn.Parameter]):
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        every = list(params)
+        self.params: List[torch.nn.Parameter] = [p for p in every if p.requires_grad]
         assert self.params, "no trainable parameters"
+        # position of each trainable parameter in the iterable the caller passed -- torch.optim.Adam(network.parameters()) numbers ALL
+        # parameters (the frozen codebook included), and checkpoints use those numbers (FusedAdam.state_dict)
+        self.positions = [i for i, p in enumerate(every) if p.requires_grad]
+        self.n_all = len(every)
         dev = self.params[0].device
         # (the buffers live in HBM in production; host tensors are accepted so that the bucketing / reduction logic can be
         #  exercised with the gloo backend -- FusedAdam itself is HIP-only)
@@ -70,12 +75,44 @@ class FusedAdam:
         self.flat.zero_grad()
 
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "step": self.step_count, "lr": self.lr}
+        """``torch.optim.Adam.state_dict()`` layout (the reference checkpoints ``optimizer`` / ``d_optimizer`` with it, run_vqvae.py:312-326):
+        ``state[i] = {step, exp_avg, exp_avg_sq}`` keyed by the parameter's position in ``network.parameters()``, one param group."""
+        f = self.flat
+        state = {}
+        for p, o, pos in zip(f.params, f.offsets, f.positions):
+            n = p.numel()
+            state[pos] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.m[o:o + n].view_as(p).clone(),
+                          "exp_avg_sq": self.v[o:o + n].view_as(p).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(f.n_all))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd["m"])
-        self.v.copy_(sd["v"])
-        self.step_count, self.lr = sd["step"], sd["lr"]
+        """Accepts the torch.optim.Adam layout (ours and the reference's checkpoints) and the round-1 private layout {m, v, step, lr}."""
+        if "param_groups" not in sd:
+            self.m.copy_(sd["m"])
+            self.v.copy_(sd["v"])
+            self.step_count, self.lr = int(sd["step"]), float(sd["lr"])
+            return
+        f = self.flat
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.weight_decay = float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])
+        ids = list(g["params"])
+        steps = set()
+        for p, o, pos in zip(f.params, f.offsets, f.positions):
+            key = ids[pos] if pos < len(ids) else pos
+            ent = sd["state"].get(key)
+            n = p.numel()
+            if ent is None:        # a parameter that never received a gradient has no state in torch's optimizer
+                self.m[o:o + n].zero_()
+                self.v[o:o + n].zero_()
+                continue
+            self.m[o:o + n].view_as(p).copy_(ent["exp_avg"])
+            self.v[o:o + n].view_as(p).copy_(ent["exp_avg_sq"])
+            steps.add(int(float(ent["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused Adam kernel keeps one bias-correction step for all")
+        self.step_count = steps.pop() if steps else 0
 
 
 class ExponentialLR:
@@ -83,6 +120,40 @@ class ExponentialLR:
 
     def __init__(self, opt: FusedAdam, gamma: float):
         self.opt, self.gamma = opt, gamma
+        self.base_lr = opt.lr
+        self.last_epoch = 0
 
     def step(self):
         self.opt.lr *= self.gamma
+        self.last_epoch += 1
+
+    def state_dict(self):
+        """The keys of ``torch.optim.lr_scheduler.ExponentialLR.state_dict()`` (checkpoint key ``lr_scheduler``)."""
+        return {"gamma": self.gamma, "base_lrs": [self.base_lr], "last_epoch": self.last_epoch, "verbose": False, "_step_count": self.last_epoch + 1,
+                "_get_lr_called_within_step": False, "_last_lr": [self.opt.lr]}
+
+    def load_state_dict(self, sd):
+        self.gamma = float(sd["gamma"])
+        self.base_lr = float(sd["base_lrs"][0])
+        self.last_epoch = int(sd["last_epoch"])
+        self.opt.lr = float(sd["_last_lr"][0]) if sd.get("_last_lr") else self.base_lr * self.gamma ** self.last_epoch
+
+
+class TrainerState:
+    """What ignite's ``Engine.state_dict()`` puts under the checkpoint key ``trainer``: ``iteration``, ``epoch_length``, ``max_epochs``."""
+
+    def __init__(self, epoch_length: int, max_epochs: int):
+        self.iteration, self.epoch_length, self.max_epochs = 0, epoch_length, max_epochs
+
+    @property
+    def epoch(self) -> int:
+        return self.iteration // max(1, self.epoch_length)
+
+    def state_dict(self):
+        return {"iteration": self.iteration, "epoch_length": self.epoch_length, "max_epochs": self.max_epochs}
+
+    def load_state_dict(self, sd):
+        if "iteration" in sd:
+            self.iteration = int(sd["iteration"])
+        elif "epoch" in sd:      # ignite also accepts {epoch, epoch_length, max_epochs}; round-1 checkpoints stored {"epoch": e} = last finished epoch
+            self.iteration = (int(sd["epoch"]) + (0 if "epoch_length" in sd else 1)) * self.epoch_length

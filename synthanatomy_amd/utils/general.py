@@ -66,28 +66,95 @@ def create_folder_structure(config: dict):
     return config
 
 
+def _epoch_of(path: str) -> int:
+    m = re.search(r"checkpoint_epoch=(\d+)\.pt$", path)
+    return int(m.group(1)) if m else -1
+
+
 def latest_checkpoint(checkpoint_directory: str):
     best, best_ep = None, -1
     for f in glob.glob(os.path.join(checkpoint_directory, "checkpoint_epoch=*.pt")):
-        m = re.search(r"checkpoint_epoch=(\d+)\.pt$", f)
-        if m and int(m.group(1)) > best_ep:
-            best, best_ep = f, int(m.group(1))
+        if _epoch_of(f) > best_ep:
+            best, best_ep = f, _epoch_of(f)
     return best, best_ep
 
 
-def save_checkpoint(config, epoch, network, optimizer=None, extra=None):
-    """One ``.pt`` with the reference's top-level keys (run_vqvae.py:312-326); DDP wrappers are unwrapped like ignite does."""
-    net = network.module if hasattr(network, "module") else network
-    obj = {"network": net.state_dict(), "trainer": {"epoch": epoch}}
-    if optimizer is not None:
-        obj["optimizer"] = optimizer.state_dict()
-    obj.update(extra or {})
-    path = os.path.join(config["checkpoint_directory"], f"checkpoint_epoch={epoch}.pt")
+def check_for_checkpoints(config: dict):
+    """Which checkpoint to start from -- the rules of reference src/utils/general.py:75-168.  Training: ``starting_epoch == -1`` -> the newest
+    ``checkpoint_epoch=<n>.pt`` (and ``starting_epoch`` becomes n), ``> 0`` -> exactly that epoch (must exist).  Any other mode:
+    ``starting_epoch > 0`` -> that epoch; else ``evaluation_checkpoint`` = "recent" (newest) or "best" (the single
+    ``checkpoint_key_metric=*.pt``).  Returns a path or None."""
+    ck = config["checkpoint_directory"]
+    if config["mode"] == "training":
+        if config["starting_epoch"] == -1:
+            path, ep = latest_checkpoint(ck)
+            config["starting_epoch"] = ep if path else 0
+        if config["starting_epoch"] > 0:
+            path = os.path.join(ck, f"checkpoint_epoch={config['starting_epoch']}.pt")
+            assert os.path.exists(path), f"Checkpoint '{path}' is not found."
+            return path
+        return None
+    if config["starting_epoch"] > 0:
+        path = os.path.join(ck, f"checkpoint_epoch={config['starting_epoch']}.pt")
+        assert os.path.exists(path), f"Checkpoint '{path}' is not found."
+        return path
+    if config.get("evaluation_checkpoint", "recent") == "best":
+        found = glob.glob(os.path.join(ck, "checkpoint_key_metric*.pt"))
+        assert len(found) == 1, f"Should only be one best metric checkpoint, found {found}"
+        return found[0]
+    return latest_checkpoint(ck)[0]
+
+
+def _state(obj):
+    if hasattr(obj, "module") and hasattr(obj.module, "state_dict"):
+        obj = obj.module            # DDP wrappers are unwrapped, as ignite's Checkpoint does
+    return obj.state_dict() if hasattr(obj, "state_dict") else obj
+
+
+def save_checkpoint(config, epoch, to_save: dict, key_metric: float = None, key_metric_name: str = None):
+    """One ``.pt`` whose top-level keys are those of the reference's ``to_save`` (run_vqvae.py:312-326: ``network``, ``optimizer``,
+    ``lr_scheduler``, ``trainer`` and, with the adversarial component, ``d_network``, ``d_optimizer``, ``d_lr_scheduler``), each the
+    object's ``state_dict()``.  Periodic checkpoints are ``checkpoint_epoch=<e>.pt`` with ``n_saved=1``; with ``key_metric`` the file is the
+    evaluator's ``checkpoint_key_metric=<value>.pt`` (``key_metric_n_saved=1``: kept only while it is the best so far)."""
+    if not isinstance(to_save, dict):   # round-1 call form: save_checkpoint(cfg, epoch, network, optimizer)
+        raise TypeError("to_save must be a dict of name -> object with state_dict()")
+    obj = {k: _state(v) for k, v in to_save.items() if v is not None}
+    ck = config["checkpoint_directory"]
+    if key_metric is None:
+        path = os.path.join(ck, f"checkpoint_epoch={epoch}.pt")
+        torch.save(obj, path)
+        for f in glob.glob(os.path.join(ck, "checkpoint_epoch=*.pt")):  # n_saved=1
+            if f != path:
+                os.remove(f)
+        return path
+    old = glob.glob(os.path.join(ck, "checkpoint_key_metric=*.pt"))
+    best = max([float(re.search(r"key_metric=(-?[0-9.eE+-]+)\.pt$", f).group(1)) for f in old], default=None)
+    if best is not None and key_metric <= best:
+        return None
+    path = os.path.join(ck, f"checkpoint_key_metric={key_metric:.4f}.pt")
     torch.save(obj, path)
-    for f in glob.glob(os.path.join(config["checkpoint_directory"], "checkpoint_epoch=*.pt")):  # n_saved=1
+    for f in old:
         if f != path:
             os.remove(f)
     return path
+
+
+def load_checkpoint(path, to_load: dict, map_location="cpu"):
+    """``CheckpointLoader(load_path, load_dict)``: restore every object of ``to_load`` whose key is in the file (a missing key is an error, as
+    in ignite).  ``network`` entries may carry the DDP ``module.`` prefix."""
+    obj = torch.load(path, map_location=map_location, weights_only=False)
+    for k, target in to_load.items():
+        if target is None:
+            continue
+        if k not in obj:
+            raise ValueError(f"Object labeled by '{k}' from `to_load` is not found in the checkpoint {path}")
+        sd = obj[k]
+        if hasattr(target, "module") and hasattr(target.module, "load_state_dict"):
+            target = target.module
+        if isinstance(target, torch.nn.Module):
+            sd = {(n[len("module."):] if n.startswith("module.") else n): v for n, v in sd.items()}
+        target.load_state_dict(sd)
+    return obj
 
 
 def load_network_state(network, path, map_location="cpu"):
@@ -95,6 +162,22 @@ def load_network_state(network, path, map_location="cpu"):
     sd = obj["network"] if isinstance(obj, dict) and "network" in obj else obj
     sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}  # final state_dict dumps keep the DDP prefix
     return network.load_state_dict(sd, strict=False), obj
+
+
+def shard_for_rank(n: int, rank: int, world: int, epoch: int = 0, seed: int = 0, shuffle: bool = True, pad: bool = True):
+    """Indices of this rank's samples for one epoch -- ``torch.utils.data.DistributedSampler`` semantics (the reference's training loaders,
+    src/utils/vqvae.py:393-444): one permutation seeded by ``seed + epoch`` shared by all ranks, padded by wrapping around to a multiple of
+    ``world`` so that EVERY rank runs the same number of steps (each step issues collectives: a short rank would hang the others), then
+    strided by rank.  ``pad=False`` is the inference form (``even_divisible=False``: no duplicates, no collectives)."""
+    if shuffle:
+        g = torch.Generator().manual_seed(seed + epoch)
+        idx = torch.randperm(n, generator=g).tolist()
+    else:
+        idx = list(range(n))
+    if pad and n % world:
+        total = (n + world - 1) // world * world
+        idx = (idx * ((total + n - 1) // n))[:total] if n else idx
+    return idx[rank::world]
 
 
 def save_npy(array, output_dir: str, filename: str, postfix: str, dtype=np.uint16):
@@ -110,15 +193,20 @@ def save_npy(array, output_dir: str, filename: str, postfix: str, dtype=np.uint1
     return path
 
 
-def list_inputs(spec):
-    """A directory, a glob, a .csv/.tsv whose first column lists files, or 'synthetic:<n>'."""
+def list_inputs(spec, postfix: str = None):
+    """A directory, a glob, a .csv/.tsv whose first column lists files, or 'synthetic:<n>'.  ``postfix`` filters a DIRECTORY listing to
+    ``*_<postfix>.npy`` -- the extraction stage writes codes (``quantization_0``) and fp32 reconstructions side by side, and the next stage
+    must only pick up its own kind."""
     if isinstance(spec, (tuple, list)):
-        return [p for s in spec for p in list_inputs(s)]
+        return [p for s in spec for p in list_inputs(s, postfix)]
     if isinstance(spec, str) and spec.startswith("synthetic"):
         n = int(spec.split(":")[1]) if ":" in spec else 8
         return [f"synthetic_{i:04d}" for i in range(n)]
     if os.path.isdir(spec):
-        return sorted(glob.glob(os.path.join(spec, "**", "*.npy"), recursive=True))
+        found = sorted(glob.glob(os.path.join(spec, "**", "*.npy"), recursive=True))
+        if postfix is not None and any(f.endswith(f"_{postfix}.npy") for f in found):
+            found = [f for f in found if f.endswith(f"_{postfix}.npy")]
+        return found
     if spec.endswith((".csv", ".tsv")):
         sep = "\t" if spec.endswith(".tsv") else ","
         with open(spec) as f:

@@ -24,11 +24,12 @@ def test_folder_layout_checkpoints_and_npy(tmp_path):
     base = tmp_path / "exp" / "baseline_vqvae"
     assert all((base / s).is_dir() for s in ("checkpoints", "logs", "outputs", "caching")) and cfg["starting_epoch"] == 0
     net = torch.nn.Linear(2, 2)
-    p0 = G.save_checkpoint(cfg, 0, net)
-    p1 = G.save_checkpoint(cfg, 1, torch.nn.DataParallel(net))
-    assert os.path.basename(p1) == "checkpoint_epoch=1.pt" and not os.path.exists(p0)  # n_saved = 1
-    assert set(torch.load(p1, weights_only=False)) >= {"network", "trainer"}
-    assert G.latest_checkpoint(cfg["checkpoint_directory"]) == (p1, 1)
+    p0 = G.save_checkpoint(cfg, 1, {"network": net, "trainer": {"iteration": 3}})
+    p1 = G.save_checkpoint(cfg, 2, {"network": torch.nn.DataParallel(net), "trainer": {"iteration": 6}, "d_network": None})
+    assert os.path.basename(p1) == "checkpoint_epoch=2.pt" and not os.path.exists(p0)  # n_saved = 1
+    obj = torch.load(p1, weights_only=False)
+    assert set(obj) == {"network", "trainer"} and set(obj["network"]) == {"weight", "bias"}     # DDP-style wrappers are unwrapped
+    assert G.latest_checkpoint(cfg["checkpoint_directory"]) == (p1, 2)
     cfg2 = dict(cfg, starting_epoch=0)
     G.create_folder_structure(cfg2)
     assert cfg2["starting_epoch"] == -1  # non-empty checkpoint dir -> resume
@@ -49,3 +50,76 @@ def test_cli_rejects_unknown_modes_before_touching_the_gpu(tmp_path):
         run_vqvae.run(base + ["--mode=bogus"])
     with pytest.raises(ValueError):
         run_transformer.run(base + ["--mode=bogus"])
+
+
+def test_checkpoint_selection_rules(tmp_path):
+    """reference src/utils/general.py:75-168: training resumes from the newest / the requested epoch; evaluation takes the requested epoch,
+    the newest ("recent") or the single key-metric checkpoint ("best")."""
+    cfg = dict(project_directory=str(tmp_path) + "/", experiment_name="exp", network="performer", starting_epoch=0, mode="training")
+    G.create_folder_structure(cfg)
+    assert G.check_for_checkpoints(cfg) is None and cfg["starting_epoch"] == 0
+    net = torch.nn.Linear(2, 2)
+    p3 = G.save_checkpoint(cfg, 3, {"network": net})
+    b1 = G.save_checkpoint(cfg, 1, {"network": net}, key_metric=-0.5)
+    assert G.save_checkpoint(cfg, 2, {"network": net}, key_metric=-0.7) is None and os.path.exists(b1)      # worse: the best one stays
+    b2 = G.save_checkpoint(cfg, 3, {"network": net}, key_metric=-0.25)
+    assert os.path.basename(b2) == "checkpoint_key_metric=-0.2500.pt" and not os.path.exists(b1) and os.path.exists(p3)
+    tr = dict(cfg, starting_epoch=-1)
+    assert G.check_for_checkpoints(tr) == p3 and tr["starting_epoch"] == 3
+    with pytest.raises(AssertionError):
+        G.check_for_checkpoints(dict(cfg, starting_epoch=7))
+    assert G.check_for_checkpoints(dict(cfg, mode="extracting", starting_epoch=0, evaluation_checkpoint="recent")) == p3
+    assert G.check_for_checkpoints(dict(cfg, mode="extracting", starting_epoch=0, evaluation_checkpoint="best")) == b2
+    assert G.check_for_checkpoints(dict(cfg, mode="inference", starting_epoch=3, evaluation_checkpoint="best")) == p3
+    with pytest.raises(ValueError):
+        G.load_checkpoint(p3, {"optimizer": net})     # ignite's CheckpointLoader: a requested key that is absent is an error
+
+
+def test_distributed_sampler_sharding():
+    """Every rank gets the same number of samples (wrap-around padding), one permutation per epoch shared by all ranks."""
+    for n, world in [(5, 2), (7, 4), (8, 4), (1, 2)]:
+        shards = [G.shard_for_rank(n, r, world, epoch=3, seed=4) for r in range(world)]
+        assert len({len(s) for s in shards}) == 1 and len(shards[0]) == (n + world - 1) // world
+        assert set(i for s in shards for i in s) == set(range(n))
+    assert G.shard_for_rank(6, 0, 2, epoch=0, seed=4) != G.shard_for_rank(6, 0, 2, epoch=1, seed=4)          # reshuffled every epoch
+    import torch.utils.data as tud
+    ds = list(range(11))
+    for r in range(3):
+        sam = tud.DistributedSampler(ds, num_replicas=3, rank=r, shuffle=True, seed=4)
+        sam.set_epoch(2)
+        assert list(sam) == G.shard_for_rank(11, r, 3, epoch=2, seed=4)      # identical to torch's sampler
+    assert [G.shard_for_rank(5, r, 2, shuffle=False, pad=False) for r in range(2)] == [[0, 2, 4], [1, 3]]
+
+
+def test_optimizer_scheduler_and_trainer_state_use_the_reference_layout():
+    """The ``optimizer`` / ``lr_scheduler`` / ``trainer`` entries of a checkpoint have the layout torch.optim.Adam / ExponentialLR / ignite write,
+    so the reference's checkpoints load here and ours load there (run_vqvae.py:312-345)."""
+    from synthanatomy_amd.runtime.optim import ExponentialLR, FlatParams, FusedAdam, TrainerState
+    torch.manual_seed(0)
+    mod = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.Embedding(4, 2), torch.nn.Linear(5, 1))
+    mod[1].weight.requires_grad_(False)                      # like the frozen codebook: numbered by Adam, never updated
+    ref_opt = torch.optim.Adam(mod.parameters(), lr=2e-3)
+    ref_sch = torch.optim.lr_scheduler.ExponentialLR(ref_opt, gamma=0.9)
+    for _ in range(3):
+        ref_opt.zero_grad()
+        mod[2](mod[0](torch.randn(4, 3))).sum().backward()
+        ref_opt.step()
+        ref_sch.step()
+    flat = FlatParams(mod.parameters())
+    opt = FusedAdam(flat, lr=1.0)
+    sch = ExponentialLR(opt, gamma=0.5)
+    opt.load_state_dict(ref_opt.state_dict())
+    sch.load_state_dict(ref_sch.state_dict())
+    assert opt.step_count == 3 and abs(opt.lr - 2e-3 * 0.9 ** 3) < 1e-12 and sch.gamma == 0.9 and sch.last_epoch == 3
+    sd = opt.state_dict()
+    assert set(sd) == {"state", "param_groups"} and sorted(sd["state"]) == [0, 1, 3, 4] and sd["param_groups"][0]["params"] == [0, 1, 2, 3, 4]
+    for k, ent in ref_opt.state_dict()["state"].items():
+        assert torch.equal(sd["state"][k]["exp_avg"], ent["exp_avg"]) and torch.equal(sd["state"][k]["exp_avg_sq"], ent["exp_avg_sq"])
+        assert float(sd["state"][k]["step"]) == 3.0
+    fresh = torch.optim.Adam(mod.parameters(), lr=1.0)
+    fresh.load_state_dict(sd)                                 # and torch accepts ours
+    assert fresh.state_dict()["param_groups"][0]["lr"] == opt.lr
+    assert set(sch.state_dict()) >= {"gamma", "base_lrs", "last_epoch", "_last_lr", "_step_count"}
+    st = TrainerState(epoch_length=7, max_epochs=10)
+    st.load_state_dict({"iteration": 21, "epoch_length": 7, "max_epochs": 10})
+    assert st.epoch == 3 and st.state_dict() == {"iteration": 21, "epoch_length": 7, "max_epochs": 10}

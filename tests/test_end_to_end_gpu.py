@@ -31,7 +31,7 @@ def test_pipeline(tmp_path):
           "--eval_batch_size=2", "--log_every=1", "--learning_rate=1e-3", "--ordering_type=hilbert_curve"]
     code_dir = proj + "e2e/baseline_vqvae/outputs/*/*_quantization_0.npy"
     run_transformer.run(tr + ["--training_subjects=" + code_dir, "--validation_subjects=" + code_dir, "--mode=training", "--epochs=3", "--checkpoint_every=1"])
-    assert glob.glob(proj + "e2e/performer/checkpoints/checkpoint_epoch=2.pt")
+    assert glob.glob(proj + "e2e/performer/checkpoints/checkpoint_epoch=3.pt")
     run_transformer.run(tr + ["--training_subjects=" + code_dir, "--validation_subjects=synthetic:2", "--mode=inference", "--spatial_shape=(4,6,4)", "--top_k=8"])
     samples = sorted(glob.glob(proj + "e2e/performer/outputs/*/*_sample.npy"))
     assert len(samples) == 2

@@ -1,0 +1,140 @@
+"""GPU: the training-loop rows next to the hot path -- the adversarial iteration against a CPU oracle
+iteration, the Jukebox spectral loss against values computed by the reference's class, and checkpoint resume (2 epochs == 1 epoch + resume +
+1 epoch, bit for bit in fp32 mode, discriminator and both optimizers included)."""
+import glob
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden  # noqa: E402
+
+VQ = dict(n_levels=2, downsample_parameters=((4, 2, 1, 1),) * 2, upsample_parameters=((4, 2, 1, 0, 1),) * 2, n_embed=64, embed_dim=16, n_channels=32,
+          n_res_channels=32, n_res_layers=1)
+
+
+def _rel(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("adaptive,crit,epoch", [(False, "least_square", 0), (True, "least_square", 3), (True, "hinge", 3), (True, "vanilla", 0)])
+def test_adversarial_iteration_matches_oracle(adaptive, crit, epoch):
+    """Two G + D iterations (reference src/engines/trainer.py:157-294) in fp32 mode: losses, the adaptive weight, every generator and
+    discriminator gradient.  ``epoch=0 < threshold=2`` exercises the fixed ``value`` branch of the adaptive weight."""
+    from oracle import losses_ref, vqvae_ref
+    from synthanatomy_amd.engines.trainer import AdversarialTrainer
+    from synthanatomy_amd.losses.adversarial import get_discriminator_loss, get_generator_loss
+    from synthanatomy_amd.losses.vqvae import MSELoss
+    from synthanatomy_amd.networks.discriminator.baseline import BaselineDiscriminator
+    from synthanatomy_amd.networks.vqvae.baseline import BaselineVQVAE
+    from synthanatomy_amd.runtime.optim import FlatParams, FusedAdam
+    cfg = vqvae_ref.VQVAEConfig(**VQ)
+    g_st = vqvae_ref.init_state(cfg, seed=6)
+    d_st = vqvae_ref.init_discriminator_state(seed=7, ndf=8)
+    net = BaselineVQVAE(**VQ, compute_dtype=torch.float32)
+    net.load_state_dict({k: v.clone() for k, v in g_st.items()})
+    disc = BaselineDiscriminator(input_nc=1, ndf=8, n_layers=3, compute_dtype=torch.float32)
+    disc.load_state_dict({k: v.clone() for k, v in d_st.items()}, strict=False)
+    net, disc = net.cuda().train(), disc.cuda().train()
+    flat, d_flat = FlatParams(net.parameters()), FlatParams(disc.parameters())
+    opt, d_opt = FusedAdam(flat, lr=1e-3), FusedAdam(d_flat, lr=5e-4)
+    opt.on_step.append(net.invalidate_packed_weights)
+    d_opt.on_step.append(lambda: [s.op.invalidate() for s in disc._stages])
+    captured = {}
+    for name, o, f in (("g", opt, flat), ("d", d_opt, d_flat)):
+        def hooked(grad_scale=1.0, _o=o, _f=f, _n=name, _step=o.step):
+            captured[_n] = _f.grad.clone()
+            _step(grad_scale=grad_scale)
+        o.step = hooked
+    tr = AdversarialTrainer(net, opt, get_generator_loss({"generator_loss": crit}), MSELoss(), disc, d_opt, get_discriminator_loss({"discriminator_loss": crit}),
+                            use_adversarial_adaptive_weight=adaptive, adaptive_adversarial_weight_threshold=2, adaptive_adversarial_weight_value=0.5)
+    torch.manual_seed(2)
+    x = torch.rand(2, 1, 32, 32, 32)
+    g_ref = {k: v.clone() for k, v in g_st.items()}
+    d_ref = {k: v.clone() for k, v in d_st.items()}
+    ro = do = None
+    for it in range(2):
+        ref = losses_ref.adversarial_step(g_ref, d_ref, cfg, x, g_lr=1e-3, d_lr=5e-4, g_criterion=crit, d_criterion=crit, use_adaptive=adaptive,
+                                          threshold=2, value=0.5, epoch=epoch, g_opt=ro, d_opt=do)
+        ro, do = ref["g_opt"], ref["d_opt"]
+        res = tr.iteration(x.cuda(), x.cuda(), epoch)
+        torch.cuda.synchronize()
+        assert abs(float(res["loss"]) - float(ref["recon_loss"])) <= 1e-4 * abs(float(ref["recon_loss"])), it
+        assert abs(float(res["adversarial_weight"]) - float(ref["weight"])) <= 1e-3 * abs(float(ref["weight"])), (it, float(res["adversarial_weight"]), float(ref["weight"]))
+        assert abs(float(res["g_loss"]) - float(ref["g_loss"])) <= 2e-4 * abs(float(ref["g_loss"])), it
+        assert abs(float(res["d_loss"]) - float(ref["d_loss"])) <= 2e-4 * abs(float(ref["d_loss"])), it
+        if it == 0:   # (after an Adam step rounding-level differences of near-zero gradients are normalised to ~lr: compare gradients before it)
+            for k, p in net.named_parameters():
+                if p.requires_grad:
+                    assert _rel(captured["g"][flat.offsets[flat.index[id(p)]]:][: p.numel()].view_as(p), ref["g_grads"][k]) < 3e-3, k
+            for k, p in disc.named_parameters():
+                assert _rel(captured["d"][d_flat.offsets[d_flat.index[id(p)]]:][: p.numel()].view_as(p), ref["d_grads"][k]) < 3e-3, k
+    if adaptive and epoch >= 2:
+        assert float(res["adversarial_weight"]) not in (0.5, 1.0)
+    for k in d_ref:
+        if "running" in k:    # three discriminator forwards per iteration update the BatchNorm statistics three times, as upstream
+            assert _rel(disc.state_dict()[k], d_ref[k]) < 1e-3, k
+
+
+def test_jukebox_loss_matches_the_reference_values():
+    from synthanatomy_amd.losses.vqvae import JukeboxLoss, get_vqvae_loss
+    g = load_golden("losses")
+    loss_fn = get_vqvae_loss({"loss": "jukebox"})
+    assert isinstance(loss_fn, JukeboxLoss)
+    pred = torch.from_numpy(g["jukebox/pred"]).cuda().requires_grad_(True)
+    loss = loss_fn({"reconstruction": [pred], "quantization_losses": [torch.from_numpy(g["jukebox/qloss"]).cuda()]}, torch.from_numpy(g["jukebox/y"]).cuda())
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["jukebox/loss"], rtol=1e-5)
+    np.testing.assert_allclose(loss_fn.get_summaries()["scalar"]["Loss-Spectral-Reconstruction"].item(), g["jukebox/spectral"], rtol=1e-5)
+    assert _rel(pred.grad, torch.from_numpy(g["jukebox/dpred"])) < 1e-4
+    with pytest.raises(ValueError):
+        get_vqvae_loss({"loss": "lpips"})
+
+
+def _vq_flags(proj, exp, extra=()):
+    return ["--project_directory=" + proj, "--experiment_name=" + exp, "--no_levels=2", "--downsample_parameters=((4,2,1,1),(4,2,1,1))",
+            "--upsample_parameters=((4,2,1,0,1),(4,2,1,0,1))", "--no_channels=32", "--num_embeddings=(64,)", "--embedding_dim=(16,)", "--decay=(0.5,)",
+            "--roi=((0,32),(0,32),(0,32))", "--batch_size=2", "--eval_batch_size=2", "--learning_rate=1e-3", "--gamma=0.9", "--amp=False",
+            "--training_subjects=synthetic:4", "--validation_subjects=synthetic:2", "--mode=training", "--eval_every=1", *extra]
+
+
+@pytest.mark.parametrize("adversarial", [False, True])
+def test_resume_equals_uninterrupted_training(tmp_path, adversarial):
+    """N4: ``optimizer`` / ``lr_scheduler`` / ``trainer`` (and ``d_*``) are restored on resume (run_vqvae.py:312-345): 2 epochs in one run and
+    1 epoch + a restarted run for the 2nd produce the same networks and Adam moments (to fp32 summation order), step counts and learning rates."""
+    import run_vqvae
+    proj = str(tmp_path) + "/"
+    extra = ["--adversarial_component=True", "--use_adversarial_adaptive_weight=True", "--loss=jukebox"] if adversarial else []
+    run_vqvae.run(_vq_flags(proj, "full", extra) + ["--epochs=2"])
+    run_vqvae.run(_vq_flags(proj, "split", extra) + ["--epochs=1"])
+    first = torch.load(glob.glob(proj + "split/baseline_vqvae/checkpoints/checkpoint_epoch=1.pt")[0], map_location="cpu", weights_only=False)
+    want = {"network", "optimizer", "lr_scheduler", "trainer"} | ({"d_network", "d_optimizer", "d_lr_scheduler"} if adversarial else set())
+    assert set(first) == want and first["trainer"]["iteration"] == 2 and first["lr_scheduler"]["last_epoch"] == 2
+    run_vqvae.run(_vq_flags(proj, "split", extra) + ["--epochs=2"])      # finds the checkpoint, sets starting_epoch = -1 -> resumes at epoch 1
+    a = torch.load(glob.glob(proj + "full/baseline_vqvae/checkpoints/checkpoint_epoch=2.pt")[0], map_location="cpu", weights_only=False)
+    b = torch.load(glob.glob(proj + "split/baseline_vqvae/checkpoints/checkpoint_epoch=2.pt")[0], map_location="cpu", weights_only=False)
+    assert a["trainer"] == b["trainer"] and a["trainer"]["iteration"] == 4
+    assert a["lr_scheduler"] == b["lr_scheduler"] and abs(a["lr_scheduler"]["_last_lr"][0] - 1e-3 * 0.9 ** 4) < 1e-12
+    nets = ["network"] + (["d_network"] if adversarial else [])
+    # equal up to the summation order of the fp32 atomics in the quantizer's statistics scatter (1e-7 relative per step); an optimizer or
+    # scheduler that restarted from scratch would be off by ~lr = 1e-3 absolute, i.e. 1e-2 relative
+    for key in nets:
+        for k in a[key]:
+            if a[key][k].is_floating_point():
+                assert _rel(a[key][k], b[key][k]) < 1e-4, (key, k, _rel(a[key][k], b[key][k]))
+            else:
+                assert torch.equal(a[key][k], b[key][k]), (key, k)
+    for key in ["optimizer"] + (["d_optimizer"] if adversarial else []):
+        assert a[key]["param_groups"] == b[key]["param_groups"]
+        for i, ent in a[key]["state"].items():
+            assert float(ent["step"]) == 4.0 == float(b[key]["state"][i]["step"])
+            assert _rel(ent["exp_avg"], b[key]["state"][i]["exp_avg"]) < 1e-3 and _rel(ent["exp_avg_sq"], b[key]["state"][i]["exp_avg_sq"]) < 1e-3, (key, i)
+    # the evaluator's best-metric checkpoint exists alongside and --evaluation_checkpoint=best selects it
+    best = glob.glob(proj + "full/baseline_vqvae/checkpoints/checkpoint_key_metric=*.pt")
+    assert len(best) == 1
+    ex = [f for f in _vq_flags(proj, "full", extra) if not f.startswith("--mode")]
+    run_vqvae.run(ex + ["--mode=extracting", "--evaluation_checkpoint=best"])
+    assert len(glob.glob(proj + "full/baseline_vqvae/outputs/*/*_quantization_0.npy")) == 2

@@ -157,6 +157,19 @@ def test_decoder_and_encoder_halves_against_oracle_at_config2_widths(setup, dtyp
           [(f"{a:.2e}", f"{b:.2e}", k) for a, b, k in table[:5]])
     assert _rel(rec, rec_ref) < (1e-3 if rd is None else 2e-2) and _rel(z, z_ref) < (1e-3 if rd is None else 2e-2)
     assert table[0][0] < gate, table[0]
+    if rd is None:
+        # Where the fp32 error floor is: the same oracle evaluated in fp64 (exact to ~1e-15) differs from ITS OWN fp32 evaluation by a few 1e-3 on
+        # these gradients (pre-activations within rounding of zero flip their ReLU mask, which changes a gradient entry outright).  The HIP fp32
+        # path must be no further from the fp64 result than the fp32 CPU path is (x1.5 + the 1e-3 of north_star).
+        leaf64 = {k: v.clone().double().requires_grad_(True) for k, v in st.items() if "quantizer" not in k}
+        z64 = vqvae_ref.encode(leaf64, cfg, x.double())
+        torch.nn.functional.mse_loss(z64, zq.double()).backward()
+        rec64 = vqvae_ref.decode(leaf64, cfg, zq.double())
+        torch.nn.functional.mse_loss(rec64, x.double()).backward()
+        hip = max((_fro(params[k].grad, g.grad), k) for k, g in leaf64.items())
+        cpu = max((_fro(leaf[k].grad, g.grad), k) for k, g in leaf64.items())
+        print(f"\n[fp64 floor] worst gradient fro-rel vs the fp64 oracle: HIP fp32 {hip}, torch-CPU fp32 {cpu}")
+        assert hip[0] < 1e-3 + 1.5 * cpu[0], (hip, cpu)
 
 
 def test_fused_residual_block_kernel_against_conv3d_chain():
