@@ -78,6 +78,7 @@ const char *sa_last_conv_kernel(void);
 #define SA_DBG_IM2COL_DIRECT     (1u << 7)   /* sa_convt1_im2col without the LDS gather */
 #define SA_DBG_SCAN_VALU         (1u << 8)   /* FAVOR+ scans on the VALU segment kernels */
 #define SA_DBG_LOCAL_ATTN_EXACT  (1u << 9)   /* local attention on the exact-fp32 MFMA kernels */
+#define SA_DBG_HALO256_4W        (1u << 13)  /* 16x16-patch halo kernels with four waves per block instead of eight (bf16) */
 #define SA_DBG_SCAN_EXACT_SHIFT  10          /* 3 bits: chunk states | scan A outputs | scan B outputs on the exact-fp32 MFMA kernels */
 uint32_t sa_get_debug_flags(void);
 uint32_t sa_set_debug_flags(uint32_t flags);

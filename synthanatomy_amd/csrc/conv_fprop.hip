@@ -210,65 +210,163 @@ __device__ __forceinline__ void load16(const void* base, int dtype, int64_t off,
     }
 }
 
-template <int MI, int NI, typename RowOv>
-__device__ __forceinline__ void fprop_epilogue_regs(const FpropArgs& a, float4_t (&acc)[NI][MI], uint32_t wm, uint32_t wn, uint32_t frow, uint32_t fq,
-                                                    uint32_t n_base, RowOv row_ov) {
-    static_assert(NI == 4, "4 column fragments per wave");
+// The epilogue's addend / mask rows come from HBM (2-4 us under load).  Fetching them row group by row group right before use serialised
+// MI round trips per block -- measured with s_memtime on the 16 x 16-patch kernels: 100 k of a block's 242 k cycles sat in the epilogue,
+// eight dependent HBM round trips -- so they are fetched in batches of EPI_BATCH row groups: all loads of a batch are issued back to back
+// (packed 16-byte pieces, 4 VGPRs each), then the batch is combined and stored.  The fused residual block issues its first batch BEFORE the
+// second GEMM, so that round trip hides behind it.
+// batch = as many row groups as fit ~64 VGPRs of packed addend / mask pieces (bf16 source: 8 VGPRs per row group, fp32: 16)
+template <bool ADD, bool MASK, bool ADD32, bool MASK32, int BUDGET>
+constexpr int epi_batch_size() {
+    constexpr int regs = (ADD ? (ADD32 ? 16 : 8) : 0) + (MASK ? (MASK32 ? 16 : 8) : 0);
+    return regs * 4 <= BUDGET ? 4 : regs * 2 <= BUDGET ? 2 : 1;
+}
+
+template <int W>
+__device__ __forceinline__ void epi_unpack16(const u32x4 (&p)[W], float (&v)[16]) {
+    if constexpr (W == 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * k + e] = __uint_as_float(p[k][e]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[8 * k + 2 * e] = __uint_as_float(p[k][e] << 16);
+                v[8 * k + 2 * e + 1] = __uint_as_float(p[k][e] & 0xffff0000u);
+            }
+    }
+}
+
+// one batch: row groups JB .. JB + EPI_BATCH - 1 (compile-time indices: a run-time index would demote the accumulators to scratch memory)
+template <int MI, int NI, int JB, bool ADD, bool MASK, bool ADD32, bool MASK32, int BUDGET, typename RowOv>
+__device__ __forceinline__ void epi_batch(const FpropArgs& a, float4_t (&acc)[NI][MI], uint32_t wm, uint32_t frow, uint32_t c0, RowOv row_ov, float alpha) {
     const sa_conv_geom& g = a.g;
     const sa_epilogue& ep = a.ep;
-    const float alpha = ep.alpha ? *ep.alpha : 1.f;
-    if (ep.bias) {
+    constexpr int AW = ADD32 ? 4 : 2, MW = MASK32 ? 4 : 2;
+    constexpr int EPI_BATCH = epi_batch_size<ADD, MASK, ADD32, MASK32, BUDGET>();
+    u32x4 adp[EPI_BATCH][AW], mkp[EPI_BATCH][MW];
+    int64_t o[EPI_BATCH];
+    bool ok[EPI_BATCH];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const float4_t bv = *(const float4_t*)(ep.bias + n_base + wn * 64 + i * 16 + fq * 4);
+    for (int jj = 0; jj < EPI_BATCH; ++jj) {
+        const long long ov = row_ov(wm * (MI * 16) + (JB + jj) * 16 + frow);
+        ok[jj] = ov >= 0;
+        o[jj] = (ok[jj] ? ov : 0ll) * g.Cout + c0;   // rows outside the volume read voxel 0 (valid memory) and are not stored
+    }
 #pragma unroll
-            for (int j = 0; j < MI; ++j) acc[i][j] += bv;
+    for (int jj = 0; jj < EPI_BATCH; ++jj) {
+        if constexpr (ADD) {
+#pragma unroll
+            for (int k = 0; k < AW; ++k)
+                adp[jj][k] = ADD32 ? *(const u32x4*)((const float*)ep.addend + o[jj] + 4 * k) : *(const u32x4*)((const bf16_t*)ep.addend + o[jj] + 8 * k);
+        }
+        if constexpr (MASK) {
+#pragma unroll
+            for (int k = 0; k < MW; ++k)
+                mkp[jj][k] = MASK32 ? *(const u32x4*)((const float*)ep.mask + o[jj] + 4 * k) : *(const u32x4*)((const bf16_t*)ep.mask + o[jj] + 8 * k);
         }
     }
-    const uint32_t c0 = n_base + wn * 64 + fq * 16;   // this lane's 16 channels after the transpose
 #pragma unroll
-    for (int j = 0; j < MI; ++j) {
+    for (int jj = 0; jj < EPI_BATCH; ++jj) {
+        constexpr int j0 = JB;
         float v[16];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float t0 = acc[0][j][r], t1 = acc[1][j][r], t2 = acc[2][j][r], t3 = acc[3][j][r];
+            float t0 = acc[0][j0 + jj][r], t1 = acc[1][j0 + jj][r], t2 = acc[2][j0 + jj][r], t3 = acc[3][j0 + jj][r];
             quarter_transpose(t0, t1, t2, t3);       // t[i'] = channel fq*16 + i'*4 + r
             v[r] = t0; v[4 + r] = t1; v[8 + r] = t2; v[12 + r] = t3;
         }
-        const long long ov = row_ov(wm * (MI * 16) + j * 16 + frow);
-        if (ov < 0) continue;
-        const int64_t o = ov * g.Cout + c0;
         float ad[16], mk[16];
-        if (ep.addend) load16(ep.addend, ep.add_dtype, o, ad);
-        if (ep.mask_mode != SA_MASK_NONE) load16(ep.mask, ep.mask_dtype, o, mk);
+        if constexpr (ADD) epi_unpack16<AW>(adp[jj], ad);
+        if constexpr (MASK) epi_unpack16<MW>(mkp[jj], mk);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             float x = v[e];
-            if (ep.addend && ep.add_before_act) x += ad[e];
+            if constexpr (ADD) { if (ep.add_before_act) x += ad[e]; }
             if (ep.act == SA_ACT_RELU) x = fmaxf(x, 0.f);
             else if (ep.act == SA_ACT_LRELU) x = x > 0.f ? x : x * ep.slope;
             else if (ep.act == SA_ACT_GELU) x = gelu_f(x);
             x *= alpha;
-            if (ep.addend && !ep.add_before_act) x += ad[e];
-            if (ep.mask_mode == SA_MASK_POS) x = mk[e] > 0.f ? x : 0.f;
-            else if (ep.mask_mode == SA_MASK_LRELU) x = mk[e] > 0.f ? x : x * ep.slope;
-            else if (ep.mask_mode == SA_MASK_GELU) x *= gelu_grad_f(mk[e]);
+            if constexpr (ADD) { if (!ep.add_before_act) x += ad[e]; }
+            if constexpr (MASK) {
+                if (ep.mask_mode == SA_MASK_POS) x = mk[e] > 0.f ? x : 0.f;
+                else if (ep.mask_mode == SA_MASK_LRELU) x = mk[e] > 0.f ? x : x * ep.slope;
+                else if (ep.mask_mode == SA_MASK_GELU) x *= gelu_grad_f(mk[e]);
+            }
             v[e] = x;
         }
-        if (ep.out_dtype == SA_F32) {
+        if (ok[jj]) {
+            if (ep.out_dtype == SA_F32) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) *(float4_t*)((float*)a.out + o + 4 * k) = (float4_t){v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
-        } else {
+                for (int k = 0; k < 4; ++k) *(float4_t*)((float*)a.out + o[jj] + 4 * k) = (float4_t){v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+            } else {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                u32x4 pk;
+                for (int k = 0; k < 2; ++k) {
+                    u32x4 pk;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = (uint32_t)f32_to_bf16(v[8 * k + 2 * e]) | ((uint32_t)f32_to_bf16(v[8 * k + 2 * e + 1]) << 16);
-                *(u32x4*)((bf16_t*)a.out + o + 8 * k) = pk;
+                    for (int e = 0; e < 4; ++e) pk[e] = (uint32_t)f32_to_bf16(v[8 * k + 2 * e]) | ((uint32_t)f32_to_bf16(v[8 * k + 2 * e + 1]) << 16);
+                    *(u32x4*)((bf16_t*)a.out + o[jj] + 8 * k) = pk;
+                }
             }
         }
     }
 }
+
+template <int MI, int NI>
+__device__ __forceinline__ void epi_add_bias(const FpropArgs& a, float4_t (&acc)[NI][MI], uint32_t wn, uint32_t fq, uint32_t n_base) {
+    if (a.ep.bias) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float4_t bv = *(const float4_t*)(a.ep.bias + n_base + wn * 64 + i * 16 + fq * 4);
+#pragma unroll
+            for (int j = 0; j < MI; ++j) acc[i][j] += bv;
+        }
+    }
+}
+
+// all batches of one (ADD, MASK, widths) specialisation
+template <int MI, int NI, int JB, bool ADD, bool MASK, bool ADD32, bool MASK32, int BUDGET, typename RowOv>
+__device__ __forceinline__ void epi_run_from(const FpropArgs& a, float4_t (&acc)[NI][MI], uint32_t wm, uint32_t frow, uint32_t c0, RowOv row_ov, float alpha) {
+    if constexpr (JB < MI) {
+        epi_batch<MI, NI, JB, ADD, MASK, ADD32, MASK32, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+        epi_run_from<MI, NI, JB + epi_batch_size<ADD, MASK, ADD32, MASK32, BUDGET>(), ADD, MASK, ADD32, MASK32, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+    }
+}
+template <int MI, int NI, bool ADD, bool MASK, bool ADD32, bool MASK32, int BUDGET, typename RowOv>
+__device__ __forceinline__ void epi_run(const FpropArgs& a, float4_t (&acc)[NI][MI], uint32_t wm, uint32_t frow, uint32_t c0, RowOv row_ov, float alpha) {
+    static_assert(MI % 4 == 0, "row groups per wave must be a multiple of the largest batch");
+    epi_run_from<MI, NI, 0, ADD, MASK, ADD32, MASK32, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+}
+
+template <int MI, int NI, int BUDGET = 64, typename RowOv>
+__device__ __forceinline__ void fprop_epilogue_regs(const FpropArgs& a, float4_t (&acc)[NI][MI], uint32_t wm, uint32_t wn, uint32_t frow, uint32_t fq,
+                                                    uint32_t n_base, RowOv row_ov, bool bias_done = false) {
+    static_assert(NI == 4, "4 column fragments per wave");
+    const sa_epilogue& ep = a.ep;
+    const float alpha = ep.alpha ? *ep.alpha : 1.f;
+    if (!bias_done) epi_add_bias<MI, NI>(a, acc, wn, fq, n_base);
+    const uint32_t c0 = n_base + wn * 64 + fq * 16;   // this lane's 16 channels after the transpose
+    const bool add = ep.addend != nullptr, mask = ep.mask_mode != SA_MASK_NONE;
+    const bool a32 = ep.add_dtype == SA_F32, m32 = ep.mask_dtype == SA_F32;
+    // block-uniform dispatch to a straight-line specialisation (loads of a batch back to back)
+    if (!add && !mask) epi_run<MI, NI, false, false, false, false, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+    else if (add && !mask) {
+        if (a32) epi_run<MI, NI, true, false, true, false, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+        else epi_run<MI, NI, true, false, false, false, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+    } else if (!add && mask) {
+        if (m32) epi_run<MI, NI, false, true, false, true, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+        else epi_run<MI, NI, false, true, false, false, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+    } else {
+        if (a32 && m32) epi_run<MI, NI, true, true, true, true, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+        else if (!a32 && !m32) epi_run<MI, NI, true, true, false, false, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+        else if (a32) epi_run<MI, NI, true, true, true, false, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+        else epi_run<MI, NI, true, true, false, true, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+    }
+}
+
 
 template <int BM, int BN, int WM, int WN, int MI, int NI, int NT = 256>
 __device__ __forceinline__ void fprop_epilogue(const FpropArgs& a, float4_t (&acc)[NI][MI], unsigned char* smem, uint32_t tid, uint32_t wm, uint32_t wn,
@@ -806,10 +904,26 @@ __global__ __launch_bounds__(256) void conv_fprop_halo_kernel(const FpropArgs a)
 // SINGLE-buffered: it is re-loaded at every (kd, chunk) switch behind a barrier, and that bubble is covered by the other block of the CU
 // (the next group's first weight slab is already in flight).  LDS 41 KiB + 2 x 16 KiB = 73 KiB.  Register epilogue only.
 // Measured on the C = 128 layer: data gradient 4.52 -> 4.30 ms (+5 %), plain forward +1.5 %; used for the non-fused launches.
-template <typename T, bool FUSE = false>
-__global__ __launch_bounds__(256, 2) void conv_fprop_halo256_kernel(const FpropArgs a) {
+#ifdef SA_TIMING
+// dev instrumentation (-DSA_TIMING): s_memtime sums of wave 0 of every block: [0] slab compute phase, [1] wait for DMA (vmcnt), [2] wait at the slab
+// barrier, [3] halo reload (issue .. barrier), [4] prologue, [5] second GEMM + epilogue, [6] whole kernel, [7] number of blocks
+__device__ unsigned long long g_timing[8];
+#define SA_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define SA_TACC(i, v) do { if (tid == 0) atomicAdd(&g_timing[i], (unsigned long long)(v)); } while (0)
+#else
+#define SA_T(var)
+#define SA_TACC(i, v)
+#endif
+// NW = 8: the same 256-voxel tile worked by EIGHT waves of 64 x 64 outputs (<= 128 VGPRs -> two blocks = four waves per SIMD).  A lone
+// 4-wave block runs at ~45 % of the MFMA rate (s_memtime: ~1 000 cycles of DMA issue, address arithmetic, LDS latency and barrier per
+// 1 024-cycle slab) and its partner block spends half its life in halo reloads / the epilogue; with four waves per SIMD the other three
+// cover those cycles.
+template <typename T, bool FUSE = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW / 2) void conv_fprop_halo256_kernel(const FpropArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int MI = 8, NI = 4;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    constexpr int MI = 32 / NW, NI = 4;
+    constexpr int WPIECES = 16 / NW;          // weight pieces (1 KiB) per wave per slab
     constexpr int BN = 128;
     constexpr int HW_ = 18, HROWS = 324, HPIECES = 41;
     constexpr int SZ = sizeof(T);
@@ -841,9 +955,9 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_halo256_kernel(const FpropA
 
     const uint32_t prow = lane >> 3;
     const uint32_t lv = (lane & 7u) ^ prow;
-    uint32_t boff[4];
+    uint32_t boff[WPIECES];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) boff[j] = (n_base + (wave * 4 + j) * 8 + prow) * (uint32_t)(g.Kpad * SZ) + lv * 16u;
+    for (int j = 0; j < WPIECES; ++j) boff[j] = (n_base + (wave * WPIECES + j) * 8 + prow) * (uint32_t)(g.Kpad * SZ) + lv * 16u;
 
     const uint32_t nchunk = (uint32_t)(g.Cin * SZ) / 128u;
     const uint32_t ngroups = 3u * nchunk;
@@ -859,7 +973,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_halo256_kernel(const FpropA
         const bool dok = (uint32_t)id < (uint32_t)g.Di;
         const uint32_t goff = (uint32_t)id * plane_bytes + ch * 128u + lv * 16u;
 #pragma unroll 1
-        for (uint32_t p = wave; p < (uint32_t)HPIECES; p += 4) {
+        for (uint32_t p = wave; p < (uint32_t)HPIECES; p += NW) {
             const uint32_t r = p * 8 + prow;
             const uint32_t hh = r / HW_, ww = r - hh * HW_;
             const int32_t ih = h0 + oh + (int32_t)hh, iw = w0 + ow + (int32_t)ww;
@@ -872,8 +986,8 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_halo256_kernel(const FpropA
         const uint32_t td = gi / nchunk, ch = gi - td * nchunk;
         const uint32_t col = ((td * 9u + t9) * (uint32_t)g.Cin) * SZ + ch * 128u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(sB + buf * (BN * 128) + (wave * 4 + j) * 1024), 16, boff[j], col, 0, 0);
+        for (int j = 0; j < WPIECES; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(sB + buf * (BN * 128) + (wave * WPIECES + j) * 1024), 16, boff[j], col, 0, 0);
     };
 
     float4_t acc[NI][MI];
@@ -883,13 +997,19 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_halo256_kernel(const FpropA
         for (int j = 0; j < MI; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
     const uint32_t frow = lane & 15u, fq = lane >> 4;
-    const uint32_t a_base = ((wm * 8u) * HW_ + frow) * 128u + fq * 16u;   // unswizzled; patch row j adds 18 * 128 j
+    const uint32_t a_base = ((wm * (uint32_t)MI) * HW_ + frow) * 128u + fq * 16u;   // unswizzled; patch row j adds 18 * 128 j
     const uint32_t b_off = tile_off(wn * (NI * 16) + frow, fq);
     const bool fh = g.tap_step[1] < 0, fw = g.tap_step[2] < 0;
 
+    SA_T(t_k0);
     issue_halo(0);
     issue_w(0, 0, 0);
     __syncthreads();
+    SA_T(t_k1);
+    SA_TACC(4, t_k1 - t_k0);
+#ifdef SA_TIMING
+    unsigned long long t_prev = t_k1, s_comp = 0, s_dma = 0, s_bar = 0, s_halo = 0;
+#endif
     uint32_t buf = 0;
     for (uint32_t gi = 0; gi < ngroups; ++gi) {
         const bool next_group = gi + 1 < ngroups;
@@ -917,14 +1037,31 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_halo256_kernel(const FpropA
 #pragma unroll
                     for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
             }
+#ifdef SA_TIMING
+            asm volatile("" ::: "memory");
+            SA_T(t_a);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SA_T(t_b);
+            __syncthreads();
+            SA_T(t_c);
+            s_comp += t_a - t_prev; s_dma += t_b - t_a; s_bar += t_c - t_b; t_prev = t_c;
+#else
             __syncthreads();   // next weight slab landed (vmcnt(0)), this one free
+#endif
             buf ^= 1u;
         }
         if (next_group) {      // every wave is past its last read of the halo image: reload it (the first weight slab of the group is in flight)
             issue_halo(gi + 1);
             __syncthreads();
+#ifdef SA_TIMING
+            SA_T(t_h);
+            s_halo += t_h - t_prev; t_prev = t_h;
+#endif
         }
     }
+#ifdef SA_TIMING
+    SA_TACC(0, s_comp); SA_TACC(1, s_dma); SA_TACC(2, s_bar); SA_TACC(3, s_halo);
+#endif
     auto row_vox = [&](uint32_t row) __attribute__((always_inline)) {
         const uint32_t h = (uint32_t)h0 + (row >> 4), w = (uint32_t)w0 + (row & 15u);
         return h < (uint32_t)g.Ho && w < (uint32_t)g.Wo ? (((long long)pn * g.Do + pd) * g.Ho + h) * g.Wo + w : -1ll;
@@ -949,19 +1086,20 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_halo256_kernel(const FpropA
                 acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
             }
         }
-        u32x4 w2[NI][4];
-        {
-            const bf16_t* wp = (const bf16_t*)a.w2pk;
+        constexpr int W2K = NW == 4 ? 4 : 1;   // 4 waves: all 16 fragments up front (registers to spare); 8 waves: 4 per K step (128-VGPR budget)
+        u32x4 w2[NI][W2K];
+        const bf16_t* const w2p = (const bf16_t*)a.w2pk;
+        if constexpr (NW == 4) {
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) w2[i][ks] = *(const u32x4*)(wp + (wn * 64 + i * 16 + frow) * 128 + ks * 32 + fq * 8);
+                for (int ks = 0; ks < 4; ++ks) w2[i][ks] = *(const u32x4*)(w2p + (wn * 64 + i * 16 + frow) * 128 + ks * 32 + fq * 8);
         }
         __syncthreads();  // h tile complete
         if (a.h_out) {    // training: the hidden activation is needed by the backward pass -> full 256-byte rows
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const uint32_t row = (tid >> 4) + 16u * it, sl = (tid >> 3) & 1u, vec = tid & 7u;
+            for (int it = 0; it < 64 / NW; ++it) {
+                const uint32_t row = (tid >> 4) + (uint32_t)(NW * 4) * it, sl = (tid >> 3) & 1u, vec = tid & 7u;
                 const long long vox = row_vox(row);
                 if (vox >= 0) *(u32x4*)((bf16_t*)a.h_out + (size_t)vox * 128 + sl * 64 + vec * 8) = *(const u32x4*)(smem + sl * (256 * 128) + tile_off(row, vec));
             }
@@ -969,17 +1107,36 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_halo256_kernel(const FpropA
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             u32x4 xf[MI];
+            if constexpr (NW != 4) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) w2[i][0] = *(const u32x4*)(w2p + (wn * 64 + i * 16 + frow) * 128 + ks * 32 + fq * 8);
+            }
 #pragma unroll
             for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(smem + (ks >> 1) * (256 * 128) + tile_off(wm * (MI * 16) + j * 16 + frow, (ks & 1) * 4 + fq));
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], w2[i][ks], xf[j]);
+                for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], w2[i][NW == 4 ? ks : 0], xf[j]);
         }
     }
-    fprop_epilogue_regs<MI, NI>(a, acc, wm, wn, frow, fq, n_base, row_vox);
+    fprop_epilogue_regs<MI, NI, (NW == 4 ? 64 : 24)>(a, acc, wm, wn, frow, fq, n_base, row_vox);
+#ifdef SA_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SA_T(t_end);
+    SA_TACC(5, t_end - t_prev); SA_TACC(6, t_end - t_k0); SA_TACC(7, 1);
+#endif
 #endif
 }
+
+#ifdef SA_TIMING
+}  // namespace sa
+extern "C" int sa_debug_timing(unsigned long long* out, int reset) {
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(sa::g_timing), 64);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(sa::g_timing), z, 64); }
+    return 0;
+}
+namespace sa {
+#endif
 
 template <typename T, int WM, int WN, int MI, int NI>
 static int launch_fprop(const FpropArgs& a, hipStream_t st) {
@@ -1047,6 +1204,15 @@ static bool halo256_eligible(const FpropArgs& a, int sz) {
     return eff >= 0.9 && (int64_t)g.N * g.Dm * hp * wp >= 256;
 }
 
+template <typename T, bool FUSE, int NW>
+static int launch_fprop_halo256_impl(const FpropArgs& a, uint32_t nbn, size_t lds, hipStream_t st) {
+    static std::atomic<uint64_t> attr_done{0};   // one bit per device (one static per template instance)
+    if (first_use_on_device(attr_done)) hipFuncSetAttribute((const void*)conv_fprop_halo256_kernel<T, FUSE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipLaunchKernelGGL((conv_fprop_halo256_kernel<T, FUSE, NW>), dim3(a.nblk_m * nbn), dim3(NW * 64), lds, st, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T, bool FUSE = false>
 static int launch_fprop_halo256(FpropArgs a, hipStream_t st) {
     a.HP = (uint32_t)(a.g.Ho + 15) / 16;
@@ -1054,12 +1220,16 @@ static int launch_fprop_halo256(FpropArgs a, hipStream_t st) {
     a.nblk_m = (uint32_t)a.g.N * (uint32_t)a.g.Dm * a.HP * a.WP;
     const uint32_t nbn = (uint32_t)a.g.cout_valid / 128;
     const size_t lds = 41 * 1024 + 2 * 128 * 128;   // 73 KiB (>= the 64 KiB hidden tile of the fused variant)
-    static std::atomic<uint64_t> attr_done{0};   // one bit per device (one static per template instance)
-    if (first_use_on_device(attr_done)) hipFuncSetAttribute((const void*)conv_fprop_halo256_kernel<T, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo256_kernel<%s, %s>", tname<T>(), FUSE ? "true" : "false");
-    hipLaunchKernelGGL((conv_fprop_halo256_kernel<T, FUSE>), dim3(a.nblk_m * nbn), dim3(256), lds, st, a);
-    SA_CHECK_LAUNCH();
-    return 0;
+    // bf16: eight waves per block (two blocks = four waves per SIMD): fused block 4.76 -> 4.51 ms, data gradient 4.73 -> 4.29 ms on the C = 128 /
+    // 80 x 112 x 80 layer.  fp32 keeps four (its 128 accumulators + wider fragments do not fit 128 VGPRs).  SA_DBG_HALO256_4W selects four for A/B runs.
+    if constexpr (sizeof(T) == 2) {
+        if (!dbg(SA_DBG_HALO256_4W)) {
+            snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo256_kernel<%s, %s, 8>", tname<T>(), FUSE ? "true" : "false");
+            return launch_fprop_halo256_impl<T, FUSE, 8>(a, nbn, lds, st);
+        }
+    }
+    snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo256_kernel<%s, %s, 4>", tname<T>(), FUSE ? "true" : "false");
+    return launch_fprop_halo256_impl<T, FUSE, 4>(a, nbn, lds, st);
 }
 
 template <typename T>
