@@ -128,6 +128,7 @@ def training(cfg, rank, local, world, dev):
     if ckpt:
         to_load = {k: v for k, v in to_save.items() if not (cfg["finetune_adversarial_component"] and k.startswith("d_"))}
         load_checkpoint(ckpt, to_load, map_location=dev)
+        state.epoch_length, state.max_epochs = epoch_length, cfg["epochs"]      # this run's data set / --epochs decide, as MaxEpochsHandler does upstream
         net.invalidate_packed_weights()
         log(rank, f"resumed from {ckpt}: epoch {state.epoch}, iteration {state.iteration}, lr {opt.lr:.6e}")
     gen = torch.Generator(device=dev).manual_seed(cfg["seed"] + rank)

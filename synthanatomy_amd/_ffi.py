@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsynthanatomy_hip.so")
+LIB_PATH = os.environ.get("SA_HIP_LIB") or os.path.join(HERE, "libsynthanatomy_hip.so")   # (SA_HIP_LIB: dev A/B builds)
 
 SA_F32, SA_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU = 0, 1, 2, 3

@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void conv_fprop_dma_kernel(const FpropArgs a) 
 // A 256-voxel tile with 32-channel slabs (4 waves of 128 x 64, two blocks per CU, half the weight bytes and 3 instead of 5 DMA pieces per
 // 32 MFMAs) was 5 % slower as well: what bounds this loop is the barrier interval (32 MFMAs per wave), not the weight bytes.
 template <typename T, bool FUSE>
-__global__ __launch_bounds__(256) void conv_fprop_halo_kernel(const FpropArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_fprop_halo_kernel(const FpropArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int WM = 2, WN = 2, MI = 4, NI = 4;
     constexpr int BM = 128, BN = 128;
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(256) void conv_fprop_halo_kernel(const FpropArgs a)
     }
     // full tile of valid channels and 16-byte aligned channel rows -> register epilogue; otherwise the LDS-staged one (block-uniform choice)
     const bool regs_ok = n_base + BN <= (uint32_t)g.cout_valid && (g.Cout & 7) == 0 && !(a.dbg & 256u);
-    if (regs_ok) fprop_epilogue_regs<MI, NI>(a, acc, wm, wn, frow, fq, n_base, row_vox);
+    if (regs_ok) fprop_epilogue_regs<MI, NI, 32>(a, acc, wm, wn, frow, fq, n_base, row_vox);
     else fprop_epilogue_ov<BM, BN, WM, WN, MI, NI, 256>(a, acc, smem, tid, wm, wn, frow, fq, n_base, row_vox);
 #endif
 }
@@ -1201,7 +1201,8 @@ static bool halo256_eligible(const FpropArgs& a, int sz) {
     if (g.cout_valid % 128 != 0 || (g.Cout & 7) != 0) return false;
     const int hp = (g.Ho + 15) / 16, wp = (g.Wo + 15) / 16;
     const double eff = (double)g.Ho * g.Wo / ((double)hp * 16 * wp * 16);
-    return eff >= 0.9 && (int64_t)g.N * g.Dm * hp * wp >= 256;
+    // (0.7: at 40 x 56 planes the 16 x 16 patches waste 27 % of their MFMAs and still beat the 8 x 16-patch kernel, 875 vs 650-735 TFLOP/s effective)
+    return eff >= 0.7 && (int64_t)g.N * g.Dm * hp * wp >= 256;
 }
 
 template <typename T, bool FUSE, int NW>

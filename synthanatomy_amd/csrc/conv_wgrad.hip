@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 }
 
 template <typename T, bool DG = false>
-__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int MK = WG<T>::MK;
     constexpr bool IS_BF16 = sizeof(T) == 2;
@@ -693,15 +693,19 @@ __global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradArgs a)
 // distinct 32-byte bank groups (rows of equal parity share a 256-byte bank line).
 __device__ __forceinline__ uint32_t roff128(uint32_t m, uint32_t c) { return m * 128u + ((((c >> 4) ^ ((m >> 1) & 3u)) << 5) | ((c & 15u) << 1)); }
 
-__global__ __launch_bounds__(512) void conv_wgrad_halo9_kernel(const WgradArgs a) {
+// NW = 16: the same step worked by sixteen waves (36 x 2 accumulator fragments each, <= 128 VGPRs -> four waves per SIMD from ONE block: the
+// 110 KiB of LDS allow no second block, and two waves per SIMD leave the MFMA pipe idle through every DMA wait / barrier).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv_wgrad_halo9_kernel(const WgradArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int XP = 23, GP = 32, NP = XP + GP, PPW = (NP + 7) / 8;   // 1 KiB pieces per step; 7 per wave (the last round is partial)
+    constexpr int NJ = 32 / NW;                                           // 16-column output-channel fragments per wave (4 or 2)
+    constexpr int XP = 23, GP = 32, NP = XP + GP, PPW = (NP + NW - 1) / NW;   // 1 KiB pieces per step, dealt round-robin to the waves
     constexpr int XT = XP * 1024, GT = GP * 1024, STAGE = XT + GT;      // 55 KiB
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const sa_conv_geom& g = a.g;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t fi = wave & 3u, wn = wave >> 2;          // 16-ci fragment of this block's 64-channel half, 64-co half
+    const uint32_t fi = wave & 3u, wn = wave >> 2;          // 16-ci fragment of this block's 64-channel half, (16 NJ)-co slice
     // block -> (split, kd, ci half, co tile); an XCD walks a contiguous range of splits, the six blocks of a split back to back
     const uint32_t nct = a.ntiles / a.nkt;
     const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
@@ -717,11 +721,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo9_kernel(const WgradArgs a
     uint32_t step1 = step0 + a.steps_per_split;
     if (step1 > a.nsteps) step1 = a.nsteps;
 
-    float4_t acc[9][4];
+    float4_t acc[9][NJ];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[t][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
     __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)a.gout, 0, (int)a.g_bytes, 0x00020000);
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo9_kernel(const WgradArgs a
     uint32_t p_off[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-        const uint32_t q = wave + 8u * i;
+        const uint32_t q = wave + (uint32_t)NW * i;
         if (q < (uint32_t)XP) {
             const uint32_t r = q * 8u + (lane >> 3), pos = lane & 7u;
             const uint32_t vec = ((((pos >> 1) ^ ((r >> 1) & 3u)) << 1) | (pos & 1u));
@@ -763,7 +767,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo9_kernel(const WgradArgs a
         const uint32_t gbase = (uint32_t)((((int32_t)n * g.Do + (int32_t)d) * g.Ho + h0) * g.Wo + w0) * (uint32_t)(g.Cout * 2);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            const uint32_t q = wave + 8u * i;
+            const uint32_t q = wave + (uint32_t)NW * i;
             if (q >= (uint32_t)NP) break;
             const int32_t hh = h0 + p_h[i], ww = w0 + p_w[i];
             if (q < (uint32_t)XP) {
@@ -793,23 +797,23 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo9_kernel(const WgradArgs a
         xa[t][0] = roff128(xr0, fi * 16 + tcol);
         xa[t][1] = roff128(xr0 + 18u, fi * 16 + tcol);
     }
-    uint32_t ga[4];
+    uint32_t ga[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ga[j] = roff(trow, wn * 64 + j * 16 + tcol);   // (+ 4096 for the high half: 16 rows keep m & 7)
+    for (int j = 0; j < NJ; ++j) ga[j] = roff(trow, wn * (16 * NJ) + j * 16 + tcol);   // (+ 4096 for the high half: 16 rows keep m & 7)
     for (uint32_t st = step0; st < step1; ++st) {
         const uint32_t buf = (st - step0) & 1u;
         if (st + 1 < step1) issue(st + 1, buf ^ 1u);
         const unsigned char* px = smem + buf * STAGE;
         const unsigned char* pg = px + XT;
-        if (do_db) tile_colsum<128, 8>(pg, tid, bs0, bs1);
+        if (do_db) tile_colsum<128, NW>(pg, tid, bs0, bs1);
 #pragma unroll 1
         for (uint32_t ks = 0; ks < 4; ++ks) {   // 32 voxels = patch rows 2 ks, 2 ks + 1  (rolled: unrolling spills the 144 accumulators)
-            short8_t gf[4];
+            short8_t gf[NJ];
             const unsigned char* pgk = pg + ks * 8192u;
             const unsigned char* pxk = px + ks * 4608u;
             const uint32_t kx = (ks & 1u) * 64u;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const v4s_t lo = lds_tr16(pgk + ga[j]);
                 const v4s_t hi = lds_tr16(pgk + ga[j] + 4096);
                 gf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -820,18 +824,18 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo9_kernel(const WgradArgs a
                 const v4s_t hi = lds_tr16(pxk + (xa[t][1] ^ kx));
                 const short8_t xf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, gf[j], acc[t][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, gf[j], acc[t][j], 0, 0, 0);
             }
         }
         __syncthreads();  // drains the DMA (vmcnt(0)) and frees this buffer
     }
-    if (do_db) colsum_finish<8>((float*)smem, tid, bs0, bs1, a.db, ct * 128u, (uint32_t)g.cout_valid);
+    if (do_db) colsum_finish<NW>((float*)smem, tid, bs0, bs1, a.db, ct * 128u, (uint32_t)g.cout_valid);
     // partial tiles of the nine taps of this kd -> workspace [split][tile = tap + 27*ct][co 128][ci 128]
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         float* wt = a.ws + ((size_t)split * a.ntiles + (td * 9u + t) + a.nkt * ct) * (128 * 128);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *(float4_t*)(wt + (wn * 64 + j * 16 + frow) * 128 + cih * 64 + fi * 16 + fq * 4) = acc[t][j];
+        for (int j = 0; j < NJ; ++j) *(float4_t*)(wt + (wn * (16 * NJ) + j * 16 + frow) * 128 + cih * 64 + fi * 16 + fq * 4) = acc[t][j];
     }
 #endif
 }
@@ -1066,12 +1070,20 @@ static int conv_wgrad_impl(const sa_conv_geom* g, int dtype, const void* in, con
         static std::atomic<uint64_t> attr_done{0};   // one bit per device
         if (first_use_on_device(attr_done)) {
             hipFuncSetAttribute((const void*)conv_wgrad_halo_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34 * 1024);
-            hipFuncSetAttribute((const void*)conv_wgrad_halo9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 55 * 1024);
+            hipFuncSetAttribute((const void*)conv_wgrad_halo9_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 55 * 1024);
+            hipFuncSetAttribute((const void*)conv_wgrad_halo9_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 55 * 1024);
         }
         const uint32_t nct = a.ntiles / a.nkt, spx = (splits + 7u) / 8u;
         if (a.halo == 9) {
-            snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_halo9_kernel");
-            hipLaunchKernelGGL(conv_wgrad_halo9_kernel, dim3(8u * spx * 6u * nct), dim3(512), 2 * 55 * 1024, st, a);
+            // (a sixteen-wave form of this kernel -- NW = 16, 128 VGPRs, four waves per SIMD -- measured 4.74 ms against 4.28 ms: kept as a template
+            //  instance for A/B runs, SA_PP_DBG bit 14)
+            if (g_tunables.pp_dbg & 16384u) {
+                snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_halo9_kernel<16>");
+                hipLaunchKernelGGL(conv_wgrad_halo9_kernel<16>, dim3(8u * spx * 6u * nct), dim3(1024), 2 * 55 * 1024, st, a);
+            } else {
+                snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_halo9_kernel");
+                hipLaunchKernelGGL(conv_wgrad_halo9_kernel<8>, dim3(8u * spx * 6u * nct), dim3(512), 2 * 55 * 1024, st, a);
+            }
         } else {
             snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_halo_kernel<4>");
             hipLaunchKernelGGL(conv_wgrad_halo_kernel<4>, dim3(8u * spx * 9u * nct), dim3(768), 2 * 34 * 1024, st, a);

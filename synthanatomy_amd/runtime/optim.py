@@ -153,6 +153,8 @@ class TrainerState:
         return {"iteration": self.iteration, "epoch_length": self.epoch_length, "max_epochs": self.max_epochs}
 
     def load_state_dict(self, sd):
+        self.epoch_length = int(sd.get("epoch_length", self.epoch_length))     # ignite restores all three
+        self.max_epochs = int(sd.get("max_epochs", self.max_epochs))
         if "iteration" in sd:
             self.iteration = int(sd["iteration"])
         elif "epoch" in sd:      # ignite also accepts {epoch, epoch_length, max_epochs}; round-1 checkpoints stored {"epoch": e} = last finished epoch
