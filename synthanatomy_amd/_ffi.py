@@ -51,6 +51,7 @@ _SIGS = {
     "sa_abi_version": (c_int, []),
     "sa_last_error": (c_char_p, []),
     "sa_last_conv_kernel": (c_char_p, []),
+    "sa_bench_mfma_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "sa_get_debug_flags": (ctypes.c_uint32, []),
     "sa_set_debug_flags": (ctypes.c_uint32, [ctypes.c_uint32]),
     "sa_conv1_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -157,6 +157,41 @@ static inline unsigned grid_for(int64_t n, int block = 256, unsigned cap = 4096)
 
 }  // namespace sa
 
+namespace sa {
+// Peak probe: every wave issues `iters` x 8 independent v_mfma_f32_32x32x16_bf16 (8 accumulator tiles, no memory traffic) -- the number the
+// roofline fractions can be read against on THIS device at ITS clocks (bench.py `roofline.peak_measured`).
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((ext_vector_type(16))) float f16x;
+    typedef __attribute__((ext_vector_type(8))) short s8x;
+    f16x acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    s8x a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = (short)(0x3f80 + threadIdx.x); b[e] = (short)(0x3c00 + e); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += acc[i][0] + acc[i][15];
+    if (t == 12345.678f) out[0] = t;   // keeps the loop alive without a store in the common case
+#endif
+}
+}  // namespace sa
+
+// FLOPs of one call = blocks * 4 waves * iters * 8 MFMAs * (2 * 32 * 32 * 16)
+extern "C" int sa_bench_mfma_bf16(float* scratch, int blocks, int iters, void* stream) {
+    if (!scratch || blocks <= 0 || iters <= 0) return SA_EINVAL;
+    hipLaunchKernelGGL(sa::mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, scratch, iters);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int sa_abi_version(void) { return SA_ABI_VERSION; }
 extern "C" const char* sa_last_error(void) { return hipGetErrorString(sa::g_last_error); }
 extern "C" const char* sa_last_conv_kernel(void) { return sa::g_last_conv_kernel; }

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Summaries of rocprofv3 rocpd databases (the sqlite files `rocprofv3 -d DIR -o NAME` leaves as DIR/NAME_results.db), dev tool.
+
+    python tools/rocpd_tools.py stats   <trace.db>                         per-kernel launch count / total / avg / min / max / share
+    python tools/rocpd_tools.py pmc     <pmc.db>                           per-kernel mean of every collected counter
+    python tools/rocpd_tools.py traffic <fetch.db> <write.db> [out.json]   HBM-side bytes per launch: (2 x FETCH_SIZE + WRITE_SIZE) KiB
+                                                                           (gfx950: 128-B read requests are tallied at 64 B, MI355X_MICROARCH.md)
+Kernel names are demangled and trimmed to the spelling `sa_last_conv_kernel()` reports (e.g. `conv_fprop_halo256_kernel<unsigned short, true, 8>`)."""
+import json
+import re
+import sqlite3
+import subprocess
+import sys
+from collections import defaultdict
+
+
+def _open(path):
+    db = sqlite3.connect(path)
+    tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
+    return db, (lambda stem: [t for t in tabs if t.startswith("rocpd_" + stem)][0])
+
+
+def _demangle(names):
+    try:
+        out = subprocess.run(["c++filt"], input="\n".join(n[:-3] if n.endswith(".kd") else n for n in names), capture_output=True, text=True).stdout.split("\n")
+    except OSError:
+        out = list(names)
+    res = {}
+    for n, d in zip(names, out):
+        d = re.sub(r"^void ", "", d)
+        d = re.sub(r"\((sa::|HIP_|float|unsigned|long|int|void|at::|std::|c10::).*$", "", d) if "(" in d else d
+        res[n] = d.replace("sa::", "").strip()
+    return res
+
+
+def _dispatches(db, T):
+    names = {r[0]: r[1] for r in db.execute(f'select id, kernel_name from "{T("info_kernel_symbol")}"')}
+    dm = _demangle(sorted(set(names.values())))
+    return {r[0]: (dm[names.get(r[1], "?")] if names.get(r[1]) in dm else "?", r[2]) for r in db.execute(f'select event_id, kernel_id, end - start from "{T("kernel_dispatch")}"')}
+
+
+def stats(path):
+    db, T = _open(path)
+    acc = defaultdict(list)
+    for k, d in _dispatches(db, T).values():
+        acc[k].append(d)
+    tot = sum(sum(v) for v in acc.values())
+    print(f"{'kernel':96s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
+    for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+        print(f"{k[:96]:96s} {len(v):7d} {sum(v) / 1e6:10.3f} {sum(v) / len(v) / 1e3:10.2f} {min(v) / 1e3:10.2f} {max(v) / 1e3:10.2f} {100 * sum(v) / tot:6.2f}")
+
+
+def _counters(path):
+    db, T = _open(path)
+    disp = _dispatches(db, T)
+    cname = {r[0]: r[1] for r in db.execute(f'select id, name from "{T("info_pmc")}"')}
+    per = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))   # kernel -> counter -> event -> value summed over instances
+    for eid, pid, val in db.execute(f'select event_id, pmc_id, value from "{T("pmc_event")}"'):
+        if eid in disp:
+            per[disp[eid][0]][cname.get(pid, str(pid))][eid] += val
+    return {k: {c: (sum(ev.values()) / len(ev), len(ev)) for c, ev in cs.items()} for k, cs in per.items()}
+
+
+def pmc(path):
+    for k, cs in _counters(path).items():
+        print(k[:110])
+        wc = cs.get("SQ_WAVE_CYCLES", (0, 0))[0] or 1.0
+        for c, (v, n) in sorted(cs.items()):
+            print(f"    {c:28s} launches={n:4d} mean={v:18.1f}  /WAVE_CYCLES={v / wc:7.3f}")
+
+
+def traffic(fetch_db, write_db, out=None, provenance=""):
+    f, w = _counters(fetch_db), _counters(write_db)
+    rec = {}
+    print(f"{'kernel':84s} {'launches':>8s} {'FETCH_SIZE KiB':>15s} {'WRITE_SIZE KiB':>15s} {'HBM GB/launch':>14s}")
+    for k in sorted(f, key=lambda k: -(2 * f[k].get("FETCH_SIZE", (0, 0))[0] + w.get(k, {}).get("WRITE_SIZE", (0, 0))[0]) * f[k].get("FETCH_SIZE", (0, 1))[1]):
+        fs, n = f[k].get("FETCH_SIZE", (0.0, 0))
+        ws = w.get(k, {}).get("WRITE_SIZE", (0.0, 0))[0]
+        b = (2.0 * fs + ws) * 1024.0
+        rec[k] = {"launches": n, "fetch_size_kib": round(fs, 1), "write_size_kib": round(ws, 1), "hbm_bytes_per_launch": int(b)}
+        print(f"{k[:84]:84s} {n:8d} {fs:15.1f} {ws:15.1f} {b / 1e9:14.3f}")
+    if out:
+        with open(out, "w") as fh:
+            json.dump({"_provenance": provenance, "kernels": rec}, fh, indent=1)
+
+
+if __name__ == "__main__":
+    cmd = sys.argv[1]
+    if cmd == "stats":
+        stats(sys.argv[2])
+    elif cmd == "pmc":
+        pmc(sys.argv[2])
+    elif cmd == "traffic":
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None, sys.argv[5] if len(sys.argv) > 5 else "")
