@@ -1081,7 +1081,7 @@ static int conv_wgrad_impl(const sa_conv_geom* g, int dtype, const void* in, con
                 snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_halo9_kernel<16>");
                 hipLaunchKernelGGL(conv_wgrad_halo9_kernel<16>, dim3(8u * spx * 6u * nct), dim3(1024), 2 * 55 * 1024, st, a);
             } else {
-                snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_halo9_kernel");
+                snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_halo9_kernel<8>");
                 hipLaunchKernelGGL(conv_wgrad_halo9_kernel<8>, dim3(8u * spx * 6u * nct), dim3(512), 2 * 55 * 1024, st, a);
             }
         } else {
