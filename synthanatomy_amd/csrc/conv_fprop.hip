@@ -576,15 +576,17 @@ __device__ __forceinline__ void resblock_second_gemm(const FpropArgs& a, float4_
 constexpr uint32_t OOB_OFF = 0xfffffff0u;
 
 template <typename T, int WM, int WN, int MI, int NI, bool UNIFORM, bool FUSE = false>
-__global__ __launch_bounds__(256) void conv_fprop_dma_kernel(const FpropArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_fprop_dma_kernel(const FpropArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins only exist in the device pass; the host pass needs just the stub
     constexpr int BM = WM * MI * 16;
     constexpr int BN = WN * NI * 16;
-    static_assert(BM == 128 && WM * WN == 4, "tile");
+    constexpr int NW = WM * WN;                           // 4 waves, or 8 (half-size wave tiles: twice the waves per SIMD to cover DMA / LDS latency)
+    static_assert(BM == 128 && (NW == 4 || NW == 8) && (!FUSE || NW == 4), "tile");
+    constexpr int A_PER_WAVE = 16 / NW;                    // 1 KiB pieces (8 rows) of the 128-row activation tile per wave
     constexpr int SZ = sizeof(T);
     constexpr int BKE = 128 / SZ;
     constexpr int B_PIECES = BN / 8;                       // 1 KiB pieces (8 rows) of the weight tile
-    constexpr int B_PER_WAVE = (B_PIECES + 3) / 4;
+    constexpr int B_PER_WAVE = (B_PIECES + NW - 1) / NW;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x;
@@ -602,10 +604,10 @@ __global__ __launch_bounds__(256) void conv_fprop_dma_kernel(const FpropArgs a) 
     // ---- this lane's fixed role inside every 8-row piece
     const uint32_t prow = lane >> 3;                       // row within the piece
     const uint32_t lv = (lane & 7u) ^ prow;                // SOURCE 16-byte vector (swizzle on the source side)
-    uint32_t rowoff[4], vm[4];
+    uint32_t rowoff[A_PER_WAVE], vm[A_PER_WAVE];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t m = m_base + (wave * 4 + j) * 8 + prow;
+    for (int j = 0; j < A_PER_WAVE; ++j) {
+        const uint32_t m = m_base + (wave * A_PER_WAVE + j) * 8 + prow;
         rowoff[j] = 0;
         vm[j] = 0;
         if (m < a.M) {
@@ -665,20 +667,20 @@ __global__ __launch_bounds__(256) void conv_fprop_dma_kernel(const FpropArgs a) 
             tap_ok = tap < a.ntaps;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < A_PER_WAVE; ++j) {
             const bool ok = tap_ok && (vm[j] & sel) == sel;
             const uint32_t voff = ok ? rowoff[j] + koff : OOB_OFF;
 #ifdef SA_PP_DEBUG_VARIANTS
             if (a.dbg & 64u) continue;
 #endif
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(pa + (wave * 4 + j) * 1024), 16, voff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(pa + (wave * A_PER_WAVE + j) * 1024), 16, voff, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < B_PER_WAVE; ++j) {
 #ifdef SA_PP_DEBUG_VARIANTS
             if (a.dbg & 128u) continue;
 #endif
-            if (B_PIECES >= 4 || wave * B_PER_WAVE + j < (uint32_t)B_PIECES)
+            if (B_PIECES >= NW || wave * B_PER_WAVE + j < (uint32_t)B_PIECES)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(pb + (wave * B_PER_WAVE + j) * 1024), 16, boff[j],
                                                          s * 128u, 0, 0);
         }
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(256) void conv_fprop_dma_kernel(const FpropArgs a) 
         resblock_second_gemm<MI, NI>(a, acc, smem, tid, wave, wm, wn, frow, fq, prow, lv,
                                      [&](uint32_t row) __attribute__((always_inline)) { return m_base + row < a.M ? (long long)(m_base + row) : -1ll; });
     }
-    fprop_epilogue<BM, BN, WM, WN, MI, NI>(a, acc, smem, tid, wm, wn, frow, fq, m_base, n_base);
+    fprop_epilogue<BM, BN, WM, WN, MI, NI, NW * 64>(a, acc, smem, tid, wm, wn, frow, fq, m_base, n_base);
 #endif
 }
 
@@ -1151,15 +1153,19 @@ static int launch_fprop(const FpropArgs& a, hipStream_t st) {
     if (a.in_bytes != 0) {  // every operand addressable with 32-bit buffer offsets -> LDS-DMA mainloop
         const bool uniform = ((size_t)a.g.Cin * sizeof(T)) % 128 == 0;
         snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma_kernel<%s, %d, %d, %d, %d, %s, false>", tname<T>(), WM, WN, MI, NI, uniform ? "true" : "false");
-        if (uniform) hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, true>), grid, dim3(256), lds, st, a);
-        else hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, false>), grid, dim3(256), lds, st, a);
+        if (uniform) hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, true>), grid, dim3(WM * WN * 64), lds, st, a);
+        else hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, false>), grid, dim3(WM * WN * 64), lds, st, a);
         SA_CHECK_LAUNCH();
         return 0;
     }
-    snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_kernel<%s, %d, %d, %d, %d>", tname<T>(), WM, WN, MI, NI);
-    hipLaunchKernelGGL((conv_fprop_kernel<T, WM, WN, MI, NI>), grid, dim3(256), lds, st, a);
-    SA_CHECK_LAUNCH();
-    return 0;
+    if constexpr (WM * WN == 4) {
+        snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_kernel<%s, %d, %d, %d, %d>", tname<T>(), WM, WN, MI, NI);
+        hipLaunchKernelGGL((conv_fprop_kernel<T, WM, WN, MI, NI>), grid, dim3(256), lds, st, a);
+        SA_CHECK_LAUNCH();
+        return 0;
+    } else {
+        return SA_EUNSUPPORTED;   // (the eight-wave tiles are only dispatched with 32-bit addressable operands)
+    }
 }
 
 // the halo mainloop applies to 3x3x3 / stride 1 / `same` geometry (forward, and the data gradient with the taps reversed)
@@ -1246,8 +1252,12 @@ static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
         // work per block: N = 1024 takes ~1 unit instead of 2.  SA_NO_SMALL_TILES=1 keeps the wide tiles.
         const uint64_t blocks128 = (uint64_t)a.nblk_m * (((uint32_t)cv + 127u) / 128u);
         const bool small_ok = !dbg(SA_DBG_NO_SMALL_TILES);
-        if (small_ok && blocks128 < 2048 && a.in_bytes != 0) return launch_fprop<T, 4, 1, 2, 4>(a, st);
-        return launch_fprop<T, 2, 2, 4, 4>(a, st);
+        // bf16 with DMA-addressable operands: eight waves per block (half-size wave tiles, same 128 x 128 / 128 x 64 block tile and LDS): strided
+        // 4x4x4 conv forward 1.83 -> 1.73 ms, its 8-parity data gradient 2.64 -> 2.17 ms, transposed conv forward 2.73 -> 2.15 ms at batch 8
+        // (tools/microbench.py); SA_DBG_HALO256_4W keeps four waves for A/B runs
+        const bool w8 = sizeof(T) == 2 && a.in_bytes != 0 && !dbg(SA_DBG_HALO256_4W);
+        if (small_ok && blocks128 < 2048 && a.in_bytes != 0) return w8 ? launch_fprop<T, 4, 2, 2, 2>(a, st) : launch_fprop<T, 4, 1, 2, 4>(a, st);
+        return w8 ? launch_fprop<T, 4, 2, 2, 4>(a, st) : launch_fprop<T, 2, 2, 4, 4>(a, st);
     }
     if (cv > 32) return launch_fprop<T, 4, 1, 2, 4>(a, st);
     if (cv > 16) return launch_fprop<T, 4, 1, 2, 2>(a, st);
