@@ -314,9 +314,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
-template <typename T, bool DG = false>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradArgs a) {
+template <typename T, bool DG = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW / 2) void conv_wgrad_dma_kernel(const WgradArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // NW = 8 (bf16, no fused data gradient): the same 128 x 128 tile worked by eight waves of 32 x 64 (<= 128 VGPRs: two blocks = four waves per
+    // SIMD) -- a chunk is only 64 voxels deep, so a four-wave block issues 32 MFMAs per wave between barriers and needs the extra waves to cover them
+    static_assert(NW == 4 || (NW == 8 && sizeof(T) == 2 && !DG), "4 waves, or 8 for the plain bf16 kernel");
+    constexpr int NIF = 16 / NW;                 // 16-row fragments of the (tap, ci) dimension per wave
     constexpr int MK = WG<T>::MK;
     constexpr bool IS_BF16 = sizeof(T) == 2;
     constexpr int TILE_BYTES = IS_BF16 ? 128 * 128 : MK * 128 * 4;  // 16 KB / 8 KB
@@ -341,9 +345,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradArgs 
     if (chunk1 > a.nchunks) chunk1 = a.nchunks;
     if (chunk0 >= chunk1) return;
 
-    float4_t acc[4][4];
+    float4_t acc[NIF][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NIF; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradArgs 
     // of both tiles.  The DMA writes lane-linearly, so the swizzle is applied to the SOURCE column: bf16 lane l fetches 16-byte
     // vector (((l&15)>>1) ^ (m&7))*2 + (l&1) of row m (two variants: even / odd piece), fp32 lane l fetches (l&31) ^ ((l>>5)<<2).
     constexpr int SZ = sizeof(T);
-    constexpr int NPIECE = IS_BF16 ? 4 : 2;      // pieces per wave per tile
+    constexpr int NPIECE = (IS_BF16 ? 16 : 8) / NW;      // pieces per wave per tile
     constexpr int ROWS_PP = IS_BF16 ? 4 : 2;     // rows per piece
     __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)a.gout, 0, (int)a.g_bytes, 0x00020000);
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradArgs 
         const unsigned char* px = sX + buf * TILE_BYTES;
         const unsigned char* pg = sG + buf * TILE_BYTES;
         if constexpr (IS_BF16) {
-            if (do_db) tile_colsum<64, 4>(pg, tid, bs0, bs1);
+            if (do_db) tile_colsum<64, NW>(pg, tid, bs0, bs1);
             if constexpr (DG) {
                 float4_t ad[4][2];
 #pragma unroll
@@ -469,11 +473,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradArgs 
             const uint32_t trow = fq * 4u + (frow >> 2), tcol = (frow & 3u) * 4u;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                short8_t xf[4], gf[4];
+                short8_t xf[NIF], gf[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const v4s_t lo = lds_tr16(px + roff(ks * 32 + trow, wm * 64 + i * 16 + tcol));
-                    const v4s_t hi = lds_tr16(px + roff(ks * 32 + 16 + trow, wm * 64 + i * 16 + tcol));
+                for (int i = 0; i < NIF; ++i) {
+                    const v4s_t lo = lds_tr16(px + roff(ks * 32 + trow, wm * (16 * NIF) + i * 16 + tcol));
+                    const v4s_t hi = lds_tr16(px + roff(ks * 32 + 16 + trow, wm * (16 * NIF) + i * 16 + tcol));
                     xf[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
@@ -483,11 +487,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradArgs 
                     gf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NIF; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], gf[j], acc[i][j], 0, 0, 0);
             }
-        } else {
+        } else if constexpr (NW == 4) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const uint32_t m = kk * 4u + fq;
@@ -506,21 +510,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgradArgs 
         __syncthreads();  // drains the DMA (vmcnt(0)) and frees this buffer
     }
 
-    if (do_db) colsum_finish<4>((float*)smem, tid, bs0, bs1, a.db, ct * 128u, (uint32_t)g.cout_valid);   // (the loop's last barrier freed the tiles)
+    if (do_db) colsum_finish<NW>((float*)smem, tid, bs0, bs1, a.db, ct * 128u, (uint32_t)g.cout_valid);   // (the loop's last barrier freed the tiles)
     // ---- epilogue: lane holds rows kidx = .. + fq*4 + r (4 consecutive ci of one tap), column co = .. + frow
     if (a.ws) {
         // partial tile to the workspace (plain 16-byte stores); wgrad_reduce_kernel sums the splits and scatters into dw
         float* wt = a.ws + ((size_t)split * a.ntiles + tile) * (128 * 128);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NIF; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *(float4_t*)(wt + (wn * 64 + j * 16 + frow) * 128 + wm * 64 + i * 16 + fq * 4) = acc[i][j];
+                *(float4_t*)(wt + (wn * 64 + j * 16 + frow) * 128 + wm * (16 * NIF) + i * 16 + fq * 4) = acc[i][j];
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t k0 = kt * 128u + wm * 64u + i * 16u + fq * 4u;
+    for (int i = 0; i < NIF; ++i) {
+        const uint32_t k0 = kt * 128u + wm * (uint32_t)(16 * NIF) + i * 16u + fq * 4u;
         if (k0 >= a.ktot) continue;
         const uint32_t tap = fdiv(k0, a.dCin);
         const uint32_t c0 = k0 - tap * g.Cin;
@@ -1090,8 +1094,11 @@ static int conv_wgrad_impl(const sa_conv_geom* g, int dtype, const void* in, con
         }
     } else if (a.in_bytes) {
         if (fuse_db) a.db = db;
-        snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_dma_kernel<%s>", dtype == SA_F32 ? "float" : "unsigned short");
+        // bf16: eight waves per block (k4s2 / transposed-conv weight gradients 2.66 -> 2.29 / 2.37 ms at batch 8); SA_DBG_HALO256_4W keeps four
+        const bool w8 = dtype == SA_BF16 && !dbg(SA_DBG_HALO256_4W);
+        snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_dma_kernel<%s%s>", dtype == SA_F32 ? "float" : "unsigned short", w8 ? ", false, 8" : "");
         if (dtype == SA_F32) hipLaunchKernelGGL(conv_wgrad_dma_kernel<float>, grid, dim3(256), lds, st, a);
+        else if (w8) hipLaunchKernelGGL((conv_wgrad_dma_kernel<bf16_t, false, 8>), grid, dim3(512), lds, st, a);
         else hipLaunchKernelGGL(conv_wgrad_dma_kernel<bf16_t>, grid, dim3(256), lds, st, a);
     } else {
         snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_kernel<%s>", dtype == SA_F32 ? "float" : "unsigned short");
