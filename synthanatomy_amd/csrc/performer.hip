@@ -1715,11 +1715,14 @@ __global__ void ce_kernel(const float* __restrict__ logits, const int64_t* __res
     s = wave_sum(s);
     const float lse = mx + logf(s);
     const int64_t tg = target[r];
-    if (lane == 0) unsafeAtomicAdd(loss_sum, lse - lr[tg]);
+    // a class id outside [0, V) never reads out of bounds: torch's ignore_index (-100) contributes nothing, anything else poisons the loss with a
+    // NaN (torch raises a device assert there; a silent wrong loss would be worse than a loud one)
+    const bool valid = tg >= 0 && tg < (int64_t)V, ignored = tg == -100;
+    if (lane == 0) unsafeAtomicAdd(loss_sum, valid ? lse - lr[tg] : (ignored ? 0.f : __uint_as_float(0x7fc00000u)));
     if (dlogits) {
         for (int c = lane; c < V; c += 64) {
             const float p = expf(lr[c] - lse);
-            store_from_f32(dlogits, d_dtype, r * V + c, (p - (c == tg ? 1.f : 0.f)) * gscale);
+            store_from_f32(dlogits, d_dtype, r * V + c, valid ? (p - (c == tg ? 1.f : 0.f)) * gscale : 0.f);
         }
     }
 }

@@ -57,6 +57,16 @@ class Quantizer_impl(nn.Module):
             torch.cuda.current_stream().wait_event(self._ema_done)
             self._ema_done = None
 
+    def _apply(self, fn, *args, **kwargs):          # .to() / .cuda() / .float(): readers of the buffers the side stream may still be writing
+        if self._ema_done is not None:
+            self.wait_ema()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        if self._ema_done is not None:
+            self.wait_ema()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     # ---- forward (Quantizer_impl.forward, baseline.py:38-87) --------------------------------------------------
     def forward(self, x: torch.Tensor, decay: float, commitment_cost: float):
         zq, loss, idx, _ = _VQFn.apply(x, self, float(decay), float(commitment_cost), self.training)
@@ -120,12 +130,15 @@ class _VQFn(torch.autograd.Function):
                 done.record()
             q._ema_done = done
         ctx.save_for_backward(rows, cb_used, idx)
-        ctx.beta = beta
+        ctx.beta, ctx.q = beta, q
         ctx.mark_non_differentiable(idx, perplexity)
         return zq.permute(0, 4, 1, 2, 3), loss, idx, perplexity
 
     @staticmethod
     def backward(ctx, g_zq, g_loss, _gi, _gp):
+        # the EMA update of this step ran on the side stream during the decoder / loss; from here on (optimizer step, DDP buffer broadcasts,
+        # handlers reading impl.weight / N / embed_avg) the main stream is ordered after it
+        ctx.q.wait_ema()
         rows, cb, idx = ctx.saved_tensors
         D = rows.shape[-1]
         M = rows.numel() // D

@@ -155,3 +155,25 @@ def test_resume_equals_uninterrupted_training(tmp_path, adversarial):
     ex = [f for f in _vq_flags(proj, "full", extra) if not f.startswith("--mode")]
     run_vqvae.run(ex + ["--mode=extracting", "--evaluation_checkpoint=best"])
     assert len(glob.glob(proj + "full/baseline_vqvae/outputs/*/*_quantization_0.npy")) == 2
+
+
+def test_cross_entropy_class_ids_outside_the_vocabulary():
+    """csrc/performer.hip ce_kernel: torch's ignore_index (-100) contributes nothing, any other id outside [0, V) makes the loss NaN instead of
+    reading out of bounds (torch raises a device assert there)."""
+    from synthanatomy_amd.losses.transformer import CELoss
+    torch.manual_seed(0)
+    logits = torch.randn(2, 7, 5, device="cuda", requires_grad=True)     # [B, V, N]
+    tgt = torch.randint(0, 7, (2, 5), device="cuda")
+    base = CELoss()(logits, tgt)
+    ref = torch.nn.functional.cross_entropy(logits.detach().cpu(), tgt.cpu())
+    assert abs(float(base) - float(ref)) < 1e-5
+    bad = tgt.clone()
+    bad[0, 0] = 7
+    assert torch.isnan(CELoss()(logits, bad))
+    ign = tgt.clone()
+    ign[1, 2] = -100
+    val = CELoss()(logits, ign)
+    val.backward()
+    ref_sum = torch.nn.functional.cross_entropy(logits.detach().cpu(), ign.cpu(), reduction="sum")
+    assert abs(float(val) * tgt.numel() - float(ref_sum)) < 1e-4 and torch.isfinite(logits.grad).all()
+    assert float(logits.grad[1, :, 2].abs().max()) == 0.0
