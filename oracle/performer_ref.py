@@ -252,21 +252,43 @@ def layer_stack(st, cfg: PerformerConfig, x):
     return x
 
 
-def embed(st, cfg: PerformerConfig, tokens, spatial_index_sequences):
-    """performer.py:241-266: token emb + zero-front-padded absolute-spatial embeddings + absolute positional embedding."""
+def fixed_spatial_table(dim, seq):
+    """FixedSpatialPositionalEmbedding (performer.py:43-66): sinusoid of the coordinate VALUE, gathered into sequence order, last row dropped.
+    Upstream writes the outer product as einsum("d,j->ij", ...) (:51), a subscript typo that raises at construction, so the reference itself
+    cannot run this setting; "i,j->ij" is the evident intent (the same expression as performer_pytorch's FixedPositionalEmbedding)."""
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim))
+    position = torch.arange(0, int(seq.max()) + 1, dtype=torch.float)
+    sin_inp = torch.einsum("i,j->ij", position, inv_freq)[seq.long(), :]
+    return torch.cat((sin_inp.sin(), sin_inp.cos()), dim=-1)[:-1]
+
+
+def embed(st, cfg: PerformerConfig, tokens, spatial_index_sequences, conditionings=None, conditioning_type="none", spatial_position_emb="absolute"):
+    """performer.py:241-266: token emb + zero-front-padded spatial embeddings (learned `absolute` tables indexed by coordinate, or `fixed`
+    sinusoids) [+ conditioning: BOS replacement or prepending] + absolute positional embedding."""
     b, n = tokens.shape
     x = F.embedding(tokens, st["token_emb.weight"])
     for a, seq in enumerate(spatial_index_sequences):
-        sc = F.embedding(seq[:-1], st[f"spatial_position_emb.{a}.emb.weight"])[None, : n - 1]
+        if spatial_position_emb == "fixed":
+            sc = fixed_spatial_table(cfg.dim, seq)[None, : n - 1]
+        else:
+            sc = F.embedding(seq[:-1], st[f"spatial_position_emb.{a}.emb.weight"])[None, : n - 1]
         x = x + F.pad(sc, (0, 0, 1, 0, 0, 0))
-    x = x + st["pos_emb.emb.weight"][:n][None]
+    if conditionings and conditioning_type == "bos_replacement":       # performer.py:252-261
+        c = sum(F.embedding(cond, st[f"conditioning_emb.{i}.weight"])[:, 0, :] for i, cond in enumerate(conditionings))
+        x = torch.cat((c[:, None, :], x[:, 1:, :]), dim=1)
+    elif conditionings and conditioning_type == "prepending":          # performer.py:262-264 (the last conditioning ends up first)
+        for i, cond in enumerate(conditionings):
+            x = torch.cat((F.embedding(cond, st[f"conditioning_emb.{i}.weight"]), x), dim=1)
+    x = x + st["pos_emb.emb.weight"][: x.shape[1]][None]
     return x
 
 
-def forward(st, cfg: PerformerConfig, tokens, spatial_index_sequences):
-    x = embed(st, cfg, tokens, spatial_index_sequences)
+def forward(st, cfg: PerformerConfig, tokens, spatial_index_sequences, conditionings=None, conditioning_type="none", spatial_position_emb="absolute"):
+    x = embed(st, cfg, tokens, spatial_index_sequences, conditionings, conditioning_type, spatial_position_emb)
     x = layer_stack(st, cfg, x)
     x = F.layer_norm(x, (cfg.dim,), st["norm.weight"], st["norm.bias"])
+    if conditionings and conditioning_type == "prepending":            # performer.py:279-281
+        x = x[:, len(conditionings):, :]
     return F.linear(x, st["to_out.weight"], st["to_out.bias"])
 
 

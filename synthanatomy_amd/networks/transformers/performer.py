@@ -59,6 +59,18 @@ class AbsoluteSpatialPositionalEmbedding(nn.Module):  # performer.py:23-40
         self.emb = nn.Embedding(len(self.spatial_indices_sequence), dim)
 
 
+class FixedSpatialPositionalEmbedding(nn.Module):
+    """performer.py:43-66: sinusoid of the coordinate value, rows in sequence order, no parameters.  (Upstream's einsum("d,j->ij") at :51 is a
+    subscript typo that raises; the outer product "i,j->ij" is the evident intent.)"""
+
+    def __init__(self, dim, spatial_indices_sequence):
+        super().__init__()
+        inv_freq = 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim))
+        position = torch.arange(0, int(torch.max(spatial_indices_sequence)) + 1, dtype=torch.float)
+        sinusoid_inp = torch.einsum("i,j->ij", position, inv_freq)[spatial_indices_sequence.long(), :]
+        self.register_buffer("emb", torch.cat((sinusoid_inp.sin(), sinusoid_inp.cos()), dim=-1)[:-1].contiguous())
+
+
 class _SinusoidalEmbeddings(nn.Module):
     def __init__(self, dim):
         super().__init__()
@@ -753,7 +765,10 @@ class _EmbedFn(torch.autograd.Function):
         B, N = ctx.BN
         dy = dy.contiguous()
         grads = []
-        for ix, pp, shp in zip(ctx.idx, ctx.per_pos, ctx.shapes):
+        for t, (ix, pp, shp) in enumerate(zip(ctx.idx, ctx.per_pos, ctx.shapes)):
+            if not ctx.needs_input_grad[5 + t]:      # fixed (sinusoidal) spatial tables are buffers
+                grads.append(None)
+                continue
             g = torch.zeros(shp, dtype=torch.float32, device=dy.device)
             _ck(_ffi.lib().sa_embed_scatter(_ffi.ptr(dy), _ffi.ptr(g), _ffi.ptr(ix), pp, shp[1], N, B * N, _ffi.stream()), "sa_embed_scatter")
             grads.append(g)
@@ -864,9 +879,9 @@ class Performer(TransformerBase):
         )
         if rotary_position_emb or fixed_position_emb or axial_position_emb or tie_embed or emb_dropout:
             raise NotImplementedError("performer on MI355X implements the absolute positional embedding path (README configuration)")
-        if conditioning_num_tokens and conditioning_type == TransformerConditioningType.PREPENDING.value:
-            raise NotImplementedError("conditioning_type='prepending'")
-        self.max_seq_len = max_seq_len
+        # accounting for the number of prepended conditionings (performer.py:119-125)
+        self.max_seq_len = max_seq_len + (len(conditioning_num_tokens)
+                                          if conditioning_num_tokens and conditioning_type == TransformerConditioningType.PREPENDING.value else 0)
         self.token_emb = nn.Embedding(num_tokens, dim)
         self.pos_emb = AbsolutePositionalEmbedding(dim, self.max_seq_len)
         self.ordering = ordering
@@ -874,12 +889,11 @@ class Performer(TransformerBase):
         if spatial_position_emb:
             assert spatial_position_emb in ["fixed", "absolute"], (
                 f"spatial_position_emb must be either 'fixed' or  'absolute', but got {spatial_position_emb}")
-            if spatial_position_emb == "fixed":
-                raise NotImplementedError("spatial_position_emb='fixed'")
             coords = np.array(np.meshgrid(*tuple(np.arange(0, s) for s in spatial_shape), indexing="ij"))
             for axis in range(len(spatial_shape)):
                 seq = self.ordering(torch.from_numpy(coords[axis, ...].flatten()))
-                self.spatial_position_emb.append(AbsoluteSpatialPositionalEmbedding(dim=dim, spatial_indices_sequence=seq))
+                cls = FixedSpatialPositionalEmbedding if spatial_position_emb == "fixed" else AbsoluteSpatialPositionalEmbedding
+                self.spatial_position_emb.append(cls(dim=dim, spatial_indices_sequence=seq))
         self.conditioning_emb = nn.ModuleList()
         self.conditioning_type = conditioning_type
         if conditioning_num_tokens:
@@ -956,7 +970,7 @@ class Performer(TransformerBase):
         pos = torch.zeros(1, dtype=torch.int32, device=dev)
         tok = torch.zeros(B, dtype=torch.int64, device=dev)
         pidx, sp = self._position_indices(npos, dev)
-        tables = [self.token_emb.weight] + [m.emb.weight for m in self.spatial_position_emb] + [self.pos_emb.emb.weight]
+        tables = [self.token_emb.weight] + [(m.emb if isinstance(m, FixedSpatialPositionalEmbedding) else m.emb.weight) for m in self.spatial_position_emb] + [self.pos_emb.emb.weight]
         idx = [tok] + sp + [pidx]
         per_pos = [0] + [1] * len(sp) + [1]
         n = len(tables)
@@ -1039,11 +1053,16 @@ class Performer(TransformerBase):
             pos = torch.arange(n, device=dev, dtype=torch.int64)
             sp = []
             for mod in self.spatial_position_emb:
-                seq = mod.spatial_indices_sequence.to(dev).long()
                 ix = torch.full((n,), -1, device=dev, dtype=torch.int64)  # position 0 is zero-padded (performer.py:31,38)
-                cnt = min(n - 1, seq.numel())
-                if cnt > 0:
-                    ix[1:1 + cnt] = seq[:cnt]
+                if isinstance(mod, FixedSpatialPositionalEmbedding):      # rows of the buffer are already in sequence order (performer.py:52-57)
+                    cnt = min(n - 1, mod.emb.shape[0])
+                    if cnt > 0:
+                        ix[1:1 + cnt] = torch.arange(cnt, device=dev)
+                else:
+                    seq = mod.spatial_indices_sequence.to(dev).long()
+                    cnt = min(n - 1, seq.numel())
+                    if cnt > 0:
+                        ix[1:1 + cnt] = seq[:cnt]
                 sp.append(ix)
             self._idx_cache[key] = (pos, sp)
         return self._idx_cache[key]
@@ -1054,10 +1073,24 @@ class Performer(TransformerBase):
         dev = self.token_emb.weight.device
         tok = x.to(dev).long().contiguous().view(-1)
         pos, sp = self._position_indices(n, dev)
-        tables = [self.token_emb.weight] + [m.emb.weight for m in self.spatial_position_emb] + [self.pos_emb.emb.weight]
-        idx = [tok] + sp + [pos]
-        per_pos = [0] + [1] * len(sp) + [1]
-        h = _EmbedFn.apply(tables, idx, per_pos, b, n, *tables)
+        sp_tables = [(m.emb if isinstance(m, FixedSpatialPositionalEmbedding) else m.emb.weight) for m in self.spatial_position_emb]
+        prepend = bool(conditionings) and self.conditioning_type == TransformerConditioningType.PREPENDING.value
+        if prepend:
+            # performer.py:262-266: token + spatial embeddings, THEN the conditioning embeddings in front (the last one ends up first), THEN the
+            # absolute positional embedding over the longer sequence; the conditioning positions are cut off again after the final norm (:279-281)
+            tables, idx, per_pos = [self.token_emb.weight] + sp_tables, [tok] + sp, [0] + [1] * len(sp)
+            h = _EmbedFn.apply(tables, idx, per_pos, b, n, *tables)
+            for i, emb in enumerate(self.conditioning_emb):
+                h = torch.cat((emb(conditionings[i].to(dev)), h), dim=1)
+            nt = h.shape[1]
+            assert nt <= self.max_seq_len, f"sequence length {nt} must be less than the max sequence length {self.max_seq_len}"
+            ptab = [self.pos_emb.emb.weight]
+            h = h + _EmbedFn.apply(ptab, [torch.arange(nt, device=dev, dtype=torch.int64)], [1], b, nt, *ptab)
+        else:
+            tables = [self.token_emb.weight] + sp_tables + [self.pos_emb.emb.weight]
+            idx = [tok] + sp + [pos]
+            per_pos = [0] + [1] * len(sp) + [1]
+            h = _EmbedFn.apply(tables, idx, per_pos, b, n, *tables)
         if conditionings and self.conditioning_type == TransformerConditioningType.BOSREPLACEMENT.value:
             # performer.py:252-261: the BOS embedding (incl. its spatial terms) is REPLACED by the summed conditioning embeddings,
             # the absolute positional embedding is added afterwards
@@ -1070,6 +1103,8 @@ class Performer(TransformerBase):
         record = torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in params))
         h = _StackFn.apply(self._chain, record, h, *params)
         h = _LayerNormFn.apply(h, self.norm.weight, self.norm.bias, self.norm.eps)
+        if prepend:
+            h = h[:, len(conditionings):, :]
         if return_encodings:
             return h
         return _LinearFn.apply(self._out_op, h, self.to_out.weight, self.to_out.bias)

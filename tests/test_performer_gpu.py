@@ -637,3 +637,59 @@ def test_small_batch_dense_kernel(B, cin, segs, act, resid, rnd):
     torch.cuda.synchronize()
     assert torch.isfinite(y).all()
     assert _rel(y.cpu(), ref) < (1.5e-2 if rnd else 1e-5)
+
+
+@pytest.mark.parametrize("variant", ["fixed", "prepending", "bos_replacement"])
+def test_embedding_variants_match_oracle(variant):
+    """`spatial_position_emb="fixed"` (sinusoids of the coordinate value, reference performer.py:43-66) and the two conditioning types
+    (BOS replacement :252-261, prepending :262-264 with the conditioning positions cut off after the norm :279-281): logits and gradients."""
+    from synthanatomy_amd.losses.transformer import CELoss
+    from synthanatomy_amd.networks.transformers.img2seq_ordering import Ordering
+    from synthanatomy_amd.networks.transformers.performer import Performer
+    shape, n, ncond = (2, 3, 4), 24, (5, 7)
+    prep = variant == "prepending"
+    cfg = P.PerformerConfig(num_tokens=33, max_seq_len=n + (len(ncond) if prep else 0), dim=32, depth=2, heads=4, dim_head=64, local_attn_heads=2,
+                            local_window_size=6, spatial_shape=shape)
+    st = P.init_state(cfg, seed=11, spatial_index_len=n - 1)
+    g = torch.Generator().manual_seed(3)
+    for i, c in enumerate(ncond):
+        st[f"conditioning_emb.{i}.weight"] = torch.randn(c, 32, generator=g)
+    for k in st:
+        if k.endswith(".g"):
+            st[k] = torch.tensor(0.4)
+    sp = "fixed" if variant == "fixed" else "absolute"
+    ctype = {"fixed": "none", "prepending": "prepending", "bos_replacement": "bos_replacement"}[variant]
+    o = Ordering("raster_scan", 3, (1,) + shape, (False,) * 3, (), ())
+    net = Performer(num_tokens=33, max_seq_len=n, dim=32, depth=2, heads=4, ordering=o, dim_head=64, local_attn_heads=2, local_window_size=6, use_rezero=True,
+                    spatial_position_emb=sp, spatial_shape=shape, feature_redraw_interval=None, compute_dtype=torch.float32,
+                    conditioning_num_tokens=ncond if variant != "fixed" else None, conditioning_type=ctype)
+    assert net.max_seq_len == n + (2 if prep else 0)
+    load = {k: v.clone() for k, v in st.items() if not (variant == "fixed" and "spatial_position_emb" in k) and not (variant == "fixed" and "conditioning_emb" in k)}
+    missing, unexpected = net.load_state_dict(load, strict=False)
+    assert not unexpected, unexpected
+    net = net.cuda().train()
+    seqs = P.spatial_index_sequences(shape, o.get_sequence_ordering())
+    if variant == "fixed":     # the product's buffers are the oracle's tables
+        for a in range(3):
+            assert torch.allclose(net.spatial_position_emb[a].emb.cpu(), P.fixed_spatial_table(32, seqs[a]), atol=1e-6)
+    tok = torch.randint(0, 33, (2, n), generator=g)
+    tgt = torch.randint(0, 32, (2, n), generator=g)
+    conds = [torch.randint(0, c, (2, 1), generator=g) for c in ncond] if variant != "fixed" else None
+    leaf = {k: v.clone().requires_grad_(True) for k, v in st.items() if "projection_matrix" not in k}
+    stt = dict(st)
+    stt.update(leaf)
+    ref = P.forward(stt, cfg, tok, seqs, conds, ctype, sp)
+    P.ce_loss(ref, tgt).backward()
+    out = net(tok.cuda(), conditionings=[c.cuda() for c in conds] if conds else None)
+    assert out.shape == ref.shape == (2, n, 33) and _rel(out, ref) < REL
+    CELoss()(out.transpose(1, 2), tgt.cuda()).backward()
+    torch.cuda.synchronize()
+    params = dict(net.named_parameters())
+    checked = 0
+    for k, p in leaf.items():
+        if k in params and p.grad is not None and params[k].grad is not None and float(p.grad.abs().max()) > 0:
+            assert _rel(params[k].grad, p.grad) < 3e-3, k
+            checked += 1
+    assert checked > 20
+    if variant != "fixed":
+        assert float(params["conditioning_emb.0.weight"].grad.abs().max()) > 0
