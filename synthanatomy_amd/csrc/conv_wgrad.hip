@@ -1067,7 +1067,7 @@ static int conv_wgrad_impl(const sa_conv_geom* g, int dtype, const void* in, con
         if (!dg_wpk || dtype != SA_BF16 || !a.in_bytes || a.ntiles != 1 || a.halo || g->Cin != 128 || g->Cout != 128 || g->cin_valid != 128 || g->cout_valid != 128)
             return SA_EUNSUPPORTED;
         if (fuse_db) a.db = db;
-        snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_dma_kernel<unsigned short, true>");
+        snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_dma_kernel<unsigned short, true, 4>");
         hipLaunchKernelGGL((conv_wgrad_dma_kernel<bf16_t, true>), grid, dim3(256), lds, st, a);
     } else if (a.halo && a.ws) {
         if (fuse_db) a.db = db;
@@ -1096,7 +1096,7 @@ static int conv_wgrad_impl(const sa_conv_geom* g, int dtype, const void* in, con
         if (fuse_db) a.db = db;
         // bf16: eight waves per block (k4s2 / transposed-conv weight gradients 2.66 -> 2.29 / 2.37 ms at batch 8); SA_DBG_HALO256_4W keeps four
         const bool w8 = dtype == SA_BF16 && !dbg(SA_DBG_HALO256_4W);
-        snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_dma_kernel<%s%s>", dtype == SA_F32 ? "float" : "unsigned short", w8 ? ", false, 8" : "");
+        snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_dma_kernel<%s, false, %d>", dtype == SA_F32 ? "float" : "unsigned short", w8 ? 8 : 4);
         if (dtype == SA_F32) hipLaunchKernelGGL(conv_wgrad_dma_kernel<float>, grid, dim3(256), lds, st, a);
         else if (w8) hipLaunchKernelGGL((conv_wgrad_dma_kernel<bf16_t, false, 8>), grid, dim3(512), lds, st, a);
         else hipLaunchKernelGGL(conv_wgrad_dma_kernel<bf16_t>, grid, dim3(256), lds, st, a);
