@@ -367,6 +367,8 @@ def main():
     ap.add_argument("--only-performer", action="store_true", help="dev/profiling: measure only the Performer workload")
     ap.add_argument("--performer-shape", default="10,14,10", help="latent grid of the Performer workload (20,28,25 = the 14 000-token variant)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: exercise the launch + reduction plumbing only (no GPU, no kernels)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="test aid: all ranks on cuda:0 with the gloo backend (RCCL refuses two ranks per device) -- the N > 1 code path on real kernels, not a number")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # started without a launcher: spawn one process per GPU ourselves
         sys.exit(_respawn(args))
@@ -379,7 +381,9 @@ def main():
     from synthanatomy_amd.runtime.ddp import GradReducer, init_distributed
     from synthanatomy_amd.runtime.optim import ExponentialLR, FlatParams, FusedAdam
 
-    rank, local, world = init_distributed()
+    if args.share_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, local, world = init_distributed(backend="gloo" if args.share_device else None)
     assert world == args.gpus or (world == 1 and args.gpus == 1), f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -479,6 +483,7 @@ def main():
             "config": {"workload": "baseline_vqvae no_levels=4 no_channels=256 embedding_dim=32 num_embeddings=2048, 160x224x160 fp32 volumes, "
                                    "training step = fwd + MSE + bwd + EMA codebook update + Adam", "batch_per_gpu": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+            **({"share_device": True} if args.share_device else {}),
             "tflops_per_gpu": round(value / world * STEP_TFLOP_PER_VOLUME, 2), "final_loss": round(final_loss, 6),
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         }

@@ -180,3 +180,22 @@ def test_two_ranks_equal_the_single_rank_full_batch_run():
     pr = full_pf["projs"]
     assert not torch.equal(pr[0], pr[1]) and torch.equal(pr[1], pr[2]) and not torch.equal(pr[2], pr[3])   # they WERE redrawn, twice
     assert torch.equal(ranks[0]["perf"]["params"], ranks[1]["perf"]["params"])
+
+
+def test_bench_two_ranks_on_one_device():
+    """`python bench.py --gpus 2` end to end on real kernels: bench.py spawns its two ranks, both on cuda:0 over gloo (`--share-device`; a test
+    aid, the number means nothing), gradients and EMA statistics are reduced every step, rank 0 prints ONE JSON line with `comm` timings."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--steps", "2", "--warmup", "1", "--batch", "1",
+                        "--no-performer", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and np.isfinite(d["final_loss"])
+    assert d["comm"]["steps"] == 2 and d["comm"]["comm_ms"] > 0 and d["comm"]["bytes_per_step"] > 100e6
+    assert "cpu_baseline" not in d and d["roofline"]["kernel"].startswith("conv_")
