@@ -110,7 +110,7 @@ def test_bf16_mode_runs_the_production_kernels_and_tracks_the_rounded_oracle(set
     want = ["conv_fprop_halo256_kernel<unsigned short, true, 8>",   # fused residual block (forward)
             "conv_fprop_halo256_kernel<unsigned short, false, 8>",  # its 3x3x3 data gradient
             "conv_wgrad_halo9_kernel",                              # nine-tap weight gradient
-            "conv_wgrad_dma_kernel<unsigned short, true>",          # fused 1x1x1 backward
+            "conv_wgrad_dma_kernel<unsigned short, true, 4>",       # fused 1x1x1 backward
             "conv1_fwd_kernel", "conv1_wgrad_kernel"]               # one-channel first layer
     for w in want:
         assert any(k.startswith(w) for k in kernels), (w, sorted(kernels))
