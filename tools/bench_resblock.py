@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--dims", default="80,112,80")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
+    ap.add_argument("--save", default="", help="write y / h / dx of the first call to this file")
+    ap.add_argument("--compare", default="", help="compare y / h / dx with a file written by --save (another kernel variant)")
     a = ap.parse_args()
     dims = tuple(int(v) for v in a.dims.split(","))
     torch.manual_seed(0)
@@ -47,6 +49,13 @@ def main():
     torch.cuda.synchronize()
     sig = lambda t: hashlib.sha1(t.cpu().view(torch.int16).numpy().tobytes()).hexdigest()[:12]
     print(f"signatures: y {sig(y)} h {sig(h)} dx {sig(dx)}", flush=True)
+    if a.save:
+        torch.save({"y": y.cpu(), "h": h.cpu(), "dx": dx.cpu()}, a.save)
+    if a.compare:
+        ref = torch.load(a.compare)
+        for k_, t_ in (("y", y), ("h", h), ("dx", dx)):
+            d_ = (t_.cpu().float() - ref[k_].float()).abs()
+            print(f"    vs saved {k_}: max abs {float(d_.max()):.3e} (ref max {float(ref[k_].float().abs().max()):.3e}), mismatching elements {float((d_ > 0).float().mean()):.4f}", flush=True)
     dw3, db3 = torch.zeros_like(mod[0].weight), torch.zeros_like(mod[0].bias)
     dw1, db1 = torch.zeros_like(mod[3].weight), torch.zeros_like(mod[3].bias)
     st.c3.wgrad(x, G, dw3, db3)
