@@ -1130,208 +1130,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_fprop_halo256_kernel(con
 #endif
 }
 
-
-// ------------------------------------------------------------------------------------------------------------------------
-// Mainloop v9 "halo, two planes rolling": a tile is a 16 x 16 patch of TWO consecutive output planes d0, d0 + 1 (512 voxels) worked by
-// SIXTEEN waves of 64 x 64 outputs (waves 0-7 plane d0, 8-15 plane d0 + 1; <= 128 VGPRs, one block per CU = four waves per SIMD).
-// The two planes need input planes d0-1 .. d0+2: four halo images per 64-channel chunk instead of six, and both plane groups use the SAME
-// weight slab in a K step (output d0 reads input plane d0-1+k with tap k, output d0+1 reads plane d0+k with tap k), so a block streams half
-// the weight bytes per MAC.  Three image slots roll: step k of a chunk reads slots A = e(k), B = e(k+1) while the image of step k + 1 lands in
-// the third (pieces dealt over slabs 0..6 of the step, each riding one slab longer under a counted vmcnt), so only the chunk switch and the
-// prologue wait for a halo image (2 waits per 512 voxels; the v8 kernel has 6 per 256).  K order = (chunk, kd, kh, kw).
-// LDS: 3 x 41 KiB + 2 x 16 KiB = 155 KiB.
-template <typename T, bool FUSE>
-__global__ __launch_bounds__(1024) void conv_fprop_halo512_kernel(const FpropArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(sizeof(T) == 2, "bf16");
-    constexpr int MI = 4, NI = 4;
-    constexpr int BN = 128;
-    constexpr int HW_ = 18, HROWS = 324, HPIECES = 41;
-    constexpr int SZ = sizeof(T);
-    constexpr int HALO_BYTES = HPIECES * 1024;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const sB = smem + 3 * HALO_BYTES;      // 2 weight slabs behind the 3 image slots
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t pg = wave >> 3, w8 = wave & 7u;          // plane group, wave inside it
-    const uint32_t wm = w8 >> 1, wn = w8 & 1u;
-    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
-    const uint32_t n_base = bn * BN;
-    const sa_conv_geom& g = a.g;
-    // tile order = (n, band of 2 patch rows, plane pair, row in band, wp)
-    const uint32_t DP = (uint32_t)g.Dm >> 1;
-    const uint32_t per_vol = a.HP * a.WP * DP, band = 2u * a.WP * DP;
-    const uint32_t pn = bm / per_vol, rv = bm - pn * per_vol;
-    const uint32_t bc = rv / band, r2 = rv - bc * band;
-    const uint32_t rows_c = a.HP - 2u * bc < 2u ? a.HP - 2u * bc : 2u;
-    const uint32_t pdp = r2 / (rows_c * a.WP), r3 = r2 - pdp * rows_c * a.WP;
-    const uint32_t hpi = r3 / a.WP, wp = r3 - hpi * a.WP, hp = 2u * bc + hpi;
-    const int32_t d0 = (int32_t)pdp * 2;
-    const int32_t h0 = (int32_t)hp * 16, w0 = (int32_t)wp * 16;
-    const int32_t oh = g.in_off[1] + (g.tap_step[1] < 0 ? 2 * g.tap_step[1] : 0), ow = g.in_off[2] + (g.tap_step[2] < 0 ? 2 * g.tap_step[2] : 0);
-    const int32_t od = g.in_off[0] + (g.tap_step[0] < 0 ? 2 * g.tap_step[0] : 0);     // first input plane of the pair = d0 + od (= d0 - 1)
-
-    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (int)a.w_bytes, 0x00020000);
-
-    const uint32_t prow = lane >> 3;
-    const uint32_t lv = (lane & 7u) ^ prow;
-    const uint32_t boff = (n_base + wave * 8 + prow) * (uint32_t)(g.Kpad * SZ) + lv * 16u;   // one weight piece per wave per slab
-
-    const uint32_t nchunk = (uint32_t)(g.Cin * SZ) / 128u;
-    const uint32_t plane_bytes = (uint32_t)(g.Hi * g.Wi * g.Cin * SZ);
-    const uint32_t vox_bytes = (uint32_t)(g.Cin * SZ);
-    const uint32_t base_vox = (uint32_t)((int32_t)pn * g.Di * g.Hi * g.Wi);
-    const bool fd = g.tap_step[0] < 0, fh = g.tap_step[1] < 0, fw = g.tap_step[2] < 0;
-
-    // piece p of the image (chunk ch, input plane d0 + od + e) -> slot (e + ch) % 3
-    auto issue_piece = [&](uint32_t ch, uint32_t e, uint32_t p) __attribute__((always_inline)) {
-        const int32_t id = d0 + od + (int32_t)e;
-        const bool dok = (uint32_t)id < (uint32_t)g.Di;
-        const uint32_t r = p * 8 + prow;
-        const uint32_t hh = r / HW_, ww = r - hh * HW_;
-        const int32_t ih = h0 + oh + (int32_t)hh, iw = w0 + ow + (int32_t)ww;
-        const bool ok = dok && r < (uint32_t)HROWS && (uint32_t)ih < (uint32_t)g.Hi && (uint32_t)iw < (uint32_t)g.Wi;
-        const uint32_t voff = ok ? (base_vox + (uint32_t)(ih * g.Wi + iw)) * vox_bytes + (uint32_t)id * plane_bytes + ch * 128u + lv * 16u : OOB_OFF;
-        const uint32_t slot = (e + ch) % 3u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(smem + slot * HALO_BYTES + p * 1024), 16, voff, 0, 0, 0);
-    };
-    auto issue_image = [&](uint32_t ch, uint32_t e) __attribute__((always_inline)) {
-#pragma unroll 1
-        for (uint32_t p = wave; p < (uint32_t)HPIECES; p += 16) issue_piece(ch, e, p);
-    };
-    // weight slab of (chunk ch, K step k, tap t9): the tap along d is k (forward) or 2 - k (data gradient: planes are walked upwards either way)
-    auto issue_w = [&](uint32_t ch, uint32_t k, uint32_t t9, uint32_t buf) __attribute__((always_inline)) {
-        const uint32_t td = fd ? 2u - k : k;
-        const uint32_t col = ((td * 9u + t9) * (uint32_t)g.Cin) * SZ + ch * 128u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(sB + buf * (BN * 128) + wave * 1024), 16, boff, col, 0, 0);
-    };
-
-    float4_t acc[NI][MI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < MI; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-
-    const uint32_t frow = lane & 15u, fq = lane >> 4;
-    const uint32_t a_base = ((wm * (uint32_t)MI) * HW_ + frow) * 128u + fq * 16u;   // unswizzled; patch row j adds 18 * 128 j
-    const uint32_t b_off = tile_off(wn * (NI * 16) + frow, fq);
-
-    issue_image(0, 0);
-    issue_image(0, 1);
-    issue_w(0, 0, 0, 0);
-    __syncthreads();
-    uint32_t buf = 0;
-    for (uint32_t ch = 0; ch < nchunk; ++ch) {
-#pragma unroll 1
-        for (uint32_t k = 0; k < 3; ++k) {
-            // this plane group's image: input plane e = k + pg
-            const unsigned char* const pa = smem + ((k + pg + ch) % 3u) * HALO_BYTES;
-            const bool last_step = k == 2 && ch + 1 == nchunk;
-            // image that lands during this step: (ch, e = k + 2) for k < 2, (ch + 1, e = 0) for k = 2
-            const uint32_t pf_ch = k < 2 ? ch : ch + 1, pf_e = k < 2 ? k + 2 : 0u;
-            const bool prefetch = pf_ch < nchunk;
-#pragma unroll 1
-            for (uint32_t t9 = 0; t9 < 9; ++t9) {
-                bool halo_issued = false;
-                {
-                    const bool same = t9 < 8;
-                    if (same) issue_w(ch, k, t9 + 1, buf ^ 1u);
-                    else if (!last_step) issue_w(k < 2 ? ch : ch + 1, k < 2 ? k + 1 : 0u, 0, buf ^ 1u);
-                    // pieces 6 t9 .. 6 t9 + 5 of the prefetched image, one per wave 0..5, slabs 0..6 (the last two slabs let them land)
-                    const uint32_t p = t9 * 6u + wave;
-                    if (prefetch && t9 < 7 && wave < 6 && p < (uint32_t)HPIECES) {
-                        issue_piece(pf_ch, pf_e, p);
-                        halo_issued = true;
-                    }
-                }
-                const uint32_t th = t9 / 3u, tw = t9 - th * 3u;
-                const uint32_t tapoff = ((fh ? 2u - th : th) * (uint32_t)HW_ + (fw ? 2u - tw : tw)) * 128u;
-                const unsigned char* pb = sB + buf * (BN * 128);
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    u32x4 xf[MI], wf[NI];
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + ((b_off + i * 2048u) ^ (ks * 64u)));
-#pragma unroll
-                    for (int j = 0; j < MI; ++j) {
-                        const uint32_t ad = a_base + tapoff + (uint32_t)j * (HW_ * 128u);
-                        xf[j] = *(const u32x4*)(pa + ((ad ^ (((ad >> 7) & 7u) << 4)) ^ (ks * 64u)));
-                    }
-#pragma unroll
-                    for (int i = 0; i < NI; ++i)
-#pragma unroll
-                        for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
-                }
-                // the next weight slab (and every older piece) must have landed; a halo piece issued in THIS slab may ride one slab longer
-                if (halo_issued) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                buf ^= 1u;
-            }
-        }
-        if (ch + 1 < nchunk) {   // chunk switch: image e = 1 of the next chunk goes into the slot step 2 just released (e = 0 already landed)
-            issue_image(ch + 1, 1);
-            __syncthreads();
-        }
-    }
-    auto row_vox = [&](uint32_t row) __attribute__((always_inline)) {   // row inside this plane group's 256-voxel patch
-        const uint32_t h = (uint32_t)h0 + (row >> 4), w = (uint32_t)w0 + (row & 15u);
-        return h < (uint32_t)g.Ho && w < (uint32_t)g.Wo ? (((long long)pn * g.Do + d0 + (int32_t)pg) * g.Ho + h) * g.Wo + w : -1ll;
-    };
-    if constexpr (FUSE) {
-        // second GEMM of the residual block, per plane group: h = relu(acc + b1) -> LDS as two [256][128 B] K-slabs (64 KiB per group, the
-        // image slots are free after the loop's last barrier)
-        unsigned char* const sH = smem + pg * (2 * 256 * 128);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const uint32_t c0 = wn * (NI * 16) + i * 16 + fq * 4;
-            const float4_t b1 = *(const float4_t*)(a.bias1 + c0);
-#pragma unroll
-            for (int j = 0; j < MI; ++j) {
-                const uint32_t row = wm * (MI * 16) + j * 16 + frow;
-                const float4_t v = acc[i][j] + b1;
-                uint2 pk;
-                pk.x = (uint32_t)f32_to_bf16(fmaxf(v[0], 0.f)) | ((uint32_t)f32_to_bf16(fmaxf(v[1], 0.f)) << 16);
-                pk.y = (uint32_t)f32_to_bf16(fmaxf(v[2], 0.f)) | ((uint32_t)f32_to_bf16(fmaxf(v[3], 0.f)) << 16);
-                *(uint2*)(sH + (c0 >> 6) * (256 * 128) + tile_off(row, (c0 & 63u) >> 3) + (c0 & 7u) * 2) = pk;
-                acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        const bf16_t* const w2p = (const bf16_t*)a.w2pk;
-        __syncthreads();  // both h tiles complete
-        if (a.h_out) {    // training: the hidden activation is needed by the backward pass -> full 256-byte rows
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const uint32_t r512 = (tid >> 4) + 64u * it, sl = (tid >> 3) & 1u, vec = tid & 7u;
-                const uint32_t gp = r512 >> 8, row = r512 & 255u;
-                const uint32_t h = (uint32_t)h0 + (row >> 4), w = (uint32_t)w0 + (row & 15u);
-                if (h < (uint32_t)g.Ho && w < (uint32_t)g.Wo) {
-                    const long long vox = (((long long)pn * g.Do + d0 + (int32_t)gp) * g.Ho + h) * g.Wo + w;
-                    *(u32x4*)((bf16_t*)a.h_out + (size_t)vox * 128 + sl * 64 + vec * 8) = *(const u32x4*)(smem + gp * (2 * 256 * 128) + sl * (256 * 128) + tile_off(row, vec));
-                }
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            u32x4 xf[MI], w2[NI];
-#pragma unroll
-            for (int i = 0; i < NI; ++i) w2[i] = *(const u32x4*)(w2p + (wn * 64 + i * 16 + frow) * 128 + ks * 32 + fq * 8);
-#pragma unroll
-            for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(sH + (ks >> 1) * (256 * 128) + tile_off(wm * (MI * 16) + j * 16 + frow, (ks & 1) * 4 + fq));
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], w2[i], xf[j]);
-        }
-    }
-    fprop_epilogue_regs<MI, NI, 24>(a, acc, wm, wn, frow, fq, n_base, row_vox);
-#endif
-}
-
 #ifdef SA_TIMING
 }  // namespace sa
 extern "C" int sa_debug_timing(unsigned long long* out, int reset) {
@@ -1441,32 +1239,9 @@ static int launch_fprop_halo256(FpropArgs a, hipStream_t st) {
     return launch_fprop_halo256_impl<T, FUSE, 4>(a, nbn, lds, st);
 }
 
-// two-plane rolling tiles: bf16, even number of planes, 16 x 16 patches (as v8)
-static bool halo512_eligible(const FpropArgs& a, int sz) {
-    return sz == 2 && (g_tunables.pp_dbg & 131072u) && (a.g.Dm & 1) == 0 && a.g.Dm >= 2 && halo256_eligible(a, sz);
-}
-
-template <bool FUSE>
-static int launch_fprop_halo512(FpropArgs a, hipStream_t st) {
-    a.HP = (uint32_t)(a.g.Ho + 15) / 16;
-    a.WP = (uint32_t)(a.g.Wo + 15) / 16;
-    a.nblk_m = (uint32_t)a.g.N * ((uint32_t)a.g.Dm / 2u) * a.HP * a.WP;
-    const uint32_t nbn = (uint32_t)a.g.cout_valid / 128;
-    const size_t lds = 3 * 41 * 1024 + 2 * 128 * 128;   // 155 KiB
-    static std::atomic<uint64_t> attr_done{0};
-    if (first_use_on_device(attr_done)) hipFuncSetAttribute((const void*)conv_fprop_halo512_kernel<bf16_t, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo512_kernel<unsigned short, %s>", FUSE ? "true" : "false");
-    hipLaunchKernelGGL((conv_fprop_halo512_kernel<bf16_t, FUSE>), dim3(a.nblk_m * nbn), dim3(1024), lds, st, a);
-    SA_CHECK_LAUNCH();
-    return 0;
-}
-
 template <typename T>
 static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
     const int cv = a.g.cout_valid;
-    if constexpr (sizeof(T) == 2) {
-        if (halo512_eligible(a, 2)) return launch_fprop_halo512<false>(a, st);
-    }
     if (halo256_eligible(a, (int)sizeof(T))) return launch_fprop_halo256<T>(a, st);
     if (halo_eligible(a, (int)sizeof(T))) return launch_fprop_halo<T, false>(a, st);
     // (measured and removed: a 3-stage ring with 8 waves and counted vmcnt = the 2-stage loop; an 8-wave ping-pong with staggered
@@ -1576,7 +1351,6 @@ extern "C" int sa_resblock_fprop(const sa_conv_geom* g, int dtype, const void* x
     a.bias1 = bias1;
     a.h_out = h_out;
     a.dbg = 0;
-    if (halo512_eligible(a, 2) && !dbg(SA_DBG_NO_HALO256_FUSE)) return launch_fprop_halo512<true>(a, (hipStream_t)stream);
     if (halo256_eligible(a, 2) && !dbg(SA_DBG_NO_HALO256_FUSE)) return launch_fprop_halo256<bf16_t, true>(a, (hipStream_t)stream);
     if (halo_eligible(a, 2)) return launch_fprop_halo<bf16_t, true>(a, (hipStream_t)stream);
     const size_t pipe = 2 * (128 + 128) * 128, epi = (size_t)128 * (128 + 4) * 4 + 128 * 8;
