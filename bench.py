@@ -45,14 +45,42 @@ def _host_description():
     return f"{model}, {os.cpu_count()} logical CPUs; torch {torch.__version__} ({libs})"
 
 
+def _physical_cores():
+    """Physical cores this process may run on: psutil's count (distinct (package, core id) pairs of /proc/cpuinfo), bounded by the affinity mask."""
+    n = None
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+    except Exception:
+        n = None
+    if not n:
+        try:
+            pairs, phys = set(), "0"
+            with open("/proc/cpuinfo") as f:
+                for line in f:
+                    if line.startswith("physical id"):
+                        phys = line.split(":")[1].strip()
+                    elif line.startswith("core id"):
+                        pairs.add((phys, line.split(":")[1].strip()))
+            n = len(pairs) or None
+        except OSError:
+            n = None
+    if not n:
+        n = max(1, (os.cpu_count() or 2) // 2)
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    return max(1, int(n))
+
+
 def cpu_baseline():
     """Reference-equivalent CPU path (the oracle restatement, fp32 torch-CPU) on this host: ONE full 160x224x160 volume, forward + MSE + backward
     of the config-2 network, after a warm-up step on a small crop that also bounds the run: if the crop's rate says the full volume
     would take more than ~45 s, the crop (scaled by voxel count) is reported instead and the sample says so."""
     from oracle import vqvae_ref
 
-    logical = os.cpu_count() or 1
-    threads = max(1, min(logical // 2, 64))   # physical cores, capped: torch-CPU conv3d stops scaling well before 64 threads on this class of host
+    threads = _physical_cores()               # SURVEY 8(d): all physical cores of the host (SMT siblings add nothing to MKL / oneDNN kernels)
     torch.set_num_threads(threads)
     cfg = vqvae_ref.VQVAEConfig(**NET)
     st = vqvae_ref.init_state(cfg, seed=4)

@@ -107,7 +107,7 @@ def training(cfg, rank, local, world, dev):
     ckpt = check_for_checkpoints(cfg)
     if ckpt:
         load_checkpoint(ckpt, to_save, map_location=dev)
-        state.epoch_length, state.max_epochs = epoch_length, cfg["epochs"]
+        state.rebase(epoch_length, cfg["epochs"])      # finished epochs by the CHECKPOINT's epoch length; this run's data set / --epochs decide the rest
         net.invalidate_packed_weights()
         log(rank, f"resumed from {ckpt}: epoch {state.epoch}, iteration {state.iteration}, lr {opt.lr:.6e}")
     for epoch in range(state.epoch, cfg["epochs"]):

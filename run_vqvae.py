@@ -128,7 +128,7 @@ def training(cfg, rank, local, world, dev):
     if ckpt:
         to_load = {k: v for k, v in to_save.items() if not (cfg["finetune_adversarial_component"] and k.startswith("d_"))}
         load_checkpoint(ckpt, to_load, map_location=dev)
-        state.epoch_length, state.max_epochs = epoch_length, cfg["epochs"]      # this run's data set / --epochs decide, as MaxEpochsHandler does upstream
+        state.rebase(epoch_length, cfg["epochs"])      # finished epochs by the CHECKPOINT's epoch length; this run's data set / --epochs decide the rest
         net.invalidate_packed_weights()
         log(rank, f"resumed from {ckpt}: epoch {state.epoch}, iteration {state.iteration}, lr {opt.lr:.6e}")
     gen = torch.Generator(device=dev).manual_seed(cfg["seed"] + rank)
@@ -138,7 +138,7 @@ def training(cfg, rank, local, world, dev):
         done = 0
         for names, x in _batches(files, order, cfg["batch_size"], cfg, gen, dev):
             if trainer is not None:
-                res = trainer.iteration(x, x, epoch)
+                res = trainer.iteration(x, x, epoch + 1)      # ignite's state.epoch is 1 during the first epoch (trainer.py:176)
                 loss = res["loss"]
             else:
                 flat.zero_grad()

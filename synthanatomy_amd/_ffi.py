@@ -51,6 +51,8 @@ _SIGS = {
     "sa_abi_version": (c_int, []),
     "sa_last_error": (c_char_p, []),
     "sa_last_conv_kernel": (c_char_p, []),
+    "sa_kernel_log_begin": (None, []),
+    "sa_kernel_log_read": (c_int, [ctypes.c_char_p, c_int, c_int]),
     "sa_bench_mfma_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "sa_get_debug_flags": (ctypes.c_uint32, []),
     "sa_set_debug_flags": (ctypes.c_uint32, [ctypes.c_uint32]),
@@ -188,3 +190,20 @@ def stream():
 def require_gpu():
     if not torch.cuda.is_available():
         raise HipLibraryError("no HIP device visible: the synthanatomy_amd product path only runs on MI355X (no CPU fallback)")
+
+
+class kernel_log:
+    """``with kernel_log() as names: ...`` -- afterwards ``names`` holds the distinct kernel names this thread's launches dispatched
+    (sa_kernel_log_begin / sa_kernel_log_read)."""
+
+    def __enter__(self):
+        self.names = []
+        lib().sa_kernel_log_begin()
+        return self.names
+
+    def __exit__(self, *exc):
+        need = lib().sa_kernel_log_read(None, 0, 0)
+        buf = ctypes.create_string_buffer(need)
+        lib().sa_kernel_log_read(buf, need, 1)
+        self.names.extend(n for n in buf.value.decode().split("\n") if n)
+        return False

@@ -241,7 +241,7 @@ int conv1_im2col_bf16(const float* g, void* gc, float* db, int N, int D, int H, 
     const int rc = c1_fill(a, N, D, H, W, 128);
     if (rc) return rc;
     a.x = g;
-    hipLaunchKernelGGL(conv1_im2col_kernel, dim3((a.cells + 255u) / 256u), dim3(256), 0, stream, a, (bf16_t*)gc, db);
+    SA_LAUNCH(conv1_im2col_kernel, dim3((a.cells + 255u) / 256u), dim3(256), 0, stream, a, (bf16_t*)gc, db);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -268,7 +268,7 @@ extern "C" int sa_conv1_fwd(const float* x, const void* wpk, const float* bias, 
     const int rc = c1_fill(a, N, D, H, W, cout);
     if (rc) return rc;
     a.x = x; a.wpk = (const bf16_t*)wpk; a.bias = bias; a.y = (bf16_t*)y; a.act = act;
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((a.cells + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, a);
+    SA_LAUNCH(conv1_fwd_kernel, dim3((a.cells + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -280,7 +280,7 @@ extern "C" int sa_conv1_wgrad(const float* x, const void* g, float* dw, float* d
     if (rc) return rc;
     a.x = x; a.g = (const bf16_t*)g; a.dw = dw; a.db = db;
     const uint32_t ntiles = (a.cells + 127u) / 128u;
-    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(ntiles < 768u ? ntiles : 768u), dim3(256), 0, (hipStream_t)stream, a, ntiles);
+    SA_LAUNCH(conv1_wgrad_kernel, dim3(ntiles < 768u ? ntiles : 768u), dim3(256), 0, (hipStream_t)stream, a, ntiles);
     SA_CHECK_LAUNCH();
     return 0;
 }

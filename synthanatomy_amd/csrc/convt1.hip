@@ -348,8 +348,8 @@ extern "C" int sa_convt1_fwd(const void* x, int dtype, const float* w, const flo
     if (fill_ct1(a, N, D, H, W)) return SA_EINVAL;
     a.x = x; a.w = w; a.bias = bias; a.out = out;
     const dim3 grid(2048);
-    if (dtype == SA_F32) hipLaunchKernelGGL(convt1_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(convt1_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (dtype == SA_F32) SA_LAUNCH(convt1_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else SA_LAUNCH(convt1_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -363,12 +363,12 @@ extern "C" int sa_convt1_bwd(const void* x, int dtype, const float* w, const flo
     a.x = x; a.w = w; a.g = g; a.dx = dx; a.mask = relu_mask; a.dw = dw; a.db = db;
     hipStream_t st = (hipStream_t)stream;
     if (dx) {
-        if (dtype == SA_F32) hipLaunchKernelGGL(convt1_dgrad_kernel<float>, dim3(2048), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(convt1_dgrad_kernel<bf16_t>, dim3(2048), dim3(256), 0, st, a);
+        if (dtype == SA_F32) SA_LAUNCH(convt1_dgrad_kernel<float>, dim3(2048), dim3(256), 0, st, a);
+        else SA_LAUNCH(convt1_dgrad_kernel<bf16_t>, dim3(2048), dim3(256), 0, st, a);
         SA_CHECK_LAUNCH();
     }
-    if (dtype == SA_F32) hipLaunchKernelGGL(convt1_wgrad_kernel<float>, dim3(512), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(convt1_wgrad_kernel<bf16_t>, dim3(512), dim3(256), 0, st, a);
+    if (dtype == SA_F32) SA_LAUNCH(convt1_wgrad_kernel<float>, dim3(512), dim3(256), 0, st, a);
+    else SA_LAUNCH(convt1_wgrad_kernel<bf16_t>, dim3(512), dim3(256), 0, st, a);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -381,7 +381,7 @@ extern "C" int sa_convt1_gather(const float* p, const float* bias, float* out, i
     const uint32_t nct = ((uint32_t)W + 7u) / 8u, nht = (2u * (uint32_t)H + 7u) / 8u, ndt = (2u * (uint32_t)D + 3u) / 4u;
     const uint64_t blocks = (uint64_t)N * ndt * nht * nct;
     if (blocks >= (1ull << 31)) return SA_EINVAL;
-    hipLaunchKernelGGL(convt1_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, nct, nht, ndt);
+    SA_LAUNCH(convt1_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, nct, nht, ndt);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -398,8 +398,8 @@ extern "C" int sa_convt1_im2col(const float* g, int dtype, void* gc, float* db, 
         const int rc = conv1_im2col_bf16(g, gc, db, N, D, H, W, (hipStream_t)stream);
         if (rc != SA_EUNSUPPORTED) return rc;
     }
-    if (dtype == SA_F32) hipLaunchKernelGGL(convt1_im2col_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(convt1_im2col_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (dtype == SA_F32) SA_LAUNCH(convt1_im2col_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else SA_LAUNCH(convt1_im2col_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     return 0;
 }

@@ -1,10 +1,24 @@
 // Small HBM-bound kernels: weight packing, dtype/channel-pad casts, MSE loss (+grad), Adam.
 #include "sa_common.h"
 
+#include <cstring>
+#include <string>
+
 namespace sa {
 
 thread_local hipError_t g_last_error = hipSuccess;
 thread_local char g_last_conv_kernel[128] = "";
+thread_local bool g_kernel_log_on = false;
+static thread_local std::string* g_kernel_log = nullptr;   // newline-separated, each distinct name once, in first-launch order
+void note_kernel_slow(const char* name) {
+    if (!g_kernel_log) g_kernel_log = new std::string();
+    std::string key(name);
+    // "(kernel<args>)" -> "kernel<args>" (template instances are passed to the launch macro in parentheses)
+    if (key.size() > 2 && key.front() == '(' && key.back() == ')') key = key.substr(1, key.size() - 2);
+    key.push_back('\n');
+    if (g_kernel_log->rfind(key, 0) == 0 || g_kernel_log->find("\n" + key) != std::string::npos) return;
+    g_kernel_log->append(key);
+}
 
 static uint32_t flags_from_env() {
     auto on = [](const char* n) { return getenv(n) != nullptr; };
@@ -187,7 +201,7 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
 // FLOPs of one call = blocks * 4 waves * iters * 8 MFMAs * (2 * 32 * 32 * 16)
 extern "C" int sa_bench_mfma_bf16(float* scratch, int blocks, int iters, void* stream) {
     if (!scratch || blocks <= 0 || iters <= 0) return SA_EINVAL;
-    hipLaunchKernelGGL(sa::mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, scratch, iters);
+    SA_LAUNCH(sa::mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, scratch, iters);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -195,6 +209,22 @@ extern "C" int sa_bench_mfma_bf16(float* scratch, int blocks, int iters, void* s
 extern "C" int sa_abi_version(void) { return SA_ABI_VERSION; }
 extern "C" const char* sa_last_error(void) { return hipGetErrorString(sa::g_last_error); }
 extern "C" const char* sa_last_conv_kernel(void) { return sa::g_last_conv_kernel; }
+extern "C" void sa_kernel_log_begin(void) {
+    if (sa::g_kernel_log) sa::g_kernel_log->clear();
+    sa::g_kernel_log_on = true;
+}
+extern "C" int sa_kernel_log_read(char* buf, int cap, int stop) {
+    const std::string empty;
+    const std::string& s = sa::g_kernel_log ? *sa::g_kernel_log : empty;
+    const int need = (int)s.size() + 1;
+    if (buf && cap > 0) {
+        const int n = need <= cap ? need - 1 : cap - 1;
+        std::memcpy(buf, s.data(), (size_t)n);
+        buf[n] = 0;
+    }
+    if (stop) sa::g_kernel_log_on = false;
+    return need;
+}
 extern "C" uint32_t sa_get_debug_flags(void) { return sa::g_debug_flags.load(); }
 extern "C" uint32_t sa_set_debug_flags(uint32_t flags) { return sa::g_debug_flags.exchange(flags); }
 
@@ -218,7 +248,7 @@ extern "C" int sa_pack_weights(const float* w, void* wpk, int dtype, int rows, i
     a.rows_pad = rows_pad;
     a.red_stride = red_stride;
     a.Kpad = Kpad;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for((int64_t)rows_pad * Kpad)), dim3(256), 0, (hipStream_t)stream, a);
+    SA_LAUNCH(pack_weights_kernel, dim3(grid_for((int64_t)rows_pad * Kpad)), dim3(256), 0, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -226,7 +256,7 @@ extern "C" int sa_pack_weights(const float* w, void* wpk, int dtype, int rows, i
 extern "C" int sa_pack_weights_batch(const sa_pack_desc* table, const int32_t* block_first, int n, int total_blocks, void* stream) {
     using namespace sa;
     if (!table || !block_first || n <= 0 || total_blocks < n) return SA_EINVAL;
-    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table, block_first, n);
+    SA_LAUNCH(pack_weights_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, table, block_first, n);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -237,11 +267,11 @@ extern "C" int sa_cast_pad(const void* src, int src_dtype, int src_c, void* dst,
     const int64_t n = rows * dst_stride;
     if (src_c == dst_stride && src_dtype == SA_F32 && dst_dtype == SA_BF16 && (n & 7) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
         // no padding: a flat fp32 -> bf16 conversion, 32 bytes in / 16 bytes out per thread and step
-        hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (uint4*)dst, n / 8);
+        SA_LAUNCH(cast_f32_bf16_kernel, dim3(grid_for(n / 8, 256, 4096)), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (uint4*)dst, n / 8);
         SA_CHECK_LAUNCH();
         return 0;
     }
-    hipLaunchKernelGGL(cast_pad_kernel, dim3(grid_for(rows * dst_stride)), dim3(256), 0, (hipStream_t)stream, src, src_dtype, src_c, dst, dst_dtype,
+    SA_LAUNCH(cast_pad_kernel, dim3(grid_for(rows * dst_stride)), dim3(256), 0, (hipStream_t)stream, src, src_dtype, src_c, dst, dst_dtype,
                        dst_stride, rows);
     SA_CHECK_LAUNCH();
     return 0;
@@ -250,7 +280,7 @@ extern "C" int sa_cast_pad(const void* src, int src_dtype, int src_c, void* dst,
 extern "C" int sa_mse(const float* a, const float* b, int64_t n, float* loss_sum, float* grad, float gscale, void* stream) {
     using namespace sa;
     if (!a || !b || !loss_sum || n <= 0) return SA_EINVAL;
-    hipLaunchKernelGGL(mse_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a, b, n, loss_sum, grad, 2.f * gscale / (float)n);
+    SA_LAUNCH(mse_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a, b, n, loss_sum, grad, 2.f * gscale / (float)n);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -261,7 +291,7 @@ extern "C" int sa_adam(float* p, const float* g, float* m, float* v, int64_t n, 
     if (!p || !g || !m || !v || n <= 0 || step < 1) return SA_EINVAL;
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1,
+    SA_LAUNCH(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1,
                        sqrtf(bc2), grad_scale);
     SA_CHECK_LAUNCH();
     return 0;

@@ -397,10 +397,10 @@ extern "C" int sa_favor_features_project_bwd(const float* dfeat, const float* fe
     const size_t lds = (size_t)2 * ((LDF + 31) / 32) * 32 * 128;
     hipFuncSetAttribute((const void*)favor_feat_proj_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (!is_query) hipMemsetAsync(tsum_ws, 0, 4, (hipStream_t)stream);   // tsum_ws[0] accumulates the sum over all rows
-    hipLaunchKernelGGL(favor_feat_proj_bwd_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);
+    SA_LAUNCH(favor_feat_proj_bwd_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     if (!is_query) {
-        hipLaunchKernelGGL(favor_key_stab_dx_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dsrc, src_stride, heads, (const unsigned long long*)gmax_ws, tsum_ws,
+        SA_LAUNCH(favor_key_stab_dx_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dsrc, src_stride, heads, (const unsigned long long*)gmax_ws, tsum_ws,
                            proj, LDF);
         SA_CHECK_LAUNCH();
     }
@@ -418,7 +418,7 @@ extern "C" int sa_favor_project(const float* x, int x_stride, int heads, const f
     if (gmax_ws) hipMemsetAsync(gmax_ws, 0, 8, (hipStream_t)stream);
     const size_t lds = (size_t)2 * LDF * 128;
     hipFuncSetAttribute((const void*)favor_project_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(favor_project_fwd_kernel<false>, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);
+    SA_LAUNCH(favor_project_fwd_kernel<false>, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -433,7 +433,7 @@ extern "C" int sa_favor_project_features(const float* x, int x_stride, int heads
     a.c2half = 0.5f * c * c; a.ratio = 1.f / sqrtf((float)m); a.eps = 1e-4f;
     const size_t lds = (size_t)2 * LDF * 128;
     hipFuncSetAttribute((const void*)favor_project_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(favor_project_fwd_kernel<true>, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);
+    SA_LAUNCH(favor_project_fwd_kernel<true>, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -446,7 +446,7 @@ extern "C" int sa_favor_project_bwd(const float* ddd, const float* proj, const f
     a.g = ddd; a.proj = proj; a.addend = addend; a.out = dx; a.rows = rows; a.m = m; a.LDF = LDF; a.o_stride = dx_stride; a.heads = heads;
     const size_t lds = (size_t)2 * ((LDF + 31) / 32) * 32 * 128;
     hipFuncSetAttribute((const void*)favor_project_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(favor_project_bwd_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);
+    SA_LAUNCH(favor_project_bwd_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(256), lds, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     return 0;
 }

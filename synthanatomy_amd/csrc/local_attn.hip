@@ -613,8 +613,8 @@ extern "C" int sa_local_attn_fwd(const float* q, int q_stride, int q_off, const 
     if (rc) return rc;
     a.q = q; a.k = k; a.v = v; a.o = o; a.lse_out = lse;
     const unsigned nblk = (unsigned)(B * L * ((N + LT - 1) / LT));
-    if (la_exact()) hipLaunchKernelGGL(local_attn_q_kernel<0>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(local_attn_q_split_kernel<0>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    if (la_exact()) SA_LAUNCH(local_attn_q_kernel<0>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    else SA_LAUNCH(local_attn_q_split_kernel<0>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -629,11 +629,11 @@ extern "C" int sa_local_attn_bwd(const float* q, int q_stride, int q_off, const 
     a.q = q; a.k = k; a.v = v; a.out = out; a.dout = dout; a.lse_in = lse; a.dq = dq; a.dk = dk; a.dv = dv; a.Dbuf_out = Dbuf; a.Dbuf_in = Dbuf;
     const unsigned nblk = (unsigned)(B * L * ((N + LT - 1) / LT));
     const bool exact = la_exact();
-    if (exact) hipLaunchKernelGGL(local_attn_q_kernel<1>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(local_attn_q_split_kernel<1>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    if (exact) SA_LAUNCH(local_attn_q_kernel<1>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    else SA_LAUNCH(local_attn_q_split_kernel<1>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
-    if (exact) hipLaunchKernelGGL(local_attn_kv_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(local_attn_kv_split_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    if (exact) SA_LAUNCH(local_attn_kv_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
+    else SA_LAUNCH(local_attn_kv_split_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     return 0;
 }

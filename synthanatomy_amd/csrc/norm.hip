@@ -128,15 +128,15 @@ extern "C" int sa_bn_forward(const void* x, int dtype, int64_t M, int C, const f
         int64_t rpb = (M + 1023) / 1024;
         if (rpb < 64) rpb = 64;
         dim3 grid((unsigned)((M + rpb - 1) / rpb), (C + 31) / 32);
-        hipLaunchKernelGGL(bn_colstats_kernel, grid, dim3(256), 0, st, x, nullptr, dtype, nullptr, nullptr, M, C, sums_ws, rpb, 0);
+        SA_LAUNCH(bn_colstats_kernel, grid, dim3(256), 0, st, x, nullptr, dtype, nullptr, nullptr, M, C, sums_ws, rpb, 0);
         SA_CHECK_LAUNCH();
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums_ws, M, C, eps, momentum, mean, rstd, running_mean, running_var);
+        SA_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums_ws, M, C, eps, momentum, mean, rstd, running_mean, running_var);
     } else {
         if (!running_mean || !running_var) return SA_EINVAL;
-        hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, st, running_mean, running_var, C, eps, mean, rstd);
+        SA_LAUNCH(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, st, running_mean, running_var, C, eps, mean, rstd);
     }
     SA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_e(M * C)), dim3(256), 0, st, x, dtype, mean, rstd, w, b, y, M * C, C, slope);
+    SA_LAUNCH(bn_apply_kernel, dim3(grid_e(M * C)), dim3(256), 0, st, x, dtype, mean, rstd, w, b, y, M * C, C, slope);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -150,18 +150,18 @@ extern "C" int sa_bn_backward(const void* x, const void* g, int dtype, int64_t M
     int64_t rpb = (M + 1023) / 1024;
     if (rpb < 64) rpb = 64;
     dim3 grid((unsigned)((M + rpb - 1) / rpb), (C + 31) / 32);
-    hipLaunchKernelGGL(bn_colstats_kernel, grid, dim3(256), 0, st, x, g, dtype, mean, rstd, M, C, sums_ws, rpb, 1);
+    SA_LAUNCH(bn_colstats_kernel, grid, dim3(256), 0, st, x, g, dtype, mean, rstd, M, C, sums_ws, rpb, 1);
     SA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_e(M * C)), dim3(256), 0, st, x, g, dtype, mean, rstd, w, sums_ws, M, dx, M * C, C, training);
+    SA_LAUNCH(bn_bwd_apply_kernel, dim3(grid_e(M * C)), dim3(256), 0, st, x, g, dtype, mean, rstd, w, sums_ws, M, dx, M * C, C, training);
     SA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, st, dw, db, sums_ws, C);
+    SA_LAUNCH(bn_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, st, dw, db, sums_ws, C);
     SA_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int sa_lrelu_mask(const void* dy, const void* y, int dtype, void* g, int64_t n, float slope, void* stream) {
     if (!dy || !y || !g || n <= 0) return SA_EINVAL;
-    hipLaunchKernelGGL(lrelu_mask_kernel, dim3(grid_e(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dtype, g, n, slope);
+    SA_LAUNCH(lrelu_mask_kernel, dim3(grid_e(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dtype, g, n, slope);
     SA_CHECK_LAUNCH();
     return 0;
 }

@@ -1745,14 +1745,14 @@ extern "C" int sa_embed_sum(int ntab, const float* const* tables, const int64_t*
     a.dim = dim;
     a.N = N;
     a.R = R;
-    hipLaunchKernelGGL(embed_sum_kernel, dim3(grid1d(R * dim)), dim3(256), 0, ST(stream), a, out);
+    SA_LAUNCH(embed_sum_kernel, dim3(grid1d(R * dim)), dim3(256), 0, ST(stream), a, out);
     SA_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int sa_embed_scatter(const float* dy, float* dtable, const int64_t* idx, int per_position, int dim, int N, int64_t R, void* stream) {
     if (!dy || !dtable || !idx || dim <= 0 || R <= 0) return SA_EINVAL;
-    hipLaunchKernelGGL(embed_scatter_kernel, dim3(grid1d(R * dim)), dim3(256), 0, ST(stream), dy, dtable, idx, per_position, dim, N, R);
+    SA_LAUNCH(embed_scatter_kernel, dim3(grid1d(R * dim)), dim3(256), 0, ST(stream), dy, dtable, idx, per_position, dim, N, R);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -1760,7 +1760,7 @@ extern "C" int sa_embed_scatter(const float* dy, float* dtable, const int64_t* i
 extern "C" int sa_layernorm_fwd(const float* x, const float* w, const float* b, float* y, void* y_lp, int lp_dtype, float* stats, int64_t R, int C,
                                 float eps, void* stream) {
     if (!x || !w || !b || !y || !stats || R <= 0 || C <= 0) return SA_EINVAL;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, ST(stream), x, w, b, y, y_lp, lp_dtype, stats, R, C, eps);
+    SA_LAUNCH(layernorm_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, ST(stream), x, w, b, y, y_lp, lp_dtype, stats, R, C, eps);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -1768,8 +1768,8 @@ extern "C" int sa_layernorm_fwd(const float* x, const float* w, const float* b, 
 extern "C" int sa_layernorm_bwd(const float* dy, const float* x, const float* w, const float* stats, float* dx, float* dw, float* db, int64_t R, int C,
                                 void* stream) {
     if (!dy || !x || !w || !stats || !dx || !dw || !db || R <= 0 || C <= 0) return SA_EINVAL;
-    if (C <= 512) hipLaunchKernelGGL(layernorm_bwd_rows_kernel, dim3((unsigned)((R + 31) / 32)), dim3(256), 0, ST(stream), dy, x, w, stats, dx, dw, db, R, C);
-    else hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, ST(stream), dy, x, w, stats, dx, dw, db, R, C);
+    if (C <= 512) SA_LAUNCH(layernorm_bwd_rows_kernel, dim3((unsigned)((R + 31) / 32)), dim3(256), 0, ST(stream), dy, x, w, stats, dx, dw, db, R, C);
+    else SA_LAUNCH(layernorm_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, ST(stream), dy, x, w, stats, dx, dw, db, R, C);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -1777,11 +1777,11 @@ extern "C" int sa_layernorm_bwd(const float* dy, const float* x, const float* w,
 extern "C" int sa_gelu(const void* u, int u_dtype, void* h, int h_dtype, int64_t n, void* stream) {
     if (!u || !h || n <= 0) return SA_EINVAL;
     if (u_dtype == SA_BF16 && h_dtype == SA_BF16 && (n & 7) == 0 && (((uintptr_t)u | (uintptr_t)h) & 15) == 0) {
-        hipLaunchKernelGGL(gelu_bf16x8_kernel, dim3(grid1d(n / 8)), dim3(256), 0, ST(stream), (const uint4*)u, (uint4*)h, n / 8);
+        SA_LAUNCH(gelu_bf16x8_kernel, dim3(grid1d(n / 8)), dim3(256), 0, ST(stream), (const uint4*)u, (uint4*)h, n / 8);
         SA_CHECK_LAUNCH();
         return 0;
     }
-    hipLaunchKernelGGL(gelu_kernel, dim3(grid1d(n)), dim3(256), 0, ST(stream), u, u_dtype, h, h_dtype, n);
+    SA_LAUNCH(gelu_kernel, dim3(grid1d(n)), dim3(256), 0, ST(stream), u, u_dtype, h, h_dtype, n);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -1789,11 +1789,11 @@ extern "C" int sa_gelu(const void* u, int u_dtype, void* h, int h_dtype, int64_t
 extern "C" int sa_rezero_fwd(const float* x, const void* F, int f_dtype, const float* g, float* y, void* y_lp, int lp_dtype, int64_t n, void* stream) {
     if (!x || !F || !g || !y || n <= 0) return SA_EINVAL;
     if (f_dtype == SA_BF16 && (!y_lp || lp_dtype == SA_BF16) && (n & 3) == 0 && (((uintptr_t)x | (uintptr_t)F | (uintptr_t)y | (uintptr_t)y_lp) & 15) == 0) {
-        hipLaunchKernelGGL(rezero_fwd_bf16x4_kernel, dim3(grid1d(n / 4)), dim3(256), 0, ST(stream), (const float4*)x, (const uint2*)F, g, (float4*)y, (uint2*)y_lp, n / 4);
+        SA_LAUNCH(rezero_fwd_bf16x4_kernel, dim3(grid1d(n / 4)), dim3(256), 0, ST(stream), (const float4*)x, (const uint2*)F, g, (float4*)y, (uint2*)y_lp, n / 4);
         SA_CHECK_LAUNCH();
         return 0;
     }
-    hipLaunchKernelGGL(rezero_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, ST(stream), x, F, f_dtype, g, y, y_lp, lp_dtype, n);
+    SA_LAUNCH(rezero_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, ST(stream), x, F, f_dtype, g, y, y_lp, lp_dtype, n);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -1801,19 +1801,19 @@ extern "C" int sa_rezero_fwd(const float* x, const void* F, int f_dtype, const f
 extern "C" int sa_rezero_bwd(const float* dy, const void* F, int f_dtype, const float* g, void* dF, int df_dtype, float* dg, int64_t n, void* stream) {
     if (!dy || !F || !g || !dF || !dg || n <= 0) return SA_EINVAL;
     if (f_dtype == SA_BF16 && df_dtype == SA_BF16 && (n & 3) == 0 && (((uintptr_t)dy | (uintptr_t)F | (uintptr_t)dF) & 15) == 0) {
-        hipLaunchKernelGGL(rezero_bwd_bf16x4_kernel, dim3(grid1d(n / 4, 256, 1024)), dim3(256), 0, ST(stream), (const float4*)dy, (const uint2*)F, g, (uint2*)dF, dg,
+        SA_LAUNCH(rezero_bwd_bf16x4_kernel, dim3(grid1d(n / 4, 256, 1024)), dim3(256), 0, ST(stream), (const float4*)dy, (const uint2*)F, g, (uint2*)dF, dg,
                            n / 4);
         SA_CHECK_LAUNCH();
         return 0;
     }
-    hipLaunchKernelGGL(rezero_bwd_kernel, dim3(grid1d(n, 256, 1024)), dim3(256), 0, ST(stream), dy, F, f_dtype, g, dF, df_dtype, dg, n);
+    SA_LAUNCH(rezero_bwd_kernel, dim3(grid1d(n, 256, 1024)), dim3(256), 0, ST(stream), dy, F, f_dtype, g, dF, df_dtype, dg, n);
     SA_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int sa_axpy(float* y, const float* x, float alpha, int64_t n, void* stream) {
     if (!y || !x || n <= 0) return SA_EINVAL;
-    hipLaunchKernelGGL(axpy_kernel, dim3(grid1d(n)), dim3(256), 0, ST(stream), y, x, alpha, n);
+    SA_LAUNCH(axpy_kernel, dim3(grid1d(n)), dim3(256), 0, ST(stream), y, x, alpha, n);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -1829,10 +1829,10 @@ extern "C" int sa_favor_features_fwd(const float* dd, const float* src, int src_
     } else if (!is_query) {
         gm = (unsigned long long*)gmax_ws;
         hipMemsetAsync(gm, 0, 8, ST(stream));
-        hipLaunchKernelGGL(favor_global_max_kernel, dim3(grid1d(rows * 16, 256, 2048)), dim3(256), 0, ST(stream), dd, rows, m, LDF, gm);
+        SA_LAUNCH(favor_global_max_kernel, dim3(grid1d(rows * 16, 256, 2048)), dim3(256), 0, ST(stream), dd, rows, m, LDF, gm);
         SA_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(favor_feat_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), dd, src, src_stride, h0, G, dh, gm, feat, rows, m,
+    SA_LAUNCH(favor_feat_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), dd, src, src_stride, h0, G, dh, gm, feat, rows, m,
                        LDF, 0.5f * c * c, ratio, 1e-4f);
     SA_CHECK_LAUNCH();
     return 0;
@@ -1843,11 +1843,11 @@ extern "C" int sa_favor_features_bwd(const float* dfeat, const float* feat, cons
                                      void* stream) {
     if (!dfeat || !feat || !dd || !src || !ddd || !dsrc || rows <= 0 || (!is_query && (!gmax_ws || !tsum_ws))) return SA_EINVAL;
     const float c = powf((float)dh, -0.25f), ratio = 1.f / sqrtf((float)m);
-    hipLaunchKernelGGL(favor_feat_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), dfeat, feat, dd, src, src_stride, h0, G, dh,
+    SA_LAUNCH(favor_feat_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), dfeat, feat, dd, src, src_stride, h0, G, dh,
                        is_query, ddd, dsrc, tsum_ws, rows, m, LDF, c * c, ratio * 1e-4f);
     SA_CHECK_LAUNCH();
     if (!is_query) {
-        hipLaunchKernelGGL(favor_key_stab_kernel, dim3(1), dim3(1024), 0, ST(stream), ddd, (const unsigned long long*)gmax_ws, tsum_ws, rows);
+        SA_LAUNCH(favor_key_stab_kernel, dim3(1), dim3(1024), 0, ST(stream), ddd, (const unsigned long long*)gmax_ws, tsum_ws, rows);
         SA_CHECK_LAUNCH();
     }
     return 0;
@@ -1855,7 +1855,7 @@ extern "C" int sa_favor_features_bwd(const float* dfeat, const float* feat, cons
 
 extern "C" int sa_favor_projection(const float* blocks, const float* rows, float* out, int nmat, int nblk, int m, int d, void* stream) {
     if (!blocks || !rows || !out || nmat <= 0 || nblk <= 0 || m <= 0 || d <= 0 || d > 64 || nblk * d < m) return SA_EINVAL;
-    hipLaunchKernelGGL(favor_projection_kernel, dim3(nmat * nblk), dim3(64), 0, ST(stream), blocks, rows, out, m, d, nblk);
+    SA_LAUNCH(favor_projection_kernel, dim3(nmat * nblk), dim3(64), 0, ST(stream), blocks, rows, out, m, d, nblk);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -1880,7 +1880,7 @@ static int run_scan(K valu_kernel, int which, ScanArgs& s, unsigned base_blocks,
     const bool no_mfma = dbg(SA_DBG_SCAN_VALU);
     if (!ws) {
         s.S = 1; s.seg_len = s.N; s.pass = 0; s.state = nullptr;
-        hipLaunchKernelGGL(valu_kernel, dim3(base_blocks), dim3(256), 0, st, s);
+        SA_LAUNCH(valu_kernel, dim3(base_blocks), dim3(256), 0, st, s);
         SA_CHECK_LAUNCH();
         return 0;
     }
@@ -1898,30 +1898,30 @@ static int run_scan(K valu_kernel, int which, ScanArgs& s, unsigned base_blocks,
         const int exact = (int)((g_debug_flags.load(std::memory_order_relaxed) >> SA_DBG_SCAN_EXACT_SHIFT) & 7u) | (s.exact ? 7 : 0);   // bit 0: state sums, bit 1: scan A outputs, bit 2: scan B outputs on the exact-fp32 MFMA kernels
         const bool fits32 = (int64_t)s.N * s.G * s.LDF * 4 < ((int64_t)1 << 31) && (int64_t)s.N * std::max(s.b_stride, std::max(s.c_stride, s.y_stride)) * 4 < ((int64_t)1 << 31);
         if (!s.state_ready) {
-            if (!(exact & 1) && fits32) hipLaunchKernelGGL(favor_chunk_state_split_kernel, dim3(nblk), dim3(256), 0, st, s);
-            else hipLaunchKernelGGL(favor_chunk_state_kernel, dim3(nblk), dim3(256), 0, st, s);
+            if (!(exact & 1) && fits32) SA_LAUNCH(favor_chunk_state_split_kernel, dim3(nblk), dim3(256), 0, st, s);
+            else SA_LAUNCH(favor_chunk_state_kernel, dim3(nblk), dim3(256), 0, st, s);
             SA_CHECK_LAUNCH();
-            hipLaunchKernelGGL(scan_state_prefix_kernel, dim3((unsigned)((bg * elems + 255) / 256)), dim3(256), 0, st, ws, bg, s.S, elems);
+            SA_LAUNCH(scan_state_prefix_kernel, dim3((unsigned)((bg * elems + 255) / 256)), dim3(256), 0, st, ws, bg, s.S, elems);
             SA_CHECK_LAUNCH();
         }
         if (which == 0) {
-            if (!(exact & 2) && fits32) hipLaunchKernelGGL(favor_chunk_out_a_split_kernel, dim3(nblk), dim3(256), 0, st, s);
-            else hipLaunchKernelGGL(favor_chunk_out_a_kernel, dim3(nblk), dim3(256), 0, st, s);
+            if (!(exact & 2) && fits32) SA_LAUNCH(favor_chunk_out_a_split_kernel, dim3(nblk), dim3(256), 0, st, s);
+            else SA_LAUNCH(favor_chunk_out_a_kernel, dim3(nblk), dim3(256), 0, st, s);
         } else {
-            if (!(exact & 4) && fits32) hipLaunchKernelGGL(favor_chunk_out_b_split_kernel, dim3(nblk), dim3(256), 0, st, s);
-            else hipLaunchKernelGGL(favor_chunk_out_b_kernel, dim3(nblk), dim3(256), 0, st, s);
+            if (!(exact & 4) && fits32) SA_LAUNCH(favor_chunk_out_b_split_kernel, dim3(nblk), dim3(256), 0, st, s);
+            else SA_LAUNCH(favor_chunk_out_b_kernel, dim3(nblk), dim3(256), 0, st, s);
         }
         SA_CHECK_LAUNCH();
         return 0;
     }
     scan_segments(s.N, s.S, s.seg_len, ws);
     s.pass = 1;
-    hipLaunchKernelGGL(valu_kernel, dim3(base_blocks * s.S), dim3(256), 0, st, s);
+    SA_LAUNCH(valu_kernel, dim3(base_blocks * s.S), dim3(256), 0, st, s);
     SA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(scan_state_prefix_kernel, dim3((unsigned)((bg * elems + 255) / 256)), dim3(256), 0, st, ws, bg, s.S, elems);
+    SA_LAUNCH(scan_state_prefix_kernel, dim3((unsigned)((bg * elems + 255) / 256)), dim3(256), 0, st, ws, bg, s.S, elems);
     SA_CHECK_LAUNCH();
     s.pass = 2;
-    hipLaunchKernelGGL(valu_kernel, dim3(base_blocks * s.S), dim3(256), 0, st, s);
+    SA_LAUNCH(valu_kernel, dim3(base_blocks * s.S), dim3(256), 0, st, s);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -1956,17 +1956,17 @@ extern "C" int sa_cumsum_rows(const float* x, const float* scale, float* out, in
     const int64_t threads = (int64_t)B * G * LDF * S;
     const unsigned nblk = (unsigned)((threads + 255) / 256);
     if (S > 1) {
-        hipLaunchKernelGGL(cumsum_rows_kernel, dim3(nblk), dim3(256), 0, ST(stream), x, scale, (float*)nullptr, seg_ws, B, N, G, LDF, reverse, S, seg_len);
+        SA_LAUNCH(cumsum_rows_kernel, dim3(nblk), dim3(256), 0, ST(stream), x, scale, (float*)nullptr, seg_ws, B, N, G, LDF, reverse, S, seg_len);
         SA_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(cumsum_rows_kernel, dim3(nblk), dim3(256), 0, ST(stream), x, scale, out, S > 1 ? seg_ws : (float*)nullptr, B, N, G, LDF, reverse, S, seg_len);
+    SA_LAUNCH(cumsum_rows_kernel, dim3(nblk), dim3(256), 0, ST(stream), x, scale, out, S > 1 ? seg_ws : (float*)nullptr, B, N, G, LDF, reverse, S, seg_len);
     SA_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int sa_favor_den(const float* q, const float* z, float eps, float* inv, int64_t rows, int m, int LDF, void* stream) {
     if (!q || !z || !inv || rows <= 0) return SA_EINVAL;
-    hipLaunchKernelGGL(favor_den_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), q, z, eps, inv, rows, m, LDF);
+    SA_LAUNCH(favor_den_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), q, z, eps, inv, rows, m, LDF);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -1974,7 +1974,7 @@ extern "C" int sa_favor_den(const float* q, const float* z, float eps, float* in
 extern "C" int sa_favor_dden(const float* dout, const float* out, int stride, int off, int G, int dv, const float* inv, float* dden, int64_t rows,
                              void* stream) {
     if (!dout || !out || !inv || !dden || rows <= 0) return SA_EINVAL;
-    hipLaunchKernelGGL(favor_dden_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), dout, out, stride, off, G, dv, inv, dden, rows);
+    SA_LAUNCH(favor_dden_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), dout, out, stride, off, G, dv, inv, dden, rows);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -1983,7 +1983,7 @@ extern "C" int sa_rotary(const float* x, int stride, int off, int L, int dh, con
                          int N, int64_t R, int transpose, int accumulate, void* stream) {
     if (!x || !cosb || !sinb || !y || L <= 0 || dh <= 0 || (dh & 1) || R <= 0) return SA_EINVAL;
     if ((dh & 7) || ((stride | off | y_stride | y_off) & 3)) return SA_EUNSUPPORTED;   // 16-byte accesses on both halves of a head row
-    hipLaunchKernelGGL(rotary_kernel, dim3(grid1d(R * L * dh / 8)), dim3(256), 0, ST(stream), x, stride, off, L, dh, cosb, sinb, y, y_stride, y_off, N, R,
+    SA_LAUNCH(rotary_kernel, dim3(grid1d(R * L * dh / 8)), dim3(256), 0, ST(stream), x, stride, off, L, dh, cosb, sinb, y, y_stride, y_off, N, R,
                        transpose, accumulate);
     SA_CHECK_LAUNCH();
     return 0;
@@ -1992,7 +1992,7 @@ extern "C" int sa_rotary(const float* x, int stride, int off, int L, int dh, con
 extern "C" int sa_cross_entropy(const float* logits, const int64_t* target, int64_t R, int V, float* loss_sum, void* dlogits, int d_dtype, float gscale,
                                 void* stream) {
     if (!logits || !target || !loss_sum || R <= 0 || V <= 0) return SA_EINVAL;
-    hipLaunchKernelGGL(ce_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, ST(stream), logits, target, R, V, loss_sum, dlogits, d_dtype, gscale);
+    SA_LAUNCH(ce_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, ST(stream), logits, target, R, V, loss_sum, dlogits, d_dtype, gscale);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -2010,7 +2010,7 @@ extern "C" int sa_embed_step(int ntab, const float* const* tables, const int64_t
         a.idx[t] = idx[t];
         a.per_position[t] = per_position[t];
     }
-    hipLaunchKernelGGL(embed_step_kernel, dim3(grid1d((int64_t)B * dim)), dim3(256), 0, ST(stream), a, pos, B, out);
+    SA_LAUNCH(embed_step_kernel, dim3(grid1d((int64_t)B * dim)), dim3(256), 0, ST(stream), a, pos, B, out);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -2020,7 +2020,7 @@ extern "C" int sa_favor_step(const float* q, int q_stride, int q_off, const floa
                              const int* pos, float* out, int out_stride, int out_off, void* stream) {
     if (!q || !k || !v || !proj || !smax || !kmax || !dd || !E || !Ez || !V1 || !pos || !out) return SA_EINVAL;
     if (dh != 64 || m > 272 || B <= 0 || G <= 0) return SA_EUNSUPPORTED;   // 16 waves x 17 features
-    hipLaunchKernelGGL(favor_step_proj_kernel, dim3(B * G), dim3(256), 0, ST(stream), q, q_stride, q_off, k, k_stride, k_off, proj, G, dh, m, LDF, dd, kmax, pos);
+    SA_LAUNCH(favor_step_proj_kernel, dim3(B * G), dim3(256), 0, ST(stream), q, q_stride, q_off, k, k_stride, k_off, proj, G, dh, m, LDF, dd, kmax, pos);
     SA_CHECK_LAUNCH();
     FavorStepArgs a;
     a.ddq = dd; a.ddk = dd + (int64_t)B * G * LDF; a.q = q; a.k = k; a.v = v;
@@ -2029,7 +2029,7 @@ extern "C" int sa_favor_step(const float* q, int q_stride, int q_off, const floa
     a.out = out; a.out_stride = out_stride; a.out_off = out_off;
     a.eps_feat = 1e-4f;
     a.eps_den = 1e-6f;
-    hipLaunchKernelGGL(favor_step_kernel, dim3(B * G), dim3(1024), 0, ST(stream), a);
+    SA_LAUNCH(favor_step_kernel, dim3(B * G), dim3(1024), 0, ST(stream), a);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -2044,7 +2044,7 @@ extern "C" int sa_local_attn_step(const float* q, int q_stride, int q_off, const
     a.q_stride = q_stride; a.q_off = q_off; a.k_stride = k_stride; a.k_off = k_off; a.v_stride = v_stride; a.v_off = v_off;
     a.cosb = cosb; a.sinb = sinb; a.kc = kcache; a.vc = vcache; a.pos = pos; a.N = N; a.W = W; a.L = L; a.dh = dh;
     a.out = out; a.out_stride = out_stride; a.out_off = out_off;
-    hipLaunchKernelGGL(local_attn_step_kernel, dim3(B * L), dim3(1024), 2 * (size_t)W * sizeof(float), ST(stream), a);
+    SA_LAUNCH(local_attn_step_kernel, dim3(B * L), dim3(1024), 2 * (size_t)W * sizeof(float), ST(stream), a);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -2066,8 +2066,8 @@ extern "C" int sa_gemv_rows(const float* x, int x_stride, int in, int B, int nse
     a.round_in = round_in; a.round_w = round_w; a.round_out = round_out;
     const unsigned blocks = (unsigned)((a.O + 15) / 16);
     for (int b0 = 0; b0 < B; b0 += 16) {
-        if (round_in) hipLaunchKernelGGL(gemv_rows_kernel<true>, dim3(blocks), dim3(512), 0, ST(stream), a, b0);
-        else hipLaunchKernelGGL(gemv_rows_kernel<false>, dim3(blocks), dim3(512), 0, ST(stream), a, b0);
+        if (round_in) SA_LAUNCH(gemv_rows_kernel<true>, dim3(blocks), dim3(512), 0, ST(stream), a, b0);
+        else SA_LAUNCH(gemv_rows_kernel<false>, dim3(blocks), dim3(512), 0, ST(stream), a, b0);
         SA_CHECK_LAUNCH();
     }
     return 0;

@@ -21,18 +21,31 @@ extern std::atomic<uint32_t> g_debug_flags;
 inline bool dbg(uint32_t bit) { return (g_debug_flags.load(std::memory_order_relaxed) & bit) != 0; }
 struct Tunables { int wgrad_rows, wgrad_min_blocks, wgrad_halo_splits; uint32_t pp_dbg; };
 extern const Tunables g_tunables;   // numeric developer knobs (SA_WGRAD_ROWS, SA_WGRAD_MIN_BLOCKS, SA_WGRAD_HALO_SPLITS, SA_PP_DBG), read once at load
-// hipFuncSetAttribute is per device: `mask` holds one bit per device ordinal that has been configured (setting twice is harmless, so the
-// race between two host threads is benign)
-inline bool first_use_on_device(std::atomic<uint64_t>& mask) {
+// hipFuncSetAttribute is per device: `mask` holds one bit per device ordinal that has been configured.  The bit is set AFTER `configure` has
+// run, so a second host thread that races the first either sees the bit (attributes are in place) or configures the kernel itself (setting
+// an attribute twice is harmless) -- it can never skip the configuration and launch before it happened.
+template <typename F> inline void configure_once_per_device(std::atomic<uint64_t>& mask, F&& configure) {
     int d = 0;
     (void)hipGetDevice(&d);
     const uint64_t bit = 1ull << (d & 63);
-    if (mask.load(std::memory_order_acquire) & bit) return false;
-    mask.fetch_or(bit, std::memory_order_acq_rel);
-    return true;
+    if (mask.load(std::memory_order_acquire) & bit) return;
+    configure();
+    mask.fetch_or(bit, std::memory_order_release);
 }
 // name of the convolution kernel instance the last sa_conv_fprop / sa_resblock_fprop / sa_conv_wgrad call launched (rocprofv3 spelling)
 extern thread_local char g_last_conv_kernel[128];
+// Optional per-thread log of the kernel names a launcher dispatched (sa_kernel_log_begin / sa_kernel_log_read): lets a test assert WHICH
+// kernels served a network without a profiler.  Off by default: one thread-local load per launch.
+void note_kernel_slow(const char* name);
+extern thread_local bool g_kernel_log_on;
+inline void note_kernel(const char* name) {
+    if (g_kernel_log_on) note_kernel_slow(name);
+}
+#define SA_LAUNCH(kern, ...)                     \
+    do {                                         \
+        sa::note_kernel(#kern);                  \
+        hipLaunchKernelGGL(kern, __VA_ARGS__);   \
+    } while (0)
 template <typename T> inline const char* tname() { return sizeof(T) == 4 ? "float" : "unsigned short"; }
 
 #define SA_CHECK_LAUNCH()                         \

@@ -232,12 +232,12 @@ extern "C" int sa_vq_assign(const float* rows, const float* codebook, int64_t M,
     if (!rows || !codebook || !idx || !zq_st || !counts || !dw || !sqerr || !wnorm) return SA_EINVAL;
     if (M <= 0 || K <= 0 || D <= 0 || (D & 3) || D > 1024) return SA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(vq_wnorm_kernel, dim3((K + 255) / 256), dim3(256), 0, st, codebook, K, D, wnorm);
+    SA_LAUNCH(vq_wnorm_kernel, dim3((K + 255) / 256), dim3(256), 0, st, codebook, K, D, wnorm);
     SA_CHECK_LAUNCH();
     const size_t lds = (size_t)(5 * 16 * (D + 4) + 16 + 64 + 64 + 16 + 4) * 4;
     if (lds > 160 * 1024) return SA_EUNSUPPORTED;
     const unsigned nblk = (unsigned)((M + 15) / 16);
-    hipLaunchKernelGGL(vq_assign_kernel, dim3(nblk), dim3(256), lds, st, rows, codebook, M, K, D, idx, zq_st, (bf16_t*)zq_lp, counts, dw, sqerr,
+    SA_LAUNCH(vq_assign_kernel, dim3(nblk), dim3(256), lds, st, rows, codebook, M, K, D, idx, zq_st, (bf16_t*)zq_lp, counts, dw, sqerr,
                        wnorm);
     SA_CHECK_LAUNCH();
     return 0;
@@ -247,7 +247,7 @@ extern "C" int sa_vq_ema_update(float* N, float* embed_avg, float* codebook, con
                                 float eps, void* stream) {
     using namespace sa;
     if (!N || !embed_avg || !codebook || !counts || !dw || K <= 0 || D <= 0) return SA_EINVAL;
-    hipLaunchKernelGGL(vq_ema_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, N, embed_avg, codebook, counts, dw, K, D, decay, eps);
+    SA_LAUNCH(vq_ema_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, N, embed_avg, codebook, counts, dw, K, D, decay, eps);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -255,7 +255,7 @@ extern "C" int sa_vq_ema_update(float* N, float* embed_avg, float* codebook, con
 extern "C" int sa_vq_perplexity(const float* counts, int K, int64_t M, float* out, void* stream) {
     using namespace sa;
     if (!counts || !out || K <= 0 || M <= 0) return SA_EINVAL;
-    hipLaunchKernelGGL(vq_perplexity_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, K, 1.f / (float)M, out);
+    SA_LAUNCH(vq_perplexity_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, K, 1.f / (float)M, out);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -268,7 +268,7 @@ extern "C" int sa_vq_backward(const float* rows, const float* codebook, const in
     const float coef = beta * 2.f / (float)n;
     unsigned nblk = (unsigned)((n + 255) / 256);
     if (nblk > 2048) nblk = 2048;
-    hipLaunchKernelGGL(vq_backward_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, rows, codebook, idx, g_zq, g_dtype, g_loss, coef, n, D, dz,
+    SA_LAUNCH(vq_backward_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, rows, codebook, idx, g_zq, g_dtype, g_loss, coef, n, D, dz,
                        dz_dtype);
     SA_CHECK_LAUNCH();
     return 0;
@@ -280,7 +280,7 @@ extern "C" int sa_vq_embed(const float* codebook, const int64_t* idx, int64_t M,
     const int64_t n = M * D;
     unsigned nblk = (unsigned)((n + 255) / 256);
     if (nblk > 2048) nblk = 2048;
-    hipLaunchKernelGGL(vq_embed_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, codebook, idx, n, K, D, out, out_dtype);
+    SA_LAUNCH(vq_embed_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, codebook, idx, n, K, D, out, out_dtype);
     SA_CHECK_LAUNCH();
     return 0;
 }

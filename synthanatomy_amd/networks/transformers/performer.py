@@ -293,8 +293,6 @@ class _LayerEngine:
         self.ops = {n: _lin(getattr(sa, n), dtype) for n in ("to_q", "to_k", "to_v", "to_out")}
         self.ops["w1"], self.ops["w2"] = _lin(ff.w1, dtype), _lin(ff.w2, dtype)
         self._pscaled = None
-        self._fused_sums = not debug.host("no_fused_sums")
-        self._no_fused_qkv = debug.host("no_fused_qkv")
         # state_flags bit 2 of the fused scans: fp32 (parity) mode keeps every product on the exact-fp32 MFMA; the bf16 throughput mode uses the
         # split-bf16 kernels (~1e-5 relative, far below the rounding of its dense layers)
         self._xf = 4 if dtype == torch.float32 else 0
@@ -328,7 +326,7 @@ class _LayerEngine:
         # to_q / to_k / to_v as ONE dense layer (one forward, one data-gradient and one weight-gradient launch instead of three each) when the
         # three bias-free weights are adjacent in memory
         wqkv = None
-        if not self._no_fused_qkv and sa.to_q.bias is None and sa.to_k.bias is None and sa.to_v.bias is None:
+        if not debug.host("no_fused_qkv") and sa.to_q.bias is None and sa.to_k.bias is None and sa.to_v.bias is None:
             wqkv = self._stacked([sa.to_q.weight.detach(), sa.to_k.weight.detach(), sa.to_v.weight.detach()])
         if wqkv is None:
             self.ops.pop("to_qkv", None)
@@ -429,13 +427,13 @@ class _LayerEngine:
                 _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddq), _ffi.ptr(qg), sst, 0, G, dh, 1, _ffi.ptr(qf), None, R * G, m, LDF, st), "favor_features(q)")
             _ck(lib.sa_favor_features_fwd(_ffi.ptr(ddk), _ffi.ptr(kg), sst, 0, G, dh, kmode, _ffi.ptr(kf), _ffi.ptr(gws), R * G, m, LDF, st), "favor_features(k)")
             ws = self._scan_ws(B, N, G, dev)
-            if tape is not None and self._fused_sums:   # training: the chunk states (sum k' (x) v, sum k') are kept for the dq' scan of the backward pass
+            if tape is not None and (not debug.host("no_fused_sums")):   # training: the chunk states (sum k' (x) v, sum k') are kept for the dq' scan of the backward pass
                 ws = torch.empty_like(ws)
             inv = torch.empty(R * G, dtype=f32, device=dev)
             Z = None
             # normaliser fused into the scan (the running key sums ride along as an extra state column): no cumsum / den passes
             rc = lib.sa_favor_scan_a_norm(_ffi.ptr(kf), _ffi.ptr(qf), _ffi.ptr(v), qs, 0, _ffi.ptr(attn), inner, 0, _ffi.ptr(inv), 1e-6, B, N, G, LDF, dh,
-                                          _ffi.ptr(ws), self._xf, st) if self._fused_sums else _ffi.SA_EUNSUPPORTED
+                                          _ffi.ptr(ws), self._xf, st) if (not debug.host("no_fused_sums")) else _ffi.SA_EUNSUPPORTED
             if rc == _ffi.SA_EUNSUPPORTED:
                 Z = torch.empty_like(kf)
                 _ck(lib.sa_cumsum_rows(_ffi.ptr(kf), None, _ffi.ptr(Z), B, N, G, LDF, 0, _ffi.ptr(ws), st), "sa_cumsum_rows")

@@ -229,7 +229,7 @@ class _ConvStage:
             tape.append((x,))
         return y
 
-    def bwd(self, G, saved, grads):
+    def bwd(self, G, saved, grads, wgrad_only=False):
         (x,) = saved
         self._sync()
         vec = vec_of(self.dtype)
@@ -238,7 +238,7 @@ class _ConvStage:
         dw, db = grads.buf(self.mod.weight), grads.buf(self.mod.bias)
         self.op.wgrad(x, G, dw, db)
         grads.done(self.mod.weight, self.mod.bias)
-        if not self.need_dx:
+        if not self.need_dx or wgrad_only:
             return None
         return self.op.dgrad(G, tuple(x.shape[1:4]), mask=x if self.in_act else None, mask_mode=MASK_POS)
 
@@ -359,7 +359,8 @@ class _ConvT1Stage:
             tape.append((x,))
         return out
 
-    def bwd(self, G, saved, grads):
+    def bwd(self, G, saved, grads, wgrad_only=False):
+        """wgrad_only: the weight / bias gradient alone (`BaselineVQVAE.last_layer_grad`: im2col of the gradient + ONE wgrad launch, no data gradient)."""
         (x,) = saved
         N, D, H, W, C = x.shape
         G = G.float().contiguous()
@@ -369,7 +370,9 @@ class _ConvT1Stage:
             self._sync()
             Gc = torch.empty((N, D, H, W, 64), dtype=x.dtype, device=x.device)
             _ffi.check(lib.sa_convt1_im2col(_ffi.ptr(G), _ffi.dtype_id(x.dtype), _ffi.ptr(Gc), _ffi.ptr(db), N, D, H, W, st), "sa_convt1_im2col")
-            dx = self.taps_bwd.fprop(Gc, mask=x if self.in_act else None, mask_mode=MASK_POS if self.in_act else MASK_NONE, use_bias=False)
+            dx = None
+            if not wgrad_only:
+                dx = self.taps_bwd.fprop(Gc, mask=x if self.in_act else None, mask_mode=MASK_POS if self.in_act else MASK_NONE, use_bias=False)
             self.taps_fwd.wgrad(x, Gc, dw, None)
         else:
             dx = torch.empty_like(x)
@@ -507,7 +510,10 @@ class _Chain:
             raise RuntimeError("last_stage_wgrad needs a recorded forward whose backward has not run yet")
         st = self.stages[-1]
         gc = _GradCtx(None)
-        st.bwd(G, self.last_tape[-1], gc)
+        if isinstance(st, (_ConvStage, _ConvT1Stage)):
+            st.bwd(G, self.last_tape[-1], gc, wgrad_only=True)   # no data gradient: the caller only wants d loss / d W_last
+        else:
+            st.bwd(G, self.last_tape[-1], gc)
         return gc.grads[st.params()[0]]
 
     def backward(self, G: torch.Tensor, tape):

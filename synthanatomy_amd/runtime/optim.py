@@ -152,6 +152,16 @@ class TrainerState:
     def state_dict(self):
         return {"iteration": self.iteration, "epoch_length": self.epoch_length, "max_epochs": self.max_epochs}
 
+    def rebase(self, epoch_length: int, max_epochs: int):
+        """After a resume: THIS run's epoch length / --epochs replace the restored ones (upstream's MaxEpochsHandler,
+        src/handlers/general.py:593-610).  The number of FINISHED epochs is taken with the checkpoint's own epoch length first -- the world
+        size, batch size or data set may differ from the saved run -- and the iteration counter is re-expressed in the new epoch length, so
+        the start epoch, the shard seed and the checkpoint numbering stay those of the saved run."""
+        finished = self.epoch
+        self.epoch_length, self.max_epochs = int(epoch_length), int(max_epochs)
+        self.iteration = finished * self.epoch_length
+        return finished
+
     def load_state_dict(self, sd):
         self.epoch_length = int(sd.get("epoch_length", self.epoch_length))     # ignite restores all three
         self.max_epochs = int(sd.get("max_epochs", self.max_epochs))

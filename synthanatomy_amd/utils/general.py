@@ -111,6 +111,32 @@ def _state(obj):
     return obj.state_dict() if hasattr(obj, "state_dict") else obj
 
 
+_BEST_SCORE = {}   # checkpoint directory -> (file, unrounded score) of the key-metric checkpoint this process wrote or read
+
+
+def _best_key_metric(ck, files):
+    """Unrounded score of the existing key-metric checkpoint: from this process' memory, else from the file's payload, else (files written by
+    the reference, which stores no score) parsed back from the file name."""
+    if not files:
+        return None
+    hit = _BEST_SCORE.get(os.path.abspath(ck))
+    if hit is not None and hit[0] in files:
+        return hit[1]
+    best = None
+    for f in files:
+        score = None
+        try:
+            score = torch.load(f, map_location="cpu", weights_only=False).get("key_metric")
+        except Exception:   # unreadable / foreign file: fall back to the name
+            score = None
+        if score is None:
+            score = float(re.search(r"key_metric=(-?[0-9.eE+-]+)\.pt$", f).group(1))
+        if best is None or score > best[1]:
+            best = (f, float(score))
+    _BEST_SCORE[os.path.abspath(ck)] = best
+    return best[1]
+
+
 def save_checkpoint(config, epoch, to_save: dict, key_metric: float = None, key_metric_name: str = None):
     """One ``.pt`` whose top-level keys are those of the reference's ``to_save`` (run_vqvae.py:312-326: ``network``, ``optimizer``,
     ``lr_scheduler``, ``trainer`` and, with the adversarial component, ``d_network``, ``d_optimizer``, ``d_lr_scheduler``), each the
@@ -128,11 +154,15 @@ def save_checkpoint(config, epoch, to_save: dict, key_metric: float = None, key_
                 os.remove(f)
         return path
     old = glob.glob(os.path.join(ck, "checkpoint_key_metric=*.pt"))
-    best = max([float(re.search(r"key_metric=(-?[0-9.eE+-]+)\.pt$", f).group(1)) for f in old], default=None)
+    best = _best_key_metric(ck, old)
     if best is not None and key_metric <= best:
         return None
+    # ignite compares the UNROUNDED score it keeps in memory; the file name only carries a rounded copy.  The exact score rides in the payload
+    # (and in a per-directory cache), so metrics below 1e-4 (validation MSE) still order correctly after a restart.
+    obj["key_metric"] = float(key_metric)
     path = os.path.join(ck, f"checkpoint_key_metric={key_metric:.4f}.pt")
     torch.save(obj, path)
+    _BEST_SCORE[os.path.abspath(ck)] = (path, float(key_metric))
     for f in old:
         if f != path:
             os.remove(f)

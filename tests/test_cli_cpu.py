@@ -75,6 +75,37 @@ def test_checkpoint_selection_rules(tmp_path):
         G.load_checkpoint(p3, {"optimizer": net})     # ignite's CheckpointLoader: a requested key that is absent is an error
 
 
+def test_best_checkpoint_is_chosen_by_the_unrounded_metric(tmp_path):
+    """key metrics of run_vqvae are -MSE, i.e. 1e-3 .. 1e-5: the comparison must not go through the '%.4f' file name (ignite keeps the score in
+    memory), neither within one process nor after a restart."""
+    cfg = dict(project_directory=str(tmp_path) + "/", experiment_name="exp", network="baseline_vqvae", starting_epoch=0, mode="training")
+    G.create_folder_structure(cfg)
+    net = torch.nn.Linear(2, 2)
+    a = G.save_checkpoint(cfg, 1, {"network": net}, key_metric=-0.00054)
+    assert os.path.basename(a) == "checkpoint_key_metric=-0.0005.pt"
+    b = G.save_checkpoint(cfg, 2, {"network": net}, key_metric=-0.00052)          # better, same rounded name
+    assert b is not None and torch.load(b, weights_only=False)["key_metric"] == -0.00052
+    assert G.save_checkpoint(cfg, 3, {"network": net}, key_metric=-0.00053) is None
+    c = G.save_checkpoint(cfg, 4, {"network": net}, key_metric=-3e-5)
+    assert os.path.basename(c) == "checkpoint_key_metric=-0.0000.pt" and not os.path.exists(b)
+    G._BEST_SCORE.clear()                                                          # a restarted process: the score comes back from the payload
+    assert G.save_checkpoint(cfg, 5, {"network": net}, key_metric=-4e-5) is None
+    d = G.save_checkpoint(cfg, 6, {"network": net}, key_metric=-1e-5)
+    assert d is not None and torch.load(d, weights_only=False)["key_metric"] == -1e-5
+    assert len(os.listdir(cfg["checkpoint_directory"])) == 1
+    G.load_checkpoint(d, {"network": net})                                         # the extra payload key does not disturb loading
+
+
+def test_resume_uses_the_checkpoints_epoch_length():
+    """10 epochs of 100 iterations saved on one GPU, resumed on two (epoch length 50): the run continues at epoch 10, not 20."""
+    from synthanatomy_amd.runtime.optim import TrainerState
+    st = TrainerState(epoch_length=50, max_epochs=30)
+    st.load_state_dict({"iteration": 1000, "epoch_length": 100, "max_epochs": 20})
+    assert st.epoch == 10
+    assert st.rebase(50, 30) == 10
+    assert st.epoch == 10 and st.iteration == 500 and st.state_dict() == {"iteration": 500, "epoch_length": 50, "max_epochs": 30}
+
+
 def test_distributed_sampler_sharding():
     """Every rank gets the same number of samples (wrap-around padding), one permutation per epoch shared by all ranks."""
     for n, world in [(5, 2), (7, 4), (8, 4), (1, 2)]:

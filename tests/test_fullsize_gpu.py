@@ -81,7 +81,7 @@ def test_full_size_halo_kernels_agree_with_im2col_order_kernels(net):
     idx_h = codes()
     loss_h, gr_h = _grads(net, x)
     from synthanatomy_amd import debug
-    with debug.override(no_halo=True, no_fused_1x1_bwd=True, no_strided_halo=True):   # ... and the two-launch 1x1x1 backward instead of sa_conv1x1_backward
+    with debug.override(no_halo=True, no_fused_1x1_bwd=True):   # ... and the two-launch 1x1x1 backward instead of sa_conv1x1_backward
         idx_r = codes()
         loss_r, gr_r = _grads(net, x)
     # bf16 activations: a different summation order moves a few of the 1 400 encoder outputs across a code boundary (4-8 measured), and every

@@ -483,7 +483,7 @@ def la_path(request):
         yield request.param
 
 
-@pytest.mark.parametrize("N,W", [(23, 5), (40, 8), (17, 32), (100, 420), (333, 64)])
+@pytest.mark.parametrize("N,W", [(23, 5), (40, 8), (17, 32), (100, 420), (333, 64), (1400, 420), (1000, 420), (841, 420)])
 def test_local_attention_kernel_against_dense_band(N, W, la_path):
     from synthanatomy_amd import _ffi
     lib, st = _ffi.lib(), _ffi.stream()
@@ -577,7 +577,7 @@ def test_stateful_sampler_equals_the_quadratic_loop(rezero, shape, window, local
     assert int(smp.min()) >= 0 and int(smp.max()) <= 18
 
 
-@pytest.mark.parametrize("N,W", [(23, 5), (100, 420), (150, 64), (200, 70), (321, 128)])
+@pytest.mark.parametrize("N,W", [(23, 5), (100, 420), (150, 64), (200, 70), (321, 128), (1400, 420), (1000, 420)])
 def test_local_attention_backward_kernels_against_autograd(N, W, la_path):
     from synthanatomy_amd import _ffi
     lib, st = _ffi.lib(), _ffi.stream()

@@ -149,14 +149,26 @@ def test_training_step_bf16_decreases_loss_and_matches_oracle_grads():
     out = net(x.cuda())
     loss = torch.nn.functional.mse_loss(out["reconstruction"][0], x.cuda()) + out["quantization_losses"][0]
     loss.backward()
-    if torch.equal(net.index_quantize(x.cuda())[0].cpu(), ref["indices"]) or True:
-        params = dict(net.named_parameters())
-        worst = 0.0
-        for k, p in leaf.items():
-            gr = params[k].grad
-            assert gr is not None and torch.isfinite(gr).all(), k
-            worst = max(worst, _relerr(gr.cpu().numpy(), p.grad.numpy()))
-        assert worst < 8e-2, worst  # bf16 activations/gradients vs the fp32-accumulated oracle
+    params = dict(net.named_parameters())
+    worst = 0.0
+    for k, p in leaf.items():
+        gr = params[k].grad
+        assert gr is not None and torch.isfinite(gr).all(), k
+        worst = max(worst, _relerr(gr.cpu().numpy(), p.grad.numpy()))
+    assert worst < 8e-2, worst  # bf16 activations/gradients vs the fp32-accumulated oracle
+    # ... and the gradients point downhill: a few Adam steps on the same batch lower the loss
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=2e-3)
+    first = last = None
+    for _ in range(12):
+        opt.zero_grad()
+        out = net(x.cuda())
+        l = torch.nn.functional.mse_loss(out["reconstruction"][0], x.cuda()) + out["quantization_losses"][0]
+        l.backward()
+        opt.step()
+        net.invalidate_packed_weights()
+        last = float(l)
+        first = last if first is None else first
+    assert last < 0.8 * first, (first, last)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
