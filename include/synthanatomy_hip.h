@@ -63,8 +63,8 @@ const char *sa_last_error(void);
 /* kernel instance (rocprofv3 spelling) the calling thread's last sa_conv_fprop / sa_resblock_fprop / sa_conv_wgrad launched:
  * lets a profiler key its per-kernel timings exactly as the dispatcher decided, without mirroring the dispatch rules */
 const char *sa_last_conv_kernel(void);
-/* Per-thread kernel log (test aid; no profiler needed): after sa_kernel_log_begin() every launcher of this library notes the name of each
- * kernel it dispatches on the calling thread -- each distinct name once, in first-launch order, spelled as in the source / rocprofv3 (template
+/* Kernel log (test aid; no profiler needed; process-wide, mutex-protected -- autograd issues the backward launches from its own thread):
+ * after sa_kernel_log_begin() every launcher of this library notes the name of each kernel it dispatches -- each distinct name once, in first-launch order, spelled as in the source / rocprofv3 (template
  * arguments included for template instances).  sa_kernel_log_read copies the newline-separated list into buf (NUL-terminated, truncated to
  * cap) and returns the bytes needed; stop != 0 ends logging.  Convolution launches are noted with the instance name of sa_last_conv_kernel. */
 void sa_kernel_log_begin(void);

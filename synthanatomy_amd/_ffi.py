@@ -193,8 +193,8 @@ def require_gpu():
 
 
 class kernel_log:
-    """``with kernel_log() as names: ...`` -- afterwards ``names`` holds the distinct kernel names this thread's launches dispatched
-    (sa_kernel_log_begin / sa_kernel_log_read)."""
+    """``with kernel_log() as names: ...`` -- afterwards ``names`` holds the distinct kernel names the launches dispatched
+    (sa_kernel_log_begin / sa_kernel_log_read; process-wide: the backward launches come from autograd's thread)."""
 
     def __enter__(self):
         self.names = []

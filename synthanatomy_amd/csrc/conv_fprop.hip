@@ -1153,14 +1153,14 @@ static int launch_fprop(const FpropArgs& a, hipStream_t st) {
     if (a.in_bytes != 0) {  // every operand addressable with 32-bit buffer offsets -> LDS-DMA mainloop
         const bool uniform = ((size_t)a.g.Cin * sizeof(T)) % 128 == 0;
         (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma_kernel<%s, %d, %d, %d, %d, %s, false>", tname<T>(), WM, WN, MI, NI, uniform ? "true" : "false"), note_kernel(g_last_conv_kernel));
-        if (uniform) SA_LAUNCH((conv_fprop_dma_kernel<T, WM, WN, MI, NI, true>), grid, dim3(WM * WN * 64), lds, st, a);
-        else SA_LAUNCH((conv_fprop_dma_kernel<T, WM, WN, MI, NI, false>), grid, dim3(WM * WN * 64), lds, st, a);
+        if (uniform) hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, true>), grid, dim3(WM * WN * 64), lds, st, a);
+        else hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, false>), grid, dim3(WM * WN * 64), lds, st, a);
         SA_CHECK_LAUNCH();
         return 0;
     }
     if constexpr (WM * WN == 4) {
         (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_kernel<%s, %d, %d, %d, %d>", tname<T>(), WM, WN, MI, NI), note_kernel(g_last_conv_kernel));
-        SA_LAUNCH((conv_fprop_kernel<T, WM, WN, MI, NI>), grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL((conv_fprop_kernel<T, WM, WN, MI, NI>), grid, dim3(256), lds, st, a);
         SA_CHECK_LAUNCH();
         return 0;
     } else {
@@ -1195,7 +1195,7 @@ static int launch_fprop_halo(FpropArgs a, hipStream_t st) {
     static std::atomic<uint64_t> attr_done{0};   // one bit per device (one static per template instance)
     configure_once_per_device(attr_done, [] { (void)hipFuncSetAttribute((const void*)conv_fprop_halo_kernel<T, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); });
     (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo_kernel<%s, %s>", tname<T>(), FUSE ? "true" : "false"), note_kernel(g_last_conv_kernel));
-    SA_LAUNCH((conv_fprop_halo_kernel<T, FUSE>), dim3(a.nblk_m * nbn_valid), dim3(256), pipe > epi ? pipe : epi, st, a);
+    hipLaunchKernelGGL((conv_fprop_halo_kernel<T, FUSE>), dim3(a.nblk_m * nbn_valid), dim3(256), pipe > epi ? pipe : epi, st, a);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -1215,7 +1215,7 @@ template <typename T, bool FUSE, int NW>
 static int launch_fprop_halo256_impl(const FpropArgs& a, uint32_t nbn, size_t lds, hipStream_t st) {
     static std::atomic<uint64_t> attr_done{0};   // one bit per device (one static per template instance)
     configure_once_per_device(attr_done, [] { (void)hipFuncSetAttribute((const void*)conv_fprop_halo256_kernel<T, FUSE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); });
-    SA_LAUNCH((conv_fprop_halo256_kernel<T, FUSE, NW>), dim3(a.nblk_m * nbn), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((conv_fprop_halo256_kernel<T, FUSE, NW>), dim3(a.nblk_m * nbn), dim3(NW * 64), lds, st, a);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -1355,7 +1355,7 @@ extern "C" int sa_resblock_fprop(const sa_conv_geom* g, int dtype, const void* x
     if (halo_eligible(a, 2)) return launch_fprop_halo<bf16_t, true>(a, (hipStream_t)stream);
     const size_t pipe = 2 * (128 + 128) * 128, epi = (size_t)128 * (128 + 4) * 4 + 128 * 8;
     (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma_kernel<unsigned short, 2, 2, 4, 4, true, true>"), note_kernel(g_last_conv_kernel));
-    SA_LAUNCH((conv_fprop_dma_kernel<bf16_t, 2, 2, 4, 4, true, true>), dim3(a.nblk_m), dim3(256), pipe > epi ? pipe : epi, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((conv_fprop_dma_kernel<bf16_t, 2, 2, 4, 4, true, true>), dim3(a.nblk_m), dim3(256), pipe > epi ? pipe : epi, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     return 0;
 }

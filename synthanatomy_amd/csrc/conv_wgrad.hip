@@ -1068,7 +1068,7 @@ static int conv_wgrad_impl(const sa_conv_geom* g, int dtype, const void* in, con
             return SA_EUNSUPPORTED;
         if (fuse_db) a.db = db;
         (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_dma_kernel<unsigned short, true, 4>"), note_kernel(g_last_conv_kernel));
-        SA_LAUNCH((conv_wgrad_dma_kernel<bf16_t, true>), grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL((conv_wgrad_dma_kernel<bf16_t, true>), grid, dim3(256), lds, st, a);
     } else if (a.halo && a.ws) {
         if (fuse_db) a.db = db;
         static std::atomic<uint64_t> attr_done{0};   // one bit per device
@@ -1083,31 +1083,31 @@ static int conv_wgrad_impl(const sa_conv_geom* g, int dtype, const void* in, con
             //  instance for A/B runs, SA_PP_DBG bit 14)
             if (g_tunables.pp_dbg & 16384u) {
                 (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_halo9_kernel<16>"), note_kernel(g_last_conv_kernel));
-                SA_LAUNCH(conv_wgrad_halo9_kernel<16>, dim3(8u * spx * 6u * nct), dim3(1024), 2 * 55 * 1024, st, a);
+                hipLaunchKernelGGL(conv_wgrad_halo9_kernel<16>, dim3(8u * spx * 6u * nct), dim3(1024), 2 * 55 * 1024, st, a);
             } else {
                 (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_halo9_kernel<8>"), note_kernel(g_last_conv_kernel));
-                SA_LAUNCH(conv_wgrad_halo9_kernel<8>, dim3(8u * spx * 6u * nct), dim3(512), 2 * 55 * 1024, st, a);
+                hipLaunchKernelGGL(conv_wgrad_halo9_kernel<8>, dim3(8u * spx * 6u * nct), dim3(512), 2 * 55 * 1024, st, a);
             }
         } else {
             (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_halo_kernel<4>"), note_kernel(g_last_conv_kernel));
-            SA_LAUNCH(conv_wgrad_halo_kernel<4>, dim3(8u * spx * 9u * nct), dim3(768), 2 * 34 * 1024, st, a);
+            hipLaunchKernelGGL(conv_wgrad_halo_kernel<4>, dim3(8u * spx * 9u * nct), dim3(768), 2 * 34 * 1024, st, a);
         }
     } else if (a.in_bytes) {
         if (fuse_db) a.db = db;
         // bf16: eight waves per block (k4s2 / transposed-conv weight gradients 2.66 -> 2.29 / 2.37 ms at batch 8); SA_DBG_HALO256_4W keeps four
         const bool w8 = dtype == SA_BF16 && !dbg(SA_DBG_HALO256_4W);
         (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_dma_kernel<%s, false, %d>", dtype == SA_F32 ? "float" : "unsigned short", w8 ? 8 : 4), note_kernel(g_last_conv_kernel));
-        if (dtype == SA_F32) SA_LAUNCH(conv_wgrad_dma_kernel<float>, grid, dim3(256), lds, st, a);
-        else if (w8) SA_LAUNCH((conv_wgrad_dma_kernel<bf16_t, false, 8>), grid, dim3(512), lds, st, a);
-        else SA_LAUNCH(conv_wgrad_dma_kernel<bf16_t>, grid, dim3(256), lds, st, a);
+        if (dtype == SA_F32) hipLaunchKernelGGL(conv_wgrad_dma_kernel<float>, grid, dim3(256), lds, st, a);
+        else if (w8) hipLaunchKernelGGL((conv_wgrad_dma_kernel<bf16_t, false, 8>), grid, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL(conv_wgrad_dma_kernel<bf16_t>, grid, dim3(256), lds, st, a);
     } else {
         (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_wgrad_kernel<%s>", dtype == SA_F32 ? "float" : "unsigned short"), note_kernel(g_last_conv_kernel));
-        if (dtype == SA_F32) SA_LAUNCH(conv_wgrad_kernel<float>, grid, dim3(256), lds, st, a);
-        else SA_LAUNCH(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, a);
+        if (dtype == SA_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, a);
     }
     SA_CHECK_LAUNCH();
     if (a.ws) {
-        SA_LAUNCH(wgrad_reduce_kernel, dim3((a.ntiles * 4096u + 255) / 256), dim3(256), 0, st, a, splits);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((a.ntiles * 4096u + 255) / 256), dim3(256), 0, st, a, splits);
         SA_CHECK_LAUNCH();
     }
     if (db && !a.db) {  // not fused (fp32, or operands beyond 32-bit offsets): stand-alone column sums over THIS geometry's rows
@@ -1117,8 +1117,8 @@ static int conv_wgrad_impl(const sa_conv_geom* g, int dtype, const void* in, con
         a.db = db;
         const int64_t rpb = ((int64_t)a.M + 1023) / 1024 < 64 ? 64 : ((int64_t)a.M + 1023) / 1024;
         const unsigned nb = (unsigned)(((int64_t)a.M + rpb - 1) / rpb);
-        if (dtype == SA_F32) SA_LAUNCH(colsum_geom_kernel<float>, dim3(nb), dim3(256), 0, st, a, rpb);
-        else SA_LAUNCH(colsum_geom_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, a, rpb);
+        if (dtype == SA_F32) hipLaunchKernelGGL(colsum_geom_kernel<float>, dim3(nb), dim3(256), 0, st, a, rpb);
+        else hipLaunchKernelGGL(colsum_geom_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, a, rpb);
         SA_CHECK_LAUNCH();
     }
     return 0;
@@ -1132,8 +1132,8 @@ extern "C" int sa_colsum(const void* gp, int dtype, int64_t M, int C, int cstrid
     int64_t rows_per_block = (M + 511) / 512;
     if (rows_per_block < 64) rows_per_block = 64;
     dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (cstride / vec + 15) / 16);
-    if (dtype == SA_F32) SA_LAUNCH(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)gp, M, C, cstride, db, rows_per_block);
-    else SA_LAUNCH(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gp, M, C, cstride, db, rows_per_block);
+    if (dtype == SA_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)gp, M, C, cstride, db, rows_per_block);
+    else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gp, M, C, cstride, db, rows_per_block);
     SA_CHECK_LAUNCH();
     return 0;
 }

@@ -2,15 +2,18 @@
 #include "sa_common.h"
 
 #include <cstring>
+#include <mutex>
 #include <string>
 
 namespace sa {
 
 thread_local hipError_t g_last_error = hipSuccess;
 thread_local char g_last_conv_kernel[128] = "";
-thread_local bool g_kernel_log_on = false;
-static thread_local std::string* g_kernel_log = nullptr;   // newline-separated, each distinct name once, in first-launch order
+std::atomic<bool> g_kernel_log_on{false};
+static std::mutex g_kernel_log_mu;
+static std::string* g_kernel_log = nullptr;   // newline-separated, each distinct name once, in first-launch order
 void note_kernel_slow(const char* name) {
+    std::lock_guard<std::mutex> lk(g_kernel_log_mu);
     if (!g_kernel_log) g_kernel_log = new std::string();
     std::string key(name);
     // "(kernel<args>)" -> "kernel<args>" (template instances are passed to the launch macro in parentheses)
@@ -210,10 +213,12 @@ extern "C" int sa_abi_version(void) { return SA_ABI_VERSION; }
 extern "C" const char* sa_last_error(void) { return hipGetErrorString(sa::g_last_error); }
 extern "C" const char* sa_last_conv_kernel(void) { return sa::g_last_conv_kernel; }
 extern "C" void sa_kernel_log_begin(void) {
+    std::lock_guard<std::mutex> lk(sa::g_kernel_log_mu);
     if (sa::g_kernel_log) sa::g_kernel_log->clear();
     sa::g_kernel_log_on = true;
 }
 extern "C" int sa_kernel_log_read(char* buf, int cap, int stop) {
+    std::lock_guard<std::mutex> lk(sa::g_kernel_log_mu);
     const std::string empty;
     const std::string& s = sa::g_kernel_log ? *sa::g_kernel_log : empty;
     const int need = (int)s.size() + 1;

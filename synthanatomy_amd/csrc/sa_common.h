@@ -34,12 +34,13 @@ template <typename F> inline void configure_once_per_device(std::atomic<uint64_t
 }
 // name of the convolution kernel instance the last sa_conv_fprop / sa_resblock_fprop / sa_conv_wgrad call launched (rocprofv3 spelling)
 extern thread_local char g_last_conv_kernel[128];
-// Optional per-thread log of the kernel names a launcher dispatched (sa_kernel_log_begin / sa_kernel_log_read): lets a test assert WHICH
-// kernels served a network without a profiler.  Off by default: one thread-local load per launch.
+// Optional process-wide log of the kernel names the launchers dispatched (sa_kernel_log_begin / sa_kernel_log_read): lets a test assert WHICH
+// kernels served a network without a profiler (process-wide because autograd runs the backward launches on its own thread).  Off by default:
+// one relaxed atomic load per launch.
 void note_kernel_slow(const char* name);
-extern thread_local bool g_kernel_log_on;
+extern std::atomic<bool> g_kernel_log_on;
 inline void note_kernel(const char* name) {
-    if (g_kernel_log_on) note_kernel_slow(name);
+    if (g_kernel_log_on.load(std::memory_order_relaxed)) note_kernel_slow(name);
 }
 #define SA_LAUNCH(kern, ...)                     \
     do {                                         \

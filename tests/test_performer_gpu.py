@@ -215,15 +215,15 @@ def test_fused_qkv_projection_matches_separate_layers(with_sink):
     res = []
     from synthanatomy_amd import debug
     for fused in (True, False):
-        with debug.override(no_fused_qkv=not fused):   # the layer engines read the switch when they are built
-            net, _ = _build(cfg, st, dtype=torch.bfloat16)
+        net, _ = _build(cfg, st, dtype=torch.bfloat16)
         net.train()
         flat = FlatParams(net.parameters())
         if with_sink:
             net.set_grad_sink(GradReducer(flat))
-        out = net(tok)
-        CELoss()(out.transpose(1, 2), tgt).backward()
-        torch.cuda.synchronize()
+        with debug.override(no_fused_qkv=not fused):   # the layer engines read the switch at launch time
+            out = net(tok)
+            CELoss()(out.transpose(1, 2), tgt).backward()
+            torch.cuda.synchronize()
         eng = net._chain.layers[0]
         assert ("to_qkv" in eng.ops) == fused
         res.append((out.detach().float().clone(), flat.grad.clone()))

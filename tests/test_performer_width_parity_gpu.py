@@ -99,7 +99,7 @@ def _run(case, dtype):
         torch.cuda.synchronize()
     grads = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
     fused = ["to_qkv" in l.ops for l in net._chain.layers]
-    return out.detach(), float(loss), grads, names, fused
+    return out.detach(), float(loss.detach()), grads, names, fused
 
 
 def test_fp32_engine_matches_oracle_at_production_width(case):
