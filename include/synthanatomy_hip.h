@@ -331,6 +331,24 @@ int sa_convt1_bwd(const void *x, int dtype, const float *w, const float *g, cons
 int sa_convt1_gather(const float *p, const float *bias, float *out, int N, int D, int H, int W, void *stream);
 int sa_convt1_im2col(const float *g, int dtype, void *gc, float *db, int N, int D, int H, int W, void *stream);
 
+/* ---- FAVOR+ global heads with the feature maps recomputed on chip (csrc/favor_fused.hip; throughput mode) ------------------------------------
+ * Replaces, for performer_pytorch.FastAttention / softmax_kernel / causal_linear_attention (reference src/networks/transformers/performer.py:194-219
+ * delegates to them), the chain sa_favor_project* -> sa_favor_features_fwd -> sa_favor_scan_a_norm (forward) and sa_favor_dden -> sa_favor_scan_b_cum x2 ->
+ * sa_favor_scan_a_state -> sa_favor_features_project_bwd x2 (backward): no [B*N*G, LDF] tensor (dd, phi, d phi) is ever written.
+ * q / k / v / dq / dk / dv: fp32 rows of `stride` floats whose first G*64 columns are the global heads; ps = projection matrix [m][64] with the
+ * data normaliser folded in; tiles = 5 * 16 KiB from sa_favor_fused_proj_tiles(ps); offq / offk [B*N*G] floats, amq [B*N*G] int32 and gmax_ws (8 bytes)
+ * from sa_favor_fused_prepass; state buffers of sa_favor_fused_state_bytes bytes.  m <= 272, head width 64. */
+int64_t sa_favor_fused_state_bytes(int B, int N, int G, int m);
+int sa_favor_fused_proj_tiles(const float *ps, int m, void *tiles, void *stream);
+int sa_favor_fused_prepass(const float *q, const float *k, int stride, int G, const float *ps, float *offq, int32_t *amq, float *offk, void *gmax_ws,
+                           int64_t rows, int m, int dh, void *stream);
+int sa_favor_fused_fwd(const float *q, const float *k, const float *v, int stride, const void *tiles, const float *ps, const float *offq, const float *offk,
+                       const void *gmax_ws, float *attn, int attn_stride, float *inv_out, float den_eps, int B, int N, int G, int m, float *state,
+                       void *stream);
+int sa_favor_fused_bwd(const float *q, const float *k, const float *v, int stride, const void *tiles, const float *ps, const float *offq, const int32_t *amq,
+                       const float *offk, const void *gmax_ws, const float *dattn, const float *attn, int attn_stride, const float *inv, float *dq, float *dk,
+                       float *dv, int B, int N, int G, int m, const float *state_fwd, float *state_ws, float *dden_ws, float *tsum_ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

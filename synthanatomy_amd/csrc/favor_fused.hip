@@ -1,0 +1,780 @@
+// FAVOR+ causal attention with the random-feature maps RECOMPUTED ON CHIP (throughput mode of the Performer, SURVEY 2.1 K7/K8: "fuse feature map so HBM
+// reads only q, k, v [N, 64]").
+//
+// The unfused chain (performer.hip / favor_proj.hip) materialises dd = x P^T and phi(x) for queries and keys as fp32 [B N 8, 272] tensors -- 73 MB
+// each per layer at the README shape -- and walks them ~10 times per training step.  Here a chunk block (64 positions of one (batch, head), the same
+// decomposition as the chunked scans: chunk state sums -> exclusive prefix over chunks -> chunk outputs) rebuilds the 64-feature slab it is
+// about to use from the chunk's q / k rows (64 floats per position) and a 64 x 64 slab of the projection matrix:
+//     dd^T = P_slab x^T  (split-bf16 MFMA, accumulators: 4 features x 1 position per lane)  ->  phi = ratio (exp(dd - rowoff) + eps)
+// where rowoff = |x|^2 c^2 / 2 + stabiliser comes from ONE pre-pass over q and k (row maxima of the queries, the global maximum of the keys:
+// performer_pytorch.softmax_kernel), 12 bytes per head row instead of 2 x 1 088.  Features that feed a reduction over positions go through an LDS
+// tile (hi / lo bf16, the layout of split_bf16.h), features of a wave's own positions go from the accumulators straight into the next MFMA's B
+// operand.  The backward kernels apply the feature-map backward and the projection adjoint to the gradient slab while it is still in registers:
+//     v = (phi - ratio eps) dphi,  t = sum_f v_f,  dx = sum_f v_f P[f] - [query] t P[argmax] - t c^2 x      (keys: -(sum of all t) P[f*] on the global-max row)
+// so d loss / d phi, d loss / d dd never exist in memory either.  Arithmetic = the unfused throughput path (split-bf16 products, fp32 accumulation).
+#include "sa_common.h"
+#include "split_bf16.h"
+
+namespace sa {
+
+constexpr int FT_BYTES = 64 * 128;   // one [64 rows][64 bf16] tile
+constexpr int FSLAB = 64;
+
+struct FeatSrc {
+    const float* x;        // rows of `stride` floats, head g at column g * 64
+    const float* rowoff;   // [B * N * G]: |x|^2 c^2 / 2 (+ the row maximum of dd for queries)
+    int32_t use_kmax;      // keys: the global maximum of dd (gmax) is subtracted as well
+    int32_t pad;
+};
+
+struct FusedArgs {
+    FeatSrc fa;            // feature map summed over positions j (the "a" operand of the scans)
+    FeatSrc fx;            // out A: the per-position ("c") feature map;  out B: the map whose input gradient is produced
+    const unsigned char* ptiles;        // [5 slabs][hi 8 KiB | lo 8 KiB]: projection rows as split-bf16 tiles (lroff layout), rows >= m zero
+    const float* ps;                    // projection matrix [m][64] (data normaliser folded in), fp32: stabiliser rows
+    const unsigned long long* gmax;     // packed (value, flat index) maximum of the keys' dd
+    const int32_t* amx;                 // out B, queries: argmax feature of every head row
+    const float* b;        // "value" operand rows [B * N][b_stride], head g at column g * 64
+    const float* b_scale;  // optional [B * N * G]
+    const float* c;        // out B: per-position operand rows [B * N][c_stride]
+    const float* c_scale;  // optional [B * N * G]
+    const float* ex_scale; // zmode 1 (out B): per-position i factor;  zmode 2: per-position j weights of the running sums
+    float* y;              // out A: rows [B * N][y_stride]
+    float* dx;             // out B: rows [B * N][stride]
+    float* state;          // [B, G, S][LDF * 64 + LDF]
+    float* inv_out;        // out A, zmode 1
+    float* tsum;           // out B, keys: sum of t over all rows
+    int32_t B, N, G, m, LDF, S, stride, b_stride, c_stride, y_stride, reverse, zmode, is_query, accumulate;
+    float ratio, reps, c2, den_eps, ex_const;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t f_rsrc(const void* base, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float f_ld1(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); }
+__device__ __forceinline__ u32x4 f_ld4(__amdgpu_buffer_rsrc_t r, uint32_t off) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); }
+__device__ __forceinline__ int f_row(const FusedArgs& s, int p) { return s.reverse ? s.N - 1 - p : p; }   // may leave [0, N): buffer loads return zeros
+
+// the x row of one position as the B operand of tile_rows_gemm (natural order d = ks*32 + g4*8 + e) + its feature offset
+struct XOperand {
+    short8_t h[2], l[2];
+    float off;
+};
+__device__ __forceinline__ void load_x_operand(XOperand& xo, const FeatSrc& f, const FusedArgs& s, int b, int g, int ri, int g4, float kmax) {
+    const __amdgpu_buffer_rsrc_t rx = f_rsrc(f.x + (int64_t)b * s.N * s.stride, (int64_t)s.N * s.stride * 4);
+    const __amdgpu_buffer_rsrc_t ro = f_rsrc(f.rowoff + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G * 4);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const u32x4 v0 = f_ld4(rx, (uint32_t)(ri * s.stride + g * 64 + ks * 32 + g4 * 8) * 4u), v1 = f_ld4(rx, (uint32_t)(ri * s.stride + g * 64 + ks * 32 + g4 * 8 + 4) * 4u);
+        const float xs[8] = {__uint_as_float(v0[0]), __uint_as_float(v0[1]), __uint_as_float(v0[2]), __uint_as_float(v0[3]),
+                             __uint_as_float(v1[0]), __uint_as_float(v1[1]), __uint_as_float(v1[2]), __uint_as_float(v1[3])};
+        split8(xs, xo.h[ks], xo.l[ks]);
+    }
+    xo.off = f_ld1(ro, (uint32_t)(ri * s.G + g) * 4u) + (f.use_kmax ? kmax : 0.f);
+}
+
+// features [slab0, slab0 + 64) of this lane's position (column lane & 15 of the wave): F[f][r] = feature slab0 + f*16 + g4*4 + r
+__device__ __forceinline__ void feat_slab(float4_t (&F)[4], const unsigned char* sPh, const unsigned char* sPl, const XOperand& xo, bool valid, int slab0,
+                                          const FusedArgs& s, int fr, int g4) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) F[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    tile_rows_gemm(F, sPh, sPl, xo.h, xo.l, fr, g4);
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mi = slab0 + f * 16 + g4 * 4 + r;
+            const float e = fmaf(s.ratio, __expf(F[f][r] - xo.off), s.reps);
+            F[f][r] = (valid && mi < s.m) ? e : 0.f;
+        }
+}
+
+// this wave's 16 positions x 64 features -> rows w*16 + fr of a [64 positions][64 features] hi / lo tile
+__device__ __forceinline__ void feat_to_tile(unsigned char* hi, unsigned char* lo, const float4_t (&F)[4], int w, int fr, int g4) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const uint32_t o = lroff(w * 16 + fr, f * 16 + g4 * 4);
+        uint2 h, l;
+        split_pair(F[f][0], F[f][1], h.x, l.x);
+        split_pair(F[f][2], F[f][3], h.y, l.y);
+        *(uint2*)(hi + o) = h;
+        *(uint2*)(lo + o) = l;
+    }
+}
+
+// one projection slab (hi + lo tiles = 16 KiB, already split and swizzled in global memory) a slab ahead in registers
+struct PSlabRegs {
+    u32x4 v[4];
+};
+__device__ __forceinline__ void pslab_load(PSlabRegs& r, const unsigned char* ptiles, int slab, int tid) {
+    const u32x4* src = (const u32x4*)(ptiles + (size_t)slab * (2 * FT_BYTES));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) r.v[t] = src[tid + 256 * t];
+}
+__device__ __forceinline__ void pslab_store(unsigned char* sP, const PSlabRegs& r, int tid) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ((u32x4*)sP)[tid + 256 * t] = r.v[t];
+}
+
+// rows [slab0, slab0 + 64) of the chunk's exclusive-prefix state (64 value columns); zeros outside the matrix
+__device__ __forceinline__ void tslab_load(u32x4 (&t)[4], __amdgpu_buffer_rsrc_t rt, int slab0, int tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) t[it] = f_ld4(rt, (uint32_t)((slab0 + (tid >> 4) + 16 * it) * 64 + (tid & 15) * 4) * 4u);
+}
+
+// value rows (head block g) of the 64 positions of a chunk, times an optional per-position scale -> swizzled hi / lo tiles
+__device__ __forceinline__ void f_stage_values(unsigned char* hi, unsigned char* lo, const float* base, int stride, const float* scale, const FusedArgs& s, int b,
+                                               int g, int chunk, int tid) {
+    const __amdgpu_buffer_rsrc_t rv = f_rsrc(base + (int64_t)b * s.N * stride, (int64_t)s.N * stride * 4);
+    const __amdgpu_buffer_rsrc_t rsc = f_rsrc((scale ? scale : base) + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G * 4);
+    u32x4 v[4];
+    float sc[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int j = (tid >> 4) + 16 * it;
+        const int i = f_row(s, chunk * 64 + j);
+        v[it] = f_ld4(rv, (uint32_t)(i * stride + g * 64 + (tid & 15) * 4) * 4u);
+        sc[it] = scale ? f_ld1(rsc, (uint32_t)(i * s.G + g) * 4u) : 1.f;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const uint32_t o = lroff((tid >> 4) + 16 * it, (tid & 15) * 4);
+        uint2 h, l;
+        split_pair(__uint_as_float(v[it][0]) * sc[it], __uint_as_float(v[it][1]) * sc[it], h.x, l.x);
+        split_pair(__uint_as_float(v[it][2]) * sc[it], __uint_as_float(v[it][3]) * sc[it], h.y, l.y);
+        *(uint2*)(hi + o) = h;
+        *(uint2*)(lo + o) = l;
+    }
+}
+
+__device__ __forceinline__ short8_t f_tr_operand(const unsigned char* t, uint32_t o0, uint32_t o1) {
+    return __builtin_shufflevector(lds_tr16_b64(t + o0), lds_tr16_b64(t + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// ------------------------------------------------------------------------------------------------ projection tiles
+// ps [m][64] fp32 -> 5 slabs of (hi tile | lo tile), tile row rho of slab sl = projection row sl*64 + rho (zero beyond m)
+__global__ __launch_bounds__(256) void favor_proj_tiles_kernel(const float* __restrict__ ps, int m, unsigned char* __restrict__ tiles) {
+    const int sl = blockIdx.x, tid = threadIdx.x;
+    unsigned char* hi = tiles + (size_t)sl * (2 * FT_BYTES);
+    unsigned char* lo = hi + FT_BYTES;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int rho = (tid >> 4) + 16 * it, c4 = tid & 15, f = sl * 64 + rho;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < m) v = *(const float4*)(ps + (int64_t)f * 64 + c4 * 4);
+        uint2 h, l;
+        split_pair(v.x, v.y, h.x, l.x);
+        split_pair(v.z, v.w, h.y, l.y);
+        const uint32_t o = lroff(rho, c4 * 4);
+        *(uint2*)(hi + o) = h;
+        *(uint2*)(lo + o) = l;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pre-pass
+// Head rows of q (blocks [0, nbq)) and k (blocks [nbq, 2 nbq)): dd = x P^T in accumulators only.
+//   queries: rowoff = |x|^2 c^2/2 + max_f dd, amx = argmax_f dd (lowest index on ties);   keys: rowoff = |x|^2 c^2/2, gmax = packed global maximum
+struct PrepassArgs {
+    const float *q, *k, *ps;
+    float *offq, *offk;
+    int32_t* amq;
+    unsigned long long* gmax;
+    int64_t rows;           // B * N * G head rows
+    int32_t m, LDF, stride, heads, nbq;
+    float c2half;
+};
+__device__ __forceinline__ int64_t head_row_off(int64_t r, int heads, int stride) { return (r / heads) * stride + (r % heads) * 64; }
+
+__global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nfr = a.LDF >> 4;
+    unsigned char* const sPh = smem;
+    unsigned char* const sPl = smem + nfr * 16 * 128;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), qi = lane & 15, g = lane >> 4;
+    const bool isq = (int)blockIdx.x < a.nbq;
+    const float* X = isq ? a.q : a.k;
+    const int64_t r0 = (int64_t)(isq ? blockIdx.x : blockIdx.x - a.nbq) * 128 + w * 32;
+    short8_t xh[2][2], xl[2][2];
+    float ss[2] = {0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const int64_t r = r0 + st * 16 + qi;
+        const bool ok = r < a.rows;
+        const float* xr = X + head_row_off(ok ? r : a.rows - 1, a.heads, a.stride);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float4 v0 = *(const float4*)(xr + ks * 32 + g * 8), v1 = *(const float4*)(xr + ks * 32 + g * 8 + 4);
+            if (!ok) v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss[st] = fmaf(xs[e], xs[e], ss[st]);
+            split8(xs, xh[st][ks], xl[st][ks]);
+        }
+    }
+    // the whole projection matrix as split tiles (rows >= m zero): 17 x 16 rows
+    for (int idx = tid; idx < nfr * 16 * 16; idx += 256) {
+        const int rho = idx >> 4, c4 = idx & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rho < a.m) v = *(const float4*)(a.ps + (int64_t)rho * 64 + c4 * 4);
+        uint2 h, l;
+        split_pair(v.x, v.y, h.x, l.x);
+        split_pair(v.z, v.w, h.y, l.y);
+        const uint32_t o = lroff(rho, c4 * 4);
+        *(uint2*)(sPh + o) = h;
+        *(uint2*)(sPl + o) = l;
+    }
+    __syncthreads();
+    const bool ok0 = r0 + qi < a.rows, ok1 = r0 + 16 + qi < a.rows;
+    float mx0 = -INFINITY, mx1 = -INFINITY;
+    int am0 = 0x7fffffff, am1 = 0x7fffffff;
+    for (int f = 0; f < nfr; ++f) {
+        short8_t ah[2], al[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint32_t o = lroff(f * 16 + qi, ks * 32 + g * 8);
+            ah[ks] = *(const short8_t*)(sPh + o);
+            al[ks] = *(const short8_t*)(sPl + o);
+        }
+        float4_t c0 = (float4_t){0.f, 0.f, 0.f, 0.f}, c1 = c0;
+        // same product order as tile_rows_gemm, so the fused kernels rebuild bit-identical dd values (the stabilised exponent never exceeds 0)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], xl[0][ks], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], xl[1][ks], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], xh[0][ks], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], xh[1][ks], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], xh[0][ks], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], xh[1][ks], c1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = f * 16 + g * 4 + r;
+            const bool in = col < a.m;
+            const bool t0 = in & ((c0[r] > mx0) | ((c0[r] == mx0) & (col < am0)));
+            mx0 = t0 ? c0[r] : mx0;
+            am0 = t0 ? col : am0;
+            const bool t1 = in & ((c1[r] > mx1) | ((c1[r] == mx1) & (col < am1)));
+            mx1 = t1 ? c1[r] : mx1;
+            am1 = t1 ? col : am1;
+        }
+    }
+    // a row lives in the four lanes qi, qi + 16, qi + 32, qi + 48
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const float om0 = __shfl_xor(mx0, o, 64), om1 = __shfl_xor(mx1, o, 64);
+        const int oa0 = __shfl_xor(am0, o, 64), oa1 = __shfl_xor(am1, o, 64);
+        const bool t0 = (om0 > mx0) | ((om0 == mx0) & (oa0 < am0)), t1 = (om1 > mx1) | ((om1 == mx1) & (oa1 < am1));
+        mx0 = t0 ? om0 : mx0; am0 = t0 ? oa0 : am0;
+        mx1 = t1 ? om1 : mx1; am1 = t1 ? oa1 : am1;
+        ss[0] += __shfl_xor(ss[0], o, 64);
+        ss[1] += __shfl_xor(ss[1], o, 64);
+    }
+    if (isq) {
+        if (g == 0) {
+            if (ok0) { a.offq[r0 + qi] = ss[0] * a.c2half + mx0; a.amq[r0 + qi] = am0; }
+            if (ok1) { a.offq[r0 + 16 + qi] = ss[1] * a.c2half + mx1; a.amq[r0 + 16 + qi] = am1; }
+        }
+    } else {
+        if (g == 0) {
+            if (ok0) a.offk[r0 + qi] = ss[0] * a.c2half;
+            if (ok1) a.offk[r0 + 16 + qi] = ss[1] * a.c2half;
+        }
+        __shared__ unsigned long long sbest[4];
+        unsigned long long best = 0ull;
+        if (ok0) best = pack_max(mx0, (uint32_t)((r0 + qi) * a.LDF) + (uint32_t)am0);
+        if (ok1) {
+            const unsigned long long b1 = pack_max(mx1, (uint32_t)((r0 + 16 + qi) * a.LDF) + (uint32_t)am1);
+            best = b1 > best ? b1 : best;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long ot = __shfl_xor(best, o, 64);
+            best = ot > best ? ot : best;
+        }
+        if (lane == 0) sbest[w] = best;
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int q = 1; q < 4; ++q) best = sbest[q] > best ? sbest[q] : best;
+            atomicMax(a.gmax, best);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ chunk state sums
+// U_c[m][d] = sum_{j in chunk} phi_a(j)[m] (b_j[d] bs_j),   z[m] = sum_j phi_a(j)[m] w_j     (zmode 1: w = 1, zmode 2: w = ex_scale_j)
+__global__ __launch_bounds__(256, 2) void favor_fstate_kernel(const FusedArgs s) {
+    __shared__ __attribute__((aligned(16))) unsigned char sBh[FT_BYTES], sBl[FT_BYTES], sAh[FT_BYTES], sAl[FT_BYTES], sP[2 * FT_BYTES];
+    __shared__ float sW[64];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
+    const int chunk = blockIdx.x % s.S, g = (blockIdx.x / s.S) % s.G, b = blockIdx.x / (s.S * s.G);
+    const float kmax = unpack_max(*s.gmax);
+    const int p = chunk * 64 + w * 16 + fr;
+    const bool valid = p < s.N;
+    const int ri = f_row(s, p);
+    XOperand xa;
+    load_x_operand(xa, s.fa, s, b, g, ri, g4, kmax);
+    PSlabRegs pre;
+    pslab_load(pre, s.ptiles, 0, tid);
+    f_stage_values(sBh, sBl, s.b, s.b_stride, s.b_scale, s, b, g, chunk, tid);
+    if (tid < 64) {
+        const int pj = chunk * 64 + tid;
+        float wv = pj < s.N ? 1.f : 0.f;
+        if (s.zmode == 2) {
+            const __amdgpu_buffer_rsrc_t rex = f_rsrc(s.ex_scale + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G * 4);
+            wv = f_ld1(rex, (uint32_t)(f_row(s, pj) * s.G + g) * 4u);
+        }
+        sW[tid] = wv;
+    }
+    __syncthreads();
+    const uint32_t trow = (uint32_t)g4 * 4u + ((uint32_t)fr >> 2), tcol = (uint32_t)(fr & 3) * 4u;
+    short8_t bh[2], bl[2], wh[2], wl[2];   // this wave's 16 value columns d = w*16 + (lane & 15); the weights of the running sums in column 0
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const uint32_t o0 = lroff(ks * 32 + trow, w * 16 + tcol), o1 = lroff(ks * 32 + 16 + trow, w * 16 + tcol);
+        bh[ks] = f_tr_operand(sBh, o0, o1);
+        bl[ks] = f_tr_operand(sBl, o0, o1);
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = fr == 0 ? sW[ks * 32 + (e >> 2) * 16 + g4 * 4 + (e & 3)] : 0.f;
+        split8(x, wh[ks], wl[ks]);
+    }
+    const int64_t zs = (int64_t)s.LDF * 64 + s.LDF;
+    float* st = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * zs;
+    float* zp = st + (int64_t)s.LDF * 64;
+    const int nslab = (s.LDF + FSLAB - 1) / FSLAB;
+    for (int sl = 0; sl < nslab; ++sl) {
+        const int slab0 = sl * FSLAB;
+        if (sl) __syncthreads();            // the previous slab's feature tile and projection slab have been consumed
+        pslab_store(sP, pre, tid);
+        __syncthreads();
+        if (sl + 1 < nslab) pslab_load(pre, s.ptiles, sl + 1, tid);
+        float4_t F[4];
+        feat_slab(F, sP, sP + FT_BYTES, xa, valid, slab0, s, fr, g4);
+        feat_to_tile(sAh, sAl, F, w, fr, g4);
+        __syncthreads();
+        float4_t acc[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        tile_cols_gemm(acc, sAh, sAl, bh, bl, lane);      // acc[f][r]: feature slab0 + f*16 + g4*4 + r, value column w*16 + fr
+        float4_t accz = (float4_t){0.f, 0.f, 0.f, 0.f};  // feature tile w of the slab
+        if (s.zmode) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint32_t o0 = lroff(ks * 32 + trow, w * 16 + tcol), o1 = lroff(ks * 32 + 16 + trow, w * 16 + tcol);
+                accz = mfma3(f_tr_operand(sAh, o0, o1), f_tr_operand(sAl, o0, o1), wh[ks], wl[ks], accz);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = slab0 + f * 16 + g4 * 4 + r;
+                if (m < s.LDF) st[m * 64 + w * 16 + fr] = acc[f][r];
+            }
+        if (s.zmode && fr == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = slab0 + w * 16 + g4 * 4 + r;
+                if (m < s.LDF) zp[m] = accz[r];
+            }
+        }
+    }
+}
+
+// state[b, g, chunk] <- sum of the states of the chunks before it (exclusive prefix), four elements per thread
+__global__ void favor_fprefix_kernel(float* __restrict__ state, int64_t BG, int S, int64_t elems4) {
+    const int64_t tix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tix >= BG * elems4) return;
+    const int64_t bg = tix / elems4, e = tix - bg * elems4;
+    float4* p = (float4*)state + bg * S * elems4 + e;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < S; ++k) {
+        const float4 v = p[k * elems4];
+        p[k * elems4] = acc;
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ chunk outputs, scan A
+// y_i[d] = sum_m T_prev[m][d] phi_x(i)[m] + sum_{j <= i} b_j[d] (phi_a(j) . phi_x(i))      (zmode 1: divided by phi_x(i) . (z_i + eps))
+__global__ __launch_bounds__(256, 2) void favor_fout_a_kernel(const FusedArgs s) {
+    __shared__ __attribute__((aligned(16))) unsigned char sBh[FT_BYTES], sBl[FT_BYTES], sAh[FT_BYTES], sAl[FT_BYTES], sTh[FT_BYTES], sTl[FT_BYTES], sP[2 * FT_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
+    const int chunk = blockIdx.x % s.S, g = (blockIdx.x / s.S) % s.G, b = blockIdx.x / (s.S * s.G);
+    const float kmax = unpack_max(*s.gmax);
+    const int64_t zs = (int64_t)s.LDF * 64 + s.LDF;
+    const float* st0 = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * zs;
+    const __amdgpu_buffer_rsrc_t rt = f_rsrc(st0, (int64_t)s.LDF * 64 * 4);
+    const __amdgpu_buffer_rsrc_t rz = f_rsrc(st0 + (int64_t)s.LDF * 64, s.zmode == 1 ? s.LDF * 4 : 0);
+    const int pi = chunk * 64 + w * 16 + fr;
+    const bool vi = pi < s.N;
+    const int ri = f_row(s, pi);
+    const int64_t rowi = ((int64_t)b * s.N + (vi ? ri : 0)) * s.G + g;
+    XOperand xa, xc;
+    load_x_operand(xa, s.fa, s, b, g, ri, g4, kmax);
+    load_x_operand(xc, s.fx, s, b, g, ri, g4, kmax);
+    PSlabRegs pre;
+    u32x4 pt[4], pz[4];
+    pslab_load(pre, s.ptiles, 0, tid);
+    tslab_load(pt, rt, 0, tid);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pz[q] = f_ld4(rz, (uint32_t)(q * 16 + g4 * 4) * 4u);
+    f_stage_values(sBh, sBl, s.b, s.b_stride, s.b_scale, s, b, g, chunk, tid);
+
+    float4_t P[4], acc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        P[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        acc[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    float den = 0.f;
+    const int nslab = (s.LDF + FSLAB - 1) / FSLAB;
+    for (int sl = 0; sl < nslab; ++sl) {
+        const int slab0 = sl * FSLAB;
+        if (sl) __syncthreads();
+        tile_stage(sTh, sTl, pt, tid);
+        pslab_store(sP, pre, tid);
+        u32x4 zc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zc[q] = pz[q];
+        __syncthreads();
+        if (sl + 1 < nslab) {
+            pslab_load(pre, s.ptiles, sl + 1, tid);
+            tslab_load(pt, rt, slab0 + FSLAB, tid);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pz[q] = f_ld4(rz, (uint32_t)(slab0 + FSLAB + q * 16 + g4 * 4) * 4u);
+        }
+        float4_t F[4];
+        feat_slab(F, sP, sP + FT_BYTES, xa, vi, slab0, s, fr, g4);
+        feat_to_tile(sAh, sAl, F, w, fr, g4);
+        feat_slab(F, sP, sP + FT_BYTES, xc, vi, slab0, s, fr, g4);
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) den = fmaf(F[f][r], __uint_as_float(zc[f][r]) + s.den_eps, den);
+        short8_t Ch[2], Cl[2];
+        acc_to_operand(Ch, Cl, F);
+        __syncthreads();
+        const int nks = (min(64, s.LDF - slab0) + 31) >> 5;
+        tile_rows_gemm_perm(P, sAh, sAl, Ch, Cl, fr, g4, nks);   // pair products phi_a(j) . phi_x(i)
+        tile_cols_gemm(acc, sTh, sTl, Ch, Cl, lane, nks);        // inter-chunk: T_prev^T phi_x(i)
+    }
+#pragma unroll
+    for (int jf = 0; jf < 4; ++jf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (jf * 16 + g4 * 4 + r > w * 16 + fr) P[jf][r] = 0.f;
+    float inv_n = 1.f;
+    if (s.zmode == 1) {
+        float part = den;
+#pragma unroll
+        for (int jf = 0; jf < 4; ++jf) part += (P[jf][0] + P[jf][1]) + (P[jf][2] + P[jf][3]);
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        inv_n = 1.f / part;
+        if (vi && g4 == 0 && s.inv_out) s.inv_out[rowi] = inv_n;
+    }
+    short8_t Ph[2], Pl[2];
+    acc_to_operand(Ph, Pl, P);
+    tile_cols_gemm(acc, sBh, sBl, Ph, Pl, lane);   // intra-chunk: sum_j b_j[d] P[j][i]
+    if (!vi) return;
+    float* yp = s.y + ((int64_t)b * s.N + ri) * s.y_stride + g * 64;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+        float4 o = make_float4(acc[df][0] * inv_n, acc[df][1] * inv_n, acc[df][2] * inv_n, acc[df][3] * inv_n);
+        float4* d4 = (float4*)(yp + df * 16 + g4 * 4);
+        if (s.accumulate) {
+            const float4 old = *d4;
+            o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *d4 = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ chunk outputs, scan B + feature-map backward + projection adjoint
+// dphi_i[m] = sum_d T_prev[m][d] c_i[d] + sum_{j <= i} phi_a(j)[m] (b_j . c_i + E[j][i]) + (running-sum terms)      (c_i times c_scale_i)
+//   zmode 1: E[j][i] = ex_scale_i,  + ex_scale_i (z_prev[m] + ex_const);     zmode 2: E[j][i] = ex_scale_j,  + z_prev[m]
+// v = (phi_x(i) - ratio eps) dphi_i,  t = sum_m v[m],  dx_i = sum_m v[m] P[m] - [query] t P[argmax_i] - t c^2 x_i
+__global__ __launch_bounds__(256, 2) void favor_fout_b_kernel(const FusedArgs s) {
+    __shared__ __attribute__((aligned(16))) unsigned char sBh[FT_BYTES], sBl[FT_BYTES], sAh[FT_BYTES], sAl[FT_BYTES], sP[2 * FT_BYTES];
+    __shared__ float sred[4];
+    unsigned char* const sTh = sBh;   // the value tile is dead once the pair products exist: the state slabs take its place
+    unsigned char* const sTl = sBl;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
+    const int chunk = blockIdx.x % s.S, g = (blockIdx.x / s.S) % s.G, b = blockIdx.x / (s.S * s.G);
+    const float kmax = unpack_max(*s.gmax);
+    const __amdgpu_buffer_rsrc_t rc = f_rsrc(s.c + (int64_t)b * s.N * s.c_stride, (int64_t)s.N * s.c_stride * 4);
+    const __amdgpu_buffer_rsrc_t rcs = f_rsrc((s.c_scale ? s.c_scale : s.c) + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G * 4);
+    const __amdgpu_buffer_rsrc_t rex = f_rsrc(s.ex_scale + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G * 4);
+    const int64_t zs = (int64_t)s.LDF * 64 + s.LDF;
+    const float* st0 = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * zs;
+    const __amdgpu_buffer_rsrc_t rt = f_rsrc(st0, (int64_t)s.LDF * 64 * 4);
+    const __amdgpu_buffer_rsrc_t rz = f_rsrc(st0 + (int64_t)s.LDF * 64, (int64_t)s.LDF * 4);
+    const int pi = chunk * 64 + w * 16 + fr;
+    const bool vi = pi < s.N;
+    const int ri = f_row(s, pi);
+    const int64_t rowi = ((int64_t)b * s.N + (vi ? ri : 0)) * s.G + g;
+    XOperand xa, xx;
+    load_x_operand(xa, s.fa, s, b, g, ri, g4, kmax);
+    load_x_operand(xx, s.fx, s, b, g, ri, g4, kmax);
+    PSlabRegs pre;
+    u32x4 pt[4];
+    pslab_load(pre, s.ptiles, 0, tid);
+    tslab_load(pt, rt, 0, tid);
+    f_stage_values(sBh, sBl, s.b, s.b_stride, s.b_scale, s, b, g, chunk, tid);
+    short8_t Ch[2], Cl[2];   // c_i (times c_scale) as B operand, natural order d = ks*32 + g4*8 + e
+    {
+        const float cs = s.c_scale ? f_ld1(rcs, (uint32_t)(ri * s.G + g) * 4u) : 1.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float x[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const u32x4 v = f_ld4(rc, (uint32_t)(ri * s.c_stride + g * 64 + ks * 32 + g4 * 8 + q * 4) * 4u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[q * 4 + e] = __uint_as_float(v[e]) * cs;
+            }
+            split8(x, Ch[ks], Cl[ks]);
+        }
+    }
+    const float exs = vi ? f_ld1(rex, (uint32_t)(ri * s.G + g) * 4u) : 0.f;   // ex_scale_i (zmode 1)
+    __syncthreads();
+    float4_t P[4];   // P[j][i] = b_j . c_i (+ E), masked to j <= i
+#pragma unroll
+    for (int jf = 0; jf < 4; ++jf) P[jf] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    tile_rows_gemm(P, sBh, sBl, Ch, Cl, fr, g4);
+#pragma unroll
+    for (int jf = 0; jf < 4; ++jf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jl = jf * 16 + g4 * 4 + r, pj = chunk * 64 + jl;
+            float e = exs;
+            if (s.zmode == 2) e = f_ld1(rex, (uint32_t)(f_row(s, pj) * s.G + g) * 4u);
+            P[jf][r] = (jl > w * 16 + fr || pj >= s.N) ? 0.f : P[jf][r] + e;
+        }
+    short8_t Ph[2], Pl[2];
+    acc_to_operand(Ph, Pl, P);
+
+    const float zf = s.zmode == 1 ? exs : 1.f;
+    const float cadd = s.zmode == 1 ? exs * s.ex_const : 0.f;
+    float4_t dxa[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) dxa[df] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    float tp = 0.f;
+    const int nslab = (s.LDF + FSLAB - 1) / FSLAB;
+    for (int sl = 0; sl < nslab; ++sl) {
+        const int slab0 = sl * FSLAB;
+        __syncthreads();   // previous slab consumed (first pass: the pair products have read the value tile)
+        tile_stage(sTh, sTl, pt, tid);
+        pslab_store(sP, pre, tid);
+        __syncthreads();
+        if (sl + 1 < nslab) {
+            pslab_load(pre, s.ptiles, sl + 1, tid);
+            tslab_load(pt, rt, slab0 + FSLAB, tid);
+        }
+        u32x4 zc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zc[q] = f_ld4(rz, (uint32_t)(slab0 + q * 16 + g4 * 4) * 4u);
+        float4_t F[4], Fx[4];
+        feat_slab(F, sP, sP + FT_BYTES, xa, vi, slab0, s, fr, g4);
+        feat_to_tile(sAh, sAl, F, w, fr, g4);
+        feat_slab(Fx, sP, sP + FT_BYTES, xx, vi, slab0, s, fr, g4);
+        __syncthreads();
+        float4_t acc[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        tile_rows_gemm(acc, sTh, sTl, Ch, Cl, fr, g4);   // inter-chunk: T_prev c_i
+        tile_cols_gemm(acc, sAh, sAl, Ph, Pl, lane);     // intra-chunk: sum_j phi_a(j)[m] P[j][i]
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mi = slab0 + f * 16 + g4 * 4 + r;
+                const float dphi = acc[f][r] + zf * __uint_as_float(zc[f][r]) + cadd;
+                const float v = (vi && mi < s.m) ? (Fx[f][r] - s.reps) * dphi : 0.f;
+                tp += v;
+                acc[f][r] = v;
+            }
+        short8_t Dh[2], Dl[2];
+        acc_to_operand(Dh, Dl, acc);
+        tile_cols_gemm(dxa, sP, sP + FT_BYTES, Dh, Dl, lane);   // dx^T[d][i] += sum_m P[m][d] v[m][i]
+    }
+    float t = tp;
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    if (vi) {
+        const int64_t xoff = ((int64_t)b * s.N + ri) * s.stride + g * 64;
+        const float* xr = s.fx.x + xoff;
+        float* dxr = s.dx + xoff;
+        const int am = s.is_query ? s.amx[rowi] : 0;
+        const float* pa = s.ps + (int64_t)min(am, s.m - 1) * 64;
+        const float ts = s.is_query ? t : 0.f, tc = t * s.c2;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+            const int d0 = df * 16 + g4 * 4;
+            const float4 xv = *(const float4*)(xr + d0), pv = *(const float4*)(pa + d0);
+            *(float4*)(dxr + d0) = make_float4(dxa[df][0] - ts * pv.x - tc * xv.x, dxa[df][1] - ts * pv.y - tc * xv.y, dxa[df][2] - ts * pv.z - tc * xv.z,
+                                               dxa[df][3] - ts * pv.w - tc * xv.w);
+        }
+    }
+    if (!s.is_query) {   // keys: the sum of t over all rows goes to the row that holds the global maximum (fix-up launch)
+        float tb = (vi && g4 == 0) ? t : 0.f;
+        tb = wave_sum(tb);
+        if (lane == 0) sred[w] = tb;
+        __syncthreads();
+        if (tid == 0) unsafeAtomicAdd(s.tsum, (sred[0] + sred[1]) + (sred[2] + sred[3]));
+    }
+}
+
+// keys: the global-max element (head row r*, feature f*) takes -(sum of all t): dk[r*] -= T P[f*]
+__global__ __launch_bounds__(64) void favor_fkey_fix_kernel(float* __restrict__ dx, int x_stride, int heads, const unsigned long long* __restrict__ gmax,
+                                                            const float* __restrict__ total, const float* __restrict__ ps, int LDF) {
+    const uint32_t idx = 0xffffffffu - (uint32_t)(*gmax & 0xffffffffull);
+    const int64_t r = idx / (uint32_t)LDF;
+    const int f = (int)(idx % (uint32_t)LDF);
+    dx[head_row_off(r, heads, x_stride) + threadIdx.x] -= total[0] * ps[(int64_t)f * 64 + threadIdx.x];
+}
+
+// dden[row] = -(dout . out) * inv over the head's 64 columns (one wave per head row)
+__global__ void favor_fdden_kernel(const float* __restrict__ dout, const float* __restrict__ out, int stride, int G, const float* __restrict__ inv,
+                                   float* __restrict__ dden, int64_t rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rp = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (rp >= rows) return;
+    const int64_t r = rp / G;
+    const int g = (int)(rp - r * G);
+    float sv = dout[r * stride + g * 64 + lane] * out[r * stride + g * 64 + lane];
+    sv = wave_sum(sv);
+    if (lane == 0) dden[rp] = -sv * inv[rp];
+}
+
+}  // namespace sa
+
+using namespace sa;
+
+static int fused_check(int B, int N, int G, int m, int dh, int stride) {
+    if (B <= 0 || N <= 0 || G <= 0 || m <= 0) return SA_EINVAL;
+    if (dh != 64 || m > 272 || (stride & 3) || stride < G * 64) return SA_EUNSUPPORTED;
+    if ((int64_t)N * stride * 4 >= ((int64_t)1 << 31) || (int64_t)B * N * G * 272 >= ((int64_t)1 << 32) - 1) return SA_EUNSUPPORTED;
+    return 0;
+}
+static inline int ldf_of(int m) { return (m + 15) / 16 * 16; }
+
+extern "C" int64_t sa_favor_fused_state_bytes(int B, int N, int G, int m) {
+    return (int64_t)B * G * ((N + 63) / 64) * ldf_of(m) * 65 * 4;
+}
+
+extern "C" int sa_favor_fused_proj_tiles(const float* ps, int m, void* tiles, void* stream) {
+    if (!ps || !tiles || m <= 0 || m > 272) return SA_EINVAL;
+    SA_LAUNCH(favor_proj_tiles_kernel, dim3(5), dim3(256), 0, (hipStream_t)stream, ps, m, (unsigned char*)tiles);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_favor_fused_prepass(const float* q, const float* k, int stride, int G, const float* ps, float* offq, int32_t* amq, float* offk, void* gmax_ws,
+                                      int64_t rows, int m, int dh, void* stream) {
+    if (!q || !k || !ps || !offq || !amq || !offk || !gmax_ws || rows <= 0 || G <= 0) return SA_EINVAL;
+    if (dh != 64 || m <= 0 || m > 272 || (stride & 3) || stride < G * 64 || rows * 272 >= ((int64_t)1 << 32) - 1) return SA_EUNSUPPORTED;
+    PrepassArgs a = {};
+    a.q = q; a.k = k; a.ps = ps; a.offq = offq; a.offk = offk; a.amq = amq; a.gmax = (unsigned long long*)gmax_ws; a.rows = rows; a.m = m; a.LDF = ldf_of(m);
+    a.stride = stride; a.heads = G; a.nbq = (int)((rows + 127) / 128);
+    const float c = powf((float)dh, -0.25f);
+    a.c2half = 0.5f * c * c;
+    const size_t lds = (size_t)2 * a.LDF * 128;
+    static std::atomic<uint64_t> attr_done{0};
+    configure_once_per_device(attr_done, [] { (void)hipFuncSetAttribute((const void*)favor_prepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 272 * 128); });
+    hipMemsetAsync(gmax_ws, 0, 8, (hipStream_t)stream);
+    SA_LAUNCH(favor_prepass_kernel, dim3((unsigned)(2 * a.nbq)), dim3(256), lds, (hipStream_t)stream, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+static void fused_common(FusedArgs& s, const void* tiles, const float* ps, const void* gmax, int B, int N, int G, int m, int stride) {
+    s.ptiles = (const unsigned char*)tiles; s.ps = ps; s.gmax = (const unsigned long long*)gmax;
+    s.B = B; s.N = N; s.G = G; s.m = m; s.LDF = ldf_of(m); s.S = (N + 63) / 64; s.stride = stride;
+    const float c = powf(64.f, -0.25f);
+    s.ratio = 1.f / sqrtf((float)m); s.reps = s.ratio * 1e-4f; s.c2 = c * c;
+}
+static int fused_prefix(float* state, int B, int G, int S, int LDF, hipStream_t st) {
+    const int64_t bg = (int64_t)B * G, e4 = ((int64_t)LDF * 65) / 4;   // LDF % 16 == 0
+    SA_LAUNCH(favor_fprefix_kernel, dim3((unsigned)((bg * e4 + 255) / 256)), dim3(256), 0, st, state, bg, S, e4);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+// forward of the global heads: attn_i = (phi_q(i) . sum_{j<=i} phi_k(j) (x) v_j) / (phi_q(i) . (sum_{j<=i} phi_k(j) + eps)); `state` keeps the chunk prefixes
+// (sum phi_k (x) v | sum phi_k) for the dq' scan of the backward pass
+extern "C" int sa_favor_fused_fwd(const float* q, const float* k, const float* v, int stride, const void* tiles, const float* ps, const float* offq,
+                                  const float* offk, const void* gmax_ws, float* attn, int attn_stride, float* inv_out, float den_eps, int B, int N, int G, int m,
+                                  float* state, void* stream) {
+    if (!q || !k || !v || !tiles || !ps || !offq || !offk || !gmax_ws || !attn || !inv_out || !state) return SA_EINVAL;
+    if (int rc = fused_check(B, N, G, m, 64, stride)) return rc;
+    if ((attn_stride & 3) || (int64_t)N * attn_stride * 4 >= ((int64_t)1 << 31)) return SA_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    FusedArgs s = {};
+    fused_common(s, tiles, ps, gmax_ws, B, N, G, m, stride);
+    s.fa = FeatSrc{k, offk, 1, 0};
+    s.fx = FeatSrc{q, offq, 0, 0};
+    s.b = v; s.b_stride = stride; s.state = state; s.zmode = 1; s.den_eps = den_eps; s.inv_out = inv_out; s.y = attn; s.y_stride = attn_stride;
+    const unsigned nblk = (unsigned)((int64_t)B * G * s.S);
+    SA_LAUNCH(favor_fstate_kernel, dim3(nblk), dim3(256), 0, st, s);
+    SA_CHECK_LAUNCH();
+    if (int rc = fused_prefix(state, B, G, s.S, s.LDF, st)) return rc;
+    SA_LAUNCH(favor_fout_a_kernel, dim3(nblk), dim3(256), 0, st, s);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+// backward of the global heads.  state_fwd: the prefixes sa_favor_fused_fwd left (or NULL: rebuilt into state_ws first); state_ws: scratch of
+// sa_favor_fused_state_bytes; dden_ws: B*N*G floats; tsum_ws: 1 float.  dq / dk / dv: head blocks (stride `stride`) like q / k / v.
+extern "C" int sa_favor_fused_bwd(const float* q, const float* k, const float* v, int stride, const void* tiles, const float* ps, const float* offq,
+                                  const int32_t* amq, const float* offk, const void* gmax_ws, const float* dattn, const float* attn, int attn_stride,
+                                  const float* inv, float* dq, float* dk, float* dv, int B, int N, int G, int m, const float* state_fwd, float* state_ws,
+                                  float* dden_ws, float* tsum_ws, void* stream) {
+    if (!q || !k || !v || !tiles || !ps || !offq || !amq || !offk || !gmax_ws || !dattn || !attn || !inv || !dq || !dk || !dv || !state_ws || !dden_ws || !tsum_ws)
+        return SA_EINVAL;
+    if (int rc = fused_check(B, N, G, m, 64, stride)) return rc;
+    if ((attn_stride & 3) || (int64_t)N * attn_stride * 4 >= ((int64_t)1 << 31)) return SA_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = (int64_t)B * N * G;
+    SA_LAUNCH(favor_fdden_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, dattn, attn, attn_stride, G, inv, dden_ws, rows);
+    SA_CHECK_LAUNCH();
+    FusedArgs s = {};
+    fused_common(s, tiles, ps, gmax_ws, B, N, G, m, stride);
+    const unsigned nblk = (unsigned)((int64_t)B * G * s.S);
+    // ---- d loss / d q: scan over j <= i of phi_k(j) (x) v_j  (the forward's states), c_i = dattn_i inv_i, running-sum term d den_i (sum_{j<=i} phi_k(j) + eps)
+    s.fa = FeatSrc{k, offk, 1, 0};
+    s.fx = FeatSrc{q, offq, 0, 0};
+    s.b = v; s.b_stride = stride; s.b_scale = nullptr;
+    s.c = dattn; s.c_stride = attn_stride; s.c_scale = inv;
+    s.ex_scale = dden_ws; s.zmode = 1; s.ex_const = 1e-6f; s.reverse = 0; s.is_query = 1; s.amx = amq; s.dx = dq; s.tsum = tsum_ws;
+    if (state_fwd) s.state = (float*)state_fwd;
+    else {
+        s.state = state_ws;
+        SA_LAUNCH(favor_fstate_kernel, dim3(nblk), dim3(256), 0, st, s);
+        SA_CHECK_LAUNCH();
+        if (int rc = fused_prefix(state_ws, B, G, s.S, s.LDF, st)) return rc;
+    }
+    SA_LAUNCH(favor_fout_b_kernel, dim3(nblk), dim3(256), 0, st, s);
+    SA_CHECK_LAUNCH();
+    // ---- d loss / d k and d loss / d v: reversed scans over i >= j of phi_q(i) (x) (dattn_i inv_i), running sums weighted by d den_i
+    s.fa = FeatSrc{q, offq, 0, 0};
+    s.fx = FeatSrc{k, offk, 1, 0};
+    s.b = dattn; s.b_stride = attn_stride; s.b_scale = inv;
+    s.c = v; s.c_stride = stride; s.c_scale = nullptr;
+    s.zmode = 2; s.ex_const = 0.f; s.reverse = 1; s.is_query = 0; s.amx = nullptr; s.dx = dk; s.state = state_ws;
+    hipMemsetAsync(tsum_ws, 0, 4, st);
+    SA_LAUNCH(favor_fstate_kernel, dim3(nblk), dim3(256), 0, st, s);
+    SA_CHECK_LAUNCH();
+    if (int rc = fused_prefix(state_ws, B, G, s.S, s.LDF, st)) return rc;
+    SA_LAUNCH(favor_fout_b_kernel, dim3(nblk), dim3(256), 0, st, s);
+    SA_CHECK_LAUNCH();
+    SA_LAUNCH(favor_fkey_fix_kernel, dim3(1), dim3(64), 0, st, dk, stride, G, (const unsigned long long*)gmax_ws, tsum_ws, ps, s.LDF);
+    SA_CHECK_LAUNCH();
+    // dv_j[d] = sum_m phi_k(j)[m] R_j[m][d]: scan A on the same states (a = phi_q, b = dattn inv, reversed), per-position map phi_k, no normaliser
+    s.zmode = 0; s.y = dv; s.y_stride = stride; s.inv_out = nullptr; s.accumulate = 0;
+    SA_LAUNCH(favor_fout_a_kernel, dim3(nblk), dim3(256), 0, st, s);
+    SA_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,116 @@
+"""GPU: FAVOR+ with the feature maps recomputed on chip (csrc/favor_fused.hip) against the fp64 statement of performer_pytorch's softmax_kernel +
+causal_linear_attention (oracle/performer_ref.py) and autograd through it, and against the unfused kernel chain it replaces."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import performer_ref as P  # noqa: E402
+
+
+def _rel(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def _fro(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).norm() / (ref.norm() + 1e-30))
+
+
+def _reference(q, k, v, proj, dattn):
+    """fp64: q, k, v [B, G, N, 64] -> attention output and the gradients of <out, dattn>."""
+    q, k, v = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    qp = P.softmax_kernel(q, proj.double(), True)
+    kp = P.softmax_kernel(k, proj.double(), False)
+    out = P.causal_linear_attention(qp, kp, v)
+    (out * dattn.double()).sum().backward()
+    return out.detach(), q.grad, k.grad, v.grad
+
+
+def _fused(q, k, v, proj, dattn, local_cols=64):
+    """The C ABI on head blocks of wider rows (as q | k | v sit in the fused qkv matrix): returns out, dq, dk, dv [B, G, N, 64]."""
+    from synthanatomy_amd import _ffi
+    lib, st = _ffi.lib(), _ffi.stream()
+    B, G, N, dh = q.shape
+    m = proj.shape[0]
+    inner = G * dh + local_cols                    # the local heads' columns follow the global ones
+    stride = 3 * inner
+    R = B * N
+    pack = lambda t: t.permute(0, 2, 1, 3).reshape(R, G * dh)
+    qkv = torch.randn(R, stride)
+    qkv[:, :G * dh], qkv[:, inner:inner + G * dh], qkv[:, 2 * inner:2 * inner + G * dh] = pack(q), pack(k), pack(v)
+    qkv = qkv.cuda()
+    qd, kd, vd = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
+    ps = (proj * dh ** -0.25).contiguous().cuda()
+    tiles = torch.empty(5 * 16384, dtype=torch.uint8, device="cuda")
+    _ffi.check(lib.sa_favor_fused_proj_tiles(_ffi.ptr(ps), m, _ffi.ptr(tiles), st))
+    offq = torch.empty(R * G, device="cuda")
+    offk = torch.empty(R * G, device="cuda")
+    amq = torch.empty(R * G, dtype=torch.int32, device="cuda")
+    gws = torch.zeros(1, dtype=torch.int64, device="cuda")
+    _ffi.check(lib.sa_favor_fused_prepass(_ffi.ptr(qd), _ffi.ptr(kd), stride, G, _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(amq), _ffi.ptr(offk), _ffi.ptr(gws), R * G, m, dh, st))
+    nst = lib.sa_favor_fused_state_bytes(B, N, G, m) // 4
+    state = torch.empty(nst, device="cuda")
+    state2 = torch.empty(nst, device="cuda")
+    attn = torch.full((R, inner), 7.0, device="cuda")
+    inv = torch.empty(R * G, device="cuda")
+    _ffi.check(lib.sa_favor_fused_fwd(_ffi.ptr(qd), _ffi.ptr(kd), _ffi.ptr(vd), stride, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(offk), _ffi.ptr(gws),
+                                      _ffi.ptr(attn), inner, _ffi.ptr(inv), 1e-6, B, N, G, m, _ffi.ptr(state), st))
+    da = torch.zeros(R, inner)
+    da[:, :G * dh] = pack(dattn)
+    da = da.cuda()
+    dqkv = torch.full((R, stride), 3.0, device="cuda")
+    dq, dk, dv = dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:]
+    dden = torch.empty(R * G, device="cuda")
+    tsum = torch.zeros(1, device="cuda")
+    _ffi.check(lib.sa_favor_fused_bwd(_ffi.ptr(qd), _ffi.ptr(kd), _ffi.ptr(vd), stride, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(amq), _ffi.ptr(offk),
+                                      _ffi.ptr(gws), _ffi.ptr(da), _ffi.ptr(attn), inner, _ffi.ptr(inv), _ffi.ptr(dq), _ffi.ptr(dk), _ffi.ptr(dv), B, N, G, m,
+                                      _ffi.ptr(state), _ffi.ptr(state2), _ffi.ptr(dden), _ffi.ptr(tsum), st))
+    torch.cuda.synchronize()
+    assert float((attn[:, G * dh:] - 7.0).abs().max()) == 0.0 and float((dqkv[:, G * dh:inner] - 3.0).abs().max()) == 0.0   # only the global-head columns are written
+    un = lambda t: t[:, :G * dh].reshape(B, N, G, dh).permute(0, 2, 1, 3).cpu()
+    return un(attn), un(dq), un(dk), un(dv), dict(offq=offq, offk=offk, amq=amq, gws=gws, ps=ps)
+
+
+@pytest.mark.parametrize("B,G,N,m", [(2, 2, 150, 266), (1, 3, 64, 266), (2, 1, 333, 266), (1, 2, 77, 120), (1, 8, 1400, 266)])
+def test_fused_favor_matches_fp64_reference(B, G, N, m):
+    g = torch.Generator().manual_seed(N + m)
+    q, k, v = (torch.randn(B, G, N, 64, generator=g) for _ in range(3))
+    dattn = torch.randn(B, G, N, 64, generator=g)
+    proj = P.gaussian_orthogonal_random_matrix(m, 64, g)
+    ref = _reference(q, k, v, proj, dattn)
+    out, dq, dk, dv, aux = _fused(q, k, v, proj, dattn)
+    # pre-pass: row offsets, argmax and the global key maximum
+    c = 64 ** -0.25
+    ddq = torch.einsum("bgnd,md->bgnm", q.double() * c, proj.double())
+    ddk = torch.einsum("bgnd,md->bgnm", k.double() * c, proj.double())
+    offq_ref = (q.double() ** 2).sum(-1) * c * c / 2 + ddq.max(-1).values
+    got_offq = aux["offq"].view(B, N, G).permute(0, 2, 1).cpu().double()
+    assert float((got_offq - offq_ref).abs().max()) < 2e-3
+    got_am = aux["amq"].view(B, N, G).permute(0, 2, 1).cpu().long()
+    picked = ddq.gather(-1, got_am[..., None]).squeeze(-1)
+    assert float((picked - ddq.max(-1).values).abs().max()) < 2e-3          # the argmax (ties / near-ties may pick a neighbour of equal value)
+    from synthanatomy_amd import _ffi  # noqa: F401
+    errs = dict(out=_rel(out, ref[0]), dq=_rel(dq, ref[1]), dk=_rel(dk, ref[2]), dv=_rel(dv, ref[3]))
+    fro = dict(out=_fro(out, ref[0]), dq=_fro(dq, ref[1]), dk=_fro(dk, ref[2]), dv=_fro(dv, ref[3]))
+    print(f"[fused favor B{B} G{G} N{N} m{m}] max-rel {errs}  fro {fro}")
+    assert errs["out"] < 1e-4 and errs["dv"] < 2e-4, errs
+    assert fro["dq"] < 2e-3 and fro["dk"] < 2e-3 and errs["dq"] < 1e-2 and errs["dk"] < 1e-2, (errs, fro)
+
+
+def test_fused_favor_is_deterministic_and_ignores_the_future():
+    g = torch.Generator().manual_seed(3)
+    B, G, N, m = 1, 2, 200, 266
+    q, k, v = (torch.randn(B, G, N, 64, generator=g) for _ in range(3))
+    dattn = torch.randn(B, G, N, 64, generator=g)
+    proj = P.gaussian_orthogonal_random_matrix(m, 64, g)
+    a = _fused(q, k, v, proj, dattn)
+    b = _fused(q, k, v, proj, dattn)
+    for x, y in zip(a[:4], b[:4]):
+        assert torch.equal(x, y)
+    v2 = v.clone()
+    v2[:, :, 130:] += 5.0
+    c = _fused(q, k, v2, proj, dattn)
+    assert torch.equal(c[0][:, :, :130], a[0][:, :, :130])      # values of later positions never reach earlier outputs (keys would, through the global maximum)
