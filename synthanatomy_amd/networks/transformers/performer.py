@@ -297,6 +297,7 @@ class _LayerEngine:
         # split-bf16 kernels (~1e-5 relative, far below the rounding of its dense layers)
         self._xf = 4 if dtype == torch.float32 else 0
         self._pop = None
+        self._ptiles = None
         self._rot = None
         self._one = None
         self._ws = None
@@ -346,6 +347,20 @@ class _LayerEngine:
             op = ConvOp("conv", self.dh, self.m, 1, 1, 0, ps, None, torch.float32)
             self._pop = (ver, op, ps)
         return self._pop[1]
+
+    def _proj_tiles(self):
+        """the projection matrix as split-bf16 slab tiles for the fused FAVOR+ kernels (rebuilt when the matrix is redrawn)"""
+        self._proj_op()
+        ver, ps = self._pop[0], self._pop[2]
+        if self._ptiles is None or self._ptiles[0] != ver:
+            tiles = torch.empty(5 * 16384, dtype=torch.uint8, device=ps.device)
+            _ck(_ffi.lib().sa_favor_fused_proj_tiles(_ffi.ptr(ps), self.m, _ffi.ptr(tiles), _ffi.stream()), "sa_favor_fused_proj_tiles")
+            self._ptiles = (ver, tiles)
+        return self._ptiles[1], ps
+
+    def _fused_favor(self):
+        """throughput mode: FAVOR+ with the feature maps recomputed on chip (csrc/favor_fused.hip) -- no [B N G, 272] tensor in HBM"""
+        return not self._xf and self.G > 0 and self.dh == 64 and self.m <= 272 and not debug.host("no_fused_favor")
 
     def _rot_tables(self, N, dev):
         if self._rot is None or self._rot[0] != (N, dev):
@@ -402,7 +417,27 @@ class _LayerEngine:
         qs = q.stride(0)   # row stride of q / k / v (3 * inner when they are column blocks of one matrix)
         attn = torch.empty(R, inner, dtype=f32, device=dev)
         sv = dict(x=x, xa=xa, xaT=xaT, st_a=st_a, q=q, k=k, v=v, attn=attn)
-        if G > 0:
+        if G > 0 and self._fused_favor():
+            tiles, ps = self._proj_tiles()
+            offq = torch.empty(R * G, dtype=f32, device=dev)
+            offk = torch.empty(R * G, dtype=f32, device=dev)
+            amq = torch.empty(R * G, dtype=torch.int32, device=dev)
+            gws = torch.empty(1, dtype=torch.int64, device=dev)
+            inv = torch.empty(R * G, dtype=f32, device=dev)
+            nst = lib.sa_favor_fused_state_bytes(B, N, G, m) // 4
+            if tape is not None:     # training: the chunk prefixes (sum k' (x) v | sum k') are kept for the dq' scan of the backward pass
+                state = torch.empty(nst, dtype=f32, device=dev)
+            else:
+                if self._ws is None or self._ws.numel() < nst or self._ws.device != dev:
+                    self._ws = torch.empty(nst, dtype=f32, device=dev)
+                state = self._ws
+            _ck(lib.sa_favor_fused_prepass(_ffi.ptr(q), _ffi.ptr(k), qs, G, _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(amq), _ffi.ptr(offk), _ffi.ptr(gws), R * G, m, dh, st),
+                "sa_favor_fused_prepass")
+            rc = lib.sa_favor_fused_fwd(_ffi.ptr(q), _ffi.ptr(k), _ffi.ptr(v), qs, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(offk), _ffi.ptr(gws),
+                                        _ffi.ptr(attn), inner, _ffi.ptr(inv), 1e-6, B, N, G, m, _ffi.ptr(state), st)
+            _ck(rc, "sa_favor_fused_fwd")
+            sv.update(fused=True, offq=offq, offk=offk, amq=amq, gws=gws, inv=inv, scan_state=state if tape is not None else None)
+        elif G > 0:
             pop = self._proj_op()
             if self._xf:   # fp32 parity mode: exact-fp32 GEMM on contiguous copies of the global-head columns
                 qg = q[:, : G * dh].contiguous()
@@ -607,7 +642,19 @@ class _LayerEngine:
             dv = torch.empty(R, inner, dtype=f32, device=dev)
         qs = dq.stride(0)   # == q.stride(0): the kernels below address v / dv (and dq / dk) with one row stride
         assert qs == q.stride(0) == v.stride(0)
-        if G > 0:
+        if G > 0 and sv.get("fused"):
+            tiles, ps = self._proj_tiles()
+            nst = lib.sa_favor_fused_state_bytes(B, N, G, m) // 4
+            if self._ws is None or self._ws.numel() < nst or self._ws.device != dev:
+                self._ws = torch.empty(nst, dtype=f32, device=dev)
+            dden = torch.empty(R * G, dtype=f32, device=dev)
+            tsum = torch.empty(1, dtype=f32, device=dev)
+            _ck(lib.sa_favor_fused_bwd(_ffi.ptr(q), _ffi.ptr(k), _ffi.ptr(v), qs, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(sv["offq"]), _ffi.ptr(sv["amq"]),
+                                       _ffi.ptr(sv["offk"]), _ffi.ptr(sv["gws"]), _ffi.ptr(dattn), _ffi.ptr(attn), inner, _ffi.ptr(sv["inv"]), _ffi.ptr(dq),
+                                       _ffi.ptr(dk), _ffi.ptr(dv), B, N, G, m, _ffi.ptr(sv.get("scan_state")), _ffi.ptr(self._ws), _ffi.ptr(dden), _ffi.ptr(tsum), st),
+                "sa_favor_fused_bwd")
+            sv["scan_state"] = None
+        elif G > 0:
             qf, kf, Z, inv = sv["qf"], sv["kf"], sv["Z"], sv["inv"]
             dden = torch.empty(R * G, dtype=f32, device=dev)
             _ck(lib.sa_favor_dden(_ffi.ptr(dattn), _ffi.ptr(attn), inner, 0, G, dh, _ffi.ptr(inv), _ffi.ptr(dden), R * G, st), "sa_favor_dden")

@@ -158,7 +158,27 @@ def test_bf16_engine_follows_oracle_at_production_width(case):
     assert agg < 2e-2 and worst[1] < 5e-2, (agg, worst)
     assert all(fused)
     joined = "\n".join(names)
-    for need in ("favor_chunk_state_split_kernel", "favor_chunk_out_a_split_kernel", "favor_chunk_out_b_split_kernel", "local_attn_q_split_kernel",
+    # FAVOR+ with the feature maps recomputed on chip (csrc/favor_fused.hip), flash-style local attention, bf16 dense layers
+    for need in ("favor_prepass_kernel", "favor_fstate_kernel", "favor_fout_a_kernel", "favor_fout_b_kernel", "local_attn_q_split_kernel",
                  "local_attn_kv_split_kernel", "conv_fprop_dma_kernel<unsigned short"):
         assert need in joined, (need, names)
-    assert ("favor_feat_proj_bwd_kernel" in joined) or ("favor_fused" in joined), names     # feature-map backward fused with the projection adjoint
+    for gone in ("favor_project_fwd_kernel", "favor_feat_fwd_kernel", "favor_feat_proj_bwd_kernel", "favor_chunk_out_b_split_kernel"):
+        assert gone not in joined, (gone, names)     # nothing writes dd / phi / d phi to HBM any more
+
+
+def test_fused_and_unfused_favor_agree_at_production_width(case):
+    """The same bf16 network through the unfused chain (projection -> feature map -> chunked split-bf16 scans -> fused feature / projection backward,
+    SA_NO_FUSED_FAVOR) and through the on-chip feature maps: logits and every gradient agree to the split-bf16 error, amplified by the bf16 dense layers."""
+    from synthanatomy_amd import debug
+    out_f, loss_f, grads_f, names_f, _ = _run(case, torch.bfloat16)
+    with debug.override(no_fused_favor=True):
+        out_u, loss_u, grads_u, names_u, _ = _run(case, torch.bfloat16)
+    ju = "\n".join(names_u)
+    for need in ("favor_chunk_state_split_kernel", "favor_chunk_out_a_split_kernel", "favor_chunk_out_b_split_kernel", "favor_feat_proj_bwd_kernel"):
+        assert need in ju, (need, names_u)
+    assert "favor_fout_b_kernel" not in ju
+    e = _rel_fro(out_f, out_u)
+    num = sum(float((grads_f[k].double() - grads_u[k].double()).pow(2).sum()) for k in grads_u)
+    den = sum(float(grads_u[k].double().pow(2).sum()) for k in grads_u)
+    print(f"[fused vs unfused N={case['n']}] logits fro {e:.2e}, gradients aggregate fro {(num / den) ** 0.5:.2e}")
+    assert e < 3e-3 and (num / den) ** 0.5 < 6e-3 and abs(loss_f - loss_u) < 1e-4 * abs(loss_u)
