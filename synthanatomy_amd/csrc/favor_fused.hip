@@ -19,6 +19,9 @@ namespace sa {
 
 constexpr int FT_BYTES = 64 * 128;   // one [64 rows][64 bf16] tile
 constexpr int FSLAB = 64;
+#ifndef FUSED_WPS
+#define FUSED_WPS 2   // waves per SIMD the chunk kernels are compiled for (measured: 3 forces ~100 spilled VGPRs and is 20 % slower end to end)
+#endif
 
 struct FeatSrc {
     const float* x;        // rows of `stride` floats, head g at column g * 64
@@ -86,6 +89,52 @@ __device__ __forceinline__ void feat_slab(float4_t (&F)[4], const unsigned char*
             const int mi = slab0 + f * 16 + g4 * 4 + r;
             const float e = fmaf(s.ratio, __expf(F[f][r] - xo.off), s.reps);
             F[f][r] = (valid && mi < s.m) ? e : 0.f;
+        }
+}
+
+// two feature maps of the same positions from ONE walk over the projection fragments (half the ds_read_b128 traffic of two feat_slab calls)
+__device__ __forceinline__ void feat_slab2(float4_t (&F0)[4], float4_t (&F1)[4], const unsigned char* sPh, const unsigned char* sPl, const XOperand& x0, const XOperand& x1,
+                                           bool valid, int slab0, const FusedArgs& s, int fr, int g4) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        F0[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        F1[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        short8_t ah[4], al[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const uint32_t o = lroff(f * 16 + fr, ks * 32 + g4 * 8);
+            ah[f] = *(const short8_t*)(sPh + o);
+            al[f] = *(const short8_t*)(sPl + o);
+        }
+        // per accumulator the product order of tile_rows_gemm (hi*lo, lo*hi, hi*hi): bit-identical dd to the pre-pass
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], x0.l[ks], F0[f], 0, 0, 0);
+            F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], x1.l[ks], F1[f], 0, 0, 0);
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], x0.h[ks], F0[f], 0, 0, 0);
+            F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], x1.h[ks], F1[f], 0, 0, 0);
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], x0.h[ks], F0[f], 0, 0, 0);
+            F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], x1.h[ks], F1[f], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mi = slab0 + f * 16 + g4 * 4 + r;
+            const bool in = valid && mi < s.m;
+            const float e0 = fmaf(s.ratio, __expf(F0[f][r] - x0.off), s.reps), e1 = fmaf(s.ratio, __expf(F1[f][r] - x1.off), s.reps);
+            F0[f][r] = in ? e0 : 0.f;
+            F1[f][r] = in ? e1 : 0.f;
         }
 }
 
@@ -303,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs
 
 // ------------------------------------------------------------------------------------------------ chunk state sums
 // U_c[m][d] = sum_{j in chunk} phi_a(j)[m] (b_j[d] bs_j),   z[m] = sum_j phi_a(j)[m] w_j     (zmode 1: w = 1, zmode 2: w = ex_scale_j)
-__global__ __launch_bounds__(256, 2) void favor_fstate_kernel(const FusedArgs s) {
+__global__ __launch_bounds__(256, FUSED_WPS) void favor_fstate_kernel(const FusedArgs s) {
     __shared__ __attribute__((aligned(16))) unsigned char sBh[FT_BYTES], sBl[FT_BYTES], sAh[FT_BYTES], sAl[FT_BYTES], sP[2 * FT_BYTES];
     __shared__ float sW[64];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
@@ -382,24 +431,32 @@ __global__ __launch_bounds__(256, 2) void favor_fstate_kernel(const FusedArgs s)
     }
 }
 
-// state[b, g, chunk] <- sum of the states of the chunks before it (exclusive prefix), four elements per thread
+// state[b, g, chunk] <- sum of the states of the chunks before it (exclusive prefix), four elements per thread.  Loads go out in batches of eight
+// before the dependent stores (the array aliases itself, so the compiler would otherwise keep every load behind the previous store: S round trips).
 __global__ void favor_fprefix_kernel(float* __restrict__ state, int64_t BG, int S, int64_t elems4) {
     const int64_t tix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tix >= BG * elems4) return;
     const int64_t bg = tix / elems4, e = tix - bg * elems4;
-    float4* p = (float4*)state + bg * S * elems4 + e;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < S; ++k) {
-        const float4 v = p[k * elems4];
-        p[k * elems4] = acc;
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    float4_t* p = (float4_t*)state + bg * S * elems4 + e;
+    float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < S; k0 += 8) {
+        float4_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = k0 + j < S ? __builtin_nontemporal_load(p + (k0 + j) * elems4) : (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (k0 + j < S) p[(k0 + j) * elems4] = acc;
+            acc += v[j];
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ chunk outputs, scan A
 // y_i[d] = sum_m T_prev[m][d] phi_x(i)[m] + sum_{j <= i} b_j[d] (phi_a(j) . phi_x(i))      (zmode 1: divided by phi_x(i) . (z_i + eps))
-__global__ __launch_bounds__(256, 2) void favor_fout_a_kernel(const FusedArgs s) {
-    __shared__ __attribute__((aligned(16))) unsigned char sBh[FT_BYTES], sBl[FT_BYTES], sAh[FT_BYTES], sAl[FT_BYTES], sTh[FT_BYTES], sTl[FT_BYTES], sP[2 * FT_BYTES];
+__global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_a_kernel(const FusedArgs s) {
+    __shared__ __attribute__((aligned(16))) unsigned char sAh[FT_BYTES], sAl[FT_BYTES], sTh[FT_BYTES], sTl[FT_BYTES], sP[2 * FT_BYTES];
+    unsigned char* const sBh = sAh;   // the value rows take the feature tile's place after the slab loop (48 KiB: three blocks per CU)
+    unsigned char* const sBl = sAl;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
     const int chunk = blockIdx.x % s.S, g = (blockIdx.x / s.S) % s.G, b = blockIdx.x / (s.S * s.G);
     const float kmax = unpack_max(*s.gmax);
@@ -420,7 +477,6 @@ __global__ __launch_bounds__(256, 2) void favor_fout_a_kernel(const FusedArgs s)
     tslab_load(pt, rt, 0, tid);
 #pragma unroll
     for (int q = 0; q < 4; ++q) pz[q] = f_ld4(rz, (uint32_t)(q * 16 + g4 * 4) * 4u);
-    f_stage_values(sBh, sBl, s.b, s.b_stride, s.b_scale, s, b, g, chunk, tid);
 
     float4_t P[4], acc[4];
 #pragma unroll
@@ -445,10 +501,9 @@ __global__ __launch_bounds__(256, 2) void favor_fout_a_kernel(const FusedArgs s)
 #pragma unroll
             for (int q = 0; q < 4; ++q) pz[q] = f_ld4(rz, (uint32_t)(slab0 + FSLAB + q * 16 + g4 * 4) * 4u);
         }
-        float4_t F[4];
-        feat_slab(F, sP, sP + FT_BYTES, xa, vi, slab0, s, fr, g4);
-        feat_to_tile(sAh, sAl, F, w, fr, g4);
-        feat_slab(F, sP, sP + FT_BYTES, xc, vi, slab0, s, fr, g4);
+        float4_t Fa[4], F[4];
+        feat_slab2(Fa, F, sP, sP + FT_BYTES, xa, xc, vi, slab0, s, fr, g4);
+        feat_to_tile(sAh, sAl, Fa, w, fr, g4);
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
@@ -477,6 +532,9 @@ __global__ __launch_bounds__(256, 2) void favor_fout_a_kernel(const FusedArgs s)
     }
     short8_t Ph[2], Pl[2];
     acc_to_operand(Ph, Pl, P);
+    __syncthreads();   // every wave is done with the last feature tile
+    f_stage_values(sBh, sBl, s.b, s.b_stride, s.b_scale, s, b, g, chunk, tid);
+    __syncthreads();
     tile_cols_gemm(acc, sBh, sBl, Ph, Pl, lane);   // intra-chunk: sum_j b_j[d] P[j][i]
     if (!vi) return;
     float* yp = s.y + ((int64_t)b * s.N + ri) * s.y_stride + g * 64;
@@ -496,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void favor_fout_a_kernel(const FusedArgs s)
 // dphi_i[m] = sum_d T_prev[m][d] c_i[d] + sum_{j <= i} phi_a(j)[m] (b_j . c_i + E[j][i]) + (running-sum terms)      (c_i times c_scale_i)
 //   zmode 1: E[j][i] = ex_scale_i,  + ex_scale_i (z_prev[m] + ex_const);     zmode 2: E[j][i] = ex_scale_j,  + z_prev[m]
 // v = (phi_x(i) - ratio eps) dphi_i,  t = sum_m v[m],  dx_i = sum_m v[m] P[m] - [query] t P[argmax_i] - t c^2 x_i
-__global__ __launch_bounds__(256, 2) void favor_fout_b_kernel(const FusedArgs s) {
+__global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_b_kernel(const FusedArgs s) {
     __shared__ __attribute__((aligned(16))) unsigned char sBh[FT_BYTES], sBl[FT_BYTES], sAh[FT_BYTES], sAl[FT_BYTES], sP[2 * FT_BYTES];
     __shared__ float sred[4];
     unsigned char* const sTh = sBh;   // the value tile is dead once the pair products exist: the state slabs take its place
@@ -577,9 +635,8 @@ __global__ __launch_bounds__(256, 2) void favor_fout_b_kernel(const FusedArgs s)
 #pragma unroll
         for (int q = 0; q < 4; ++q) zc[q] = f_ld4(rz, (uint32_t)(slab0 + q * 16 + g4 * 4) * 4u);
         float4_t F[4], Fx[4];
-        feat_slab(F, sP, sP + FT_BYTES, xa, vi, slab0, s, fr, g4);
+        feat_slab2(F, Fx, sP, sP + FT_BYTES, xa, xx, vi, slab0, s, fr, g4);
         feat_to_tile(sAh, sAl, F, w, fr, g4);
-        feat_slab(Fx, sP, sP + FT_BYTES, xx, vi, slab0, s, fr, g4);
         __syncthreads();
         float4_t acc[4];
 #pragma unroll

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summaries of rocprofv3 rocpd databases (the sqlite files `rocprofv3 -d DIR -o NAME` leaves as DIR/NAME_results.db), dev tool.
 
-    python tools/rocpd_tools.py stats   <trace.db>                         per-kernel launch count / total / avg / min / max / share
+    python tools/rocpd_tools.py stats   <trace.db> [--by-grid]             per-kernel launch count / total / avg / min / max / share
+                                                                           (--by-grid: one row per (kernel, launch size): per-level numbers)
     python tools/rocpd_tools.py pmc     <pmc.db>                           per-kernel mean of every collected counter
     python tools/rocpd_tools.py traffic <fetch.db> <write.db> [out.json]   HBM-side bytes per launch: (2 x FETCH_SIZE + WRITE_SIZE) KiB
                                                                            (gfx950: 128-B read requests are tallied at 64 B, MI355X_MICROARCH.md)
@@ -33,16 +34,26 @@ def _demangle(names):
     return res
 
 
-def _dispatches(db, T):
+def _dispatches(db, T, by_grid=False):
+    """event id -> (kernel name, duration ns).  by_grid: the name carries the launch size as ` [blocks x threads]`, so launches of one kernel instance on
+    different problem sizes (80x112x80 vs 40x56x40 levels, training vs eval) are separate rows."""
     names = {r[0]: r[1] for r in db.execute(f'select id, kernel_name from "{T("info_kernel_symbol")}"')}
     dm = _demangle(sorted(set(names.values())))
-    return {r[0]: (dm[names.get(r[1], "?")] if names.get(r[1]) in dm else "?", r[2]) for r in db.execute(f'select event_id, kernel_id, end - start from "{T("kernel_dispatch")}"')}
+    res = {}
+    for ev, kid, dur, gx, gy, gz, wx, wy, wz in db.execute(
+            f'select event_id, kernel_id, end - start, grid_size_x, grid_size_y, grid_size_z, workgroup_size_x, workgroup_size_y, workgroup_size_z from "{T("kernel_dispatch")}"'):
+        k = dm[names.get(kid, "?")] if names.get(kid) in dm else "?"
+        if by_grid:
+            blocks = (gx // max(wx, 1)) * (gy // max(wy, 1)) * (gz // max(wz, 1))
+            k = f"{k} [{blocks} x {wx * wy * wz}]"
+        res[ev] = (k, dur)
+    return res
 
 
-def stats(path):
+def stats(path, by_grid=False):
     db, T = _open(path)
     acc = defaultdict(list)
-    for k, d in _dispatches(db, T).values():
+    for k, d in _dispatches(db, T, by_grid).values():
         acc[k].append(d)
     tot = sum(sum(v) for v in acc.values())
     print(f"{'kernel':96s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
@@ -87,7 +98,7 @@ def traffic(fetch_db, write_db, out=None, provenance=""):
 if __name__ == "__main__":
     cmd = sys.argv[1]
     if cmd == "stats":
-        stats(sys.argv[2])
+        stats(sys.argv[2], by_grid="--by-grid" in sys.argv[3:])
     elif cmd == "pmc":
         pmc(sys.argv[2])
     elif cmd == "traffic":
