@@ -379,6 +379,114 @@ def bench_fp32_mode(dev, batch=2, steps=2):
             "ms_per_step": round(dt * 1e3, 2), "tflops_per_gpu": round(batch / dt * STEP_TFLOP_PER_VOLUME, 2), "peak_f32_tflops": PEAK_F32_TFLOPS}
 
 
+def bench_bf16_vs_fp32(dev, batch=2):
+    """The benchmarked mode against the fp32 product path (the mode pinned to the reference at 1e-3) on the real config: same weights, `batch`
+    160x224x160 volumes, eval.  Index agreement of the bf16 encoder + quantizer with the fp32 one, and the bf16 decoder against the fp32 decoder
+    on the SAME (fp32) indices."""
+    from synthanatomy_amd.networks.vqvae.baseline import BaselineVQVAE
+    torch.manual_seed(4)
+    ref = BaselineVQVAE(**NET, compute_dtype=torch.float32).to(dev).eval()
+    low = BaselineVQVAE(**NET, compute_dtype=torch.bfloat16)
+    low.load_state_dict(ref.state_dict())
+    low = low.to(dev).eval()
+    x = torch.rand(batch, 1, *VOL, generator=torch.Generator(device=dev).manual_seed(4), device=dev)
+    with torch.no_grad():
+        i32, i16 = ref.index_quantize(x)[0], low.index_quantize(x)[0]
+        z32, z16 = ref.encode(x)[0].double(), low.encode(x)[0].double()
+        r32, r16 = ref.decode_samples([i32]).double(), low.decode_samples([i32]).double()
+    res = {"index_agreement_vs_fp32": round(float((i32 == i16).float().mean()), 5), "positions": int(i32.numel()),
+           "z_max_rel": float(f"{float((z16 - z32).abs().max() / z32.abs().max()):.3e}"),
+           "recon_max_rel_same_indices": float(f"{float((r16 - r32).abs().max() / r32.abs().max()):.3e}"),
+           "what": f"bf16 product path vs fp32 product path, same random-init weights, {batch} volumes {VOL[0]}x{VOL[1]}x{VOL[2]}, eval"}
+    del ref, low, x
+    torch.cuda.empty_cache()
+    return res
+
+
+def bench_latency_b1(dev, dtype, steps=5):
+    """config 2 at B = 1 -- latency of one training step and of one extract + decode pass on ONE volume."""
+    from synthanatomy_amd.losses.vqvae import MSELoss
+    from synthanatomy_amd.networks.vqvae.baseline import BaselineVQVAE
+    from synthanatomy_amd.runtime.optim import FlatParams, FusedAdam
+    torch.manual_seed(4)
+    net = BaselineVQVAE(**NET, compute_dtype=dtype).to(dev).train()
+    flat = FlatParams(net.parameters())
+    opt = FusedAdam(flat, lr=1.65e-4)
+    opt.on_step.append(net.invalidate_packed_weights)
+    loss_fn = MSELoss()
+    x = torch.rand(1, 1, *VOL, generator=torch.Generator(device=dev).manual_seed(4), device=dev)
+
+    def step():
+        flat.zero_grad()
+        loss_fn(net(x), x).backward()
+        opt.step()
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    t_train = (time.perf_counter() - t0) / steps
+    net.eval()
+    with torch.no_grad():
+        for _ in range(2):
+            net.decode_samples(net.index_quantize(x))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net.decode_samples(net.index_quantize(x))
+        torch.cuda.synchronize()
+        t_inf = (time.perf_counter() - t0) / steps
+    del net, flat, opt, x
+    torch.cuda.empty_cache()
+    return {"batch": 1, "train_step_ms": round(t_train * 1e3, 3), "train_volumes_per_sec": round(1.0 / t_train, 3),
+            "train_tflops": round(STEP_TFLOP_PER_VOLUME / t_train, 1), "extract_decode_ms": round(t_inf * 1e3, 3),
+            "extract_decode_volumes_per_sec": round(1.0 / t_inf, 3), "steps": steps}
+
+
+DISC_FWD_TFLOP_PER_VOLUME = 0.3108   # SURVEY 8(a) A8: 155.4 GMAC forward per 160x224x160 volume
+
+
+def bench_adversarial(dev, dtype, batch, steps=3):
+    """The README's training command (reference README.md:62-67): --adversarial_component=True with baseline_discriminator (ndf 64), least-square
+    criteria weight 0.005, adaptive weight off -- one G + D iteration (src/engines/trainer.py:157-256) per step.  Added work per volume: the
+    discriminator runs forward on the fakes and back to the reconstruction in the G step (2 x fwd), forward + full backward on fakes and reals in
+    the D step (2 x 3 x fwd): 8 x 0.311 = 2.49 TFLOP on top of the generator's 14.97."""
+    from synthanatomy_amd.engines.trainer import AdversarialTrainer
+    from synthanatomy_amd.losses.adversarial import get_discriminator_loss, get_generator_loss
+    from synthanatomy_amd.losses.vqvae import MSELoss
+    from synthanatomy_amd.networks.discriminator.baseline import BaselineDiscriminator
+    from synthanatomy_amd.networks.vqvae.baseline import BaselineVQVAE
+    from synthanatomy_amd.runtime.optim import FlatParams, FusedAdam
+    torch.manual_seed(4)
+    net = BaselineVQVAE(**NET, compute_dtype=dtype).to(dev).train()
+    disc = BaselineDiscriminator(input_nc=1, ndf=64, n_layers=3, compute_dtype=dtype).to(dev).train()
+    flat, d_flat = FlatParams(net.parameters()), FlatParams(disc.parameters())
+    opt, d_opt = FusedAdam(flat, lr=1.65e-4), FusedAdam(d_flat, lr=5e-5)
+    opt.on_step.append(net.invalidate_packed_weights)
+    d_opt.on_step.append(lambda: [st.op.invalidate() for st in disc._stages])
+    tr = AdversarialTrainer(net, opt, get_generator_loss({"generator_loss": "least_square"}), MSELoss(), disc, d_opt,
+                            get_discriminator_loss({"discriminator_loss": "least_square"}))
+    x = torch.rand(batch, 1, *VOL, generator=torch.Generator(device=dev).manual_seed(4), device=dev)
+    res = tr.iteration(x, x, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = tr.iteration(x, x, 1)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tf = STEP_TFLOP_PER_VOLUME + 8 * DISC_FWD_TFLOP_PER_VOLUME
+    out = {"metric": "vqvae_adversarial_train_volumes_per_sec", "value": round(batch / dt, 3), "unit": "volumes/s", "ms_per_step": round(dt * 1e3, 2),
+           "batch_per_gpu": batch, "steps": steps, "tflop_per_volume": round(tf, 2), "tflops_per_gpu": round(batch / dt * tf, 1),
+           "losses": {k: round(float(res[k]), 6) for k in ("loss", "g_loss", "d_loss")},
+           "workload": "G + D iteration: baseline_vqvae config 2 + baseline_discriminator(1, 64, 3), MSE + 0.005 x least-square GAN terms, two Adam steps"}
+    del net, disc, tr, flat, d_flat, opt, d_opt, x
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -557,10 +665,14 @@ def main():
                 line["roofline_hbm"]["peak_measured_gbs"] = pk["copy_gbs"]
         if dtype == torch.bfloat16:
             line["fp32_mode"] = bench_fp32_mode(dev)
+            line["fp32_mode"]["bf16_vs_fp32"] = bench_bf16_vs_fp32(dev)
     secondary = secondary_14k = None
+    del net, flat, opt, reducer, x
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_extras:
+        line["latency_b1"] = bench_latency_b1(dev, dtype)
+        line["adversarial"] = bench_adversarial(dev, dtype, args.batch)
     if not args.no_performer:
-        del net, flat, opt, reducer, x
-        torch.cuda.empty_cache()
         secondary = bench_performer(args, rank, world, dev)
         torch.cuda.empty_cache()
         if args.performer_shape == "10,14,10":   # BASELINE.json configs[3] says "~14k-token" latents: also the 20x28x25 grid, one sequence per GPU

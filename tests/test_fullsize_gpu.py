@@ -100,6 +100,75 @@ def test_full_size_halo_kernels_agree_with_im2col_order_kernels(net):
     assert enc[0] < bound, enc
 
 
+def test_bf16_mode_against_the_fp32_product_path_at_full_size():
+    """The benchmarked mode (bf16 MFMA) against the fp32 product path -- the mode pinned to the reference at 1e-3 by tests/test_width_parity_gpu.py -- on the
+    REAL config: same weights, two 160x224x160 volumes.  Code indices must agree at >= 97 % of the 2 800 positions (random-init weights: the
+    encoder output is a nearly flat distribution over 2 048 codes, the hardest case for an argmin under bf16 rounding) and the decoder alone,
+    fed the fp32 path's indices, must agree to bf16 rounding.  bench.py reports the same two numbers as `fp32_mode.bf16_vs_fp32`."""
+    from synthanatomy_amd.networks.vqvae.baseline import BaselineVQVAE
+    torch.manual_seed(4)
+    ref = BaselineVQVAE(**NET, compute_dtype=torch.float32).cuda().eval()
+    low = BaselineVQVAE(**NET, compute_dtype=torch.bfloat16)
+    low.load_state_dict(ref.state_dict())
+    low = low.cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.rand(2, 1, *VOL, generator=g, device="cuda")
+    with torch.no_grad():
+        i32 = ref.index_quantize(x)[0]
+        i16 = low.index_quantize(x)[0]
+        z32, z16 = ref.encode(x)[0].float(), low.encode(x)[0].float()
+        r32 = ref.decode_samples([i32]).float()
+        r16 = low.decode_samples([i32]).float()
+    agree = float((i32 == i16).float().mean())
+    ez, er = _rel(z16, z32), _rel(r16, r32)
+    print(f"[bf16 vs fp32 product path, full size] index agreement {agree:.4f} ({int((i32 != i16).sum())} of {i32.numel()} differ), z max-rel {ez:.2e}, "
+          f"reconstruction (same indices) max-rel {er:.2e}")
+    assert agree >= 0.97, agree
+    assert ez < 2e-2 and er < 2e-2, (ez, er)
+    del ref, low
+    torch.cuda.empty_cache()
+
+
+def test_adversarial_iteration_at_full_size():
+    """The README's training command (--adversarial_component=True, baseline_discriminator, least-square criteria weight 0.005: reference README.md:62-67,
+    src/engines/trainer.py:157-256, src/networks/discriminator/baseline.py:21-88) on 160x224x160 volumes, discriminator at ndf=64: two G + D
+    iterations run, every loss is finite, both networks move, the adaptive weight is finite and positive, and the BatchNorm statistics of the
+    discriminator were updated three times per iteration (fake for G, fake + real for D) as upstream."""
+    from synthanatomy_amd.engines.trainer import AdversarialTrainer
+    from synthanatomy_amd.losses.adversarial import get_discriminator_loss, get_generator_loss
+    from synthanatomy_amd.losses.vqvae import MSELoss
+    from synthanatomy_amd.networks.discriminator.baseline import BaselineDiscriminator
+    from synthanatomy_amd.networks.vqvae.baseline import BaselineVQVAE
+    from synthanatomy_amd.runtime.optim import FlatParams, FusedAdam
+    torch.manual_seed(4)
+    net = BaselineVQVAE(**NET, compute_dtype=torch.bfloat16).cuda().train()
+    disc = BaselineDiscriminator(input_nc=1, ndf=64, n_layers=3, compute_dtype=torch.bfloat16).cuda().train()
+    flat, d_flat = FlatParams(net.parameters()), FlatParams(disc.parameters())
+    opt, d_opt = FusedAdam(flat, lr=1.65e-4), FusedAdam(d_flat, lr=5e-5)
+    opt.on_step.append(net.invalidate_packed_weights)
+    d_opt.on_step.append(lambda: [s_.op.invalidate() for s_ in disc._stages])
+    tr = AdversarialTrainer(net, opt, get_generator_loss({"generator_loss": "least_square"}), MSELoss(), disc, d_opt,
+                            get_discriminator_loss({"discriminator_loss": "least_square"}), use_adversarial_adaptive_weight=True,
+                            adaptive_adversarial_weight_threshold=0, adaptive_adversarial_weight_value=1.0)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(2, 1, *VOL, generator=g, device="cuda")
+    w0, d0 = flat.data.clone(), d_flat.data.clone()
+    nb0 = [int(b) for n_, b in disc.named_buffers() if n_.endswith("num_batches_tracked")]
+    for it in range(2):
+        res = tr.iteration(x, x, 1)
+        torch.cuda.synchronize()
+        for k in ("loss", "g_loss", "d_loss", "adversarial_weight"):
+            assert np.isfinite(float(res[k])), (it, k, float(res[k]))
+        assert float(res["adversarial_weight"]) > 0
+    assert res["pred"]["reconstruction"][0].shape == x.shape
+    assert float((flat.data - w0).abs().max()) > 0 and float((d_flat.data - d0).abs().max()) > 0
+    assert torch.isfinite(flat.data).all() and torch.isfinite(d_flat.data).all()
+    nb1 = [int(b) for n_, b in disc.named_buffers() if n_.endswith("num_batches_tracked")]
+    assert all(b1 - b0 == 6 for b0, b1 in zip(nb0, nb1)), (nb0, nb1)
+    del net, disc, tr
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------------------------------------------ Performer, full sizes
 PERF = dict(vocab=2048, dim=512, depth=24, heads=16, local_heads=8, window=420)
 # README latents (10x14x10 = 1 400 tokens, config 2's own grid) and BASELINE.json configs[3]'s "~14k-token" sequence (20x28x25 = 14 000)

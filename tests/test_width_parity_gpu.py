@@ -199,3 +199,36 @@ def test_fused_residual_block_kernel_against_conv3d_chain():
     assert _rel(h.float().permute(0, 4, 1, 2, 3), h_ref) < 6e-3
     assert _rel(y.float().permute(0, 4, 1, 2, 3), y_ref) < 6e-3
     assert _fro(y.float().permute(0, 4, 1, 2, 3), y_ref) < 3e-3
+
+
+def test_discriminator_production_width_matches_oracle_on_crop():
+    """BaselineDiscriminator(1, 64, 3) -- the README's --discriminator_network=baseline_discriminator (reference src/networks/discriminator/baseline.py:21-88,
+    README.md:62-67) -- at its production width ndf=64 on a 2 x 64x96x64 crop, fp32 engine against the CPU oracle: logits <= 1e-3, input gradient and every
+    parameter gradient <= 3e-3 (training-mode BatchNorm); the bf16 engine is printed and sanity-gated."""
+    from oracle import vqvae_ref
+    from synthanatomy_amd.networks.discriminator.baseline import BaselineDiscriminator
+    d_st = vqvae_ref.init_discriminator_state(seed=21, ndf=64)
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(2, 1, 64, 96, 64, generator=g)
+    st = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "num_batches" not in k) for k, v in d_st.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = vqvae_ref.discriminator_forward(st, xr, training=True)
+    w = torch.randn(yr.shape, generator=g)
+    (yr * w).sum().backward()
+    for dtype in (torch.float32, torch.bfloat16):
+        net = BaselineDiscriminator(input_nc=1, ndf=64, n_layers=3, compute_dtype=dtype)
+        net.load_state_dict({k: v.clone() for k, v in d_st.items()}, strict=False)
+        net = net.cuda().train()
+        xd = x.cuda().requires_grad_(True)
+        y = net(xd)
+        assert y.shape == yr.shape
+        (y * w.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        e_log = _rel(y, yr)
+        worst = max(((k, _fro(p.grad, st[k].grad)) for k, p in net.named_parameters()), key=lambda t: t[1])
+        e_dx = _fro(xd.grad, xr.grad)
+        print(f"[discriminator ndf=64 {dtype}] logits max-rel {e_log:.2e}, d input fro {e_dx:.2e}, worst parameter gradient fro {worst[1]:.2e} ({worst[0]})")
+        if dtype == torch.float32:
+            assert e_log < 1e-3 and e_dx < 3e-3 and worst[1] < 3e-3, (e_log, e_dx, worst)
+        else:
+            assert e_log < 5e-2 and e_dx < 0.15 and worst[1] < 0.15, (e_log, e_dx, worst)
