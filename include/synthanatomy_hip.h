@@ -317,6 +317,12 @@ int sa_lrelu_mask(const void *dy, const void *y, int dtype, void *g, int64_t n, 
  * cout != 128 -> SA_EUNSUPPORTED: use sa_convt1_im2col + sa_conv_fprop / sa_conv_wgrad on the [cells][64] matrix. */
 int sa_conv1_fwd(const float *x, const void *wpk, const float *bias, void *y, int N, int D, int H, int W, int cout, int act, void *stream);
 int sa_conv1_wgrad(const float *x, const void *g, float *dw, float *db, int N, int D, int H, int W, int cout, void *stream);
+/* Backward of the last decoder layer nn.ConvTranspose3d(128 -> 1, k4 s2 p1) (baseline.py:283-293, last level), bf16, on the two kernels above:
+ * g = d loss / d output [N,2D,2H,2W] fp32, x = the layer input [N,D,H,W,128] bf16, wpk = the transposed-convolution weight [128][64 taps] as bf16
+ * (the operand sa_conv1_fwd takes).  dx [N,D,H,W,128] bf16 = sum_t g[2 cell - 1 + t] W[c][t] (zeroed where x <= 0 when mask_input),
+ * dw [128][64] += sum_cells x[cell][c] g[2 cell - 1 + t], db [1] += sum g (fp32 atomics: zero dw / db first). */
+int sa_convt1_backward(const float *g, const void *x, const void *wpk, int mask_input, void *dx, float *dw, float *db, int N, int D, int H, int W,
+                       void *stream);
 
 /* ==== final decoder layer nn.ConvTranspose3d(128 -> 1, k4 s2 p1) (baseline.py:283-293, last level): HBM-bound direct kernels ====
  * x [N,D,H,W,128] (dtype), w [128][64] fp32 (the reference weight [Cin,1,4,4,4]), out / g [N,2D,2H,2W] fp32.

@@ -998,6 +998,16 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_fprop_halo256_kernel(con
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
+#ifdef SA_MFMA32_PROBE
+    typedef float f32x16_t __attribute__((ext_vector_type(16)));
+    f32x16_t acc32[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+#endif
     const uint32_t frow = lane & 15u, fq = lane >> 4;
     const uint32_t a_base = ((wm * (uint32_t)MI) * HW_ + frow) * 128u + fq * 16u;   // unswizzled; patch row j adds 18 * 128 j
     const uint32_t b_off = tile_off(wn * (NI * 16) + frow, fq);
@@ -1034,10 +1044,25 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_fprop_halo256_kernel(con
                     const uint32_t ad = a_base + tapoff + (uint32_t)j * (HW_ * 128u);
                     xf[j] = *(const u32x4*)(sA + ((ad ^ (((ad >> 7) & 7u) << 4)) ^ (ks * 64u)));
                 }
+#ifdef SA_MFMA32_PROBE
+                // TIMING PROBE ONLY (wrong results): the same fragments through half as many v_mfma_f32_32x32x16_bf16 -- what the other instruction
+                // shape would buy this loop at unchanged LDS traffic
+                if constexpr (sizeof(T) == 2 && NW == 8) {
 #pragma unroll
-                for (int i = 0; i < NI; ++i)
+                    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
+                        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                            for (int j2 = 0; j2 < 2; ++j2)
+                                acc32[i2][j2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const short8_t*)&wf[i2 * 2 + kk], *(const short8_t*)&xf[j2 * 2 + kk], acc32[i2][j2], 0, 0, 0);
+                } else
+#endif
+                {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
+                }
             }
 #ifdef SA_TIMING
             asm volatile("" ::: "memory");
@@ -1068,6 +1093,16 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_fprop_halo256_kernel(con
         const uint32_t h = (uint32_t)h0 + (row >> 4), w = (uint32_t)w0 + (row & 15u);
         return h < (uint32_t)g.Ho && w < (uint32_t)g.Wo ? (((long long)pn * g.Do + pd) * g.Ho + h) * g.Wo + w : -1ll;
     };
+#ifdef SA_MFMA32_PROBE
+    if constexpr (sizeof(T) == 2 && NW == 8) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = acc32[i >> 1][j >> 1][((i & 1) * 2 + (j & 1)) * 4 + r];
+    }
+#endif
     if constexpr (FUSE) {
         static_assert(!FUSE || sizeof(T) == 2, "fused residual block: bf16");
         // Second GEMM of the residual block for the 256 rows: h = relu(acc + b1) goes to LDS as two [256][128 B] K-slabs (64 KiB, the

@@ -366,7 +366,18 @@ class _ConvT1Stage:
         G = G.float().contiguous()
         dw, db = grads.buf(self.mod.weight), grads.buf(self.mod.bias)
         lib, st = _ffi.lib(), _ffi.stream()
-        if self._gemm(x):
+        if self._gemm(x) and x.dtype == torch.bfloat16 and not debug.host("no_convt1_fused_bwd"):
+            # csrc/conv1.hip: the data gradient is the FIRST layer's forward on the volume G, the weight gradient its weight gradient with x in the
+            # role of the output gradient; no [cells][64] matrix in HBM
+            self._sync()
+            wpk = self.taps_bwd.packed_fwd_operand(N, (D, H, W))
+            dx = torch.empty_like(x)
+            _launch("convt1_backward(conv1_fwd_kernel+conv1_wgrad_kernel)", 4.0 * x.numel() * 64,
+                    lambda: _ffi.check(lib.sa_convt1_backward(_ffi.ptr(G), _ffi.ptr(x), _ffi.ptr(wpk), 1 if self.in_act else 0, _ffi.ptr(dx), _ffi.ptr(dw), _ffi.ptr(db),
+                                                              N, D, H, W, st), "sa_convt1_backward"))
+            if wgrad_only:
+                dx = None
+        elif self._gemm(x):
             self._sync()
             Gc = torch.empty((N, D, H, W, 64), dtype=x.dtype, device=x.device)
             _ffi.check(lib.sa_convt1_im2col(_ffi.ptr(G), _ffi.dtype_id(x.dtype), _ffi.ptr(Gc), _ffi.ptr(db), N, D, H, W, st), "sa_convt1_im2col")

@@ -491,3 +491,51 @@ def test_conv1x1_backward_fused(dims):
     _close(dx.float().cpu(), _cl(xr.grad * (x > 0)), dt, "masked dgrad")
     _close(dw.cpu(), wr.grad, dt, "wgrad")
     _close(db.cpu(), br.grad, dt, "bgrad")
+
+
+def _rel_t(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("shape,in_act", [((2, 8, 10, 12), True), ((1, 20, 28, 20), True), ((3, 5, 7, 9), False)])
+def test_last_layer_backward_on_the_first_layer_kernels(shape, in_act):
+    """sa_convt1_backward (data gradient = conv1 forward on the gradient volume, weight gradient = conv1 weight gradient with the layer input as
+    `g`, bias gradient = sum of the volume) against the im2col + GEMM route it replaces and against torch autograd on the same bf16-rounded operands."""
+    from synthanatomy_amd import debug
+    from synthanatomy_amd.networks.vqvae.baseline import _ConvT1Stage, _GradCtx
+    torch.manual_seed(sum(shape))
+    mod = torch.nn.ConvTranspose3d(128, 1, 4, 2, 1).cuda()
+    st = _ConvT1Stage(mod, in_act=in_act, dtype=torch.bfloat16)
+    st.GEMM_MIN_CELLS = 1
+    N, D, H, W = shape
+    x = torch.randn(N, D, H, W, 128, device="cuda")
+    if in_act:
+        x = torch.relu(x)
+    x = x.to(torch.bfloat16)
+    G = torch.randn(N, 2 * D, 2 * H, 2 * W, 1, device="cuda")
+    res = []
+    for fused in (True, False):
+        with debug.override(no_convt1_fused_bwd=not fused):
+            gc = _GradCtx(None)
+            dx = st.bwd(G, (x,), gc)
+            torch.cuda.synchronize()
+            res.append((dx.float().clone(), gc.grads[mod.weight].clone(), gc.grads[mod.bias].clone()))
+    # torch reference on the bf16-rounded operands (the gathered gradient taps are rounded to bf16 by both routes)
+    xr = x.float().permute(0, 4, 1, 2, 3).contiguous().requires_grad_(True)
+    wr = mod.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    br = mod.bias.detach().clone().requires_grad_(True)
+    Gr = G.to(torch.bfloat16).float().permute(0, 4, 1, 2, 3)
+    y = torch.nn.functional.conv_transpose3d(xr, wr, br, stride=2, padding=1)
+    (y * Gr).sum().backward()
+    dx_ref = xr.grad.permute(0, 2, 3, 4, 1)
+    if in_act:
+        dx_ref = dx_ref * (x.float() > 0)
+    for dx, dw, db in res:
+        assert _rel_t(dx, dx_ref) < 1e-2 and _rel_t(dw, wr.grad) < 5e-3
+        assert abs(float(db) - float(G.sum())) < 1e-3 * float(G.abs().sum()) ** 0.5 + 1e-2
+    assert _rel_t(res[0][0], res[1][0]) < 8e-3 and _rel_t(res[0][1], res[1][1]) < 2e-3
+    # the wgrad-only form used by the adaptive adversarial weight
+    gc = _GradCtx(None)
+    assert st.bwd(G, (x,), gc, wgrad_only=True) is None
+    assert _rel_t(gc.grads[mod.weight], res[0][1]) < 1e-5
