@@ -157,6 +157,19 @@ def measured_peaks(dev):
     e1.record()
     torch.cuda.synchronize()
     tf = blocks * 4 * iters * 8 * 32768.0 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    # cross-check at other occupancies and with the instruction shape the convolution kernels use: waves per CU x shape
+    cross = {}
+    for shape, flop in ((0, 32768.0), (1, 16384.0)):
+        for threads in (256, 512, 1024):
+            blk, it2 = 256 * 8 * 256 // threads, 8192
+            _ffi.check(lib.sa_bench_mfma_bf16_ex(_ffi.ptr(scratch), blk, threads, 64, shape, _ffi.stream()), "sa_bench_mfma_bf16_ex")
+            torch.cuda.synchronize()
+            e0.record()
+            _ffi.check(lib.sa_bench_mfma_bf16_ex(_ffi.ptr(scratch), blk, threads, it2, shape, _ffi.stream()), "sa_bench_mfma_bf16_ex")
+            e1.record()
+            torch.cuda.synchronize()
+            cross[f"{'32x32x16' if shape == 0 else '16x16x32'}_{threads // 64}waves_per_block"] = round(blk * (threads // 64) * it2 * 4 * flop / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+    tf = max(tf, max(cross.values()))
     src = torch.empty(1 << 30, dtype=torch.int16, device=dev)
     dst = torch.empty_like(src)
     dst.copy_(src)
@@ -168,7 +181,7 @@ def measured_peaks(dev):
     torch.cuda.synchronize()
     gbs = 4 * 2 * src.numel() * 2 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del src, dst
-    return {"mfma_bf16_tflops": round(tf, 1), "copy_gbs": round(gbs, 1),
+    return {"mfma_bf16_tflops": round(tf, 1), "copy_gbs": round(gbs, 1), "mfma_cross_check_tflops": cross,
             "how": "sa_bench_mfma_bf16: 2048 blocks x 4 waves x 4096 x 8 independent v_mfma_f32_32x32x16_bf16; torch device-to-device copy of 2 GiB, read + write bytes"}
 
 

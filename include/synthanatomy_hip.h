@@ -89,6 +89,9 @@ int sa_kernel_log_read(char *buf, int cap, int stop);
 /* measurement aid (bench.py `roofline.peak_measured`): `blocks` x 4 waves each issue iters x 8 independent v_mfma_f32_32x32x16_bf16;
  * FLOPs per call = blocks * 4 * iters * 8 * 32768.  `scratch` = any 4 device bytes (never written in practice). */
 int sa_bench_mfma_bf16(float *scratch, int blocks, int iters, void *stream);
+/* the same probe at other occupancies / instruction shapes: `threads` per block (64 .. 1024), four accumulator tiles per wave, shape 0 =
+ * v_mfma_f32_32x32x16_bf16 (32 768 FLOP each), 1 = v_mfma_f32_16x16x32_bf16 (16 384): FLOPs per call = blocks * threads/64 * iters * 4 * (32 768 | 16 384) */
+int sa_bench_mfma_bf16_ex(float *scratch, int blocks, int threads, int iters, int shape, void *stream);
 uint32_t sa_get_debug_flags(void);
 uint32_t sa_set_debug_flags(uint32_t flags);
 
@@ -346,7 +349,7 @@ int sa_convt1_im2col(const float *g, int dtype, void *gc, float *db, int N, int 
  * from sa_favor_fused_prepass; state buffers of sa_favor_fused_state_bytes bytes.  m <= 272, head width 64. */
 int64_t sa_favor_fused_state_bytes(int B, int N, int G, int m);
 int sa_favor_fused_proj_tiles(const float *ps, int m, void *tiles, void *stream);
-int sa_favor_fused_prepass(const float *q, const float *k, int stride, int G, const float *ps, float *offq, int32_t *amq, float *offk, void *gmax_ws,
+int sa_favor_fused_prepass(const float *q, const float *k, int stride, int G, const void *tiles, float *offq, int32_t *amq, float *offk, void *gmax_ws,
                            int64_t rows, int m, int dh, void *stream);
 int sa_favor_fused_fwd(const float *q, const float *k, const float *v, int stride, const void *tiles, const float *ps, const float *offq, const float *offk,
                        const void *gmax_ws, float *attn, int attn_stride, float *inv_out, float den_eps, int B, int N, int G, int m, float *state,

@@ -54,6 +54,7 @@ _SIGS = {
     "sa_kernel_log_begin": (None, []),
     "sa_kernel_log_read": (c_int, [ctypes.c_char_p, c_int, c_int]),
     "sa_bench_mfma_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "sa_bench_mfma_bf16_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sa_get_debug_flags": (ctypes.c_uint32, []),
     "sa_set_debug_flags": (ctypes.c_uint32, [ctypes.c_uint32]),
     "sa_conv1_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

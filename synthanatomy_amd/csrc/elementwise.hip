@@ -199,7 +199,53 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
     if (t == 12345.678f) out[0] = t;   // keeps the loop alive without a store in the common case
 #endif
 }
+// Cross-check of the probe above at other occupancies and with the instruction shape the convolution kernels use: four accumulator tiles per wave
+// (64 VGPRs: up to 8 waves per SIMD), `iters` x 4 MFMAs.  SHAPE 0: v_mfma_f32_32x32x16_bf16 (32 768 FLOP), 1: v_mfma_f32_16x16x32_bf16 (16 384 FLOP).
+template <int SHAPE>
+__global__ __launch_bounds__(1024) void mfma_peak2_kernel(float* out, int iters) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((ext_vector_type(16))) float f16x;
+    typedef __attribute__((ext_vector_type(8))) short s8x;
+    s8x a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = (short)(0x3f80 + (threadIdx.x & 127)); b[e] = (short)(0x3c00 + e); }
+    float t = 0.f;
+    if constexpr (SHAPE == 0) {
+        f16x acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t += acc[i][0] + acc[i][15];
+    } else {
+        float4_t acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t += acc[i][0] + acc[i][3];
+    }
+    if (t == 12345.678f) out[0] = t;
+#endif
+}
 }  // namespace sa
+
+// FLOPs of one call = blocks * (threads / 64) waves * iters * 4 MFMAs * (32 768 | 16 384)
+extern "C" int sa_bench_mfma_bf16_ex(float* scratch, int blocks, int threads, int iters, int shape, void* stream) {
+    if (!scratch || blocks <= 0 || iters <= 0 || threads < 64 || threads > 1024 || (threads & 63) || (shape != 0 && shape != 1)) return SA_EINVAL;
+    if (shape == 0) SA_LAUNCH(sa::mfma_peak2_kernel<0>, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, scratch, iters);
+    else SA_LAUNCH(sa::mfma_peak2_kernel<1>, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, scratch, iters);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
 
 // FLOPs of one call = blocks * 4 waves * iters * 8 MFMAs * (2 * 32 * 32 * 16)
 extern "C" int sa_bench_mfma_bf16(float* scratch, int blocks, int iters, void* stream) {

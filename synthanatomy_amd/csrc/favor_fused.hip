@@ -224,7 +224,8 @@ __global__ __launch_bounds__(256) void favor_proj_tiles_kernel(const float* __re
 // Head rows of q (blocks [0, nbq)) and k (blocks [nbq, 2 nbq)): dd = x P^T in accumulators only.
 //   queries: rowoff = |x|^2 c^2/2 + max_f dd, amx = argmax_f dd (lowest index on ties);   keys: rowoff = |x|^2 c^2/2, gmax = packed global maximum
 struct PrepassArgs {
-    const float *q, *k, *ps;
+    const float *q, *k;
+    const unsigned char* ptiles;   // the projection matrix as split slab tiles (sa_favor_fused_proj_tiles)
     float *offq, *offk;
     int32_t* amq;
     unsigned long long* gmax;
@@ -235,18 +236,25 @@ struct PrepassArgs {
 __device__ __forceinline__ int64_t head_row_off(int64_t r, int heads, int stride) { return (r / heads) * stride + (r % heads) * 64; }
 
 __global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs a) {
+    // block = 256 head rows (wave = 4 x 16 of them); the projection matrix comes in as the pre-split slab tiles (a straight 80 KiB copy, no split work)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nfr = a.LDF >> 4;
-    unsigned char* const sPh = smem;
-    unsigned char* const sPl = smem + nfr * 16 * 128;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), qi = lane & 15, g = lane >> 4;
     const bool isq = (int)blockIdx.x < a.nbq;
     const float* X = isq ? a.q : a.k;
-    const int64_t r0 = (int64_t)(isq ? blockIdx.x : blockIdx.x - a.nbq) * 128 + w * 32;
-    short8_t xh[2][2], xl[2][2];
-    float ss[2] = {0.f, 0.f};
+    const int64_t r0 = (int64_t)(isq ? blockIdx.x : blockIdx.x - a.nbq) * 256 + w * 64;
+    {
+        const u32x4* src = (const u32x4*)a.ptiles;
+        u32x4 v[20];
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+        for (int t = 0; t < 20; ++t) v[t] = src[tid + 256 * t];
+#pragma unroll
+        for (int t = 0; t < 20; ++t) ((u32x4*)smem)[tid + 256 * t] = v[t];
+    }
+    short8_t xh[4][2], xl[4][2];
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
         const int64_t r = r0 + st * 16 + qi;
         const bool ok = r < a.rows;
         const float* xr = X + head_row_off(ok ? r : a.rows - 1, a.heads, a.stride);
@@ -260,81 +268,72 @@ __global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs
             split8(xs, xh[st][ks], xl[st][ks]);
         }
     }
-    // the whole projection matrix as split tiles (rows >= m zero): 17 x 16 rows
-    for (int idx = tid; idx < nfr * 16 * 16; idx += 256) {
-        const int rho = idx >> 4, c4 = idx & 15;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rho < a.m) v = *(const float4*)(a.ps + (int64_t)rho * 64 + c4 * 4);
-        uint2 h, l;
-        split_pair(v.x, v.y, h.x, l.x);
-        split_pair(v.z, v.w, h.y, l.y);
-        const uint32_t o = lroff(rho, c4 * 4);
-        *(uint2*)(sPh + o) = h;
-        *(uint2*)(sPl + o) = l;
-    }
     __syncthreads();
-    const bool ok0 = r0 + qi < a.rows, ok1 = r0 + 16 + qi < a.rows;
-    float mx0 = -INFINITY, mx1 = -INFINITY;
-    int am0 = 0x7fffffff, am1 = 0x7fffffff;
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int am[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
     for (int f = 0; f < nfr; ++f) {
+        const unsigned char* sPh = smem + (f >> 2) * (2 * FT_BYTES);
+        const unsigned char* sPl = sPh + FT_BYTES;
         short8_t ah[2], al[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const uint32_t o = lroff(f * 16 + qi, ks * 32 + g * 8);
+            const uint32_t o = lroff((f & 3) * 16 + qi, ks * 32 + g * 8);
             ah[ks] = *(const short8_t*)(sPh + o);
             al[ks] = *(const short8_t*)(sPl + o);
         }
-        float4_t c0 = (float4_t){0.f, 0.f, 0.f, 0.f}, c1 = c0;
-        // same product order as tile_rows_gemm, so the fused kernels rebuild bit-identical dd values (the stabilised exponent never exceeds 0)
+        float4_t c[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) c[st] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        // per accumulator the product order of tile_rows_gemm (hi*lo, lo*hi, hi*hi), so the fused kernels rebuild bit-identical dd values
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], xl[0][ks], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], xl[1][ks], c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], xh[0][ks], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], xh[1][ks], c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], xh[0][ks], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], xh[1][ks], c1, 0, 0, 0);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) c[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], xl[st][ks], c[st], 0, 0, 0);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) c[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], xh[st][ks], c[st], 0, 0, 0);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) c[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], xh[st][ks], c[st], 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int col = f * 16 + g * 4 + r;
             const bool in = col < a.m;
-            const bool t0 = in & ((c0[r] > mx0) | ((c0[r] == mx0) & (col < am0)));
-            mx0 = t0 ? c0[r] : mx0;
-            am0 = t0 ? col : am0;
-            const bool t1 = in & ((c1[r] > mx1) | ((c1[r] == mx1) & (col < am1)));
-            mx1 = t1 ? c1[r] : mx1;
-            am1 = t1 ? col : am1;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const bool t0 = in & ((c[st][r] > mx[st]) | ((c[st][r] == mx[st]) & (col < am[st])));
+                mx[st] = t0 ? c[st][r] : mx[st];
+                am[st] = t0 ? col : am[st];
+            }
         }
     }
     // a row lives in the four lanes qi, qi + 16, qi + 32, qi + 48
 #pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
-        const float om0 = __shfl_xor(mx0, o, 64), om1 = __shfl_xor(mx1, o, 64);
-        const int oa0 = __shfl_xor(am0, o, 64), oa1 = __shfl_xor(am1, o, 64);
-        const bool t0 = (om0 > mx0) | ((om0 == mx0) & (oa0 < am0)), t1 = (om1 > mx1) | ((om1 == mx1) & (oa1 < am1));
-        mx0 = t0 ? om0 : mx0; am0 = t0 ? oa0 : am0;
-        mx1 = t1 ? om1 : mx1; am1 = t1 ? oa1 : am1;
-        ss[0] += __shfl_xor(ss[0], o, 64);
-        ss[1] += __shfl_xor(ss[1], o, 64);
+    for (int o = 16; o <= 32; o <<= 1)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const float om = __shfl_xor(mx[st], o, 64);
+            const int oa = __shfl_xor(am[st], o, 64);
+            const bool t0 = (om > mx[st]) | ((om == mx[st]) & (oa < am[st]));
+            mx[st] = t0 ? om : mx[st];
+            am[st] = t0 ? oa : am[st];
+            ss[st] += __shfl_xor(ss[st], o, 64);
+        }
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int64_t r = r0 + st * 16 + qi;
+        if (r < a.rows) {
+            if (isq) {
+                if (g == 0) { a.offq[r] = ss[st] * a.c2half + mx[st]; a.amq[r] = am[st]; }
+            } else {
+                if (g == 0) a.offk[r] = ss[st] * a.c2half;
+                const unsigned long long b1 = pack_max(mx[st], (uint32_t)(r * a.LDF) + (uint32_t)am[st]);
+                best = b1 > best ? b1 : best;
+            }
+        }
     }
-    if (isq) {
-        if (g == 0) {
-            if (ok0) { a.offq[r0 + qi] = ss[0] * a.c2half + mx0; a.amq[r0 + qi] = am0; }
-            if (ok1) { a.offq[r0 + 16 + qi] = ss[1] * a.c2half + mx1; a.amq[r0 + 16 + qi] = am1; }
-        }
-    } else {
-        if (g == 0) {
-            if (ok0) a.offk[r0 + qi] = ss[0] * a.c2half;
-            if (ok1) a.offk[r0 + 16 + qi] = ss[1] * a.c2half;
-        }
+    if (!isq) {
         __shared__ unsigned long long sbest[4];
-        unsigned long long best = 0ull;
-        if (ok0) best = pack_max(mx0, (uint32_t)((r0 + qi) * a.LDF) + (uint32_t)am0);
-        if (ok1) {
-            const unsigned long long b1 = pack_max(mx1, (uint32_t)((r0 + 16 + qi) * a.LDF) + (uint32_t)am1);
-            best = b1 > best ? b1 : best;
-        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned long long ot = __shfl_xor(best, o, 64);
@@ -352,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs
 
 // ------------------------------------------------------------------------------------------------ chunk state sums
 // U_c[m][d] = sum_{j in chunk} phi_a(j)[m] (b_j[d] bs_j),   z[m] = sum_j phi_a(j)[m] w_j     (zmode 1: w = 1, zmode 2: w = ex_scale_j)
-__global__ __launch_bounds__(256, FUSED_WPS) void favor_fstate_kernel(const FusedArgs s) {
+__global__ __launch_bounds__(256, 3) void favor_fstate_kernel(const FusedArgs s) {
     __shared__ __attribute__((aligned(16))) unsigned char sBh[FT_BYTES], sBl[FT_BYTES], sAh[FT_BYTES], sAl[FT_BYTES], sP[2 * FT_BYTES];
     __shared__ float sW[64];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
@@ -729,18 +728,18 @@ extern "C" int sa_favor_fused_proj_tiles(const float* ps, int m, void* tiles, vo
     return 0;
 }
 
-extern "C" int sa_favor_fused_prepass(const float* q, const float* k, int stride, int G, const float* ps, float* offq, int32_t* amq, float* offk, void* gmax_ws,
+extern "C" int sa_favor_fused_prepass(const float* q, const float* k, int stride, int G, const void* tiles, float* offq, int32_t* amq, float* offk, void* gmax_ws,
                                       int64_t rows, int m, int dh, void* stream) {
-    if (!q || !k || !ps || !offq || !amq || !offk || !gmax_ws || rows <= 0 || G <= 0) return SA_EINVAL;
+    if (!q || !k || !tiles || !offq || !amq || !offk || !gmax_ws || rows <= 0 || G <= 0) return SA_EINVAL;
     if (dh != 64 || m <= 0 || m > 272 || (stride & 3) || stride < G * 64 || rows * 272 >= ((int64_t)1 << 32) - 1) return SA_EUNSUPPORTED;
     PrepassArgs a = {};
-    a.q = q; a.k = k; a.ps = ps; a.offq = offq; a.offk = offk; a.amq = amq; a.gmax = (unsigned long long*)gmax_ws; a.rows = rows; a.m = m; a.LDF = ldf_of(m);
-    a.stride = stride; a.heads = G; a.nbq = (int)((rows + 127) / 128);
+    a.q = q; a.k = k; a.ptiles = (const unsigned char*)tiles; a.offq = offq; a.offk = offk; a.amq = amq; a.gmax = (unsigned long long*)gmax_ws; a.rows = rows; a.m = m;
+    a.LDF = ldf_of(m); a.stride = stride; a.heads = G; a.nbq = (int)((rows + 255) / 256);
     const float c = powf((float)dh, -0.25f);
     a.c2half = 0.5f * c * c;
-    const size_t lds = (size_t)2 * a.LDF * 128;
+    const size_t lds = (size_t)5 * 2 * FT_BYTES;
     static std::atomic<uint64_t> attr_done{0};
-    configure_once_per_device(attr_done, [] { (void)hipFuncSetAttribute((const void*)favor_prepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 272 * 128); });
+    configure_once_per_device(attr_done, [] { (void)hipFuncSetAttribute((const void*)favor_prepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 2 * FT_BYTES); });
     hipMemsetAsync(gmax_ws, 0, 8, (hipStream_t)stream);
     SA_LAUNCH(favor_prepass_kernel, dim3((unsigned)(2 * a.nbq)), dim3(256), lds, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();

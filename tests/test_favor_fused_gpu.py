@@ -50,7 +50,7 @@ def _fused(q, k, v, proj, dattn, local_cols=64):
     offk = torch.empty(R * G, device="cuda")
     amq = torch.empty(R * G, dtype=torch.int32, device="cuda")
     gws = torch.zeros(1, dtype=torch.int64, device="cuda")
-    _ffi.check(lib.sa_favor_fused_prepass(_ffi.ptr(qd), _ffi.ptr(kd), stride, G, _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(amq), _ffi.ptr(offk), _ffi.ptr(gws), R * G, m, dh, st))
+    _ffi.check(lib.sa_favor_fused_prepass(_ffi.ptr(qd), _ffi.ptr(kd), stride, G, _ffi.ptr(tiles), _ffi.ptr(offq), _ffi.ptr(amq), _ffi.ptr(offk), _ffi.ptr(gws), R * G, m, dh, st))
     nst = lib.sa_favor_fused_state_bytes(B, N, G, m) // 4
     state = torch.empty(nst, device="cuda")
     state2 = torch.empty(nst, device="cuda")
