@@ -346,7 +346,8 @@ int sa_convt1_im2col(const float *g, int dtype, void *gc, float *db, int N, int 
  * sa_favor_scan_a_state -> sa_favor_features_project_bwd x2 (backward): no [B*N*G, LDF] tensor (dd, phi, d phi) is ever written.
  * q / k / v / dq / dk / dv: fp32 rows of `stride` floats whose first G*64 columns are the global heads; ps = projection matrix [m][64] with the
  * data normaliser folded in; tiles = 5 * 16 KiB from sa_favor_fused_proj_tiles(ps); offq / offk [B*N*G] floats, amq [B*N*G] int32 and gmax_ws (8 bytes)
- * from sa_favor_fused_prepass; state buffers of sa_favor_fused_state_bytes bytes.  m <= 272, head width 64. */
+ * from sa_favor_fused_prepass; state buffers of sa_favor_fused_state_bytes bytes; dden_ws B*N*G floats, tsum_ws B*G*ceil(N/64) floats.
+ * No fp32 atomics: results are run-to-run deterministic.  m <= 272, head width 64. */
 int64_t sa_favor_fused_state_bytes(int B, int N, int G, int m);
 int sa_favor_fused_proj_tiles(const float *ps, int m, void *tiles, void *stream);
 int sa_favor_fused_prepass(const float *q, const float *k, int stride, int G, const void *tiles, float *offq, int32_t *amq, float *offk, void *gmax_ws,

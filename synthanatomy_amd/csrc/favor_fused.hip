@@ -46,7 +46,7 @@ struct FusedArgs {
     float* dx;             // out B: rows [B * N][stride]
     float* state;          // [B, G, S][LDF * 64 + LDF]
     float* inv_out;        // out A, zmode 1
-    float* tsum;           // out B, keys: sum of t over all rows
+    float* tsum;           // out B, keys: per-block partial sums of t [B * G * S]
     int32_t B, N, G, m, LDF, S, stride, b_stride, c_stride, y_stride, reverse, zmode, is_query, accumulate;
     float ratio, reps, c2, den_eps, ex_const;
 };
@@ -441,7 +441,7 @@ __global__ void favor_fprefix_kernel(float* __restrict__ state, int64_t BG, int 
     for (int k0 = 0; k0 < S; k0 += 8) {
         float4_t v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = k0 + j < S ? __builtin_nontemporal_load(p + (k0 + j) * elems4) : (float4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 8; ++j) v[j] = k0 + j < S ? p[(k0 + j) * elems4] : (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (k0 + j < S) p[(k0 + j) * elems4] = acc;
@@ -679,17 +679,20 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_b_kernel(const Fuse
         tb = wave_sum(tb);
         if (lane == 0) sred[w] = tb;
         __syncthreads();
-        if (tid == 0) unsafeAtomicAdd(s.tsum, (sred[0] + sred[1]) + (sred[2] + sred[3]));
+        if (tid == 0) s.tsum[blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);   // one partial per block, summed in a fixed order by the fix-up launch
     }
 }
 
-// keys: the global-max element (head row r*, feature f*) takes -(sum of all t): dk[r*] -= T P[f*]
+// keys: the global-max element (head row r*, feature f*) takes -(sum of all t): dk[r*] -= T P[f*];  T = the per-block partials in a fixed order (deterministic)
 __global__ __launch_bounds__(64) void favor_fkey_fix_kernel(float* __restrict__ dx, int x_stride, int heads, const unsigned long long* __restrict__ gmax,
-                                                            const float* __restrict__ total, const float* __restrict__ ps, int LDF) {
+                                                            const float* __restrict__ partial, int nblk, const float* __restrict__ ps, int LDF) {
+    float t = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 64) t += partial[i];
+    t = wave_sum(t);
     const uint32_t idx = 0xffffffffu - (uint32_t)(*gmax & 0xffffffffull);
     const int64_t r = idx / (uint32_t)LDF;
     const int f = (int)(idx % (uint32_t)LDF);
-    dx[head_row_off(r, heads, x_stride) + threadIdx.x] -= total[0] * ps[(int64_t)f * 64 + threadIdx.x];
+    dx[head_row_off(r, heads, x_stride) + threadIdx.x] -= t * ps[(int64_t)f * 64 + threadIdx.x];
 }
 
 // dden[row] = -(dout . out) * inv over the head's 64 columns (one wave per head row)
@@ -783,7 +786,7 @@ extern "C" int sa_favor_fused_fwd(const float* q, const float* k, const float* v
 }
 
 // backward of the global heads.  state_fwd: the prefixes sa_favor_fused_fwd left (or NULL: rebuilt into state_ws first); state_ws: scratch of
-// sa_favor_fused_state_bytes; dden_ws: B*N*G floats; tsum_ws: 1 float.  dq / dk / dv: head blocks (stride `stride`) like q / k / v.
+// sa_favor_fused_state_bytes; dden_ws: B*N*G floats; tsum_ws: B*G*ceil(N/64) floats (per-block partial sums).  dq / dk / dv: head blocks (stride `stride`) like q / k / v.
 extern "C" int sa_favor_fused_bwd(const float* q, const float* k, const float* v, int stride, const void* tiles, const float* ps, const float* offq,
                                   const int32_t* amq, const float* offk, const void* gmax_ws, const float* dattn, const float* attn, int attn_stride,
                                   const float* inv, float* dq, float* dk, float* dv, int B, int N, int G, int m, const float* state_fwd, float* state_ws,
@@ -820,13 +823,12 @@ extern "C" int sa_favor_fused_bwd(const float* q, const float* k, const float* v
     s.b = dattn; s.b_stride = attn_stride; s.b_scale = inv;
     s.c = v; s.c_stride = stride; s.c_scale = nullptr;
     s.zmode = 2; s.ex_const = 0.f; s.reverse = 1; s.is_query = 0; s.amx = nullptr; s.dx = dk; s.state = state_ws;
-    hipMemsetAsync(tsum_ws, 0, 4, st);
     SA_LAUNCH(favor_fstate_kernel, dim3(nblk), dim3(256), 0, st, s);
     SA_CHECK_LAUNCH();
     if (int rc = fused_prefix(state_ws, B, G, s.S, s.LDF, st)) return rc;
     SA_LAUNCH(favor_fout_b_kernel, dim3(nblk), dim3(256), 0, st, s);
     SA_CHECK_LAUNCH();
-    SA_LAUNCH(favor_fkey_fix_kernel, dim3(1), dim3(64), 0, st, dk, stride, G, (const unsigned long long*)gmax_ws, tsum_ws, ps, s.LDF);
+    SA_LAUNCH(favor_fkey_fix_kernel, dim3(1), dim3(64), 0, st, dk, stride, G, (const unsigned long long*)gmax_ws, tsum_ws, (int)nblk, ps, s.LDF);
     SA_CHECK_LAUNCH();
     // dv_j[d] = sum_m phi_k(j)[m] R_j[m][d]: scan A on the same states (a = phi_q, b = dattn inv, reversed), per-position map phi_k, no normaliser
     s.zmode = 0; s.y = dv; s.y_stride = stride; s.inv_out = nullptr; s.accumulate = 0;

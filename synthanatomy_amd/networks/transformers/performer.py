@@ -648,7 +648,7 @@ class _LayerEngine:
             if self._ws is None or self._ws.numel() < nst or self._ws.device != dev:
                 self._ws = torch.empty(nst, dtype=f32, device=dev)
             dden = torch.empty(R * G, dtype=f32, device=dev)
-            tsum = torch.empty(1, dtype=f32, device=dev)
+            tsum = torch.empty(B * G * ((N + 63) // 64), dtype=f32, device=dev)
             _ck(lib.sa_favor_fused_bwd(_ffi.ptr(q), _ffi.ptr(k), _ffi.ptr(v), qs, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(sv["offq"]), _ffi.ptr(sv["amq"]),
                                        _ffi.ptr(sv["offk"]), _ffi.ptr(sv["gws"]), _ffi.ptr(dattn), _ffi.ptr(attn), inner, _ffi.ptr(sv["inv"]), _ffi.ptr(dq),
                                        _ffi.ptr(dk), _ffi.ptr(dv), B, N, G, m, _ffi.ptr(sv.get("scan_state")), _ffi.ptr(self._ws), _ffi.ptr(dden), _ffi.ptr(tsum), st),
@@ -992,14 +992,15 @@ class Performer(TransformerBase):
         growing prefix per token); ``stateful=True`` (default without conditioning) carries the FAVOR+ running sums and the local-attention
         key/value caches from token to token -- O(N), same logits up to fp32 rounding -- and replays one captured
         HIP graph per token."""
-        if stateful is None:
-            stateful = conditioning is None
+        bos = self.conditioning_type == TransformerConditioningType.BOSREPLACEMENT.value
+        if stateful is None:     # O(N) decoding unless the conditioning lengthens the sequence (prepending: the reference-faithful loop)
+            stateful = conditioning is None or bos
         if not stateful:
             return super().sample(prefix, conditioning=conditioning, temperature=temperature, sample=sample, top_k=top_k)
-        assert conditioning is None, "stateful sampling does not take conditionings (use stateful=False)"
-        return self._sample_stateful(prefix, temperature, sample, top_k, use_graph)
+        assert conditioning is None or bos, "stateful sampling takes BOS-replacement conditionings only (use stateful=False)"
+        return self._sample_stateful(prefix, temperature, sample, top_k, use_graph, conditioning)
 
-    def _sample_stateful(self, prefix, temperature, sample, top_k, use_graph):
+    def _sample_stateful(self, prefix, temperature, sample, top_k, use_graph, conditioning=None):
         _ffi.require_gpu()
         self.eval()
         dev = self.token_emb.weight.device
@@ -1015,7 +1016,15 @@ class Performer(TransformerBase):
         pos = torch.zeros(1, dtype=torch.int32, device=dev)
         tok = torch.zeros(B, dtype=torch.int64, device=dev)
         pidx, sp = self._position_indices(npos, dev)
-        tables = [self.token_emb.weight] + [(m.emb if isinstance(m, FixedSpatialPositionalEmbedding) else m.emb.weight) for m in self.spatial_position_emb] + [self.pos_emb.emb.weight]
+        tok_table = self.token_emb.weight
+        if conditioning:
+            # BOS replacement (performer.py:252-261): position 0 carries the summed conditioning embeddings instead of its token (+ spatial, which are zero
+            # there) embedding -> B extra rows behind the token table, and position 0 of sequence b points at row num_tokens + b
+            c = sum(emb(conditioning[i].to(dev))[:, 0, :] for i, emb in enumerate(self.conditioning_emb))
+            tok_table = torch.cat((self.token_emb.weight.detach(), c.to(self.token_emb.weight.dtype)), dim=0).contiguous()
+            seq[:, 0] = tok_table.shape[0] - B + torch.arange(B, device=dev)
+            seq0 = seq.clone()
+        tables = [tok_table] + [(m.emb if isinstance(m, FixedSpatialPositionalEmbedding) else m.emb.weight) for m in self.spatial_position_emb] + [self.pos_emb.emb.weight]
         idx = [tok] + sp + [pidx]
         per_pos = [0] + [1] * len(sp) + [1]
         n = len(tables)

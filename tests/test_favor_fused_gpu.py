@@ -64,7 +64,7 @@ def _fused(q, k, v, proj, dattn, local_cols=64):
     dqkv = torch.full((R, stride), 3.0, device="cuda")
     dq, dk, dv = dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:]
     dden = torch.empty(R * G, device="cuda")
-    tsum = torch.zeros(1, device="cuda")
+    tsum = torch.zeros(B * G * ((N + 63) // 64), device="cuda")
     _ffi.check(lib.sa_favor_fused_bwd(_ffi.ptr(qd), _ffi.ptr(kd), _ffi.ptr(vd), stride, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(amq), _ffi.ptr(offk),
                                       _ffi.ptr(gws), _ffi.ptr(da), _ffi.ptr(attn), inner, _ffi.ptr(inv), _ffi.ptr(dq), _ffi.ptr(dk), _ffi.ptr(dv), B, N, G, m,
                                       _ffi.ptr(state), _ffi.ptr(state2), _ffi.ptr(dden), _ffi.ptr(tsum), st))

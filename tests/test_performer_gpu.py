@@ -693,3 +693,41 @@ def test_embedding_variants_match_oracle(variant):
     assert checked > 20
     if variant != "fixed":
         assert float(params["conditioning_emb.0.weight"].grad.abs().max()) > 0
+
+
+def test_stateful_sampler_with_bos_replacement_conditioning():
+    """O(N) decoding with `conditioning_type="bos_replacement"` (reference performer.py:252-261 through transformer.py:58-101): position 0 carries the
+    summed conditioning embeddings; token for token equal to the reference-faithful loop and to the CPU oracle's greedy chain."""
+    from synthanatomy_amd.networks.transformers.img2seq_ordering import Ordering
+    from synthanatomy_amd.networks.transformers.performer import Performer
+    shape, n, ncond = (2, 3, 4), 24, (5, 7)
+    cfg = P.PerformerConfig(num_tokens=19, max_seq_len=n, dim=32, depth=2, heads=4, dim_head=64, local_attn_heads=2, local_window_size=6, spatial_shape=shape)
+    st = P.init_state(cfg, seed=13)
+    g = torch.Generator().manual_seed(5)
+    for i, c in enumerate(ncond):
+        st[f"conditioning_emb.{i}.weight"] = torch.randn(c, 32, generator=g)
+    for k in st:
+        if k.endswith(".g"):
+            st[k] = torch.full_like(st[k], 0.7)
+    o = Ordering("raster_scan", 3, (1,) + shape, (False,) * 3, (), ())
+    net = Performer(num_tokens=19, max_seq_len=n, dim=32, depth=2, heads=4, ordering=o, dim_head=64, local_attn_heads=2, local_window_size=6, use_rezero=True,
+                    spatial_position_emb="absolute", spatial_shape=shape, feature_redraw_interval=None, conditioning_num_tokens=ncond,
+                    conditioning_type="bos_replacement")
+    net.load_state_dict({k: v.clone() for k, v in st.items()}, strict=False)
+    net = net.cuda()
+    B = 3
+    prefix = torch.full((B, 1), 18, dtype=torch.long, device="cuda")
+    conds = [torch.randint(0, c, (B, 1), generator=g) for c in ncond]
+    cd = [c.cuda() for c in conds]
+    quad = net.sample(prefix, conditioning=cd, sample=False, stateful=False)
+    fast = net.sample(prefix, conditioning=cd, sample=False)                 # default: stateful for BOS replacement
+    fast_eager = net.sample(prefix, conditioning=cd, sample=False, stateful=True, use_graph=False)
+    assert torch.equal(fast, quad) and torch.equal(fast_eager, quad)
+    other = net.sample(prefix, conditioning=[(c + 1) % k for c, k in zip(cd, ncond)], sample=False)
+    assert not torch.equal(other, fast)                                      # the conditioning matters
+    seqs = P.spatial_index_sequences(shape, o.get_sequence_ordering())
+    x = torch.full((B, 1), 18, dtype=torch.long)
+    for _ in range(n):
+        x = torch.cat((x, P.forward(st, cfg, x, seqs, conds, "bos_replacement")[:, -1].argmax(-1, keepdim=True)), 1)
+    ref = x[:, 1:][:, o.get_revert_sequence_ordering()].reshape(B, *shape)
+    assert torch.equal(fast.cpu(), ref)
