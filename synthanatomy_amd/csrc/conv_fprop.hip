@@ -581,8 +581,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fprop_dma_kernel(const Fpro
     constexpr int BM = WM * MI * 16;
     constexpr int BN = WN * NI * 16;
     constexpr int NW = WM * WN;                           // 4 waves, or 8 (half-size wave tiles: twice the waves per SIMD to cover DMA / LDS latency)
-    static_assert(BM == 128 && (NW == 4 || NW == 8) && (!FUSE || NW == 4), "tile");
-    constexpr int A_PER_WAVE = 16 / NW;                    // 1 KiB pieces (8 rows) of the 128-row activation tile per wave
+    static_assert((BM == 128 || (BM == 256 && NW == 8 && MI == 4 && NI == 4)) && (NW == 4 || NW == 8) && (!FUSE || NW == 4), "tile");
+    constexpr int A_PER_WAVE = (BM / 8) / NW;              // 1 KiB pieces (8 rows) of the activation tile per wave
     constexpr int SZ = sizeof(T);
     constexpr int BKE = 128 / SZ;
     constexpr int B_PIECES = BN / 8;                       // 1 KiB pieces (8 rows) of the weight tile
@@ -718,6 +718,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fprop_dma_kernel(const Fpro
         static_assert(!FUSE || (sizeof(T) == 2 && BM == 128 && BN == 128), "fused residual block: bf16, 128 x 128 tile");
         resblock_second_gemm<MI, NI>(a, acc, smem, tid, wave, wm, wn, frow, fq, prow, lv,
                                      [&](uint32_t row) __attribute__((always_inline)) { return m_base + row < a.M ? (long long)(m_base + row) : -1ll; });
+    }
+    if constexpr (BM == 256) {
+        // 256 x 128 tile (eight waves of 64 x 64): full tiles of valid channels with 16-byte aligned rows leave through the register epilogue
+        const bool regs_ok = n_base + BN <= (uint32_t)g.cout_valid && (g.Cout & 7) == 0 && !(a.dbg & 256u);
+        if (regs_ok) {
+            fprop_epilogue_regs<MI, NI, 24>(a, acc, wm, wn, frow, fq, n_base,
+                                            [&](uint32_t row) __attribute__((always_inline)) { return linear_row_voxel(a, m_base + row); });
+            return;
+        }
     }
     fprop_epilogue<BM, BN, WM, WN, MI, NI, NW * 64>(a, acc, smem, tid, wm, wn, frow, fq, m_base, n_base);
 #endif
@@ -1187,6 +1196,13 @@ static int launch_fprop(const FpropArgs& a, hipStream_t st) {
     dim3 grid(a.nblk_m * nbn_valid);
     if (a.in_bytes != 0) {  // every operand addressable with 32-bit buffer offsets -> LDS-DMA mainloop
         const bool uniform = ((size_t)a.g.Cin * sizeof(T)) % 128 == 0;
+        if constexpr (BM == 256) {
+            static std::atomic<uint64_t> attr_done{0};
+            configure_once_per_device(attr_done, [] {
+                (void)hipFuncSetAttribute((const void*)conv_fprop_dma_kernel<T, WM, WN, MI, NI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)conv_fprop_dma_kernel<T, WM, WN, MI, NI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            });
+        }
         (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma_kernel<%s, %d, %d, %d, %d, %s, false>", tname<T>(), WM, WN, MI, NI, uniform ? "true" : "false"), note_kernel(g_last_conv_kernel));
         if (uniform) hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, true>), grid, dim3(WM * WN * 64), lds, st, a);
         else hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, false>), grid, dim3(WM * WN * 64), lds, st, a);
@@ -1291,6 +1307,17 @@ static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
         // 4x4x4 conv forward 1.83 -> 1.73 ms, its 8-parity data gradient 2.64 -> 2.17 ms, transposed conv forward 2.73 -> 2.15 ms at batch 8
         // (tools/microbench.py); SA_DBG_HALO256_4W keeps four waves for A/B runs
         const bool w8 = sizeof(T) == 2 && a.in_bytes != 0 && !dbg(SA_DBG_HALO256_4W);
+        // A/B instance only (SA_TILE256=1): 256 x 128 tiles (eight waves of 64 x 64 outputs, 96 KiB of LDS: ONE block per CU) move 87 FLOP per staged byte
+        // instead of 64 (128 x 128) or 43 (128 x 64), but MEASURED SLOWER in round 3: Performer step 40.2 vs 37.7 ms, VQ-VAE step 62.1 vs 63.3 volumes/s --
+        // again two or three independent blocks per CU beat the better operand reuse of one big block
+        if constexpr (sizeof(T) == 2) {
+            const uint64_t blocks256 = (uint64_t)((a.M + 255u) / 256u) * (((uint32_t)cv + 127u) / 128u);
+            if (w8 && dbg(SA_DBG_TILE256) && (uint32_t)cv % 128u == 0 && blocks256 >= 200) {
+                FpropArgs b = a;
+                b.nblk_m = (a.M + 255u) / 256u;
+                return launch_fprop<T, 4, 2, 4, 4>(b, st);
+            }
+        }
         if (small_ok && blocks128 < 2048 && a.in_bytes != 0) return w8 ? launch_fprop<T, 4, 2, 2, 2>(a, st) : launch_fprop<T, 4, 1, 2, 4>(a, st);
         return w8 ? launch_fprop<T, 4, 2, 2, 4>(a, st) : launch_fprop<T, 2, 2, 4, 4>(a, st);
     }
