@@ -351,8 +351,8 @@ __global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs
 
 // ------------------------------------------------------------------------------------------------ chunk state sums
 // U_c[m][d] = sum_{j in chunk} phi_a(j)[m] (b_j[d] bs_j),   z[m] = sum_j phi_a(j)[m] w_j     (zmode 1: w = 1, zmode 2: w = ex_scale_j)
-__global__ __launch_bounds__(256, 3) void favor_fstate_kernel(const FusedArgs s) {
-    __shared__ __attribute__((aligned(16))) unsigned char sBh[FT_BYTES], sBl[FT_BYTES], sAh[FT_BYTES], sAl[FT_BYTES], sP[2 * FT_BYTES];
+__global__ __launch_bounds__(256, 2) void favor_fstate_kernel(const FusedArgs s) {
+    __shared__ __attribute__((aligned(16))) unsigned char sBh[FT_BYTES], sBl[FT_BYTES], sAh[FT_BYTES], sAl[FT_BYTES], sP[2][2 * FT_BYTES];   // (the projection slab is double-buffered: two barriers per slab)
     __shared__ float sW[64];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
     const int chunk = blockIdx.x % s.S, g = (blockIdx.x / s.S) % s.G, b = blockIdx.x / (s.S * s.G);
@@ -374,6 +374,7 @@ __global__ __launch_bounds__(256, 3) void favor_fstate_kernel(const FusedArgs s)
         }
         sW[tid] = wv;
     }
+    pslab_store(sP[0], pre, tid);
     __syncthreads();
     const uint32_t trow = (uint32_t)g4 * 4u + ((uint32_t)fr >> 2), tcol = (uint32_t)(fr & 3) * 4u;
     short8_t bh[2], bl[2], wh[2], wl[2];   // this wave's 16 value columns d = w*16 + (lane & 15); the weights of the running sums in column 0
@@ -393,13 +394,13 @@ __global__ __launch_bounds__(256, 3) void favor_fstate_kernel(const FusedArgs s)
     const int nslab = (s.LDF + FSLAB - 1) / FSLAB;
     for (int sl = 0; sl < nslab; ++sl) {
         const int slab0 = sl * FSLAB;
-        if (sl) __syncthreads();            // the previous slab's feature tile and projection slab have been consumed
-        pslab_store(sP, pre, tid);
-        __syncthreads();
+        const unsigned char* sPc = sP[sl & 1];
         if (sl + 1 < nslab) pslab_load(pre, s.ptiles, sl + 1, tid);
         float4_t F[4];
-        feat_slab(F, sP, sP + FT_BYTES, xa, valid, slab0, s, fr, g4);
+        feat_slab(F, sPc, sPc + FT_BYTES, xa, valid, slab0, s, fr, g4);
+        if (sl) __syncthreads();            // the previous slab's feature tile has been consumed
         feat_to_tile(sAh, sAl, F, w, fr, g4);
+        if (sl + 1 < nslab) pslab_store(sP[(sl + 1) & 1], pre, tid);   // (its last readers finished before the barrier above)
         __syncthreads();
         float4_t acc[4];
 #pragma unroll
@@ -453,7 +454,7 @@ __global__ void favor_fprefix_kernel(float* __restrict__ state, int64_t BG, int 
 // ------------------------------------------------------------------------------------------------ chunk outputs, scan A
 // y_i[d] = sum_m T_prev[m][d] phi_x(i)[m] + sum_{j <= i} b_j[d] (phi_a(j) . phi_x(i))      (zmode 1: divided by phi_x(i) . (z_i + eps))
 __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_a_kernel(const FusedArgs s) {
-    __shared__ __attribute__((aligned(16))) unsigned char sAh[FT_BYTES], sAl[FT_BYTES], sTh[FT_BYTES], sTl[FT_BYTES], sP[2 * FT_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char sAh[FT_BYTES], sAl[FT_BYTES], sT[2][2 * FT_BYTES], sP[2][2 * FT_BYTES];   // state and projection slabs double-buffered
     unsigned char* const sBh = sAh;   // the value rows take the feature tile's place after the slab loop (48 KiB: three blocks per CU)
     unsigned char* const sBl = sAl;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
@@ -485,15 +486,17 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_a_kernel(const Fuse
     }
     float den = 0.f;
     const int nslab = (s.LDF + FSLAB - 1) / FSLAB;
+    tile_stage(sT[0], sT[0] + FT_BYTES, pt, tid);
+    pslab_store(sP[0], pre, tid);
+    __syncthreads();
     for (int sl = 0; sl < nslab; ++sl) {
         const int slab0 = sl * FSLAB;
-        if (sl) __syncthreads();
-        tile_stage(sTh, sTl, pt, tid);
-        pslab_store(sP, pre, tid);
+        const unsigned char* sPc = sP[sl & 1];
+        const unsigned char* sTh = sT[sl & 1];
+        const unsigned char* sTl = sTh + FT_BYTES;
         u32x4 zc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) zc[q] = pz[q];
-        __syncthreads();
         if (sl + 1 < nslab) {
             pslab_load(pre, s.ptiles, sl + 1, tid);
             tslab_load(pt, rt, slab0 + FSLAB, tid);
@@ -501,7 +504,8 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_a_kernel(const Fuse
             for (int q = 0; q < 4; ++q) pz[q] = f_ld4(rz, (uint32_t)(slab0 + FSLAB + q * 16 + g4 * 4) * 4u);
         }
         float4_t Fa[4], F[4];
-        feat_slab2(Fa, F, sP, sP + FT_BYTES, xa, xc, vi, slab0, s, fr, g4);
+        feat_slab2(Fa, F, sPc, sPc + FT_BYTES, xa, xc, vi, slab0, s, fr, g4);
+        if (sl) __syncthreads();   // the previous slab's GEMMs are done with the feature tile (and with the other slab buffers)
         feat_to_tile(sAh, sAl, Fa, w, fr, g4);
 #pragma unroll
         for (int f = 0; f < 4; ++f)
@@ -509,6 +513,10 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_a_kernel(const Fuse
             for (int r = 0; r < 4; ++r) den = fmaf(F[f][r], __uint_as_float(zc[f][r]) + s.den_eps, den);
         short8_t Ch[2], Cl[2];
         acc_to_operand(Ch, Cl, F);
+        if (sl + 1 < nslab) {      // next slab's operands into the other buffers while this slab's GEMMs run
+            tile_stage(sT[(sl + 1) & 1], sT[(sl + 1) & 1] + FT_BYTES, pt, tid);
+            pslab_store(sP[(sl + 1) & 1], pre, tid);
+        }
         __syncthreads();
         const int nks = (min(64, s.LDF - slab0) + 31) >> 5;
         tile_rows_gemm_perm(P, sAh, sAl, Ch, Cl, fr, g4, nks);   // pair products phi_a(j) . phi_x(i)
@@ -554,10 +562,10 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_a_kernel(const Fuse
 //   zmode 1: E[j][i] = ex_scale_i,  + ex_scale_i (z_prev[m] + ex_const);     zmode 2: E[j][i] = ex_scale_j,  + z_prev[m]
 // v = (phi_x(i) - ratio eps) dphi_i,  t = sum_m v[m],  dx_i = sum_m v[m] P[m] - [query] t P[argmax_i] - t c^2 x_i
 __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_b_kernel(const FusedArgs s) {
-    __shared__ __attribute__((aligned(16))) unsigned char sBh[FT_BYTES], sBl[FT_BYTES], sAh[FT_BYTES], sAl[FT_BYTES], sP[2 * FT_BYTES];
-    __shared__ float sred[4];
-    unsigned char* const sTh = sBh;   // the value tile is dead once the pair products exist: the state slabs take its place
-    unsigned char* const sTl = sBl;
+    __shared__ __attribute__((aligned(16))) unsigned char sT[2][2 * FT_BYTES], sAh[FT_BYTES], sAl[FT_BYTES], sP[2][2 * FT_BYTES];   // double-buffered slabs
+    float* const sred = (float*)sAh;    // (block reduction of the keys' t after the slab loop: the feature tile is dead by then; 80 KiB exactly -> two blocks per CU)
+    unsigned char* const sBh = sT[0];   // the value tile is dead once the pair products exist: the first state slab takes its place
+    unsigned char* const sBl = sT[0] + FT_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
     const int chunk = blockIdx.x % s.S, g = (blockIdx.x / s.S) % s.G, b = blockIdx.x / (s.S * s.G);
     const float kmax = unpack_max(*s.gmax);
@@ -620,12 +628,15 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_b_kernel(const Fuse
     for (int df = 0; df < 4; ++df) dxa[df] = (float4_t){0.f, 0.f, 0.f, 0.f};
     float tp = 0.f;
     const int nslab = (s.LDF + FSLAB - 1) / FSLAB;
+    __syncthreads();   // the pair products have read the value tile
+    tile_stage(sT[0], sT[0] + FT_BYTES, pt, tid);
+    pslab_store(sP[0], pre, tid);
+    __syncthreads();
     for (int sl = 0; sl < nslab; ++sl) {
         const int slab0 = sl * FSLAB;
-        __syncthreads();   // previous slab consumed (first pass: the pair products have read the value tile)
-        tile_stage(sTh, sTl, pt, tid);
-        pslab_store(sP, pre, tid);
-        __syncthreads();
+        const unsigned char* sPc = sP[sl & 1];
+        const unsigned char* sTh = sT[sl & 1];
+        const unsigned char* sTl = sTh + FT_BYTES;
         if (sl + 1 < nslab) {
             pslab_load(pre, s.ptiles, sl + 1, tid);
             tslab_load(pt, rt, slab0 + FSLAB, tid);
@@ -634,8 +645,13 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_b_kernel(const Fuse
 #pragma unroll
         for (int q = 0; q < 4; ++q) zc[q] = f_ld4(rz, (uint32_t)(slab0 + q * 16 + g4 * 4) * 4u);
         float4_t F[4], Fx[4];
-        feat_slab2(F, Fx, sP, sP + FT_BYTES, xa, xx, vi, slab0, s, fr, g4);
+        feat_slab2(F, Fx, sPc, sPc + FT_BYTES, xa, xx, vi, slab0, s, fr, g4);
+        if (sl) __syncthreads();   // the previous slab's GEMMs are done with the feature tile (and with the other slab buffers)
         feat_to_tile(sAh, sAl, F, w, fr, g4);
+        if (sl + 1 < nslab) {      // next slab's operands into the other buffers while this slab's GEMMs run
+            tile_stage(sT[(sl + 1) & 1], sT[(sl + 1) & 1] + FT_BYTES, pt, tid);
+            pslab_store(sP[(sl + 1) & 1], pre, tid);
+        }
         __syncthreads();
         float4_t acc[4];
 #pragma unroll
@@ -654,7 +670,7 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_b_kernel(const Fuse
             }
         short8_t Dh[2], Dl[2];
         acc_to_operand(Dh, Dl, acc);
-        tile_cols_gemm(dxa, sP, sP + FT_BYTES, Dh, Dl, lane);   // dx^T[d][i] += sum_m P[m][d] v[m][i]
+        tile_cols_gemm(dxa, sPc, sPc + FT_BYTES, Dh, Dl, lane);   // dx^T[d][i] += sum_m P[m][d] v[m][i]
     }
     float t = tp;
     t += __shfl_xor(t, 16, 64);
@@ -677,6 +693,7 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_b_kernel(const Fuse
     if (!s.is_query) {   // keys: the sum of t over all rows goes to the row that holds the global maximum (fix-up launch)
         float tb = (vi && g4 == 0) ? t : 0.f;
         tb = wave_sum(tb);
+        __syncthreads();   // every wave is past its last read of the feature tile
         if (lane == 0) sred[w] = tb;
         __syncthreads();
         if (tid == 0) s.tsum[blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);   // one partial per block, summed in a fixed order by the fix-up launch

@@ -3,8 +3,8 @@
 
     python tools/rocpd_tools.py stats   <trace.db> [--by-grid]             per-kernel launch count / total / avg / min / max / share
                                                                            (--by-grid: one row per (kernel, launch size): per-level numbers)
-    python tools/rocpd_tools.py pmc     <pmc.db>                           per-kernel mean of every collected counter
-    python tools/rocpd_tools.py traffic <fetch.db> <write.db> [out.json]   HBM-side bytes per launch: (2 x FETCH_SIZE + WRITE_SIZE) KiB
+    python tools/rocpd_tools.py pmc     <pmc.db> [--by-grid]               per-kernel mean of every collected counter
+    python tools/rocpd_tools.py traffic <fetch.db> <write.db> [out.json] [provenance] [--by-grid]   HBM-side bytes per launch: (2 x FETCH_SIZE + WRITE_SIZE) KiB
                                                                            (gfx950: 128-B read requests are tallied at 64 B, MI355X_MICROARCH.md)
 Kernel names are demangled and trimmed to the spelling `sa_last_conv_kernel()` reports (e.g. `conv_fprop_halo256_kernel<unsigned short, true, 8>`)."""
 import json
@@ -61,9 +61,9 @@ def stats(path, by_grid=False):
         print(f"{k[:96]:96s} {len(v):7d} {sum(v) / 1e6:10.3f} {sum(v) / len(v) / 1e3:10.2f} {min(v) / 1e3:10.2f} {max(v) / 1e3:10.2f} {100 * sum(v) / tot:6.2f}")
 
 
-def _counters(path):
+def _counters(path, by_grid=False):
     db, T = _open(path)
-    disp = _dispatches(db, T)
+    disp = _dispatches(db, T, by_grid)
     cname = {r[0]: r[1] for r in db.execute(f'select id, name from "{T("info_pmc")}"')}
     per = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))   # kernel -> counter -> event -> value summed over instances
     for eid, pid, val in db.execute(f'select event_id, pmc_id, value from "{T("pmc_event")}"'):
@@ -72,16 +72,23 @@ def _counters(path):
     return {k: {c: (sum(ev.values()) / len(ev), len(ev)) for c, ev in cs.items()} for k, cs in per.items()}
 
 
-def pmc(path):
-    for k, cs in _counters(path).items():
+def pmc(path, by_grid=False):
+    for k, cs in _counters(path, by_grid).items():
         print(k[:110])
         wc = cs.get("SQ_WAVE_CYCLES", (0, 0))[0] or 1.0
         for c, (v, n) in sorted(cs.items()):
             print(f"    {c:28s} launches={n:4d} mean={v:18.1f}  /WAVE_CYCLES={v / wc:7.3f}")
 
 
-def traffic(fetch_db, write_db, out=None, provenance=""):
-    f, w = _counters(fetch_db), _counters(write_db)
+def traffic(fetch_db, write_db, out=None, provenance="", by_grid=False):
+    """by_grid: rows per (kernel, launch size); the JSON then ALSO keeps the per-kernel means under the plain names (what bench.py looks up)."""
+    f, w = _counters(fetch_db, by_grid), _counters(write_db, by_grid)
+    if by_grid:
+        f0, w0 = _counters(fetch_db), _counters(write_db)
+        for k in f0:
+            f.setdefault(k, f0[k])
+        for k in w0:
+            w.setdefault(k, w0[k])
     rec = {}
     print(f"{'kernel':84s} {'launches':>8s} {'FETCH_SIZE KiB':>15s} {'WRITE_SIZE KiB':>15s} {'HBM GB/launch':>14s}")
     for k in sorted(f, key=lambda k: -(2 * f[k].get("FETCH_SIZE", (0, 0))[0] + w.get(k, {}).get("WRITE_SIZE", (0, 0))[0]) * f[k].get("FETCH_SIZE", (0, 1))[1]):
@@ -100,6 +107,7 @@ if __name__ == "__main__":
     if cmd == "stats":
         stats(sys.argv[2], by_grid="--by-grid" in sys.argv[3:])
     elif cmd == "pmc":
-        pmc(sys.argv[2])
+        pmc(sys.argv[2], by_grid="--by-grid" in sys.argv[3:])
     elif cmd == "traffic":
-        traffic(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None, sys.argv[5] if len(sys.argv) > 5 else "")
+        args = [x for x in sys.argv[2:] if x != "--by-grid"]
+        traffic(args[0], args[1], args[2] if len(args) > 2 else None, args[3] if len(args) > 3 else "", by_grid="--by-grid" in sys.argv[2:])
