@@ -7,6 +7,8 @@
  *   - raw device pointers + explicit sizes; no torch types; activations are channels-last [N, D, H, W, C]
  *   - no allocation, no synchronisation, no global state; `stream` is a hipStream_t passed as void*
  *   - return 0 on success, a negative SA_E* code or a positive hipError_t otherwise; never throws
+ *   - collectives are NOT part of this ABI: the reference reduces gradients / EMA statistics through torch.distributed (NCCL), and so does this
+ *     build (backend "nccl" = RCCL over xGMI, runtime/ddp.py); there are no sa_comm_* entry points
  *   - dtype: SA_F32 (exact-f32 MFMA 16x16x4) or SA_BF16 (MFMA 16x16x32, fp32 accumulate)
  */
 #ifndef SYNTHANATOMY_HIP_H
@@ -55,6 +57,13 @@ typedef struct sa_epilogue {
     int32_t add_before_act;
     int32_t out_dtype, add_dtype, mask_dtype;
     float slope;          /* LeakyReLU slope */
+    /* optional extra outputs of the same launch (bf16, laid out like out; the LDS-staged epilogue of the im2col-order kernels only -- a launch that
+     * would take another epilogue returns SA_EUNSUPPORTED):
+     *   out_pre: the value BEFORE activation / alpha / addend (acc + bias): the pre-activation a GELU backward needs (nn.Linear -> GELU in one launch),
+     *            or the branch output F of a ReZero block x + g F
+     *   out_lp : a bf16 copy of the final value (the operand of the next dense layer when out itself is the fp32 residual stream) */
+    void *out_pre;
+    void *out_lp;
 } sa_epilogue;
 
 int sa_abi_version(void);

@@ -44,6 +44,7 @@ class Epilogue(Structure):
         ("act", c_int32), ("mask_mode", c_int32), ("add_before_act", c_int32),
         ("out_dtype", c_int32), ("add_dtype", c_int32), ("mask_dtype", c_int32),
         ("slope", c_float),
+        ("out_pre", c_void_p), ("out_lp", c_void_p),
     ]
 
 

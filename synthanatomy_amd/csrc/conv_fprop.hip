@@ -123,6 +123,12 @@ __device__ __forceinline__ void fprop_epilogue_ov(const FpropArgs& a, float4_t (
             const float4_t tv = *(const float4_t*)(sT + row * LDT + grp * 4);
             float v[4] = {tv[0], tv[1], tv[2], tv[3]};
             const bool full = vec_ok && co0 + 3 < (uint32_t)g.cout_valid;
+            if (ep.out_pre && full) {   // pre-activation copy (bf16): acc + bias
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                *(uint2*)((bf16_t*)ep.out_pre + o) = pk;
+            }
             float ad[4] = {0.f, 0.f, 0.f, 0.f}, mk[4] = {1.f, 1.f, 1.f, 1.f};
             if (full) {
                 if (ep.addend) {
@@ -175,6 +181,12 @@ __device__ __forceinline__ void fprop_epilogue_ov(const FpropArgs& a, float4_t (
                     pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
                     pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
                     *(uint2*)((bf16_t*)a.out + o) = pk;
+                }
+                if (ep.out_lp) {        // bf16 copy of the final value
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *(uint2*)((bf16_t*)ep.out_lp + o) = pk;
                 }
             } else {
 #pragma unroll
@@ -1293,6 +1305,10 @@ static int launch_fprop_halo256(FpropArgs a, hipStream_t st) {
 template <typename T>
 static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
     const int cv = a.g.cout_valid;
+    if (a.ep.out_pre || a.ep.out_lp) {
+        // the extra outputs exist in the LDS-staged epilogue of the im2col-order kernels (dense layers): whole 4-channel groups only
+        if (halo256_eligible(a, (int)sizeof(T)) || halo_eligible(a, (int)sizeof(T)) || (cv & 3) || (a.g.Cout & 3) || dbg(SA_DBG_TILE256)) return SA_EUNSUPPORTED;
+    }
     if (halo256_eligible(a, (int)sizeof(T))) return launch_fprop_halo256<T>(a, st);
     if (halo_eligible(a, (int)sizeof(T))) return launch_fprop_halo<T, false>(a, st);
     // (measured and removed: a 3-stage ring with 8 waves and counted vmcnt = the 2-stage loop; an 8-wave ping-pong with staggered

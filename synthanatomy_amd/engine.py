@@ -246,8 +246,10 @@ class ConvOp:
 
     # ------------------------------------------------------------------ launches
     @staticmethod
-    def _epilogue(bias, addend, mask, alpha, act, mask_mode, add_before_act, out_dtype, slope) -> Epilogue:
+    def _epilogue(bias, addend, mask, alpha, act, mask_mode, add_before_act, out_dtype, slope, out_pre=None, out_lp=None) -> Epilogue:
         ep = Epilogue()
+        ep.out_pre = out_pre.data_ptr() if out_pre is not None else None
+        ep.out_lp = out_lp.data_ptr() if out_lp is not None else None
         ep.bias = bias.data_ptr() if bias is not None else None
         ep.addend = addend.data_ptr() if addend is not None else None
         ep.mask = mask.data_ptr() if mask is not None else None
@@ -260,7 +262,9 @@ class ConvOp:
         return ep
 
     def fprop(self, x: torch.Tensor, *, act=ACT_NONE, addend=None, add_before_act=False, mask=None, mask_mode=MASK_NONE, alpha=None,
-              out_dtype=None, out_channels_stride=None, slope=0.2, use_bias=True) -> torch.Tensor:
+              out_dtype=None, out_channels_stride=None, slope=0.2, use_bias=True, want_pre=False, want_lp=False):
+        """want_pre / want_lp (dense layers, bf16 extras of the same launch, sa_epilogue.out_pre / out_lp): returns (out, pre, lp) where pre = acc + bias
+        before activation / alpha / addend and lp = a bf16 copy of out."""
         N, D, H, W, C = x.shape
         assert x.dtype == self.dtype and x.is_contiguous() and C == self.cs_in(), (x.dtype, x.shape, self.cs_in())
         out_dtype = out_dtype or self.dtype
@@ -271,12 +275,16 @@ class ConvOp:
         out = torch.empty((N, *od, cout_s), dtype=out_dtype, device=x.device)
         if cout_s != self.cout:
             out.zero_()
-        ep = self._epilogue(self._bias_padded() if use_bias else None, addend, mask, alpha, act, mask_mode, add_before_act, out_dtype, slope)
+        pre = torch.empty((N, *od, cout_s), dtype=torch.bfloat16, device=x.device) if want_pre else None
+        lp = torch.empty((N, *od, cout_s), dtype=torch.bfloat16, device=x.device) if want_lp else None
+        ep = self._epilogue(self._bias_padded() if use_bias else None, addend, mask, alpha, act, mask_mode, add_before_act, out_dtype, slope, pre, lp)
         lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
         for pl in plans["fwd"]:
             _launch(None, _geom_flops(pl.geom),
                     lambda pl=pl: _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(x), _ffi.ptr(pl.wpk), _ffi.ptr(out), ctypes.byref(ep), st),
                                              "sa_conv_fprop"))
+        if want_pre or want_lp:
+            return out, pre, lp
         return out
 
     def dgrad(self, g: torch.Tensor, idims: Tuple[int, int, int], *, addend=None, mask=None, mask_mode=MASK_NONE, out_dtype=None, slope=0.2,

@@ -489,23 +489,37 @@ class _LayerEngine:
                                       B, N, L, self.W, dh, st), "sa_local_attn_fwd")
             sv.update(qr=qr, kr=kr, lse=lse)
         attnT = _cast(attn, T)
-        Fa = self.ops["to_out"].fprop(_as5(attnT)).view(R, self.dim)
-        x1 = torch.empty_like(x)
         ga = self._gate(self.aw, dev)
-        x1T = torch.empty(x.shape, dtype=T, device=dev) if lp else None
-        _ck(lib.sa_rezero_fwd(_ffi.ptr(x), _ffi.ptr(Fa), _ffi.dtype_id(Fa.dtype), _ffi.ptr(ga), _ffi.ptr(x1), _ffi.ptr(x1T), _ffi.dtype_id(T) if lp else 0, x.numel(), st),
-            "sa_rezero_fwd")
+        gf = self._gate(self.fw, dev)
+        fuse_epi = lp and not debug.host("no_fused_epilogues")
+        if fuse_epi:
+            # throughput mode: x1 = x + g F leaves the to_out launch itself (fp32 residual stream + its bf16 copy for the next dense layer + the branch
+            # output F the ReZero backward needs) -- no sa_rezero_fwd launch, F is never re-read
+            x1, Fa, x1T = self.ops["to_out"].fprop(_as5(attnT), out_dtype=f32, alpha=ga, addend=_as5(x), want_pre=True, want_lp=True)
+            x1, Fa, x1T = x1.view(R, self.dim), Fa.view(R, self.dim), x1T.view(R, self.dim)
+        else:
+            Fa = self.ops["to_out"].fprop(_as5(attnT)).view(R, self.dim)
+            x1 = torch.empty_like(x)
+            x1T = torch.empty(x.shape, dtype=T, device=dev) if lp else None
+            _ck(lib.sa_rezero_fwd(_ffi.ptr(x), _ffi.ptr(Fa), _ffi.dtype_id(Fa.dtype), _ffi.ptr(ga), _ffi.ptr(x1), _ffi.ptr(x1T), _ffi.dtype_id(T) if lp else 0, x.numel(), st),
+                "sa_rezero_fwd")
         xf, st_f = self._pre(self.fw, x1, R)
         xfT = x1T if lp else _cast(xf, T)
-        u = self.ops["w1"].fprop(_as5(xfT)).view(R, -1)
-        h = torch.empty_like(u)
-        _ck(lib.sa_gelu(_ffi.ptr(u), _ffi.dtype_id(u.dtype), _ffi.ptr(h), _ffi.dtype_id(h.dtype), u.numel(), st), "sa_gelu")
-        Ff = self.ops["w2"].fprop(_as5(h)).view(R, self.dim)
-        x2 = torch.empty_like(x)
-        gf = self._gate(self.fw, dev)
-        x2T = torch.empty(x.shape, dtype=T, device=dev) if lp else None
-        _ck(lib.sa_rezero_fwd(_ffi.ptr(x1), _ffi.ptr(Ff), _ffi.dtype_id(Ff.dtype), _ffi.ptr(gf), _ffi.ptr(x2), _ffi.ptr(x2T), _ffi.dtype_id(T) if lp else 0, x.numel(), st),
-            "sa_rezero_fwd")
+        if fuse_epi:
+            # h = gelu(u) and the pre-activation u (for the GELU backward) from ONE launch; x2 = x1 + g F from the w2 launch
+            h, u, _ = self.ops["w1"].fprop(_as5(xfT), act=_ffi.ACT_GELU, want_pre=True)
+            h, u = h.view(R, -1), u.view(R, -1)
+            x2, Ff, x2T = self.ops["w2"].fprop(_as5(h), out_dtype=f32, alpha=gf, addend=_as5(x1), want_pre=True, want_lp=True)
+            x2, Ff, x2T = x2.view(R, self.dim), Ff.view(R, self.dim), x2T.view(R, self.dim)
+        else:
+            u = self.ops["w1"].fprop(_as5(xfT)).view(R, -1)
+            h = torch.empty_like(u)
+            _ck(lib.sa_gelu(_ffi.ptr(u), _ffi.dtype_id(u.dtype), _ffi.ptr(h), _ffi.dtype_id(h.dtype), u.numel(), st), "sa_gelu")
+            Ff = self.ops["w2"].fprop(_as5(h)).view(R, self.dim)
+            x2 = torch.empty_like(x)
+            x2T = torch.empty(x.shape, dtype=T, device=dev) if lp else None
+            _ck(lib.sa_rezero_fwd(_ffi.ptr(x1), _ffi.ptr(Ff), _ffi.dtype_id(Ff.dtype), _ffi.ptr(gf), _ffi.ptr(x2), _ffi.ptr(x2T), _ffi.dtype_id(T) if lp else 0, x.numel(), st),
+                "sa_rezero_fwd")
         self.out_lp = x2T
         if tape is not None:
             sv.update(attnT=attnT, Fa=Fa, x1=x1, xf=xf, xfT=xfT, st_f=st_f, u=u, h=h, Ff=Ff)
