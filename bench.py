@@ -279,7 +279,7 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
     return res
 
 
-PMC_FILE = "r02_pmc_traffic.json"   # profiles/: HBM bytes per launch from the committed PMC passes (its `_provenance` names the command and commit)
+PMC_FILE = "r03_pmc_traffic.json"   # profiles/: HBM bytes per launch from the committed PMC passes (its `_provenance` names the command and commit)
 
 
 def _pmc_traffic(kernel, args):
