@@ -299,6 +299,9 @@ int sa_favor_dden(const float *dout, const float *out, int stride, int off, int 
 /* rotary embedding of the local heads (local-attention >= 1.2); transpose=1 applies the adjoint (backward) */
 int sa_rotary(const float *x, int stride, int off, int L, int dh, const float *cosb, const float *sinb, float *y, int y_stride, int y_off,
               int N, int64_t R, int transpose, int accumulate, void *stream);
+/* the same rotation for `ngroups` operands in one launch (q and k of a layer): operand gi is read x_goff and written y_goff ELEMENTS behind operand 0 */
+int sa_rotary_groups(const float *x, int stride, int off, int L, int dh, const float *cosb, const float *sinb, float *y, int y_stride, int y_off,
+                     int N, int64_t R, int transpose, int accumulate, int ngroups, int64_t x_goff, int64_t y_goff, void *stream);
 /* causal local-window attention (window W, look back one window): per query softmax over keys [max(0,(n/W-1)W), n].
  * fp32 in / out; products are evaluated as split-bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate; ~1e-5 relative) unless the environment
  * has SA_LOCAL_ATTN_EXACT=1 (exact-fp32 MFMA).  N * max(stride) * 4 must stay below 2^31 (SA_EUNSUPPORTED otherwise). */

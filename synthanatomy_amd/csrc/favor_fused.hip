@@ -12,6 +12,8 @@
 // operand.  The backward kernels apply the feature-map backward and the projection adjoint to the gradient slab while it is still in registers:
 //     v = (phi - ratio eps) dphi,  t = sum_f v_f,  dx = sum_f v_f P[f] - [query] t P[argmax] - t c^2 x      (keys: -(sum of all t) P[f*] on the global-max row)
 // so d loss / d phi, d loss / d dd never exist in memory either.  Arithmetic = the unfused throughput path (split-bf16 products, fp32 accumulation).
+#include <algorithm>
+
 #include "sa_common.h"
 #include "split_bf16.h"
 
@@ -236,13 +238,12 @@ struct PrepassArgs {
 __device__ __forceinline__ int64_t head_row_off(int64_t r, int heads, int stride) { return (r / heads) * stride + (r % heads) * 64; }
 
 __global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs a) {
-    // block = 256 head rows (wave = 4 x 16 of them); the projection matrix comes in as the pre-split slab tiles (a straight 80 KiB copy, no split work)
+    // PERSISTENT blocks (two per CU: the projection matrix, 80 KiB of pre-split slab tiles, is staged once per block) walk tiles of 64 head rows
+    // (wave = 16 of them) of q (tiles [0, ntq)) and k (tiles [ntq, 2 ntq)): fine-grained tiles keep the last round of the walk short
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long sbest[4];
     const int nfr = a.LDF >> 4;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), qi = lane & 15, g = lane >> 4;
-    const bool isq = (int)blockIdx.x < a.nbq;
-    const float* X = isq ? a.q : a.k;
-    const int64_t r0 = (int64_t)(isq ? blockIdx.x : blockIdx.x - a.nbq) * 256 + w * 64;
     {
         const u32x4* src = (const u32x4*)a.ptiles;
         u32x4 v[20];
@@ -251,101 +252,80 @@ __global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs
 #pragma unroll
         for (int t = 0; t < 20; ++t) ((u32x4*)smem)[tid + 256 * t] = v[t];
     }
-    short8_t xh[4][2], xl[4][2];
-    float ss[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-        const int64_t r = r0 + st * 16 + qi;
+    __syncthreads();
+    unsigned long long best = 0ull;
+    for (int tile = blockIdx.x; tile < 2 * a.nbq; tile += gridDim.x) {
+        const bool isq = tile < a.nbq;
+        const float* X = isq ? a.q : a.k;
+        const int64_t r = (int64_t)(isq ? tile : tile - a.nbq) * 64 + w * 16 + qi;
         const bool ok = r < a.rows;
         const float* xr = X + head_row_off(ok ? r : a.rows - 1, a.heads, a.stride);
+        short8_t xh[2], xl[2];
+        float ss = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             float4 v0 = *(const float4*)(xr + ks * 32 + g * 8), v1 = *(const float4*)(xr + ks * 32 + g * 8 + 4);
             if (!ok) v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
             const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ss[st] = fmaf(xs[e], xs[e], ss[st]);
-            split8(xs, xh[st][ks], xl[st][ks]);
+            for (int e = 0; e < 8; ++e) ss = fmaf(xs[e], xs[e], ss);
+            split8(xs, xh[ks], xl[ks]);
         }
-    }
-    __syncthreads();
-    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    int am[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
-    for (int f = 0; f < nfr; ++f) {
-        const unsigned char* sPh = smem + (f >> 2) * (2 * FT_BYTES);
-        const unsigned char* sPl = sPh + FT_BYTES;
-        short8_t ah[2], al[2];
+        float mx = -INFINITY;
+        int am = 0x7fffffff;
+#pragma unroll 2
+        for (int f = 0; f < nfr; ++f) {
+            const unsigned char* sPh = smem + (f >> 2) * (2 * FT_BYTES);
+            const unsigned char* sPl = sPh + FT_BYTES;
+            float4_t c = (float4_t){0.f, 0.f, 0.f, 0.f};
+            // per accumulator the product order of tile_rows_gemm (hi*lo, lo*hi, hi*hi), so the chunk kernels rebuild bit-identical dd values
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const uint32_t o = lroff((f & 3) * 16 + qi, ks * 32 + g * 8);
-            ah[ks] = *(const short8_t*)(sPh + o);
-            al[ks] = *(const short8_t*)(sPl + o);
-        }
-        float4_t c[4];
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint32_t o = lroff((f & 3) * 16 + qi, ks * 32 + g * 8);
+                const short8_t ah = *(const short8_t*)(sPh + o), al = *(const short8_t*)(sPl + o);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[ks], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[ks], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[ks], c, 0, 0, 0);
+            }
 #pragma unroll
-        for (int st = 0; st < 4; ++st) c[st] = (float4_t){0.f, 0.f, 0.f, 0.f};
-        // per accumulator the product order of tile_rows_gemm (hi*lo, lo*hi, hi*hi), so the fused kernels rebuild bit-identical dd values
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int st = 0; st < 4; ++st) c[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], xl[st][ks], c[st], 0, 0, 0);
-#pragma unroll
-            for (int st = 0; st < 4; ++st) c[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], xh[st][ks], c[st], 0, 0, 0);
-#pragma unroll
-            for (int st = 0; st < 4; ++st) c[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], xh[st][ks], c[st], 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int col = f * 16 + g * 4 + r;
-            const bool in = col < a.m;
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const bool t0 = in & ((c[st][r] > mx[st]) | ((c[st][r] == mx[st]) & (col < am[st])));
-                mx[st] = t0 ? c[st][r] : mx[st];
-                am[st] = t0 ? col : am[st];
+            for (int rr = 0; rr < 4; ++rr) {
+                const int col = f * 16 + g * 4 + rr;
+                const bool t0 = (col < a.m) & ((c[rr] > mx) | ((c[rr] == mx) & (col < am)));
+                mx = t0 ? c[rr] : mx;
+                am = t0 ? col : am;
             }
         }
-    }
-    // a row lives in the four lanes qi, qi + 16, qi + 32, qi + 48
+        // a row lives in the four lanes qi, qi + 16, qi + 32, qi + 48
 #pragma unroll
-    for (int o = 16; o <= 32; o <<= 1)
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const float om = __shfl_xor(mx[st], o, 64);
-            const int oa = __shfl_xor(am[st], o, 64);
-            const bool t0 = (om > mx[st]) | ((om == mx[st]) & (oa < am[st]));
-            mx[st] = t0 ? om : mx[st];
-            am[st] = t0 ? oa : am[st];
-            ss[st] += __shfl_xor(ss[st], o, 64);
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float om = __shfl_xor(mx, o, 64);
+            const int oa = __shfl_xor(am, o, 64);
+            const bool t0 = (om > mx) | ((om == mx) & (oa < am));
+            mx = t0 ? om : mx;
+            am = t0 ? oa : am;
+            ss += __shfl_xor(ss, o, 64);
         }
-    unsigned long long best = 0ull;
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-        const int64_t r = r0 + st * 16 + qi;
-        if (r < a.rows) {
+        if (ok) {
             if (isq) {
-                if (g == 0) { a.offq[r] = ss[st] * a.c2half + mx[st]; a.amq[r] = am[st]; }
+                if (g == 0) { a.offq[r] = ss * a.c2half + mx; a.amq[r] = am; }
             } else {
-                if (g == 0) a.offk[r] = ss[st] * a.c2half;
-                const unsigned long long b1 = pack_max(mx[st], (uint32_t)(r * a.LDF) + (uint32_t)am[st]);
+                if (g == 0) a.offk[r] = ss * a.c2half;
+                const unsigned long long b1 = pack_max(mx, (uint32_t)(r * a.LDF) + (uint32_t)am);
                 best = b1 > best ? b1 : best;
             }
         }
     }
-    if (!isq) {
-        __shared__ unsigned long long sbest[4];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long ot = __shfl_xor(best, o, 64);
-            best = ot > best ? ot : best;
-        }
-        if (lane == 0) sbest[w] = best;
-        __syncthreads();
-        if (tid == 0) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ot = __shfl_xor(best, o, 64);
+        best = ot > best ? ot : best;
+    }
+    if (lane == 0) sbest[w] = best;
+    __syncthreads();
+    if (tid == 0) {
 #pragma unroll
-            for (int q = 1; q < 4; ++q) best = sbest[q] > best ? sbest[q] : best;
-            atomicMax(a.gmax, best);
-        }
+        for (int q = 1; q < 4; ++q) best = sbest[q] > best ? sbest[q] : best;
+        if (best) atomicMax(a.gmax, best);
     }
 }
 
@@ -754,14 +734,24 @@ extern "C" int sa_favor_fused_prepass(const float* q, const float* k, int stride
     if (dh != 64 || m <= 0 || m > 272 || (stride & 3) || stride < G * 64 || rows * 272 >= ((int64_t)1 << 32) - 1) return SA_EUNSUPPORTED;
     PrepassArgs a = {};
     a.q = q; a.k = k; a.ptiles = (const unsigned char*)tiles; a.offq = offq; a.offk = offk; a.amq = amq; a.gmax = (unsigned long long*)gmax_ws; a.rows = rows; a.m = m;
-    a.LDF = ldf_of(m); a.stride = stride; a.heads = G; a.nbq = (int)((rows + 255) / 256);
+    a.LDF = ldf_of(m); a.stride = stride; a.heads = G; a.nbq = (int)((rows + 63) / 64);   // tiles of 64 head rows per operand
     const float c = powf((float)dh, -0.25f);
     a.c2half = 0.5f * c * c;
     const size_t lds = (size_t)5 * 2 * FT_BYTES;
     static std::atomic<uint64_t> attr_done{0};
     configure_once_per_device(attr_done, [] { (void)hipFuncSetAttribute((const void*)favor_prepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 2 * FT_BYTES); });
     hipMemsetAsync(gmax_ws, 0, 8, (hipStream_t)stream);
-    SA_LAUNCH(favor_prepass_kernel, dim3((unsigned)(2 * a.nbq)), dim3(256), lds, (hipStream_t)stream, a);
+    static std::atomic<int> cu_count[64];   // per device ordinal, queried once (0 = not yet)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int cus = cu_count[dev & 63].load(std::memory_order_relaxed);
+    if (cus <= 0) {
+        cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        cu_count[dev & 63].store(cus, std::memory_order_relaxed);
+    }
+    const unsigned nblk = (unsigned)std::min<int64_t>(2 * (int64_t)a.nbq, 2 * (int64_t)cus);   // persistent: two blocks per CU
+    SA_LAUNCH(favor_prepass_kernel, dim3(nblk), dim3(256), lds, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     return 0;
 }

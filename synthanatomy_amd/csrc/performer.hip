@@ -1309,10 +1309,15 @@ __global__ void favor_dden_kernel(const float* __restrict__ dout, const float* _
 // thread = four consecutive dimensions of the first half of one head row and their partners in the second half (16-byte accesses)
 __global__ void rotary_kernel(const float* __restrict__ x, int stride, int off, int L, int dh, const float* __restrict__ cosb,
                               const float* __restrict__ sinb, float* __restrict__ y, int y_stride, int y_off, int N, int64_t R, int mode,
-                              int accumulate) {
+                              int accumulate, int ngroups, int64_t x_goff, int64_t y_goff) {
+    // ngroups > 1: the same rotation for several operands in one launch (q and k): group gi reads at x + gi * x_goff and writes at y + gi * y_goff
     const int half = dh / 2, q4 = half / 4;
-    const int64_t total = R * L * q4;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t per = R * L * q4, total = per * ngroups;
+    for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += (int64_t)gridDim.x * blockDim.x) {
+        const int gi = (int)(e0 / per);
+        const int64_t e = e0 - gi * per;
+        x += gi * x_goff;
+        y += gi * y_goff;
         const int j = (int)(e % q4);
         const int64_t rh = e / q4;
         const int h = (int)(rh % L);
@@ -1338,6 +1343,8 @@ __global__ void rotary_kernel(const float* __restrict__ x, int stride, int off, 
         }
         *(float4*)yp = ol;
         *(float4*)(yp + half) = oh;
+        x -= gi * x_goff;
+        y -= gi * y_goff;
     }
 }
 
@@ -1984,7 +1991,18 @@ extern "C" int sa_rotary(const float* x, int stride, int off, int L, int dh, con
     if (!x || !cosb || !sinb || !y || L <= 0 || dh <= 0 || (dh & 1) || R <= 0) return SA_EINVAL;
     if ((dh & 7) || ((stride | off | y_stride | y_off) & 3)) return SA_EUNSUPPORTED;   // 16-byte accesses on both halves of a head row
     SA_LAUNCH(rotary_kernel, dim3(grid1d(R * L * dh / 8)), dim3(256), 0, ST(stream), x, stride, off, L, dh, cosb, sinb, y, y_stride, y_off, N, R,
-                       transpose, accumulate);
+                       transpose, accumulate, 1, (int64_t)0, (int64_t)0);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+// the same for `ngroups` operands in one launch (q and k of a layer): operand gi lives x_goff / y_goff ELEMENTS behind operand 0
+extern "C" int sa_rotary_groups(const float* x, int stride, int off, int L, int dh, const float* cosb, const float* sinb, float* y, int y_stride, int y_off,
+                                int N, int64_t R, int transpose, int accumulate, int ngroups, int64_t x_goff, int64_t y_goff, void* stream) {
+    if (!x || !cosb || !sinb || !y || L <= 0 || dh <= 0 || (dh & 1) || R <= 0 || ngroups < 1) return SA_EINVAL;
+    if ((dh & 7) || ((stride | off | y_stride | y_off) & 3) || ((x_goff | y_goff) & 3)) return SA_EUNSUPPORTED;
+    SA_LAUNCH(rotary_kernel, dim3(grid1d(R * L * dh / 8 * ngroups)), dim3(256), 0, ST(stream), x, stride, off, L, dh, cosb, sinb, y, y_stride, y_off, N, R,
+                       transpose, accumulate, ngroups, x_goff, y_goff);
     SA_CHECK_LAUNCH();
     return 0;
 }

@@ -480,10 +480,14 @@ class _LayerEngine:
             sv.update(qg=qg, kg=kg, ddq=ddq, ddk=ddk, qf=qf, kf=kf, gws=gws, Z=Z, inv=inv, scan_state=ws if (Z is None and tape is not None) else None)
         if L > 0:
             cosb, sinb = self._rot_tables(N, dev)
-            qr = torch.empty(R, L * dh, dtype=f32, device=dev)
-            kr = torch.empty(R, L * dh, dtype=f32, device=dev)
-            _ck(lib.sa_rotary(_ffi.ptr(q), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(qr), L * dh, 0, N, R, 0, 0, st), "sa_rotary(q)")
-            _ck(lib.sa_rotary(_ffi.ptr(k), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(kr), L * dh, 0, N, R, 0, 0, st), "sa_rotary(k)")
+            qkr = torch.empty(2, R, L * dh, dtype=f32, device=dev)
+            qr, kr = qkr[0], qkr[1]
+            if k.data_ptr() - q.data_ptr() == inner * 4 and q.stride(0) == k.stride(0):   # q | k are column blocks of one matrix: one launch rotates both
+                _ck(lib.sa_rotary_groups(_ffi.ptr(q), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(qkr), L * dh, 0, N, R, 0, 0, 2, inner, R * L * dh, st),
+                    "sa_rotary_groups(q|k)")
+            else:
+                _ck(lib.sa_rotary(_ffi.ptr(q), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(qr), L * dh, 0, N, R, 0, 0, st), "sa_rotary(q)")
+                _ck(lib.sa_rotary(_ffi.ptr(k), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(kr), L * dh, 0, N, R, 0, 0, st), "sa_rotary(k)")
             lse = torch.empty(R * L, dtype=f32, device=dev)
             _ck(lib.sa_local_attn_fwd(_ffi.ptr(qr), L * dh, 0, _ffi.ptr(kr), L * dh, 0, _ffi.ptr(v), qs, G * dh, _ffi.ptr(attn), inner, G * dh, _ffi.ptr(lse),
                                       B, N, L, self.W, dh, st), "sa_local_attn_fwd")
@@ -721,14 +725,18 @@ class _LayerEngine:
                                                       _ffi.ptr(sv["gws"]), _ffi.ptr(tsum), R * G, m, LDF, dh, st), "sa_favor_features_project_bwd(k)")
         if L > 0:
             cosb, sinb = self._rot_tables(N, dev)
-            dqr = torch.empty(R, L * dh, dtype=f32, device=dev)
-            dkr = torch.empty(R, L * dh, dtype=f32, device=dev)
+            dqkr = torch.empty(2, R, L * dh, dtype=f32, device=dev)
+            dqr, dkr = dqkr[0], dqkr[1]
             Db = torch.empty(R * L, dtype=f32, device=dev)
             _ck(lib.sa_local_attn_bwd(_ffi.ptr(sv["qr"]), L * dh, 0, _ffi.ptr(sv["kr"]), L * dh, 0, _ffi.ptr(v), qs, G * dh, _ffi.ptr(attn), _ffi.ptr(dattn),
                                       inner, G * dh, _ffi.ptr(sv["lse"]), _ffi.ptr(dqr), _ffi.ptr(dkr), _ffi.ptr(dv), _ffi.ptr(Db), B, N, L, self.W, dh, st),
                 "sa_local_attn_bwd")
-            _ck(lib.sa_rotary(_ffi.ptr(dqr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dq), qs, G * dh, N, R, 1, 0, st), "sa_rotary^T(q)")
-            _ck(lib.sa_rotary(_ffi.ptr(dkr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dk), qs, G * dh, N, R, 1, 0, st), "sa_rotary^T(k)")
+            if fused_qkv:   # dq | dk are column blocks of one matrix: one launch
+                _ck(lib.sa_rotary_groups(_ffi.ptr(dqkr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dq), qs, G * dh, N, R, 1, 0, 2, R * L * dh, inner, st),
+                    "sa_rotary_groups^T(q|k)")
+            else:
+                _ck(lib.sa_rotary(_ffi.ptr(dqr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dq), qs, G * dh, N, R, 1, 0, st), "sa_rotary^T(q)")
+                _ck(lib.sa_rotary(_ffi.ptr(dkr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dk), qs, G * dh, N, R, 1, 0, st), "sa_rotary^T(k)")
         xaT = _as5(sv["xaT"])
         base = _as5(dx1) if self.rezero else None
         if fused_qkv:
