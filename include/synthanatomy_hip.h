@@ -95,6 +95,7 @@ int sa_kernel_log_read(char *buf, int cap, int stop);
 #define SA_DBG_LOCAL_ATTN_EXACT  (1u << 9)   /* local attention on the exact-fp32 MFMA kernels */
 #define SA_DBG_HALO256_4W        (1u << 13)  /* bf16 forward / data- / weight-gradient kernels with four waves per block instead of eight */
 #define SA_DBG_TILE256           (1u << 14)  /* A/B: 256 x 128 tiles for the im2col-order forward / data-gradient kernel (measured slower) */
+#define SA_DBG_DENSE_NARROW      (1u << 15)  /* A/B: 128 x 64 tiles for every small dense grid (the round-2 rule) */
 #define SA_DBG_SCAN_EXACT_SHIFT  10          /* 3 bits: chunk states | scan A outputs | scan B outputs on the exact-fp32 MFMA kernels */
 /* measurement aid (bench.py `roofline.peak_measured`): `blocks` x 4 waves each issue iters x 8 independent v_mfma_f32_32x32x16_bf16;
  * FLOPs per call = blocks * 4 * iters * 8 * 32768.  `scratch` = any 4 device bytes (never written in practice). */

@@ -1334,7 +1334,11 @@ static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
                 return launch_fprop<T, 4, 2, 4, 4>(b, st);
             }
         }
-        if (small_ok && blocks128 < 2048 && a.in_bytes != 0) return w8 ? launch_fprop<T, 4, 2, 2, 2>(a, st) : launch_fprop<T, 4, 1, 2, 4>(a, st);
+        // Round 3, per shape (tools/bench_dense_tiles.py, M = 8 400): the narrow tile only pays for SHORT reductions over few output columns
+        // (K <= 512 and N <= 2 048: 51.9 vs 51.2, 31.0 vs 31.8 us); with K >= 1 024 the wide tile wins by 14-32 % (w2 forward 52.7 -> 39.3 us,
+        // q|k|v data gradient 76.3 -> 51.6 us) and q|k|v forward (N = 3 072) by 15 %.  SA_DENSE_NARROW=1 restores the round-2 rule for A/B runs.
+        const bool narrow_shape = (a.nk <= 8 && cv <= 2048) || dbg(SA_DBG_DENSE_NARROW);
+        if (small_ok && narrow_shape && blocks128 < 2048 && a.in_bytes != 0) return w8 ? launch_fprop<T, 4, 2, 2, 2>(a, st) : launch_fprop<T, 4, 1, 2, 4>(a, st);
         return w8 ? launch_fprop<T, 4, 2, 2, 4>(a, st) : launch_fprop<T, 2, 2, 4, 4>(a, st);
     }
     if (cv > 32) return launch_fprop<T, 4, 1, 2, 4>(a, st);
