@@ -205,6 +205,12 @@ def run(argv):
     cfg.update(rank=rank, local_rank=local, world_size=world)
     torch.manual_seed(cfg["seed"])
     np.random.seed(cfg["seed"])
+    if cfg.get("deterministic"):
+        # upstream: torch.backends.cudnn.deterministic (src/utils/general.py:336-338).  Here the forward passes, the FAVOR+ / local-attention / dense
+        # kernels and every weight gradient that goes through a workspace + reduce are run-to-run deterministic; the statistics / bias-gradient /
+        # embedding kernels that accumulate with fp32 atomics are not -- say so instead of silently ignoring the flag
+        log(rank, "--deterministic: seeds are fixed, but a two-pass form of the fp32-atomic reductions (quantizer statistics, bias gradients, first / "
+                  "last layer weight gradients, BatchNorm sums, embedding gradients) is not implemented: last-bit run-to-run differences remain")
     create_folder_structure(cfg)
     dev = torch.device("cuda", local)
     (training if cfg["mode"] == "training" else inference)(cfg, rank, local, world, dev)
