@@ -338,6 +338,9 @@ int sa_conv1_wgrad(const float *x, const void *g, float *dw, float *db, int N, i
  * g = d loss / d output [N,2D,2H,2W] fp32, x = the layer input [N,D,H,W,128] bf16, wpk = the transposed-convolution weight [128][64 taps] as bf16
  * (the operand sa_conv1_fwd takes).  dx [N,D,H,W,128] bf16 = sum_t g[2 cell - 1 + t] W[c][t] (zeroed where x <= 0 when mask_input),
  * dw [128][64] += sum_cells x[cell][c] g[2 cell - 1 + t], db [1] += sum g (fp32 atomics: zero dw / db first). */
+/* Forward of the same layer in ONE launch (bf16 input [N,D,H,W,128], fp32 output [N,2D,2H,2W]): the per-cell tap products stay in LDS (two rolling depth
+ * planes of an 8 x 8-cell patch + halo), no [cells][64] matrix in HBM.  wpk = the weight as [64 taps][128 channels] bf16 (row stride 128). */
+int sa_convt1_fused_fwd(const void *x, const void *wpk, const float *bias, float *out, int N, int D, int H, int W, void *stream);
 int sa_convt1_backward(const float *g, const void *x, const void *wpk, int mask_input, void *dx, float *dw, float *db, int N, int D, int H, int W,
                        void *stream);
 

@@ -337,6 +337,123 @@ static int fill_map(CT1Map& a, int N, int D, int H, int W) {
 
 int conv1_im2col_bf16(const float* g, void* gc, float* db, int N, int D, int H, int W, hipStream_t stream);   // csrc/conv1.hip
 
+
+// ---- forward in ONE kernel (bf16): no [cells][64] product matrix in HBM -------------------------------------------------------------------------
+// P[cell][tap] = x[cell] . W[:, tap] is what the GEMM route writes (1.47 GB fp32 at batch 8) and convt1_gather_kernel reads back.  Here a block owns
+// an 8 x 8 patch of cells in (H, W) and walks the depth: per plane it computes P for the patch and its one-cell halo (10 x 10 cells x 64 taps, MFMA:
+// the 64 x 128 weight is a register-resident A operand, the activation rows stream from global memory straight into B operands), keeps the planes
+// d - 1 and d in LDS and emits the two output planes 2d - 1 and 2d they determine (per dimension output o = 2q + p is fed by
+// (cell, tap) = p ? {(q+1, 0), (q, 2)} : {(q, 1), (q-1, 3)}).  Cells outside the volume load as zeros, so only the depth needs validity flags.
+// HBM traffic: the input 1.56 x (the halo in H and W), the output once.
+constexpr int CF_TH = 8, CF_TW = 8, CF_PH = CF_TH + 2, CF_PW = CF_TW + 2, CF_NP = CF_PH * CF_PW;   // 100 patch cells per plane
+constexpr int CF_LD = 68;                                                                            // floats per P row (64 taps + 4: bank spread)
+
+struct CFArgs {
+    const bf16_t* x;     // [N, D, H, W, 128]
+    const bf16_t* wpk;   // [>= 64 taps][128 channels] bf16 (the taps-as-output-channels operand)
+    const float* bias;
+    float* out;          // [N, 2D, 2H, 2W]
+    int32_t N, D, H, W, nhp, nwp;
+};
+
+__global__ __launch_bounds__(256, 3) void convt1_fused_fwd_kernel(const CFArgs a) {
+    __shared__ __attribute__((aligned(16))) float sP[2][CF_NP * CF_LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g = lane >> 4;
+    int t = blockIdx.x;
+    const int wp = t % a.nwp; t /= a.nwp;
+    const int hp = t % a.nhp;
+    const int n = t / a.nhp;
+    const int h0 = hp * CF_TH, w0 = wp * CF_TW;
+    // weights: A operand, tap tile tt (16 taps) x k-step ks (32 channels)
+    short8_t wf[4][4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wf[tt][ks] = *(const short8_t*)(a.wpk + (tt * 16 + fr) * 128 + ks * 32 + g * 8);
+    // this lane's cells: column tiles ct = w and w + 4 (7 tiles of 16 cover the 100 patch cells)
+    int64_t cbase[2];
+    bool cok[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int cell = (w + 4 * q) * 16 + fr;
+        const int ph = cell / CF_PW, pw = cell - ph * CF_PW;
+        const int gh = h0 - 1 + ph, gw = w0 - 1 + pw;
+        cok[q] = (w + 4 * q) < 7 && cell < CF_NP && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+        cbase[q] = (((int64_t)n * a.D * a.H + (cok[q] ? gh : 0)) * a.W + (cok[q] ? gw : 0)) * 128 + g * 8;   // + d * H * W * 128 + ks * 32
+    }
+    const int64_t plane = (int64_t)a.H * a.W * 128;
+    u32x4 xb[2][4];
+    auto load_plane = [&](int d) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+                if (cok[q] && d < a.D) v = *(const u32x4*)(a.x + cbase[q] + d * plane + ks * 32);
+                xb[q][ks] = v;
+            }
+    };
+    load_plane(0);
+    // gather role: thread = output (oh_l, ow_l) of the 16 x 16 output tile; per dimension two (cell, tap) pairs
+    const int oh_l = tid >> 4, ow_l = tid & 15;
+    const int oh = 2 * h0 + oh_l, ow = 2 * w0 + ow_l;
+    const bool o_ok = oh < 2 * a.H && ow < 2 * a.W;
+    int prow[2], ptap_h[2], pcol[2], ptap_w[2];
+    {
+        const int ph_ = oh_l & 1, qh = oh_l >> 1;          // local cell index qh (0..7) -> patch row qh + 1
+        prow[0] = ph_ ? qh + 2 : qh + 1; ptap_h[0] = ph_ ? 0 : 1;
+        prow[1] = ph_ ? qh + 1 : qh;     ptap_h[1] = ph_ ? 2 : 3;
+        const int pw_ = ow_l & 1, qw = ow_l >> 1;
+        pcol[0] = pw_ ? qw + 2 : qw + 1; ptap_w[0] = pw_ ? 0 : 1;
+        pcol[1] = pw_ ? qw + 1 : qw;     ptap_w[1] = pw_ ? 2 : 3;
+    }
+    const float bias = a.bias ? a.bias[0] : 0.f;
+    for (int d = 0; d <= a.D; ++d) {
+        float* cur = sP[d & 1];
+        const float* prev = sP[(d & 1) ^ 1];
+        if (d < a.D) {
+            // P[cell][tap] of plane d for this wave's column tiles
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (w + 4 * q >= 7) continue;
+                float4_t acc[4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[tt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tt][ks], *(const short8_t*)&xb[q][ks], acc[tt], 0, 0, 0);
+                const int cell = (w + 4 * q) * 16 + fr;
+                if (cell < CF_NP) {
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) *(float4_t*)(cur + cell * CF_LD + tt * 16 + g * 4) = acc[tt];
+                }
+            }
+        }
+        __syncthreads();
+        if (d + 1 < a.D) load_plane(d + 1);     // in flight during the gather
+        // outputs od = 2d - 1 (cells d: kd 0, d - 1: kd 2) and od = 2d (cells d: kd 1, d - 1: kd 3)
+        const bool cur_ok = d < a.D, prev_ok = d > 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int od = 2 * d - 1 + e;
+            if (od < 0 || od >= 2 * a.D || !o_ok) continue;
+            float sum = bias;
+#pragma unroll
+            for (int uh = 0; uh < 2; ++uh)
+#pragma unroll
+                for (int uw = 0; uw < 2; ++uw) {
+                    const int cell = prow[uh] * CF_PW + pcol[uw];
+                    const int tap_hw = ptap_h[uh] * 4 + ptap_w[uw];
+                    if (cur_ok) sum += cur[cell * CF_LD + (e ? 1 : 0) * 16 + tap_hw];
+                    if (prev_ok) sum += prev[cell * CF_LD + (e ? 3 : 2) * 16 + tap_hw];
+                }
+            a.out[(((int64_t)n * 2 * a.D + od) * 2 * a.H + oh) * 2 * a.W + ow] = sum;
+        }
+        __syncthreads();                        // this plane's readers are done before the buffer of plane d - 1 is overwritten
+    }
+}
+
 }  // namespace sa
 
 using namespace sa;
@@ -400,6 +517,20 @@ extern "C" int sa_convt1_im2col(const float* g, int dtype, void* gc, float* db, 
     }
     if (dtype == SA_F32) SA_LAUNCH(convt1_im2col_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     else SA_LAUNCH(convt1_im2col_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+// forward of the last decoder layer in one launch (bf16 activations, 128 input channels): out [N,2D,2H,2W] fp32 = bias + sum_{cell, tap} x[cell] . W[:, tap];
+// wpk = the layer's weight as [taps][128 channels] bf16 (sa_pack_weights of the taps-as-output-channels 1x1x1 convolution: rows = 64, red = 128)
+extern "C" int sa_convt1_fused_fwd(const void* x, const void* wpk, const float* bias, float* out, int N, int D, int H, int W, void* stream) {
+    if (!x || !wpk || !out || N <= 0 || D <= 0 || H <= 0 || W <= 0) return SA_EINVAL;
+    CFArgs a = {};
+    a.x = (const bf16_t*)x; a.wpk = (const bf16_t*)wpk; a.bias = bias; a.out = out; a.N = N; a.D = D; a.H = H; a.W = W;
+    a.nhp = (H + CF_TH - 1) / CF_TH; a.nwp = (W + CF_TW - 1) / CF_TW;
+    const int64_t blocks = (int64_t)N * a.nhp * a.nwp;
+    if (blocks >= ((int64_t)1 << 31)) return SA_EUNSUPPORTED;
+    SA_LAUNCH(convt1_fused_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     return 0;
 }

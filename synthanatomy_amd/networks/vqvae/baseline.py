@@ -348,7 +348,13 @@ class _ConvT1Stage:
         N, D, H, W, C = x.shape
         out = torch.empty((N, 2 * D, 2 * H, 2 * W, 1), dtype=torch.float32, device=x.device)
         lib, st = _ffi.lib(), _ffi.stream()
-        if self._gemm(x):
+        if self._gemm(x) and x.dtype == torch.bfloat16 and not debug.host("no_convt1_fused_fwd"):
+            # one launch: the per-cell tap products stay in LDS (csrc/convt1.hip: convt1_fused_fwd_kernel)
+            self._sync()
+            wpk = self.taps_fwd.packed_fwd_operand(N, (D, H, W))      # [taps (padded to 128 rows)][128 channels] bf16
+            _launch("convt1_fused_fwd_kernel", 2.0 * x.numel() * 64,
+                    lambda: _ffi.check(lib.sa_convt1_fused_fwd(_ffi.ptr(x), _ffi.ptr(wpk), _ffi.ptr(self.mod.bias), _ffi.ptr(out), N, D, H, W, st), "sa_convt1_fused_fwd"))
+        elif self._gemm(x):
             self._sync()
             P = self.taps_fwd.fprop(x, out_dtype=torch.float32, use_bias=False)          # [N, D, H, W, 64]
             _ffi.check(lib.sa_convt1_gather(_ffi.ptr(P), _ffi.ptr(self.mod.bias), _ffi.ptr(out), N, D, H, W, st), "sa_convt1_gather")
