@@ -96,6 +96,7 @@ int sa_kernel_log_read(char *buf, int cap, int stop);
 #define SA_DBG_HALO256_4W        (1u << 13)  /* bf16 forward / data- / weight-gradient kernels with four waves per block instead of eight */
 #define SA_DBG_TILE256           (1u << 14)  /* A/B: 256 x 128 tiles for the im2col-order forward / data-gradient kernel (measured slower) */
 #define SA_DBG_DENSE_NARROW      (1u << 15)  /* A/B: 128 x 64 tiles for every small dense grid (the round-2 rule) */
+#define SA_DBG_DETERMINISTIC     (1u << 16)  /* fixed-order reductions where the library itself chooses (BatchNorm sums); see the deterministic-mode section */
 #define SA_DBG_SCAN_EXACT_SHIFT  10          /* 3 bits: chunk states | scan A outputs | scan B outputs on the exact-fp32 MFMA kernels */
 /* measurement aid (bench.py `roofline.peak_measured`): `blocks` x 4 waves each issue iters x 8 independent v_mfma_f32_32x32x16_bf16;
  * FLOPs per call = blocks * 4 * iters * 8 * 32768.  `scratch` = any 4 device bytes (never written in practice). */
@@ -375,6 +376,19 @@ int sa_favor_fused_fwd(const float *q, const float *k, const float *v, int strid
 int sa_favor_fused_bwd(const float *q, const float *k, const float *v, int stride, const void *tiles, const float *ps, const float *offq, const int32_t *amq,
                        const float *offk, const void *gmax_ws, const float *dattn, const float *attn, int attn_stride, const float *inv, float *dq, float *dk,
                        float *dv, int B, int N, int G, int m, const float *state_fwd, float *state_ws, float *dden_ws, float *tsum_ws, void *stream);
+
+/* ---- deterministic mode (the reference's --deterministic flag: torch.backends.cudnn.deterministic, src/utils/general.py:336-338) -------------------
+ * Fixed-order forms of the reductions the throughput path accumulates with fp32 atomics (csrc/deterministic.hip); the host calls them INSTEAD of the
+ * fused / atomic forms when the flag is set, and SA_DBG_DETERMINISTIC makes sa_bn_forward / sa_bn_backward keep per-block partial sums in a larger
+ * sums_ws ((1 + 64) * 2 * C floats).  Results are bit-identical from run to run.
+ *   sa_colsum_det   : db[c] += sum_m g[m][c] (bias gradients); ws >= sa_colsum_det_workspace_bytes(C)
+ *   sa_vq_stats_det : counts / dw / sqerr of sa_vq_assign recomputed from its idx output (baseline.py:66-69, :82); err_ws = K floats
+ *   sa_embed_scatter_det : sa_embed_scatter over a table of nrows rows */
+int64_t sa_colsum_det_workspace_bytes(int C);
+int sa_colsum_det(const void *g, int dtype, int64_t M, int C, int cstride, float *db, void *ws, int64_t ws_bytes, void *stream);
+int sa_vq_stats_det(const float *rows, const float *codebook, const int64_t *idx, int64_t M, int K, int D, float *counts, float *dw, float *sqerr,
+                    float *err_ws, void *stream);
+int sa_embed_scatter_det(const float *dy, float *dtable, const int64_t *idx, int per_position, int dim, int N, int64_t R, int nrows, void *stream);
 
 #ifdef __cplusplus
 }

@@ -206,11 +206,11 @@ def run(argv):
     torch.manual_seed(cfg["seed"])
     np.random.seed(cfg["seed"])
     if cfg.get("deterministic"):
-        # upstream: torch.backends.cudnn.deterministic (src/utils/general.py:336-338).  Here the forward passes, the FAVOR+ / local-attention / dense
-        # kernels and every weight gradient that goes through a workspace + reduce are run-to-run deterministic; the statistics / bias-gradient /
-        # embedding kernels that accumulate with fp32 atomics are not -- say so instead of silently ignoring the flag
-        log(rank, "--deterministic: seeds are fixed, but a two-pass form of the fp32-atomic reductions (quantizer statistics, bias gradients, first / "
-                  "last layer weight gradients, BatchNorm sums, embedding gradients) is not implemented: last-bit run-to-run differences remain")
+        # upstream: torch.backends.cudnn.deterministic (src/utils/general.py:336-338).  Here: fixed-order reductions instead of fp32 atomics (quantizer
+        # statistics, bias gradients, BatchNorm sums) and the unfused first / last layer routes -- bit-identical runs (tests/test_deterministic_gpu.py)
+        from synthanatomy_amd import debug
+        debug.set_deterministic(True)
+        log(rank, "--deterministic: fixed-order reductions (csrc/deterministic.hip); slower than the default path")
     create_folder_structure(cfg)
     dev = torch.device("cuda", local)
     (training if cfg["mode"] == "training" else inference)(cfg, rank, local, world, dev)

@@ -1,0 +1,140 @@
+// Order-independent-by-construction forms of the reductions that the throughput path accumulates with fp32 atomics (the reference's
+// --deterministic flag, run_vqvae.py / src/utils/general.py:336-338: torch.backends.cudnn.deterministic).  Every sum below is taken in a FIXED
+// order -- per-block partials in a caller-supplied workspace, then one pass over the partials -- so two runs of the same step give bit-identical
+// gradients, codebook statistics and parameters.  Selected by the host when `--deterministic` / SA_DETERMINISTIC is set; slower than the
+// atomic forms (extra passes), never used by the benchmarked configuration.
+#include "sa_common.h"
+
+namespace sa {
+
+constexpr int CD_BLOCKS = 256;   // row blocks of the two-stage column sums
+
+// stage 1: partial[bx][c] = sum over the block's rows (4 row lanes, combined in a fixed order) of g[r][c]
+__global__ __launch_bounds__(256) void colsum_det_stage1_kernel(const void* __restrict__ gp, int dtype, int64_t M, int C, int cstride, float* __restrict__ partial,
+                                                                int64_t rows_per_block) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float s = 0.f;
+    if (c < C)
+        for (int64_t r = r0 + rl; r < r1; r += 4) s += load_as_f32(gp, dtype, r * cstride + c);
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) partial[(int64_t)blockIdx.x * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+// stage 2: db[c] += sum over the blocks, in block order
+__global__ void colsum_det_stage2_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ db) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * C + c];
+    db[c] += s;
+}
+
+// codebook statistics of the EMA quantizer (reference baseline.py:66-69: encodings.sum(0), encodings^T @ flat_inputs) and the commitment error:
+// block k walks ALL rows in index order and sums those assigned to code k; thread j owns dimension j.  err[k] = sum over its rows of |w_k - x|^2.
+__global__ __launch_bounds__(256) void vq_stats_det_kernel(const float* __restrict__ rows, const float* __restrict__ cb, const int64_t* __restrict__ idx, int64_t M,
+                                                           int D, float* __restrict__ counts, float* __restrict__ dw, float* __restrict__ err) {
+    __shared__ float red[256];
+    const int k = blockIdx.x, t = threadIdx.x;
+    float cnt = 0.f, e = 0.f;
+    for (int j0 = 0; j0 < D; j0 += 256) {   // (D <= 256 in every configuration: one pass)
+        const int j = j0 + t;
+        const float w = j < D ? cb[(int64_t)k * D + j] : 0.f;
+        float acc = 0.f;
+        for (int64_t i = 0; i < M; ++i) {
+            if (idx[i] == k) {
+                if (j0 == 0 && t == 0) cnt += 1.f;
+                if (j < D) {
+                    const float x = rows[i * D + j];
+                    acc += x;
+                    e += (w - x) * (w - x);
+                }
+            }
+        }
+        if (j < D) dw[(int64_t)k * D + j] = acc;
+    }
+    red[t] = e;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {   // fixed tree
+        if (t < o) red[t] += red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) {
+        counts[k] = cnt;
+        err[k] = red[0];
+    }
+}
+__global__ __launch_bounds__(1024) void vq_err_det_kernel(const float* __restrict__ err, int K, float* __restrict__ sqerr) {
+    __shared__ float red[1024];
+    float s = 0.f;
+    for (int k = threadIdx.x; k < K; k += 1024) s += err[k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sqerr[0] = red[0];
+}
+
+// embedding gradient: block = one table row, thread = dimension; positions are visited in order
+__global__ __launch_bounds__(256) void embed_scatter_det_kernel(const float* __restrict__ dy, float* __restrict__ dtable, const int64_t* __restrict__ idx, int per_position,
+                                                                int dim, int N, int64_t R) {
+    const int64_t row = blockIdx.x;
+    const int64_t n_idx = per_position ? N : R;
+    for (int c = threadIdx.x; c < dim; c += 256) {
+        float acc = 0.f;
+        if (per_position) {
+            for (int64_t p = 0; p < n_idx; ++p)
+                if (idx[p] == row)
+                    for (int64_t r = p; r < R; r += N) acc += dy[r * dim + c];   // the same position of every sequence, in batch order
+        } else {
+            for (int64_t r = 0; r < R; ++r)
+                if (idx[r] == row) acc += dy[r * dim + c];
+        }
+        dtable[row * dim + c] += acc;
+    }
+}
+
+}  // namespace sa
+
+using namespace sa;
+
+extern "C" int64_t sa_colsum_det_workspace_bytes(int C) { return (int64_t)CD_BLOCKS * (C > 0 ? C : 1) * 4; }
+
+// db[c] += sum_m g[m][c] in a fixed order (bias gradients in deterministic mode); ws >= sa_colsum_det_workspace_bytes(C)
+extern "C" int sa_colsum_det(const void* gp, int dtype, int64_t M, int C, int cstride, float* db, void* ws, int64_t ws_bytes, void* stream) {
+    if (!gp || !db || !ws || M <= 0 || C <= 0 || cstride < C) return SA_EINVAL;
+    if (dtype != SA_F32 && dtype != SA_BF16) return SA_EUNSUPPORTED;
+    if (ws_bytes < sa_colsum_det_workspace_bytes(C)) return SA_EINVAL;
+    const int64_t rpb = (M + CD_BLOCKS - 1) / CD_BLOCKS;
+    const int nblk = (int)((M + rpb - 1) / rpb);
+    SA_LAUNCH(colsum_det_stage1_kernel, dim3(nblk, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, gp, dtype, M, C, cstride, (float*)ws, rpb);
+    SA_CHECK_LAUNCH();
+    SA_LAUNCH(colsum_det_stage2_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws, nblk, C, db);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+// counts[K], dw[K][D], sqerr[1] of sa_vq_assign recomputed in a fixed order from its idx output (overwrites them); err_ws: K floats
+extern "C" int sa_vq_stats_det(const float* rows, const float* codebook, const int64_t* idx, int64_t M, int K, int D, float* counts, float* dw, float* sqerr,
+                               float* err_ws, void* stream) {
+    if (!rows || !codebook || !idx || !counts || !dw || !sqerr || !err_ws || M <= 0 || K <= 0 || D <= 0) return SA_EINVAL;
+    SA_LAUNCH(vq_stats_det_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, rows, codebook, idx, M, D, counts, dw, err_ws);
+    SA_CHECK_LAUNCH();
+    SA_LAUNCH(vq_err_det_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)err_ws, K, sqerr);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+// sa_embed_scatter in a fixed order: dtable [nrows][dim] += gathered rows of dy
+extern "C" int sa_embed_scatter_det(const float* dy, float* dtable, const int64_t* idx, int per_position, int dim, int N, int64_t R, int nrows, void* stream) {
+    if (!dy || !dtable || !idx || dim <= 0 || R <= 0 || nrows <= 0 || (per_position && N <= 0)) return SA_EINVAL;
+    SA_LAUNCH(embed_scatter_det_kernel, dim3(nrows), dim3(256), 0, (hipStream_t)stream, dy, dtable, idx, per_position, dim, N, R);
+    SA_CHECK_LAUNCH();
+    return 0;
+}

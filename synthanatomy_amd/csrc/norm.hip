@@ -7,7 +7,7 @@ namespace sa {
 
 // sums[c] += sum_m f(x[m][c]); sums[C + c] += sum_m f2(...)   mode 0: (x, x^2)   mode 1: (g, g * xhat) with xhat from (x, mean, rstd)
 __global__ void bn_colstats_kernel(const void* x, const void* g, int dtype, const float* __restrict__ mean, const float* __restrict__ rstd, int64_t M,
-                                   int C, float* __restrict__ sums, int64_t rows_per_block, int mode) {
+                                   int C, float* __restrict__ sums, int64_t rows_per_block, int mode, int partial) {
     const int c = blockIdx.y * 32 + (threadIdx.x & 31);
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
@@ -38,9 +38,22 @@ __global__ void bn_colstats_kernel(const void* x, const void* g, int dtype, cons
             t1 += red[0][threadIdx.x + 32 * k];
             t2 += red[1][threadIdx.x + 32 * k];
         }
-        unsafeAtomicAdd(sums + c, t1);
-        unsafeAtomicAdd(sums + C + c, t2);
+        if (partial) {   // deterministic mode: one slot per row block behind the totals, summed in block order by bn_sum_partials_kernel
+            sums[(int64_t)(1 + blockIdx.x) * 2 * C + c] = t1;
+            sums[(int64_t)(1 + blockIdx.x) * 2 * C + C + c] = t2;
+        } else {
+            unsafeAtomicAdd(sums + c, t1);
+            unsafeAtomicAdd(sums + C + c, t2);
+        }
     }
+}
+
+__global__ void bn_sum_partials_kernel(float* __restrict__ sums, int nblk, int C) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * C) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += sums[(int64_t)(1 + b) * 2 * C + e];
+    sums[e] = s;
 }
 
 __global__ void bn_finalize_kernel(const float* __restrict__ sums, int64_t M, int C, float eps, float momentum, float* __restrict__ mean,
@@ -125,11 +138,16 @@ extern "C" int sa_bn_forward(const void* x, int dtype, int64_t M, int C, const f
     hipStream_t st = (hipStream_t)stream;
     if (training) {
         hipMemsetAsync(sums_ws, 0, sizeof(float) * 2 * C, st);
-        int64_t rpb = (M + 1023) / 1024;
+        const bool det = dbg(SA_DBG_DETERMINISTIC);   // sums_ws then holds (1 + 64) * 2 * C floats: totals + per-block partials
+        int64_t rpb = det ? (M + 63) / 64 : (M + 1023) / 1024;
         if (rpb < 64) rpb = 64;
         dim3 grid((unsigned)((M + rpb - 1) / rpb), (C + 31) / 32);
-        SA_LAUNCH(bn_colstats_kernel, grid, dim3(256), 0, st, x, nullptr, dtype, nullptr, nullptr, M, C, sums_ws, rpb, 0);
+        SA_LAUNCH(bn_colstats_kernel, grid, dim3(256), 0, st, x, nullptr, dtype, nullptr, nullptr, M, C, sums_ws, rpb, 0, det ? 1 : 0);
         SA_CHECK_LAUNCH();
+        if (det) {
+            SA_LAUNCH(bn_sum_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, sums_ws, (int)grid.x, C);
+            SA_CHECK_LAUNCH();
+        }
         SA_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums_ws, M, C, eps, momentum, mean, rstd, running_mean, running_var);
     } else {
         if (!running_mean || !running_var) return SA_EINVAL;
@@ -147,11 +165,16 @@ extern "C" int sa_bn_backward(const void* x, const void* g, int dtype, int64_t M
     if (!x || !g || !w || !mean || !rstd || !dx || !dw || !db || !sums_ws || M <= 0 || C <= 0) return SA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     hipMemsetAsync(sums_ws, 0, sizeof(float) * 2 * C, st);
-    int64_t rpb = (M + 1023) / 1024;
+    const bool det = dbg(SA_DBG_DETERMINISTIC);
+    int64_t rpb = det ? (M + 63) / 64 : (M + 1023) / 1024;
     if (rpb < 64) rpb = 64;
     dim3 grid((unsigned)((M + rpb - 1) / rpb), (C + 31) / 32);
-    SA_LAUNCH(bn_colstats_kernel, grid, dim3(256), 0, st, x, g, dtype, mean, rstd, M, C, sums_ws, rpb, 1);
+    SA_LAUNCH(bn_colstats_kernel, grid, dim3(256), 0, st, x, g, dtype, mean, rstd, M, C, sums_ws, rpb, 1, det ? 1 : 0);
     SA_CHECK_LAUNCH();
+    if (det) {
+        SA_LAUNCH(bn_sum_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, sums_ws, (int)grid.x, C);
+        SA_CHECK_LAUNCH();
+    }
     SA_LAUNCH(bn_bwd_apply_kernel, dim3(grid_e(M * C)), dim3(256), 0, st, x, g, dtype, mean, rstd, w, sums_ws, M, dx, M * C, C, training);
     SA_CHECK_LAUNCH();
     SA_LAUNCH(bn_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, st, dw, db, sums_ws, C);

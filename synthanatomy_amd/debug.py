@@ -14,7 +14,7 @@ import contextlib
 import os
 
 LIB_FLAGS = dict(no_halo=1 << 0, no_halo256=1 << 1, no_halo256_fuse=1 << 2, no_dma=1 << 3, no_small_tiles=1 << 4, no_fused_db=1 << 5,
-                 no_wgrad_halo9=1 << 6, im2col_direct=1 << 7, scan_valu=1 << 8, local_attn_exact=1 << 9, halo256_4w=1 << 13, tile256=1 << 14, dense_narrow=1 << 15)
+                 no_wgrad_halo9=1 << 6, im2col_direct=1 << 7, scan_valu=1 << 8, local_attn_exact=1 << 9, halo256_4w=1 << 13, tile256=1 << 14, dense_narrow=1 << 15, deterministic=1 << 16)
 SCAN_EXACT_SHIFT = 10   # scan_exact=0..7
 
 _HOST_ENV = dict(no_fused_res="SA_NO_FUSED_RES", no_fused_1x1_bwd="SA_NO_FUSED_1X1_BWD", no_conv1_gemm="SA_NO_CONV1_GEMM",
@@ -25,6 +25,20 @@ _host = {k: os.environ.get(v) is not None for k, v in _HOST_ENV.items()}
 
 def host(name: str) -> bool:
     return _host[name]
+
+
+def deterministic() -> bool:
+    """The reference's --deterministic flag (SA_DETERMINISTIC / run_*.py --deterministic=True / debug.override(deterministic=True)): fixed-order reductions
+    instead of fp32 atomics (csrc/deterministic.hip) and the unfused first / last layer routes."""
+    from . import _ffi
+    return bool(_ffi.lib().sa_get_debug_flags() & LIB_FLAGS["deterministic"])
+
+
+def set_deterministic(on: bool = True):
+    from . import _ffi
+    lib = _ffi.lib()
+    f = lib.sa_get_debug_flags()
+    lib.sa_set_debug_flags((f | LIB_FLAGS["deterministic"]) if on else (f & ~LIB_FLAGS["deterministic"]))
 
 
 @contextlib.contextmanager

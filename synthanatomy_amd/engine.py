@@ -317,6 +317,11 @@ class ConvOp:
         assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.shape == self.weight.shape
         plans = self._get_plans(N, (D, H, W), fwd_out_stride or self.cout, g.shape[-1])
         lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
+        if db is not None and debug.deterministic():
+            # --deterministic: no fused / atomic bias gradient; the launch geometries of one layer partition its output voxels, so the bias gradient is ONE
+            # fixed-order column sum over the whole gradient tensor (csrc/deterministic.hip)
+            colsum_det(g, self.cout, db)
+            db = None
         for pl in plans["wgrad"]:
             nbytes = lib.sa_conv_wgrad_workspace_bytes(ctypes.byref(pl.geom), did)
             if nbytes < 0:
@@ -373,6 +378,16 @@ class PackSet:
             ent[1] = op._pack_version()
 
 
+def colsum_det(g: torch.Tensor, C: int, db: torch.Tensor):
+    """db[c] += sum over all rows of g[..., c] in a fixed order (sa_colsum_det)."""
+    lib = _ffi.lib()
+    cs = g.shape[-1]
+    M = g.numel() // cs
+    nb = lib.sa_colsum_det_workspace_bytes(C)
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=g.device)
+    _ffi.check(lib.sa_colsum_det(_ffi.ptr(g), _ffi.dtype_id(g.dtype), M, C, cs, _ffi.ptr(db), _ffi.ptr(ws), nb, _ffi.stream()), "sa_colsum_det")
+
+
 def conv1x1_backward(op: "ConvOp", x: torch.Tensor, g: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     """Weight, bias and (ReLU-masked) data gradient of a 1x1x1 128 -> 128 bf16 convolution in one launch (sa_conv1x1_backward); returns dx,
     or None when the layer is not of that shape (the caller then uses wgrad + dgrad)."""
@@ -390,6 +405,9 @@ def conv1x1_backward(op: "ConvOp", x: torch.Tensor, g: torch.Tensor, dw: torch.T
         return None
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
+    if db is not None and debug.deterministic():
+        colsum_det(g, op.cout, db)
+        db = None
     flops = 2.0 * _geom_flops(pw.geom)
     _launch("+wgrad_reduce_kernel", flops, nbytes=3.0 * x.numel() * x.element_size(),   # algorithmic bytes: read x and g once, write dx once
             fn=lambda: _ffi.check(lib.sa_conv1x1_backward(ctypes.byref(pw.geom), did, _ffi.ptr(x), _ffi.ptr(g), _ffi.ptr(dw), _ffi.ptr(db), pw.s_row, pw.s_red, _ffi.ptr(ws),

@@ -837,7 +837,10 @@ class _EmbedFn(torch.autograd.Function):
                 grads.append(None)
                 continue
             g = torch.zeros(shp, dtype=torch.float32, device=dy.device)
-            _ck(_ffi.lib().sa_embed_scatter(_ffi.ptr(dy), _ffi.ptr(g), _ffi.ptr(ix), pp, shp[1], N, B * N, _ffi.stream()), "sa_embed_scatter")
+            if debug.deterministic():
+                _ck(_ffi.lib().sa_embed_scatter_det(_ffi.ptr(dy), _ffi.ptr(g), _ffi.ptr(ix), pp, shp[1], N, B * N, shp[0], _ffi.stream()), "sa_embed_scatter_det")
+            else:
+                _ck(_ffi.lib().sa_embed_scatter(_ffi.ptr(dy), _ffi.ptr(g), _ffi.ptr(ix), pp, shp[1], N, B * N, _ffi.stream()), "sa_embed_scatter")
             grads.append(g)
         return (None, None, None, None, None, *grads)
 

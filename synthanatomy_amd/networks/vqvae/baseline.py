@@ -108,6 +108,10 @@ class _VQFn(torch.autograd.Function):
         cb_used = cb.clone() if training else cb  # backward needs the pre-update codebook (baseline.py:63)
         _ffi.check(lib.sa_vq_assign(_ffi.ptr(rows), _ffi.ptr(cb), M, K, D, _ffi.ptr(idx), _ffi.ptr(zq), None, _ffi.ptr(counts), _ffi.ptr(dw),
                                     _ffi.ptr(sqerr), _ffi.ptr(wnorm), st), "sa_vq_assign")
+        if debug.deterministic():   # counts / dw / commitment error again, summed in a fixed order (the launch above used fp32 atomics)
+            err_ws = torch.empty(K, dtype=torch.float32, device=dev)
+            _ffi.check(lib.sa_vq_stats_det(_ffi.ptr(rows), _ffi.ptr(cb), _ffi.ptr(idx), M, K, D, _ffi.ptr(counts), _ffi.ptr(dw), _ffi.ptr(sqerr), _ffi.ptr(err_ws), st),
+                       "sa_vq_stats_det")
         _ffi.check(lib.sa_vq_perplexity(_ffi.ptr(counts), K, M, _ffi.ptr(ppl), st), "sa_vq_perplexity")
         loss = (sqerr * (beta / float(M * D))).reshape(())
         perplexity = ppl.clone().reshape(())
@@ -280,7 +284,7 @@ class _Conv1Stage:
         self._sync()
         lib, st = _ffi.lib(), _ffi.stream()
         Do, Ho, Wo, cout = D // 2, H // 2, W // 2, self.op.cout
-        if self.dtype == torch.bfloat16 and cout == 128 and not debug.host("no_conv1_fused"):
+        if self.dtype == torch.bfloat16 and cout == 128 and not debug.host("no_conv1_fused") and not debug.deterministic():   # (its weight gradient ends in fp32 atomics)
             # csrc/conv1.hip: taps gathered into LDS straight from the volume; nothing but the output touches HBM
             wpk = self.op.packed_fwd_operand(N, (Do, Ho, Wo))
             y = torch.empty((N, Do, Ho, Wo, cout), dtype=self.dtype, device=x.device)
@@ -342,7 +346,7 @@ class _ConvT1Stage:
         self.taps_fwd.weight = self.taps_bwd.weight = self.mod.weight
 
     def _gemm(self, x):
-        return x.numel() // 128 >= self.GEMM_MIN_CELLS and not debug.host("convt1_direct")
+        return (x.numel() // 128 >= self.GEMM_MIN_CELLS and not debug.host("convt1_direct")) or debug.deterministic()   # (the direct kernels accumulate with atomics)
 
     def fwd(self, x, tape):
         N, D, H, W, C = x.shape
@@ -372,7 +376,7 @@ class _ConvT1Stage:
         G = G.float().contiguous()
         dw, db = grads.buf(self.mod.weight), grads.buf(self.mod.bias)
         lib, st = _ffi.lib(), _ffi.stream()
-        if self._gemm(x) and x.dtype == torch.bfloat16 and not debug.host("no_convt1_fused_bwd"):
+        if self._gemm(x) and x.dtype == torch.bfloat16 and not debug.host("no_convt1_fused_bwd") and not debug.deterministic():
             # csrc/conv1.hip: the data gradient is the FIRST layer's forward on the volume G, the weight gradient its weight gradient with x in the
             # role of the output gradient; no [cells][64] matrix in HBM
             self._sync()
@@ -386,6 +390,10 @@ class _ConvT1Stage:
         elif self._gemm(x):
             self._sync()
             Gc = torch.empty((N, D, H, W, 64), dtype=x.dtype, device=x.device)
+            if debug.deterministic():
+                from ...engine import colsum_det
+                colsum_det(G.view(-1, 1), 1, db)     # bias gradient = sum of the gradient volume, in a fixed order
+                db = None
             _ffi.check(lib.sa_convt1_im2col(_ffi.ptr(G), _ffi.dtype_id(x.dtype), _ffi.ptr(Gc), _ffi.ptr(db), N, D, H, W, st), "sa_convt1_im2col")
             dx = None
             if not wgrad_only:
