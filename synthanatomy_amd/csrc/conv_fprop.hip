@@ -42,6 +42,8 @@ struct FpropArgs {
     const float* bias1;
     void* h_out;
     uint32_t HP, WP;      // halo mainloop: patches per plane along H (8 voxels) and W (16 voxels)
+    uint32_t group_m;     // im2col-order DMA mainloop, dense (1x1x1) layers with several channel tiles: blocks are ordered in groups of `group_m` row tiles x
+                          // all channel tiles (0: row tiles fastest, the order in which convolution tiles share their halos)
     uint32_t dbg;         // dev only (env SA_PP_DBG): 256 = LDS-staged epilogue instead of the register one; with -DSA_PP_DEBUG_VARIANTS also the
                           // ablation bits (halo: 1 skip halo DMA, 2 skip weight DMA, 64 skip epilogue; im2col-order: 64 / 128 skip activation / weight DMA)
 };
@@ -606,7 +608,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fprop_dma_kernel(const Fpro
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wm = wave / WN, wn = wave % WN;
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
+    uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
+    if (a.group_m) {
+        // dense layer: the blocks one XCD runs at a time cover group_m row tiles x (up to) all channel tiles, so its L2 fetches group_m activation
+        // panels + the weight panels once instead of one activation panel PER BLOCK (row tiles fastest = no activation reuse inside an XCD at all)
+        const uint32_t nbn = gridDim.x / a.nblk_m, per = a.group_m * nbn;
+        const uint32_t gid = bid / per, first = gid * a.group_m, r = bid - gid * per;
+        const uint32_t gsz = a.nblk_m - first < a.group_m ? a.nblk_m - first : a.group_m;
+        bm = first + r % gsz;
+        bn = r / gsz;
+    }
     const uint32_t m_base = bm * BM, n_base = bn * BN;
     const sa_conv_geom& g = a.g;
 
@@ -1216,8 +1227,14 @@ static int launch_fprop(const FpropArgs& a, hipStream_t st) {
             });
         }
         (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma_kernel<%s, %d, %d, %d, %d, %s, false>", tname<T>(), WM, WN, MI, NI, uniform ? "true" : "false"), note_kernel(g_last_conv_kernel));
-        if (uniform) hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, true>), grid, dim3(WM * WN * 64), lds, st, a);
-        else hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, false>), grid, dim3(WM * WN * 64), lds, st, a);
+        FpropArgs b = a;
+        // Dense layers with >= 8 channel tiles (M = 8 400 rows, tools/bench_dense_tiles.py; FETCH_SIZE per launch 203 -> 65 MB for q|k|v): q|k|v forward 77.1 -> 68.0 us,
+        // w1 forward 52.8 -> 45.0, w2 data gradient 52.1 -> 43.1, to_out data gradient 30.5 -> 26.3.  With 4 channel tiles (N = 512, one block per CU) the fetch
+        // bytes halve as well (139 -> 65 MB) but the time does not move (52.1 -> 54.7 us): those launches wait on the per-slab DMA round trip, not on the fabric.
+        // SA_PP_DBG bits 16-23: group size override for A/B runs (255 = off).
+        if (b.ntaps == 1 && nbn_valid > 1) b.group_m = (g_tunables.pp_dbg >> 16) ? ((g_tunables.pp_dbg >> 16) & 255u) % 255u : (nbn_valid >= 8 ? 8u : 0u);
+        if (uniform) hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, true>), grid, dim3(WM * WN * 64), lds, st, b);
+        else hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, false>), grid, dim3(WM * WN * 64), lds, st, b);
         SA_CHECK_LAUNCH();
         return 0;
     }
@@ -1382,6 +1399,7 @@ extern "C" int sa_conv_fprop(const sa_conv_geom* g, int dtype, const void* in, c
     a.bias1 = nullptr;
     a.h_out = nullptr;
     a.dbg = g_tunables.pp_dbg;
+    a.group_m = 0;
     {
         const int sz = dtype == SA_F32 ? 4 : 2;
         const uint64_t ib = (uint64_t)g->N * g->Di * g->Hi * g->Wi * g->Cin * sz, wb = (uint64_t)g->CoutPad * g->Kpad * sz;
@@ -1433,6 +1451,7 @@ extern "C" int sa_resblock_fprop(const sa_conv_geom* g, int dtype, const void* x
     a.bias1 = bias1;
     a.h_out = h_out;
     a.dbg = 0;
+    a.group_m = 0;
     if (halo256_eligible(a, 2) && !dbg(SA_DBG_NO_HALO256_FUSE)) return launch_fprop_halo256<bf16_t, true>(a, (hipStream_t)stream);
     if (halo_eligible(a, 2)) return launch_fprop_halo<bf16_t, true>(a, (hipStream_t)stream);
     const size_t pipe = 2 * (128 + 128) * 128, epi = (size_t)128 * (128 + 4) * 4 + 128 * 8;
