@@ -303,16 +303,19 @@ int sa_rotary(const float *x, int stride, int off, int L, int dh, const float *c
               int N, int64_t R, int transpose, int accumulate, void *stream);
 /* the same rotation for `ngroups` operands in one launch (q and k of a layer): operand gi is read x_goff and written y_goff ELEMENTS behind operand 0 */
 int sa_rotary_groups(const float *x, int stride, int off, int L, int dh, const float *cosb, const float *sinb, float *y, int y_stride, int y_off,
-                     int N, int64_t R, int transpose, int accumulate, int ngroups, int64_t x_goff, int64_t y_goff, void *stream);
+                     int N, int64_t R, int transpose, int accumulate, int ngroups, int64_t x_goff, int64_t y_goff, void *y_lp, void *stream);
+/* "_lp" outputs (here and in sa_local_attn_* / sa_favor_fused_*): optional (NULL = none) bf16 mirror of an fp32 output matrix -- every element written
+ * to the fp32 rows is also written, rounded to nearest even, at the SAME element offset (strides and offsets in elements) of the bf16 buffer.  It is the
+ * operand the next dense layer consumes, so the stand-alone fp32 -> bf16 cast launch (and its read of the fp32 matrix) disappears. */
 /* causal local-window attention (window W, look back one window): per query softmax over keys [max(0,(n/W-1)W), n].
  * fp32 in / out; products are evaluated as split-bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate; ~1e-5 relative) unless the environment
  * has SA_LOCAL_ATTN_EXACT=1 (exact-fp32 MFMA).  N * max(stride) * 4 must stay below 2^31 (SA_EUNSUPPORTED otherwise). */
 int sa_local_attn_fwd(const float *q, int q_stride, int q_off, const float *k, int k_stride, int k_off, const float *v, int v_stride, int v_off,
-                      float *o, int o_stride, int o_off, float *lse, int B, int N, int L, int W, int dh, void *stream);
+                      float *o, int o_stride, int o_off, float *lse, int B, int N, int L, int W, int dh, void *o_lp, void *stream);
 /* dq/dk/dv use the strides and offsets of q/k/v */
 int sa_local_attn_bwd(const float *q, int q_stride, int q_off, const float *k, int k_stride, int k_off, const float *v, int v_stride, int v_off,
                       const float *out, const float *dout, int o_stride, int o_off, const float *lse, float *dq, float *dk, float *dv,
-                      float *Dbuf, int B, int N, int L, int W, int dh, void *stream);
+                      float *Dbuf, int B, int N, int L, int W, int dh, void *dv_lp, void *stream);
 /* CELoss (losses/transformer/transformer.py:24-33): loss_sum += sum_r (lse_r - logit[r,target_r]); dlogits = (softmax - onehot) * gscale */
 int sa_cross_entropy(const float *logits, const int64_t *target, int64_t R, int V, float *loss_sum, void *dlogits, int d_dtype, float gscale,
                      void *stream);
@@ -372,10 +375,11 @@ int sa_favor_fused_prepass(const float *q, const float *k, int stride, int G, co
                            int64_t rows, int m, int dh, void *stream);
 int sa_favor_fused_fwd(const float *q, const float *k, const float *v, int stride, const void *tiles, const float *ps, const float *offq, const float *offk,
                        const void *gmax_ws, float *attn, int attn_stride, float *inv_out, float den_eps, int B, int N, int G, int m, float *state,
-                       void *stream);
+                       void *attn_lp, void *stream);
 int sa_favor_fused_bwd(const float *q, const float *k, const float *v, int stride, const void *tiles, const float *ps, const float *offq, const int32_t *amq,
                        const float *offk, const void *gmax_ws, const float *dattn, const float *attn, int attn_stride, const float *inv, float *dq, float *dk,
-                       float *dv, int B, int N, int G, int m, const float *state_fwd, float *state_ws, float *dden_ws, float *tsum_ws, void *stream);
+                       float *dv, int B, int N, int G, int m, const float *state_fwd, float *state_ws, float *dden_ws, float *tsum_ws, void *dq_lp,
+                       void *dk_lp, void *dv_lp, void *stream);
 
 /* ---- deterministic mode (the reference's --deterministic flag: torch.backends.cudnn.deterministic, src/utils/general.py:336-338) -------------------
  * Fixed-order forms of the reductions the throughput path accumulates with fp32 atomics (csrc/deterministic.hip); the host calls them INSTEAD of the

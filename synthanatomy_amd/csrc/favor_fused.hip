@@ -46,6 +46,7 @@ struct FusedArgs {
     const float* ex_scale; // zmode 1 (out B): per-position i factor;  zmode 2: per-position j weights of the running sums
     float* y;              // out A: rows [B * N][y_stride]
     float* dx;             // out B: rows [B * N][stride]
+    unsigned short *y_lp, *dx_lp;   // optional bf16 copies of what is written to y / dx (same element strides): the operand of the next dense layer
     float* state;          // [B, G, S][LDF * 64 + LDF]
     float* inv_out;        // out A, zmode 1
     float* tsum;           // out B, keys: per-block partial sums of t [B * G * S]
@@ -534,6 +535,12 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_a_kernel(const Fuse
             o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
         }
         *d4 = o;
+        if (s.y_lp) {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16);
+            pk.y = (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16);
+            *(uint2*)(s.y_lp + ((int64_t)b * s.N + ri) * s.y_stride + g * 64 + df * 16 + g4 * 4) = pk;
+        }
     }
 }
 
@@ -666,8 +673,15 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_b_kernel(const Fuse
         for (int df = 0; df < 4; ++df) {
             const int d0 = df * 16 + g4 * 4;
             const float4 xv = *(const float4*)(xr + d0), pv = *(const float4*)(pa + d0);
-            *(float4*)(dxr + d0) = make_float4(dxa[df][0] - ts * pv.x - tc * xv.x, dxa[df][1] - ts * pv.y - tc * xv.y, dxa[df][2] - ts * pv.z - tc * xv.z,
-                                               dxa[df][3] - ts * pv.w - tc * xv.w);
+            const float4 o = make_float4(dxa[df][0] - ts * pv.x - tc * xv.x, dxa[df][1] - ts * pv.y - tc * xv.y, dxa[df][2] - ts * pv.z - tc * xv.z,
+                                         dxa[df][3] - ts * pv.w - tc * xv.w);
+            *(float4*)(dxr + d0) = o;
+            if (s.dx_lp) {
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16);
+                pk.y = (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16);
+                *(uint2*)(s.dx_lp + xoff + d0) = pk;
+            }
         }
     }
     if (!s.is_query) {   // keys: the sum of t over all rows goes to the row that holds the global maximum (fix-up launch)
@@ -681,15 +695,19 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_b_kernel(const Fuse
 }
 
 // keys: the global-max element (head row r*, feature f*) takes -(sum of all t): dk[r*] -= T P[f*];  T = the per-block partials in a fixed order (deterministic)
-__global__ __launch_bounds__(64) void favor_fkey_fix_kernel(float* __restrict__ dx, int x_stride, int heads, const unsigned long long* __restrict__ gmax,
-                                                            const float* __restrict__ partial, int nblk, const float* __restrict__ ps, int LDF) {
+__global__ __launch_bounds__(64) void favor_fkey_fix_kernel(float* __restrict__ dx, unsigned short* __restrict__ dx_lp, int x_stride, int heads,
+                                                            const unsigned long long* __restrict__ gmax, const float* __restrict__ partial, int nblk,
+                                                            const float* __restrict__ ps, int LDF) {
     float t = 0.f;
     for (int i = threadIdx.x; i < nblk; i += 64) t += partial[i];
     t = wave_sum(t);
     const uint32_t idx = 0xffffffffu - (uint32_t)(*gmax & 0xffffffffull);
     const int64_t r = idx / (uint32_t)LDF;
     const int f = (int)(idx % (uint32_t)LDF);
-    dx[head_row_off(r, heads, x_stride) + threadIdx.x] -= t * ps[(int64_t)f * 64 + threadIdx.x];
+    const int64_t o = head_row_off(r, heads, x_stride) + threadIdx.x;
+    const float v = dx[o] - t * ps[(int64_t)f * 64 + threadIdx.x];
+    dx[o] = v;
+    if (dx_lp) dx_lp[o] = f32_to_bf16(v);
 }
 
 // dden[row] = -(dout . out) * inv over the head's 64 columns (one wave per head row)
@@ -773,7 +791,7 @@ static int fused_prefix(float* state, int B, int G, int S, int LDF, hipStream_t 
 // (sum phi_k (x) v | sum phi_k) for the dq' scan of the backward pass
 extern "C" int sa_favor_fused_fwd(const float* q, const float* k, const float* v, int stride, const void* tiles, const float* ps, const float* offq,
                                   const float* offk, const void* gmax_ws, float* attn, int attn_stride, float* inv_out, float den_eps, int B, int N, int G, int m,
-                                  float* state, void* stream) {
+                                  float* state, void* attn_lp, void* stream) {
     if (!q || !k || !v || !tiles || !ps || !offq || !offk || !gmax_ws || !attn || !inv_out || !state) return SA_EINVAL;
     if (int rc = fused_check(B, N, G, m, 64, stride)) return rc;
     if ((attn_stride & 3) || (int64_t)N * attn_stride * 4 >= ((int64_t)1 << 31)) return SA_EUNSUPPORTED;
@@ -783,6 +801,7 @@ extern "C" int sa_favor_fused_fwd(const float* q, const float* k, const float* v
     s.fa = FeatSrc{k, offk, 1, 0};
     s.fx = FeatSrc{q, offq, 0, 0};
     s.b = v; s.b_stride = stride; s.state = state; s.zmode = 1; s.den_eps = den_eps; s.inv_out = inv_out; s.y = attn; s.y_stride = attn_stride;
+    s.y_lp = (unsigned short*)attn_lp;
     const unsigned nblk = (unsigned)((int64_t)B * G * s.S);
     SA_LAUNCH(favor_fstate_kernel, dim3(nblk), dim3(256), 0, st, s);
     SA_CHECK_LAUNCH();
@@ -797,7 +816,7 @@ extern "C" int sa_favor_fused_fwd(const float* q, const float* k, const float* v
 extern "C" int sa_favor_fused_bwd(const float* q, const float* k, const float* v, int stride, const void* tiles, const float* ps, const float* offq,
                                   const int32_t* amq, const float* offk, const void* gmax_ws, const float* dattn, const float* attn, int attn_stride,
                                   const float* inv, float* dq, float* dk, float* dv, int B, int N, int G, int m, const float* state_fwd, float* state_ws,
-                                  float* dden_ws, float* tsum_ws, void* stream) {
+                                  float* dden_ws, float* tsum_ws, void* dq_lp, void* dk_lp, void* dv_lp, void* stream) {
     if (!q || !k || !v || !tiles || !ps || !offq || !amq || !offk || !gmax_ws || !dattn || !attn || !inv || !dq || !dk || !dv || !state_ws || !dden_ws || !tsum_ws)
         return SA_EINVAL;
     if (int rc = fused_check(B, N, G, m, 64, stride)) return rc;
@@ -815,6 +834,7 @@ extern "C" int sa_favor_fused_bwd(const float* q, const float* k, const float* v
     s.b = v; s.b_stride = stride; s.b_scale = nullptr;
     s.c = dattn; s.c_stride = attn_stride; s.c_scale = inv;
     s.ex_scale = dden_ws; s.zmode = 1; s.ex_const = 1e-6f; s.reverse = 0; s.is_query = 1; s.amx = amq; s.dx = dq; s.tsum = tsum_ws;
+    s.dx_lp = (unsigned short*)dq_lp;
     if (state_fwd) s.state = (float*)state_fwd;
     else {
         s.state = state_ws;
@@ -830,15 +850,17 @@ extern "C" int sa_favor_fused_bwd(const float* q, const float* k, const float* v
     s.b = dattn; s.b_stride = attn_stride; s.b_scale = inv;
     s.c = v; s.c_stride = stride; s.c_scale = nullptr;
     s.zmode = 2; s.ex_const = 0.f; s.reverse = 1; s.is_query = 0; s.amx = nullptr; s.dx = dk; s.state = state_ws;
+    s.dx_lp = (unsigned short*)dk_lp;
     SA_LAUNCH(favor_fstate_kernel, dim3(nblk), dim3(256), 0, st, s);
     SA_CHECK_LAUNCH();
     if (int rc = fused_prefix(state_ws, B, G, s.S, s.LDF, st)) return rc;
     SA_LAUNCH(favor_fout_b_kernel, dim3(nblk), dim3(256), 0, st, s);
     SA_CHECK_LAUNCH();
-    SA_LAUNCH(favor_fkey_fix_kernel, dim3(1), dim3(64), 0, st, dk, stride, G, (const unsigned long long*)gmax_ws, tsum_ws, (int)nblk, ps, s.LDF);
+    SA_LAUNCH(favor_fkey_fix_kernel, dim3(1), dim3(64), 0, st, dk, (unsigned short*)dk_lp, stride, G, (const unsigned long long*)gmax_ws, tsum_ws, (int)nblk, ps, s.LDF);
     SA_CHECK_LAUNCH();
     // dv_j[d] = sum_m phi_k(j)[m] R_j[m][d]: scan A on the same states (a = phi_q, b = dattn inv, reversed), per-position map phi_k, no normaliser
     s.zmode = 0; s.y = dv; s.y_stride = stride; s.inv_out = nullptr; s.accumulate = 0;
+    s.y_lp = (unsigned short*)dv_lp;
     SA_LAUNCH(favor_fout_a_kernel, dim3(nblk), dim3(256), 0, st, s);
     SA_CHECK_LAUNCH();
     return 0;

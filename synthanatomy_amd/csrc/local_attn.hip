@@ -34,12 +34,20 @@ namespace sa {
 struct LAArgs {
     const float *q, *k, *v, *out, *dout, *lse_in, *Dbuf_in;
     float *o, *lse_out, *dq, *dk, *dv, *Dbuf_out;
+    unsigned short *o_lp, *dv_lp;          // optional bf16 copies of the rows written to o / dv (same strides and offsets)
     int32_t q_stride, q_off, k_stride, k_off, v_stride, v_off, o_stride, o_off;
     int32_t B, N, L, W;
     float scale;
     int32_t use_order;                     // split-bf16 kernels: launch the heaviest tiles first
     uint16_t order_q[256], order_k[256];   // rank -> query tile / key tile
 };
+
+__device__ __forceinline__ void la_store_lp(unsigned short* p, const float4 v) {
+    uint2 pk;
+    pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *(uint2*)p = pk;
+}
 
 constexpr int LT = 64;   // tile edge
 constexpr int LLD = 68;  // LDS row stride in floats
@@ -175,8 +183,11 @@ __global__ __launch_bounds__(256) void local_attn_q_kernel(const LAArgs a) {
     if (MODE == 0) {
         const float inv = 1.f / l_run;
 #pragma unroll
-        for (int df = 0; df < 4; ++df)
-            *(float4*)(a.o + (rb + iq) * a.o_stride + ooff + df * 16 + g * 4) = make_float4(acc[df][0] * inv, acc[df][1] * inv, acc[df][2] * inv, acc[df][3] * inv);
+        for (int df = 0; df < 4; ++df) {
+            const float4 ov4 = make_float4(acc[df][0] * inv, acc[df][1] * inv, acc[df][2] * inv, acc[df][3] * inv);
+            *(float4*)(a.o + (rb + iq) * a.o_stride + ooff + df * 16 + g * 4) = ov4;
+            if (a.o_lp) la_store_lp(a.o_lp + (rb + iq) * a.o_stride + ooff + df * 16 + g * 4, ov4);
+        }
         if (g == 0) a.lse_out[(rb + iq) * a.L + h] = m_run + __logf(l_run);
     } else {
 #pragma unroll
@@ -259,6 +270,7 @@ __global__ __launch_bounds__(256) void local_attn_kv_kernel(const LAArgs a) {
 #pragma unroll
     for (int df = 0; df < 4; ++df) {
         *(float4*)(a.dv + (rb + kj) * a.v_stride + voff + df * 16 + g * 4) = make_float4(dva[df][0], dva[df][1], dva[df][2], dva[df][3]);
+        if (a.dv_lp) la_store_lp(a.dv_lp + (rb + kj) * a.v_stride + voff + df * 16 + g * 4, make_float4(dva[df][0], dva[df][1], dva[df][2], dva[df][3]));
         *(float4*)(a.dk + (rb + kj) * a.k_stride + koff + df * 16 + g * 4) = make_float4(dka[df][0], dka[df][1], dka[df][2], dka[df][3]);
     }
 }
@@ -452,8 +464,11 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void local_attn_q_split_ker
     if (MODE == 0) {
         const float inv = 1.f / l_run;
 #pragma unroll
-        for (int df = 0; df < 4; ++df)
-            *(float4*)(a.o + (rb + iq) * a.o_stride + ooff + df * 16 + g * 4) = make_float4(acc[df][0] * inv, acc[df][1] * inv, acc[df][2] * inv, acc[df][3] * inv);
+        for (int df = 0; df < 4; ++df) {
+            const float4 ov4 = make_float4(acc[df][0] * inv, acc[df][1] * inv, acc[df][2] * inv, acc[df][3] * inv);
+            *(float4*)(a.o + (rb + iq) * a.o_stride + ooff + df * 16 + g * 4) = ov4;
+            if (a.o_lp) la_store_lp(a.o_lp + (rb + iq) * a.o_stride + ooff + df * 16 + g * 4, ov4);
+        }
         if (g == 0) a.lse_out[(rb + iq) * a.L + h] = m_run + __logf(l_run);
     } else {
 #pragma unroll
@@ -563,6 +578,7 @@ __global__ __launch_bounds__(256) void local_attn_kv_split_kernel(const LAArgs a
 #pragma unroll
     for (int df = 0; df < 4; ++df) {
         *(float4*)(a.dv + (rb + kj) * a.v_stride + voff + df * 16 + g * 4) = make_float4(dva[df][0], dva[df][1], dva[df][2], dva[df][3]);
+        if (a.dv_lp) la_store_lp(a.dv_lp + (rb + kj) * a.v_stride + voff + df * 16 + g * 4, make_float4(dva[df][0], dva[df][1], dva[df][2], dva[df][3]));
         *(float4*)(a.dk + (rb + kj) * a.k_stride + koff + df * 16 + g * 4) = make_float4(dka[df][0], dka[df][1], dka[df][2], dka[df][3]);
     }
 }
@@ -606,12 +622,12 @@ static int fill_la(LAArgs& a, int q_stride, int q_off, int k_stride, int k_off, 
 using namespace sa;
 
 extern "C" int sa_local_attn_fwd(const float* q, int q_stride, int q_off, const float* k, int k_stride, int k_off, const float* v, int v_stride, int v_off,
-                                 float* o, int o_stride, int o_off, float* lse, int B, int N, int L, int W, int dh, void* stream) {
+                                 float* o, int o_stride, int o_off, float* lse, int B, int N, int L, int W, int dh, void* o_lp, void* stream) {
     if (!q || !k || !v || !o || !lse) return SA_EINVAL;
     LAArgs a = {};
     const int rc = fill_la(a, q_stride, q_off, k_stride, k_off, v_stride, v_off, o_stride, o_off, B, N, L, W, dh);
     if (rc) return rc;
-    a.q = q; a.k = k; a.v = v; a.o = o; a.lse_out = lse;
+    a.q = q; a.k = k; a.v = v; a.o = o; a.lse_out = lse; a.o_lp = (unsigned short*)o_lp;
     const unsigned nblk = (unsigned)(B * L * ((N + LT - 1) / LT));
     if (la_exact()) SA_LAUNCH(local_attn_q_kernel<0>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
     else SA_LAUNCH(local_attn_q_split_kernel<0>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);
@@ -621,12 +637,12 @@ extern "C" int sa_local_attn_fwd(const float* q, int q_stride, int q_off, const 
 
 extern "C" int sa_local_attn_bwd(const float* q, int q_stride, int q_off, const float* k, int k_stride, int k_off, const float* v, int v_stride, int v_off,
                                  const float* out, const float* dout, int o_stride, int o_off, const float* lse, float* dq, float* dk, float* dv,
-                                 float* Dbuf, int B, int N, int L, int W, int dh, void* stream) {
+                                 float* Dbuf, int B, int N, int L, int W, int dh, void* dv_lp, void* stream) {
     if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !Dbuf) return SA_EINVAL;
     LAArgs a = {};
     const int rc = fill_la(a, q_stride, q_off, k_stride, k_off, v_stride, v_off, o_stride, o_off, B, N, L, W, dh);
     if (rc) return rc;
-    a.q = q; a.k = k; a.v = v; a.out = out; a.dout = dout; a.lse_in = lse; a.dq = dq; a.dk = dk; a.dv = dv; a.Dbuf_out = Dbuf; a.Dbuf_in = Dbuf;
+    a.q = q; a.k = k; a.v = v; a.out = out; a.dout = dout; a.lse_in = lse; a.dq = dq; a.dk = dk; a.dv = dv; a.Dbuf_out = Dbuf; a.Dbuf_in = Dbuf; a.dv_lp = (unsigned short*)dv_lp;
     const unsigned nblk = (unsigned)(B * L * ((N + LT - 1) / LT));
     const bool exact = la_exact();
     if (exact) SA_LAUNCH(local_attn_q_kernel<1>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a);

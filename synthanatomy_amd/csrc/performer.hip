@@ -1309,7 +1309,7 @@ __global__ void favor_dden_kernel(const float* __restrict__ dout, const float* _
 // thread = four consecutive dimensions of the first half of one head row and their partners in the second half (16-byte accesses)
 __global__ void rotary_kernel(const float* __restrict__ x, int stride, int off, int L, int dh, const float* __restrict__ cosb,
                               const float* __restrict__ sinb, float* __restrict__ y, int y_stride, int y_off, int N, int64_t R, int mode,
-                              int accumulate, int ngroups, int64_t x_goff, int64_t y_goff) {
+                              int accumulate, int ngroups, int64_t x_goff, int64_t y_goff, unsigned short* __restrict__ y_lp) {
     // ngroups > 1: the same rotation for several operands in one launch (q and k): group gi reads at x + gi * x_goff and writes at y + gi * y_goff
     const int half = dh / 2, q4 = half / 4;
     const int64_t per = R * L * q4, total = per * ngroups;
@@ -1343,6 +1343,16 @@ __global__ void rotary_kernel(const float* __restrict__ x, int stride, int off, 
         }
         *(float4*)yp = ol;
         *(float4*)(yp + half) = oh;
+        if (y_lp) {   // bf16 copy at the same element offsets (the operand of the next dense layer)
+            unsigned short* lp = y_lp + (gi * y_goff + r * y_stride + y_off + h * dh + d);
+            uint2 pl, ph;
+            pl.x = (uint32_t)f32_to_bf16(ol.x) | ((uint32_t)f32_to_bf16(ol.y) << 16);
+            pl.y = (uint32_t)f32_to_bf16(ol.z) | ((uint32_t)f32_to_bf16(ol.w) << 16);
+            ph.x = (uint32_t)f32_to_bf16(oh.x) | ((uint32_t)f32_to_bf16(oh.y) << 16);
+            ph.y = (uint32_t)f32_to_bf16(oh.z) | ((uint32_t)f32_to_bf16(oh.w) << 16);
+            *(uint2*)lp = pl;
+            *(uint2*)(lp + half) = ph;
+        }
         x -= gi * x_goff;
         y -= gi * y_goff;
     }
@@ -1991,18 +2001,18 @@ extern "C" int sa_rotary(const float* x, int stride, int off, int L, int dh, con
     if (!x || !cosb || !sinb || !y || L <= 0 || dh <= 0 || (dh & 1) || R <= 0) return SA_EINVAL;
     if ((dh & 7) || ((stride | off | y_stride | y_off) & 3)) return SA_EUNSUPPORTED;   // 16-byte accesses on both halves of a head row
     SA_LAUNCH(rotary_kernel, dim3(grid1d(R * L * dh / 8)), dim3(256), 0, ST(stream), x, stride, off, L, dh, cosb, sinb, y, y_stride, y_off, N, R,
-                       transpose, accumulate, 1, (int64_t)0, (int64_t)0);
+                       transpose, accumulate, 1, (int64_t)0, (int64_t)0, (unsigned short*)nullptr);
     SA_CHECK_LAUNCH();
     return 0;
 }
 
 // the same for `ngroups` operands in one launch (q and k of a layer): operand gi lives x_goff / y_goff ELEMENTS behind operand 0
 extern "C" int sa_rotary_groups(const float* x, int stride, int off, int L, int dh, const float* cosb, const float* sinb, float* y, int y_stride, int y_off,
-                                int N, int64_t R, int transpose, int accumulate, int ngroups, int64_t x_goff, int64_t y_goff, void* stream) {
+                                int N, int64_t R, int transpose, int accumulate, int ngroups, int64_t x_goff, int64_t y_goff, void* y_lp, void* stream) {
     if (!x || !cosb || !sinb || !y || L <= 0 || dh <= 0 || (dh & 1) || R <= 0 || ngroups < 1) return SA_EINVAL;
     if ((dh & 7) || ((stride | off | y_stride | y_off) & 3) || ((x_goff | y_goff) & 3)) return SA_EUNSUPPORTED;
     SA_LAUNCH(rotary_kernel, dim3(grid1d(R * L * dh / 8 * ngroups)), dim3(256), 0, ST(stream), x, stride, off, L, dh, cosb, sinb, y, y_stride, y_off, N, R,
-                       transpose, accumulate, ngroups, x_goff, y_goff);
+                       transpose, accumulate, ngroups, x_goff, y_goff, (unsigned short*)y_lp);
     SA_CHECK_LAUNCH();
     return 0;
 }

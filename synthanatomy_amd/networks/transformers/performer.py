@@ -416,6 +416,9 @@ class _LayerEngine:
             v = self.ops["to_v"].fprop(_as5(xaT), out_dtype=f32).view(R, inner)
         qs = q.stride(0)   # row stride of q / k / v (3 * inner when they are column blocks of one matrix)
         attn = torch.empty(R, inner, dtype=f32, device=dev)
+        # throughput mode: the attention kernels write the bf16 operand of to_out next to the fp32 rows (no cast launch); needs every head on a kernel that can
+        attn_lp = (torch.empty(R, inner, dtype=T, device=dev)
+                   if (T == torch.bfloat16 and (G == 0 or self._fused_favor()) and not debug.host("no_lp_mirrors")) else None)
         sv = dict(x=x, xa=xa, xaT=xaT, st_a=st_a, q=q, k=k, v=v, attn=attn)
         if G > 0 and self._fused_favor():
             tiles, ps = self._proj_tiles()
@@ -434,7 +437,7 @@ class _LayerEngine:
             _ck(lib.sa_favor_fused_prepass(_ffi.ptr(q), _ffi.ptr(k), qs, G, _ffi.ptr(tiles), _ffi.ptr(offq), _ffi.ptr(amq), _ffi.ptr(offk), _ffi.ptr(gws), R * G, m, dh, st),
                 "sa_favor_fused_prepass")
             rc = lib.sa_favor_fused_fwd(_ffi.ptr(q), _ffi.ptr(k), _ffi.ptr(v), qs, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(offk), _ffi.ptr(gws),
-                                        _ffi.ptr(attn), inner, _ffi.ptr(inv), 1e-6, B, N, G, m, _ffi.ptr(state), st)
+                                        _ffi.ptr(attn), inner, _ffi.ptr(inv), 1e-6, B, N, G, m, _ffi.ptr(state), _ffi.ptr(attn_lp), st)
             _ck(rc, "sa_favor_fused_fwd")
             sv.update(fused=True, offq=offq, offk=offk, amq=amq, gws=gws, inv=inv, scan_state=state if tape is not None else None)
         elif G > 0:
@@ -483,16 +486,16 @@ class _LayerEngine:
             qkr = torch.empty(2, R, L * dh, dtype=f32, device=dev)
             qr, kr = qkr[0], qkr[1]
             if k.data_ptr() - q.data_ptr() == inner * 4 and q.stride(0) == k.stride(0):   # q | k are column blocks of one matrix: one launch rotates both
-                _ck(lib.sa_rotary_groups(_ffi.ptr(q), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(qkr), L * dh, 0, N, R, 0, 0, 2, inner, R * L * dh, st),
+                _ck(lib.sa_rotary_groups(_ffi.ptr(q), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(qkr), L * dh, 0, N, R, 0, 0, 2, inner, R * L * dh, None, st),
                     "sa_rotary_groups(q|k)")
             else:
                 _ck(lib.sa_rotary(_ffi.ptr(q), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(qr), L * dh, 0, N, R, 0, 0, st), "sa_rotary(q)")
                 _ck(lib.sa_rotary(_ffi.ptr(k), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(kr), L * dh, 0, N, R, 0, 0, st), "sa_rotary(k)")
             lse = torch.empty(R * L, dtype=f32, device=dev)
             _ck(lib.sa_local_attn_fwd(_ffi.ptr(qr), L * dh, 0, _ffi.ptr(kr), L * dh, 0, _ffi.ptr(v), qs, G * dh, _ffi.ptr(attn), inner, G * dh, _ffi.ptr(lse),
-                                      B, N, L, self.W, dh, st), "sa_local_attn_fwd")
+                                      B, N, L, self.W, dh, _ffi.ptr(attn_lp), st), "sa_local_attn_fwd")
             sv.update(qr=qr, kr=kr, lse=lse)
-        attnT = _cast(attn, T)
+        attnT = attn_lp if attn_lp is not None else _cast(attn, T)
         ga = self._gate(self.aw, dev)
         gf = self._gate(self.fw, dev)
         fuse_epi = lp and not debug.host("no_fused_epilogues")
@@ -651,13 +654,19 @@ class _LayerEngine:
         dattn = ops["to_out"].dgrad(_as5(dFa), r5, out_dtype=f32).view(R, inner)
         q, k, v, attn = sv["q"], sv["k"], sv["v"], sv["attn"]
         fused_qkv = "to_qkv" in ops and q.stride(0) == 3 * inner
+        dqkv_lp = None
         if fused_qkv:   # gradients as column blocks of one matrix, like q / k / v themselves: one cast, one wgrad, one dgrad below
             dqkv = torch.empty(R, 3 * inner, dtype=f32, device=dev)
             dq, dk, dv = dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:]
+            if T == torch.bfloat16 and (G == 0 or sv.get("fused")) and not debug.host("no_lp_mirrors"):
+                dqkv_lp = torch.empty(R, 3 * inner, dtype=T, device=dev)   # bf16 mirror written by the same kernels: operand of the q|k|v weight / data gradient
+                dq_lp, dk_lp, dv_lp = dqkv_lp[:, :inner], dqkv_lp[:, inner:2 * inner], dqkv_lp[:, 2 * inner:]
         else:
             dq = torch.empty(R, inner, dtype=f32, device=dev)
             dk = torch.empty(R, inner, dtype=f32, device=dev)
             dv = torch.empty(R, inner, dtype=f32, device=dev)
+        if not fused_qkv or dqkv_lp is None:
+            dqkv_lp = dq_lp = dk_lp = dv_lp = None
         qs = dq.stride(0)   # == q.stride(0): the kernels below address v / dv (and dq / dk) with one row stride
         assert qs == q.stride(0) == v.stride(0)
         if G > 0 and sv.get("fused"):
@@ -669,7 +678,8 @@ class _LayerEngine:
             tsum = torch.empty(B * G * ((N + 63) // 64), dtype=f32, device=dev)
             _ck(lib.sa_favor_fused_bwd(_ffi.ptr(q), _ffi.ptr(k), _ffi.ptr(v), qs, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(sv["offq"]), _ffi.ptr(sv["amq"]),
                                        _ffi.ptr(sv["offk"]), _ffi.ptr(sv["gws"]), _ffi.ptr(dattn), _ffi.ptr(attn), inner, _ffi.ptr(sv["inv"]), _ffi.ptr(dq),
-                                       _ffi.ptr(dk), _ffi.ptr(dv), B, N, G, m, _ffi.ptr(sv.get("scan_state")), _ffi.ptr(self._ws), _ffi.ptr(dden), _ffi.ptr(tsum), st),
+                                       _ffi.ptr(dk), _ffi.ptr(dv), B, N, G, m, _ffi.ptr(sv.get("scan_state")), _ffi.ptr(self._ws), _ffi.ptr(dden), _ffi.ptr(tsum),
+                                       _ffi.ptr(dq_lp), _ffi.ptr(dk_lp), _ffi.ptr(dv_lp), st),
                 "sa_favor_fused_bwd")
             sv["scan_state"] = None
         elif G > 0:
@@ -729,10 +739,10 @@ class _LayerEngine:
             dqr, dkr = dqkr[0], dqkr[1]
             Db = torch.empty(R * L, dtype=f32, device=dev)
             _ck(lib.sa_local_attn_bwd(_ffi.ptr(sv["qr"]), L * dh, 0, _ffi.ptr(sv["kr"]), L * dh, 0, _ffi.ptr(v), qs, G * dh, _ffi.ptr(attn), _ffi.ptr(dattn),
-                                      inner, G * dh, _ffi.ptr(sv["lse"]), _ffi.ptr(dqr), _ffi.ptr(dkr), _ffi.ptr(dv), _ffi.ptr(Db), B, N, L, self.W, dh, st),
+                                      inner, G * dh, _ffi.ptr(sv["lse"]), _ffi.ptr(dqr), _ffi.ptr(dkr), _ffi.ptr(dv), _ffi.ptr(Db), B, N, L, self.W, dh, _ffi.ptr(dv_lp), st),
                 "sa_local_attn_bwd")
             if fused_qkv:   # dq | dk are column blocks of one matrix: one launch
-                _ck(lib.sa_rotary_groups(_ffi.ptr(dqkr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dq), qs, G * dh, N, R, 1, 0, 2, R * L * dh, inner, st),
+                _ck(lib.sa_rotary_groups(_ffi.ptr(dqkr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dq), qs, G * dh, N, R, 1, 0, 2, R * L * dh, inner, _ffi.ptr(dq_lp), st),
                     "sa_rotary_groups^T(q|k)")
             else:
                 _ck(lib.sa_rotary(_ffi.ptr(dqr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dq), qs, G * dh, N, R, 1, 0, st), "sa_rotary^T(q)")
@@ -740,7 +750,7 @@ class _LayerEngine:
         xaT = _as5(sv["xaT"])
         base = _as5(dx1) if self.rezero else None
         if fused_qkv:
-            dqkvT = _as5(_cast(dqkv, T))
+            dqkvT = _as5(dqkv_lp if dqkv_lp is not None else _cast(dqkv, T))
             gbufs = [gc.buf(sa.to_q.weight), gc.buf(sa.to_k.weight), gc.buf(sa.to_v.weight)]
             gw = self._stacked([t.view(inner, self.dim) for t in gbufs])
             if gw is not None:

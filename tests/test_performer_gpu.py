@@ -296,6 +296,18 @@ def test_rotary_and_rezero_backward_kernels():
     rhs = float((x[:, 64:64 + L * dh].double() * gx[:, 64:64 + L * dh].double()).sum())
     assert abs(lhs - rhs) < 1e-6 * abs(lhs) + 1e-6
     assert float(gx[:, :64].abs().max()) == 0.0 and float(gx[:, 64 + L * dh:].abs().max()) == 0.0
+    # two operands in one launch (q | k as column blocks of one matrix, 2 * wide apart ... here: two stacked gradient matrices -> two column blocks), with the
+    # bf16 mirror of what is written (the operand of the q|k|v weight / data gradient)
+    g2 = torch.randn(2, R, L * dh, device="cuda")
+    both = torch.full((R, 2 * wide), 5.0, device="cuda")
+    both_lp = torch.full((R, 2 * wide), 5.0, device="cuda", dtype=torch.bfloat16)
+    _ffi.check(lib.sa_rotary_groups(_ffi.ptr(g2), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(both), 2 * wide, 64, N, R, 1, 0, 2, R * L * dh, wide,
+                                    _ffi.ptr(both_lp), st))
+    for i in range(2):
+        one = torch.zeros(R, wide, device="cuda")
+        _ffi.check(lib.sa_rotary(_ffi.ptr(g2[i]), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(one), wide, 64, N, R, 1, 0, st))
+        assert torch.equal(both[:, i * wide + 64:i * wide + 64 + L * dh], one[:, 64:64 + L * dh])
+    assert torch.equal(both_lp, both.to(torch.bfloat16))     # written columns: rounded copies; everything else untouched (5.0 is exact in bf16)
     once = gx.clone()
     _ffi.check(lib.sa_rotary(_ffi.ptr(g), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(gx), wide, 64, N, R, 1, 1, st))
     assert _rel(gx, 2 * once) < 1e-6
@@ -495,7 +507,7 @@ def test_local_attention_kernel_against_dense_band(N, W, la_path):
     qd, kd, vd = pack(q), pack(k), pack(v)
     o = torch.empty_like(qd)
     lse = torch.empty(B * N * L, device="cuda")
-    _ffi.check(lib.sa_local_attn_fwd(_ffi.ptr(qd), L * dh, 0, _ffi.ptr(kd), L * dh, 0, _ffi.ptr(vd), L * dh, 0, _ffi.ptr(o), L * dh, 0, _ffi.ptr(lse), B, N, L, W, dh, st))
+    _ffi.check(lib.sa_local_attn_fwd(_ffi.ptr(qd), L * dh, 0, _ffi.ptr(kd), L * dh, 0, _ffi.ptr(vd), L * dh, 0, _ffi.ptr(o), L * dh, 0, _ffi.ptr(lse), B, N, L, W, dh, None, st))
     got = o.view(B, N, L, dh).permute(0, 2, 1, 3)
     assert _rel(got, ref) < 1e-4
 
@@ -590,13 +602,16 @@ def test_local_attention_backward_kernels_against_autograd(N, W, la_path):
     pack = lambda t: t.detach().permute(0, 2, 1, 3).reshape(B * N, L * dh).contiguous().cuda()
     qd, kd, vd, god = pack(q), pack(k), pack(v), pack(go)
     o = torch.empty_like(qd)
+    o_lp = torch.empty_like(qd, dtype=torch.bfloat16)     # bf16 mirrors (the operands of the next dense layers) ride along with the fp32 outputs
     lse = torch.empty(B * N * L, device="cuda")
-    _ffi.check(lib.sa_local_attn_fwd(_ffi.ptr(qd), L * dh, 0, _ffi.ptr(kd), L * dh, 0, _ffi.ptr(vd), L * dh, 0, _ffi.ptr(o), L * dh, 0, _ffi.ptr(lse), B, N, L, W, dh, st))
+    _ffi.check(lib.sa_local_attn_fwd(_ffi.ptr(qd), L * dh, 0, _ffi.ptr(kd), L * dh, 0, _ffi.ptr(vd), L * dh, 0, _ffi.ptr(o), L * dh, 0, _ffi.ptr(lse), B, N, L, W, dh, _ffi.ptr(o_lp), st))
     dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    dv_lp = torch.empty_like(vd, dtype=torch.bfloat16)
     Db = torch.empty(B * N * L, device="cuda")
     _ffi.check(lib.sa_local_attn_bwd(_ffi.ptr(qd), L * dh, 0, _ffi.ptr(kd), L * dh, 0, _ffi.ptr(vd), L * dh, 0, _ffi.ptr(o), _ffi.ptr(god), L * dh, 0, _ffi.ptr(lse),
-                                     _ffi.ptr(dq), _ffi.ptr(dk), _ffi.ptr(dv), _ffi.ptr(Db), B, N, L, W, dh, st))
+                                     _ffi.ptr(dq), _ffi.ptr(dk), _ffi.ptr(dv), _ffi.ptr(Db), B, N, L, W, dh, _ffi.ptr(dv_lp), st))
     unpack = lambda t: t.view(B, N, L, dh).permute(0, 2, 1, 3)
+    assert torch.equal(o_lp, o.to(torch.bfloat16)) and torch.equal(dv_lp, dv.to(torch.bfloat16))
     assert _rel(unpack(o), ref) < 1e-4
     assert _rel(unpack(dq), q.grad) < 1e-4 and _rel(unpack(dk), k.grad) < 1e-4 and _rel(unpack(dv), v.grad) < 1e-4
 

@@ -43,9 +43,9 @@ def main():
         dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
         Db = torch.empty(B * N * L, device="cuda")
         fwd = lambda: _ffi.check(lib.sa_local_attn_fwd(_ffi.ptr(qd), L * dh, 0, _ffi.ptr(kd), L * dh, 0, _ffi.ptr(vd), L * dh, 0, _ffi.ptr(o), L * dh, 0,
-                                                       _ffi.ptr(lse), B, N, L, W, dh, st))
+                                                       _ffi.ptr(lse), B, N, L, W, dh, None, st))
         bwd = lambda: _ffi.check(lib.sa_local_attn_bwd(_ffi.ptr(qd), L * dh, 0, _ffi.ptr(kd), L * dh, 0, _ffi.ptr(vd), L * dh, 0, _ffi.ptr(o), _ffi.ptr(god),
-                                                       L * dh, 0, _ffi.ptr(lse), _ffi.ptr(dq), _ffi.ptr(dk), _ffi.ptr(dv), _ffi.ptr(Db), B, N, L, W, dh, st))
+                                                       L * dh, 0, _ffi.ptr(lse), _ffi.ptr(dq), _ffi.ptr(dk), _ffi.ptr(dv), _ffi.ptr(Db), B, N, L, W, dh, None, st))
         tf, tb = timeit(fwd), timeit(bwd)
         rel = lambda a, b: float((a.double() - b).norm() / b.norm())
         mx = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
