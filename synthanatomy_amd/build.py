@@ -27,7 +27,10 @@ def _sources():
 
 def _digest(path):
     h = hashlib.sha1()
-    for dep in [path, os.path.join(CSRC, "sa_common.h"), os.path.join(CSRC, "split_bf16.h"), os.path.join(HERE, "..", "include", "synthanatomy_hip.h")]:
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    if not path.endswith(("conv_fprop.hip", "dense_ring.hip")):
+        hdrs = [h for h in hdrs if not h.endswith("conv_fprop_common.h")]     # only its two includers depend on it
+    for dep in [path, *hdrs, os.path.join(HERE, "..", "include", "synthanatomy_hip.h")]:
         with open(dep, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())

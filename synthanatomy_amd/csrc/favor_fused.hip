@@ -332,11 +332,17 @@ __global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs
 
 // ------------------------------------------------------------------------------------------------ chunk state sums
 // U_c[m][d] = sum_{j in chunk} phi_a(j)[m] (b_j[d] bs_j),   z[m] = sum_j phi_a(j)[m] w_j     (zmode 1: w = 1, zmode 2: w = ex_scale_j)
-__global__ __launch_bounds__(256, 2) void favor_fstate_kernel(const FusedArgs s) {
-    __shared__ __attribute__((aligned(16))) unsigned char sBh[FT_BYTES], sBl[FT_BYTES], sAh[FT_BYTES], sAl[FT_BYTES], sP[2][2 * FT_BYTES];   // (the projection slab is double-buffered: two barriers per slab)
-    __shared__ float sW[64];
+// (the three chunk kernels are bodies over a block id and ONE 80 KiB LDS buffer, so that two of them that do not depend on each other can share a launch:
+//  favor_fpair_kernel below)
+constexpr int FUSED_LDS = 10 * FT_BYTES;
+typedef unsigned char FSlab2[2 * FT_BYTES];
+
+__device__ __forceinline__ void favor_fstate_body(const FusedArgs& s, const int bid, unsigned char* const lds) {
+    unsigned char* const sBh = lds, * const sBl = lds + FT_BYTES, * const sAh = lds + 2 * FT_BYTES, * const sAl = lds + 3 * FT_BYTES;
+    FSlab2* const sP = (FSlab2*)(lds + 4 * FT_BYTES);   // (the projection slab is double-buffered: two barriers per slab)
+    float* const sW = (float*)(lds + 8 * FT_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
-    const int chunk = blockIdx.x % s.S, g = (blockIdx.x / s.S) % s.G, b = blockIdx.x / (s.S * s.G);
+    const int chunk = bid % s.S, g = (bid / s.S) % s.G, b = bid / (s.S * s.G);
     const float kmax = unpack_max(*s.gmax);
     const int p = chunk * 64 + w * 16 + fr;
     const bool valid = p < s.N;
@@ -434,12 +440,14 @@ __global__ void favor_fprefix_kernel(float* __restrict__ state, int64_t BG, int 
 
 // ------------------------------------------------------------------------------------------------ chunk outputs, scan A
 // y_i[d] = sum_m T_prev[m][d] phi_x(i)[m] + sum_{j <= i} b_j[d] (phi_a(j) . phi_x(i))      (zmode 1: divided by phi_x(i) . (z_i + eps))
-__global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_a_kernel(const FusedArgs s) {
-    __shared__ __attribute__((aligned(16))) unsigned char sAh[FT_BYTES], sAl[FT_BYTES], sT[2][2 * FT_BYTES], sP[2][2 * FT_BYTES];   // state and projection slabs double-buffered
-    unsigned char* const sBh = sAh;   // the value rows take the feature tile's place after the slab loop (48 KiB: three blocks per CU)
+__device__ __forceinline__ void favor_fout_a_body(const FusedArgs& s, const int bid, unsigned char* const lds) {
+    unsigned char* const sAh = lds, * const sAl = lds + FT_BYTES;
+    FSlab2* const sT = (FSlab2*)(lds + 2 * FT_BYTES);   // state and projection slabs double-buffered
+    FSlab2* const sP = (FSlab2*)(lds + 6 * FT_BYTES);
+    unsigned char* const sBh = sAh;   // the value rows take the feature tile's place after the slab loop
     unsigned char* const sBl = sAl;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
-    const int chunk = blockIdx.x % s.S, g = (blockIdx.x / s.S) % s.G, b = blockIdx.x / (s.S * s.G);
+    const int chunk = bid % s.S, g = (bid / s.S) % s.G, b = bid / (s.S * s.G);
     const float kmax = unpack_max(*s.gmax);
     const int64_t zs = (int64_t)s.LDF * 64 + s.LDF;
     const float* st0 = s.state + (((int64_t)b * s.G + g) * s.S + chunk) * zs;
@@ -548,13 +556,15 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_a_kernel(const Fuse
 // dphi_i[m] = sum_d T_prev[m][d] c_i[d] + sum_{j <= i} phi_a(j)[m] (b_j . c_i + E[j][i]) + (running-sum terms)      (c_i times c_scale_i)
 //   zmode 1: E[j][i] = ex_scale_i,  + ex_scale_i (z_prev[m] + ex_const);     zmode 2: E[j][i] = ex_scale_j,  + z_prev[m]
 // v = (phi_x(i) - ratio eps) dphi_i,  t = sum_m v[m],  dx_i = sum_m v[m] P[m] - [query] t P[argmax_i] - t c^2 x_i
-__global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_b_kernel(const FusedArgs s) {
-    __shared__ __attribute__((aligned(16))) unsigned char sT[2][2 * FT_BYTES], sAh[FT_BYTES], sAl[FT_BYTES], sP[2][2 * FT_BYTES];   // double-buffered slabs
+__device__ __forceinline__ void favor_fout_b_body(const FusedArgs& s, const int bid, unsigned char* const lds) {
+    FSlab2* const sT = (FSlab2*)lds;   // double-buffered slabs
+    unsigned char* const sAh = lds + 4 * FT_BYTES, * const sAl = lds + 5 * FT_BYTES;
+    FSlab2* const sP = (FSlab2*)(lds + 6 * FT_BYTES);
     float* const sred = (float*)sAh;    // (block reduction of the keys' t after the slab loop: the feature tile is dead by then; 80 KiB exactly -> two blocks per CU)
     unsigned char* const sBh = sT[0];   // the value tile is dead once the pair products exist: the first state slab takes its place
     unsigned char* const sBl = sT[0] + FT_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
-    const int chunk = blockIdx.x % s.S, g = (blockIdx.x / s.S) % s.G, b = blockIdx.x / (s.S * s.G);
+    const int chunk = bid % s.S, g = (bid / s.S) % s.G, b = bid / (s.S * s.G);
     const float kmax = unpack_max(*s.gmax);
     const __amdgpu_buffer_rsrc_t rc = f_rsrc(s.c + (int64_t)b * s.N * s.c_stride, (int64_t)s.N * s.c_stride * 4);
     const __amdgpu_buffer_rsrc_t rcs = f_rsrc((s.c_scale ? s.c_scale : s.c) + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G * 4);
@@ -690,8 +700,34 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_b_kernel(const Fuse
         __syncthreads();   // every wave is past its last read of the feature tile
         if (lane == 0) sred[w] = tb;
         __syncthreads();
-        if (tid == 0) s.tsum[blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);   // one partial per block, summed in a fixed order by the fix-up launch
+        if (tid == 0) s.tsum[bid] = (sred[0] + sred[1]) + (sred[2] + sred[3]);   // one partial per block, summed in a fixed order by the fix-up launch
     }
+}
+
+__global__ __launch_bounds__(256, 2) void favor_fstate_kernel(const FusedArgs s) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
+    favor_fstate_body(s, (int)blockIdx.x, lds);
+}
+__global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_a_kernel(const FusedArgs s) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
+    favor_fout_a_body(s, (int)blockIdx.x, lds);
+}
+__global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_b_kernel(const FusedArgs s) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
+    favor_fout_b_body(s, (int)blockIdx.x, lds);
+}
+// Two chunk kernels that do not depend on each other in ONE launch (blocks [0, nb) run scan B, the rest the other body): B * G * ceil(N / 64) = 1 056 blocks are
+// 2.06 rounds on the 512 resident slots, i.e. every one of these launches ends in a tail of 32 blocks on an otherwise idle chip (measured: N = 1 344 -- 1 008
+// blocks -- is 15-18 % faster than N = 1 400); back to back the pair is 4.1 rounds with ONE tail, and the lighter body's blocks fill it.
+__global__ __launch_bounds__(256, FUSED_WPS) void favor_fpair_b_state_kernel(const FusedArgs sb, const FusedArgs ss, const int nb) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
+    if ((int)blockIdx.x < nb) favor_fout_b_body(sb, (int)blockIdx.x, lds);
+    else favor_fstate_body(ss, (int)blockIdx.x - nb, lds);
+}
+__global__ __launch_bounds__(256, FUSED_WPS) void favor_fpair_b_a_kernel(const FusedArgs sb, const FusedArgs sa, const int nb) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
+    if ((int)blockIdx.x < nb) favor_fout_b_body(sb, (int)blockIdx.x, lds);
+    else favor_fout_a_body(sa, (int)blockIdx.x - nb, lds);
 }
 
 // keys: the global-max element (head row r*, feature f*) takes -(sum of all t): dk[r*] -= T P[f*];  T = the per-block partials in a fixed order (deterministic)
@@ -835,6 +871,9 @@ extern "C" int sa_favor_fused_bwd(const float* q, const float* k, const float* v
     s.c = dattn; s.c_stride = attn_stride; s.c_scale = inv;
     s.ex_scale = dden_ws; s.zmode = 1; s.ex_const = 1e-6f; s.reverse = 0; s.is_query = 1; s.amx = amq; s.dx = dq; s.tsum = tsum_ws;
     s.dx_lp = (unsigned short*)dq_lp;
+    // Independent launches share a grid (favor_fpair_*): [scan B for dq | reversed chunk states] when the forward's states were kept, and [scan B for dk | scan A for dv].
+    // SA_PP_DBG bit 9 keeps the five separate launches (A/B runs; results are bit-identical either way).
+    const bool pair = !(g_tunables.pp_dbg & 512u);
     if (state_fwd) s.state = (float*)state_fwd;
     else {
         s.state = state_ws;
@@ -842,8 +881,7 @@ extern "C" int sa_favor_fused_bwd(const float* q, const float* k, const float* v
         SA_CHECK_LAUNCH();
         if (int rc = fused_prefix(state_ws, B, G, s.S, s.LDF, st)) return rc;
     }
-    SA_LAUNCH(favor_fout_b_kernel, dim3(nblk), dim3(256), 0, st, s);
-    SA_CHECK_LAUNCH();
+    const FusedArgs sq = s;
     // ---- d loss / d k and d loss / d v: reversed scans over i >= j of phi_q(i) (x) (dattn_i inv_i), running sums weighted by d den_i
     s.fa = FeatSrc{q, offq, 0, 0};
     s.fx = FeatSrc{k, offk, 1, 0};
@@ -851,17 +889,32 @@ extern "C" int sa_favor_fused_bwd(const float* q, const float* k, const float* v
     s.c = v; s.c_stride = stride; s.c_scale = nullptr;
     s.zmode = 2; s.ex_const = 0.f; s.reverse = 1; s.is_query = 0; s.amx = nullptr; s.dx = dk; s.state = state_ws;
     s.dx_lp = (unsigned short*)dk_lp;
-    SA_LAUNCH(favor_fstate_kernel, dim3(nblk), dim3(256), 0, st, s);
-    SA_CHECK_LAUNCH();
+    const FusedArgs sk = s;
+    if (pair && state_fwd) {
+        SA_LAUNCH(favor_fpair_b_state_kernel, dim3(2 * nblk), dim3(256), 0, st, sq, sk, (int)nblk);
+        SA_CHECK_LAUNCH();
+    } else {
+        SA_LAUNCH(favor_fout_b_kernel, dim3(nblk), dim3(256), 0, st, sq);
+        SA_CHECK_LAUNCH();
+        SA_LAUNCH(favor_fstate_kernel, dim3(nblk), dim3(256), 0, st, sk);
+        SA_CHECK_LAUNCH();
+    }
     if (int rc = fused_prefix(state_ws, B, G, s.S, s.LDF, st)) return rc;
-    SA_LAUNCH(favor_fout_b_kernel, dim3(nblk), dim3(256), 0, st, s);
-    SA_CHECK_LAUNCH();
-    SA_LAUNCH(favor_fkey_fix_kernel, dim3(1), dim3(64), 0, st, dk, (unsigned short*)dk_lp, stride, G, (const unsigned long long*)gmax_ws, tsum_ws, (int)nblk, ps, s.LDF);
-    SA_CHECK_LAUNCH();
     // dv_j[d] = sum_m phi_k(j)[m] R_j[m][d]: scan A on the same states (a = phi_q, b = dattn inv, reversed), per-position map phi_k, no normaliser
     s.zmode = 0; s.y = dv; s.y_stride = stride; s.inv_out = nullptr; s.accumulate = 0;
     s.y_lp = (unsigned short*)dv_lp;
-    SA_LAUNCH(favor_fout_a_kernel, dim3(nblk), dim3(256), 0, st, s);
+    if (pair) {
+        SA_LAUNCH(favor_fpair_b_a_kernel, dim3(2 * nblk), dim3(256), 0, st, sk, s, (int)nblk);
+        SA_CHECK_LAUNCH();
+    } else {
+        SA_LAUNCH(favor_fout_b_kernel, dim3(nblk), dim3(256), 0, st, sk);
+        SA_CHECK_LAUNCH();
+    }
+    SA_LAUNCH(favor_fkey_fix_kernel, dim3(1), dim3(64), 0, st, dk, (unsigned short*)dk_lp, stride, G, (const unsigned long long*)gmax_ws, tsum_ws, (int)nblk, ps, s.LDF);
     SA_CHECK_LAUNCH();
+    if (!pair) {
+        SA_LAUNCH(favor_fout_a_kernel, dim3(nblk), dim3(256), 0, st, s);
+        SA_CHECK_LAUNCH();
+    }
     return 0;
 }
