@@ -233,20 +233,38 @@ __global__ void rezero_bwd_bf16x4_kernel(const float4* __restrict__ dy, const ui
                                          float* __restrict__ dg, int64_t n4) {
     const float gv = g[0];
     float s = 0.f;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
-        const float4 d = dy[e];
-        const uint2 f = F[e];
+    auto one = [&](const float4 d, const uint2 f, int64_t e) __attribute__((always_inline)) {
         s += d.x * __uint_as_float(f.x << 16) + d.y * __uint_as_float(f.x & 0xffff0000u) + d.z * __uint_as_float(f.y << 16) + d.w * __uint_as_float(f.y & 0xffff0000u);
         uint2 o;
         o.x = (uint32_t)f32_to_bf16(gv * d.x) | ((uint32_t)f32_to_bf16(gv * d.y) << 16);
         o.y = (uint32_t)f32_to_bf16(gv * d.z) | ((uint32_t)f32_to_bf16(gv * d.w) << 16);
         dF[e] = o;
+    };
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // four positions per trip with all eight loads in flight before the first use: one trip per thread at the Performer's size (a plain grid-stride loop made
+    // four dependent HBM round trips: 19 us for 34 MB)
+    for (; e + 3 * step < n4; e += 4 * step) {
+        float4 d[4];
+        uint2 f[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            d[u] = dy[e + u * step];
+            f[u] = F[e + u * step];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(d[u], f[u], e + u * step);
     }
+    for (; e < n4; e += step) one(dy[e], F[e], e);
     s = wave_sum(s);
-    __shared__ float red[4];
+    __shared__ float red[16];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(dg, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {   // one atomic per block: same-address fp32 atomics serialise in L2, so the launch uses few, large blocks (1 024 blocks = 10 us of atomics)
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+        unsafeAtomicAdd(dg, t);
+    }
 }
 
 __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, int64_t n) {
@@ -1313,16 +1331,28 @@ __global__ void rotary_kernel(const float* __restrict__ x, int stride, int off, 
     // ngroups > 1: the same rotation for several operands in one launch (q and k): group gi reads at x + gi * x_goff and writes at y + gi * y_goff
     const int half = dh / 2, q4 = half / 4;
     const int64_t per = R * L * q4, total = per * ngroups;
+    const bool small = total < ((int64_t)1 << 31);       // index arithmetic in 32 bits (five run-time divisions per element: the 64-bit forms cost more than the loads)
     for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += (int64_t)gridDim.x * blockDim.x) {
-        const int gi = (int)(e0 / per);
-        const int64_t e = e0 - gi * per;
+        int gi, j, h, n;
+        int64_t r;
+        if (small) {
+            const uint32_t u0 = (uint32_t)e0, up = (uint32_t)per;
+            const uint32_t ug = u0 / up, ue = u0 - ug * up;
+            const uint32_t urh = ue / (uint32_t)q4, uj = ue - urh * (uint32_t)q4;
+            const uint32_t ur = urh / (uint32_t)L, uh = urh - ur * (uint32_t)L;
+            gi = (int)ug; j = (int)uj; h = (int)uh; r = ur; n = (int)(ur % (uint32_t)N);
+        } else {
+            gi = (int)(e0 / per);
+            const int64_t e = e0 - gi * per;
+            j = (int)(e % q4);
+            const int64_t rh = e / q4;
+            h = (int)(rh % L);
+            r = rh / L;
+            n = (int)(r % N);
+        }
         x += gi * x_goff;
         y += gi * y_goff;
-        const int j = (int)(e % q4);
-        const int64_t rh = e / q4;
-        const int h = (int)(rh % L);
-        const int64_t r = rh / L;
-        const int n = (int)(r % N), d = j * 4;
+        const int d = j * 4;
         const float* xr = x + r * stride + off + h * dh;
         const float4 xl = *(const float4*)(xr + d), xh = *(const float4*)(xr + d + half);
         const float4 cl = *(const float4*)(cosb + n * dh + d), ch = *(const float4*)(cosb + n * dh + d + half);
@@ -1818,7 +1848,7 @@ extern "C" int sa_rezero_fwd(const float* x, const void* F, int f_dtype, const f
 extern "C" int sa_rezero_bwd(const float* dy, const void* F, int f_dtype, const float* g, void* dF, int df_dtype, float* dg, int64_t n, void* stream) {
     if (!dy || !F || !g || !dF || !dg || n <= 0) return SA_EINVAL;
     if (f_dtype == SA_BF16 && df_dtype == SA_BF16 && (n & 3) == 0 && (((uintptr_t)dy | (uintptr_t)F | (uintptr_t)dF) & 15) == 0) {
-        SA_LAUNCH(rezero_bwd_bf16x4_kernel, dim3(grid1d(n / 4, 256, 1024)), dim3(256), 0, ST(stream), (const float4*)dy, (const uint2*)F, g, (uint2*)dF, dg,
+        SA_LAUNCH(rezero_bwd_bf16x4_kernel, dim3(grid1d(n / 4, 1024, 256)), dim3(1024), 0, ST(stream), (const float4*)dy, (const uint2*)F, g, (uint2*)dF, dg,
                            n / 4);
         SA_CHECK_LAUNCH();
         return 0;
