@@ -217,7 +217,7 @@ int sa_local_attn_step(const float *q, int q_stride, int q_off, const float *k, 
 /* small-batch dense layer of the decode step (B <= 32 rows; a stream over the fp32 nn.Linear weights, up to three tensors concatenated
  * along the outputs, e.g. q | k | v): y[b][o] = epi(sum_i x[b][i] W[o][i] + bias[o]); act 0 none / 1 GELU; then y = res + gate * y when
  * res is given (gate: device scalar or NULL = 1).  round_in / round_w / round_out reproduce the bf16 operand / output rounding of the
- * MFMA path. */
+ * MFMA path; round_w = 2: the `w` tensors already HOLD bf16 values ([out][in] bf16 copies of the parameters: half the bytes per token). */
 int sa_gemv_rows(const float *x, int x_stride, int in, int B, int nseg, const float *const *w, const float *const *bias, const int32_t *seg_out,
                  float *y, int y_stride, int act, const float *res, int res_stride, const float *gate, int round_in, int round_w, int round_out,
                  void *stream);

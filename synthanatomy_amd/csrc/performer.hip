@@ -1586,7 +1586,7 @@ __device__ __forceinline__ float bf16_round(float f) { return __uint_as_float((u
 // (mfma_f32_16x16x4f32, K permuted so that a lane still reads 16 contiguous bytes).
 // The K range is split over the block's 8 waves (a single wave streaming a whole weight row is pure HBM latency: 34 us for K = 2048);
 // their partial 16 x 16 tiles are summed through LDS by wave 0, which runs the epilogue.
-template <bool BF16>
+template <bool BF16, bool WB = false>   // WB: the weight tensors hold bf16 values (decode copies of the fp32 parameters: half the bytes, no conversion in the loop)
 __global__ __launch_bounds__(512) void gemv_rows_kernel(const GemvArgs a, int b0) {
     __shared__ float part[8][64][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, fr = lane & 15, kg = lane >> 4;
@@ -1605,13 +1605,18 @@ __global__ __launch_bounds__(512) void gemv_rows_kernel(const GemvArgs a, int b0
     const float* xr = a.x + (int64_t)(brow ? b : 0) * a.x_stride;
     float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f};
     if constexpr (BF16) {
-#pragma unroll 4
+        const bf16_t* wrb = (const bf16_t*)a.w[sgi] + (int64_t)oo * a.in;
+#pragma unroll 8
         for (int k0 = kbeg; k0 < kend; k0 += 32) {
-            const float4 w0 = *(const float4*)(wr + k0 + kg * 8), w1 = *(const float4*)(wr + k0 + kg * 8 + 4);
-            const float4 x0 = *(const float4*)(xr + k0 + kg * 8), x1 = *(const float4*)(xr + k0 + kg * 8 + 4);
             short8_t wa, xb;
-            wa[0] = (short)f32_to_bf16(w0.x); wa[1] = (short)f32_to_bf16(w0.y); wa[2] = (short)f32_to_bf16(w0.z); wa[3] = (short)f32_to_bf16(w0.w);
-            wa[4] = (short)f32_to_bf16(w1.x); wa[5] = (short)f32_to_bf16(w1.y); wa[6] = (short)f32_to_bf16(w1.z); wa[7] = (short)f32_to_bf16(w1.w);
+            if constexpr (WB) {
+                wa = *(const short8_t*)(wrb + k0 + kg * 8);
+            } else {
+                const float4 w0 = *(const float4*)(wr + k0 + kg * 8), w1 = *(const float4*)(wr + k0 + kg * 8 + 4);
+                wa[0] = (short)f32_to_bf16(w0.x); wa[1] = (short)f32_to_bf16(w0.y); wa[2] = (short)f32_to_bf16(w0.z); wa[3] = (short)f32_to_bf16(w0.w);
+                wa[4] = (short)f32_to_bf16(w1.x); wa[5] = (short)f32_to_bf16(w1.y); wa[6] = (short)f32_to_bf16(w1.z); wa[7] = (short)f32_to_bf16(w1.w);
+            }
+            const float4 x0 = *(const float4*)(xr + k0 + kg * 8), x1 = *(const float4*)(xr + k0 + kg * 8 + 4);
             xb[0] = (short)f32_to_bf16(x0.x); xb[1] = (short)f32_to_bf16(x0.y); xb[2] = (short)f32_to_bf16(x0.z); xb[3] = (short)f32_to_bf16(x0.w);
             xb[4] = (short)f32_to_bf16(x1.x); xb[5] = (short)f32_to_bf16(x1.y); xb[6] = (short)f32_to_bf16(x1.z); xb[7] = (short)f32_to_bf16(x1.w);
             if (!brow) xb = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
@@ -2111,7 +2116,7 @@ extern "C" int sa_gemv_rows(const float* x, int x_stride, int in, int B, int nse
                             float* y, int y_stride, int act, const float* res, int res_stride, const float* gate, int round_in, int round_w, int round_out,
                             void* stream) {
     if (!x || !w || !seg_out || !y || nseg < 1 || nseg > 3 || B <= 0 || in <= 0 || (in & (round_in ? 31 : 15)) || (x_stride & 3)) return SA_EINVAL;   // K steps of 32 (bf16) / 16 (fp32)
-    if (round_in != round_w) return SA_EUNSUPPORTED;   // both operands in bf16 (MFMA bf16) or both exact
+    if ((round_in != 0) != (round_w != 0) || round_w > 2) return SA_EUNSUPPORTED;   // both operands in bf16 (MFMA bf16) or both exact; round_w = 2: w holds bf16 tensors
     GemvArgs a;
     a.x = x; a.x_stride = x_stride; a.in = in; a.B = B; a.nseg = nseg; a.O = 0;
     for (int s = 0; s < 3; ++s) {
@@ -2124,7 +2129,8 @@ extern "C" int sa_gemv_rows(const float* x, int x_stride, int in, int B, int nse
     a.round_in = round_in; a.round_w = round_w; a.round_out = round_out;
     const unsigned blocks = (unsigned)((a.O + 15) / 16);
     for (int b0 = 0; b0 < B; b0 += 16) {
-        if (round_in) SA_LAUNCH(gemv_rows_kernel<true>, dim3(blocks), dim3(512), 0, ST(stream), a, b0);
+        if (round_w == 2) SA_LAUNCH((gemv_rows_kernel<true, true>), dim3(blocks), dim3(512), 0, ST(stream), a, b0);
+        else if (round_in) SA_LAUNCH(gemv_rows_kernel<true>, dim3(blocks), dim3(512), 0, ST(stream), a, b0);
         else SA_LAUNCH(gemv_rows_kernel<false>, dim3(blocks), dim3(512), 0, ST(stream), a, b0);
         SA_CHECK_LAUNCH();
     }

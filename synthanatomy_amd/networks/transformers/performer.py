@@ -562,13 +562,31 @@ class _LayerEngine:
         lib, st = _ffi.lib(), _ffi.stream()
         B, cin = x.shape
         n = len(mods)
-        wp = (ctypes.c_void_p * n)(*[m.weight.data_ptr() for m in mods])
+        rnd = 1 if self.dtype == torch.bfloat16 else 0
+        rw = rnd
+        ws = [m.weight for m in mods]
+        if rnd and not debug.host("no_decode_bf16_weights"):
+            # bf16 compute: the decode step streams bf16 COPIES of the parameters (the values the kernel would round to anyway): half the bytes per token, and the
+            # 200 MB of a 24-layer network stay resident in the 256 MB Infinity Cache between tokens.  Made on first use per parameter version (outside graph capture:
+            # the sampler's warm-up step runs first).
+            ws = [self._decode_weight(m) for m in mods]
+            rw = 2
+        wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
         bp = (ctypes.c_void_p * n)(*[(m.bias.data_ptr() if m.bias is not None else None) for m in mods])
         so = (ctypes.c_int32 * n)(*[m.weight.shape[0] for m in mods])
-        rnd = 1 if self.dtype == torch.bfloat16 else 0
         _ck(lib.sa_gemv_rows(_ffi.ptr(x), x.stride(0), cin, B, n, wp, bp, so, _ffi.ptr(y), y.stride(0), act, _ffi.ptr(res) if res is not None else None,
-                             res.stride(0) if res is not None else 0, _ffi.ptr(gate), rnd, rnd, 1 if (round_out and rnd) else 0, st), "sa_gemv_rows")
+                             res.stride(0) if res is not None else 0, _ffi.ptr(gate), rnd, rw, 1 if (round_out and rnd) else 0, st), "sa_gemv_rows")
         return y
+
+    def _decode_weight(self, mod):
+        cache = self.__dict__.setdefault("_dec_w", {})
+        ent = cache.get(id(mod))
+        w = mod.weight
+        # (the optimizer writes parameters through raw pointers, which `_version` does not see: the sampler drops this cache at the start of every sample())
+        if ent is None or ent[0] != w._version or ent[1].device != w.device or ent[2] != w.data_ptr():
+            ent = (w._version, w.detach().to(torch.bfloat16).contiguous(), w.data_ptr())
+            cache[id(mod)] = ent
+        return ent[1]
 
     def step(self, x, B, N, pos, stt):
         """x [B, dim] fp32 = the block input at position *pos (device int32) -> block output; updates `stt`.  Seven launches, no host
@@ -1069,6 +1087,8 @@ class Performer(TransformerBase):
         dim = tables[0].shape[1]
         layers = self._chain.layers
         states = [l.new_state(B, npos, dev) for l in layers]
+        for l in layers:
+            l.__dict__.pop("_dec_w", None)     # bf16 decode copies of the parameters: rebuilt from the current values by the warm-up step
         col = torch.arange(total, device=dev)[None, :]
 
         def one_step():

@@ -652,6 +652,14 @@ def test_small_batch_dense_kernel(B, cin, segs, act, resid, rnd):
     torch.cuda.synchronize()
     assert torch.isfinite(y).all()
     assert _rel(y.cpu(), ref) < (1.5e-2 if rnd else 1e-5)
+    if rnd:   # round_w = 2: the weight tensors already hold bf16 copies (what the sampler streams) -> the same bits as rounding the fp32 weights in the kernel
+        w16 = [w.to(torch.bfloat16).contiguous() for w in wd]
+        wp16 = (ctypes.c_void_p * n)(*[w.data_ptr() for w in w16])
+        y2 = torch.full((B, sum(segs)), float("nan"), device="cuda")
+        _ffi.check(lib.sa_gemv_rows(_ffi.ptr(xd), cin, cin, B, n, wp16, bp, so, _ffi.ptr(y2), sum(segs), act, _ffi.ptr(resd), sum(segs) if resid else 0,
+                                    _ffi.ptr(gd) if resid else None, rnd, 2, rnd, st))
+        torch.cuda.synchronize()
+        assert torch.equal(y2, y)
 
 
 @pytest.mark.parametrize("variant", ["fixed", "prepending", "bos_replacement"])
