@@ -214,6 +214,12 @@ int sa_favor_step(const float *q, int q_stride, int q_off, const float *k, int k
 int sa_local_attn_step(const float *q, int q_stride, int q_off, const float *k, int k_stride, int k_off, const float *v, int v_stride, int v_off,
                        const float *cosb, const float *sinb, float *kcache, float *vcache, const int *pos, int B, int N, int L, int W, int dh,
                        float *out, int out_stride, int out_off, void *stream);
+/* sa_favor_step + sa_local_attn_step of one layer in TWO launches when it has both kinds of heads (q | k | v = column blocks of `qkv`, row stride
+ * `stride`, inner = (G + L) * dh, global heads first): [projections | local heads over four key segments] then [FAVOR+ update | combine].  part: B * L * 4 * 66
+ * floats of scratch.  Equal to the two calls up to the summation order of the local softmax. */
+int sa_attn_step(const float *qkv, int stride, int inner, const float *proj, int B, int G, int L, int dh, int m, int LDF, float *smax, int *kmax, float *dd,
+                 float *E, float *Ez, float *V1, const float *cosb, const float *sinb, float *kcache, float *vcache, int N, int W, float *part,
+                 const int *pos, float *out, int out_stride, void *stream);
 /* small-batch dense layer of the decode step (B <= 32 rows; a stream over the fp32 nn.Linear weights, up to three tensors concatenated
  * along the outputs, e.g. q | k | v): y[b][o] = epi(sum_i x[b][i] W[o][i] + bias[o]); act 0 none / 1 GELU; then y = res + gate * y when
  * res is given (gate: device scalar or NULL = 1).  round_in / round_w / round_out reproduce the bf16 operand / output rounding of the

@@ -88,6 +88,8 @@ _SIGS = {
     "sa_embed_step": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "sa_favor_step": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "sa_attn_step": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "sa_gemv_rows": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), c_void_p, c_int, c_int, c_void_p,
                              c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sa_local_attn_step": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

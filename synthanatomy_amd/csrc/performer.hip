@@ -1415,13 +1415,24 @@ __global__ void embed_step_kernel(const EmbedArgs a, const int* __restrict__ pos
 __device__ __forceinline__ int f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
-__global__ __launch_bounds__(256) void favor_step_proj_kernel(const float* __restrict__ q, int q_stride, int q_off, const float* __restrict__ k, int k_stride,
-                                                              int k_off, const float* __restrict__ proj, int G, int dh, int m, int LDF,
-                                                              float* __restrict__ dd /* [2][B*G][LDF] */, int* __restrict__ kmax /* [2] */,
-                                                              const int* __restrict__ pos) {
+struct FavorProjArgs {
+    const float *q, *k, *proj;
+    int q_stride, q_off, k_stride, k_off, G, dh, m, LDF;
+    float* dd;      // [2][B*G][LDF]
+    int* kmax;      // [2]
+    const int* pos;
+    int rows;       // B * G
+};
+
+__device__ __forceinline__ void favor_step_proj_body(const FavorProjArgs& a, const int bg) {
     __shared__ float sq[64], sk[64], red[4];
-    const int bg = blockIdx.x, b = bg / G, g = bg % G, tid = threadIdx.x;
-    const int64_t rows = gridDim.x;
+    const float *q = a.q, *k = a.k, *proj = a.proj;
+    float* dd = a.dd;
+    int* kmax = a.kmax;
+    const int* pos = a.pos;
+    const int q_stride = a.q_stride, q_off = a.q_off, k_stride = a.k_stride, k_off = a.k_off, G = a.G, dh = a.dh, m = a.m, LDF = a.LDF;
+    const int b = bg / G, g = bg % G, tid = threadIdx.x;
+    const int64_t rows = a.rows;
     if (tid < dh) {
         sq[tid] = q[(int64_t)b * q_stride + q_off + g * dh + tid];
         sk[tid] = k[(int64_t)b * k_stride + k_off + g * dh + tid];
@@ -1447,6 +1458,8 @@ __global__ __launch_bounds__(256) void favor_step_proj_kernel(const float* __res
     if (tid == 0) atomicMax(kmax + (*pos & 1), f2ord(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 
+__global__ __launch_bounds__(256) void favor_step_proj_kernel(const FavorProjArgs a) { favor_step_proj_body(a, (int)blockIdx.x); }
+
 struct FavorStepArgs {
     const float *ddq, *ddk;            // [B*G, LDF] projections (data_normalizer folded into the projection matrix)
     const float *q, *k, *v;            // rows of the fused qkv output
@@ -1461,11 +1474,11 @@ struct FavorStepArgs {
     float eps_feat, eps_den;
 };
 
-__global__ __launch_bounds__(1024) void favor_step_kernel(const FavorStepArgs a) {
+__device__ __forceinline__ void favor_step_body(const FavorStepArgs& a, const int bg) {
     // 16 waves: wave w owns features w, w+16, ... (17 of the 266): their 64-float state rows are independent read-modify-writes, so all of
     // a wave's loads are in flight together -- with 4 waves and 67 dependent-looking iterations this kernel took 33 us of pure latency.
     __shared__ float sq[64], sk[64], sv[64], sqf[320], sek[320], red[32], snum[16][64];
-    const int bg = blockIdx.x, b = bg / a.G, g = bg % a.G, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = bg / a.G, g = bg % a.G, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int dh = a.dh, m = a.m;
     if (tid < dh) {
         sq[tid] = a.q[(int64_t)b * a.q_stride + a.q_off + g * dh + tid];
@@ -1556,6 +1569,8 @@ __global__ __launch_bounds__(1024) void favor_step_kernel(const FavorStepArgs a)
         a.out[(int64_t)b * a.out_stride + a.out_off + g * dh + tid] = ratio * (num + a.eps_feat * qsum * v1) / den;
     }
 }
+
+__global__ __launch_bounds__(1024) void favor_step_kernel(const FavorStepArgs a) { favor_step_body(a, (int)blockIdx.x); }
 
 // ---- small-batch dense layer of the decode step: y[b][o] = epi( sum_i x[b][i] W[o][i] + bias[o] ), B <= 32 rows.
 // At B rows the layer is a stream over the weights (HBM bound).  Up to three weight tensors are concatenated along the output dimension
@@ -1748,6 +1763,123 @@ __global__ __launch_bounds__(1024) void local_attn_step_kernel(const LocalStepAr
         for (int i = 0; i < 16; ++i) acc += sacc[i][tid];
         a.out[(int64_t)b * a.out_stride + a.out_off + l * dh + tid] = acc / sum;
     }
+}
+
+
+// ---- a layer's attention step in TWO launches (global + local heads present).  The three launches above leave most of the chip idle (48 + 48 + 48 blocks)
+// and the local step walks up to 2 W keys in ONE block per (batch, head) (5 -> 29 us as the window fills).  Here:
+//   launch A = [projections of the global heads (favor_step_proj_body) | local heads, keys split over LSPLIT blocks each: partial (max, sum, weighted values)]
+//   launch B = [FAVOR+ state update + output (favor_step_body)          | combine of the local partials -> attention rows]
+// The new key / value row is appended to the cache by split 0; every split keeps it in LDS as well, so no block reads another block's store.
+constexpr int LSPLIT = 4;
+constexpr int LPART = 66;      // per (batch, head, split): running maximum, sum of exp, 64 weighted value sums
+
+__device__ __forceinline__ void local_step_partial_body(const LocalStepArgs& a, float* __restrict__ part, const int blk) {
+    __shared__ __attribute__((aligned(16))) float sq[64], skt[64], svt[64];
+    __shared__ float sc[256], red[4], sacc[4][64];
+    const int bl = blk / LSPLIT, sp = blk % LSPLIT, b = bl / a.L, l = bl % a.L, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int dh = a.dh, half = dh / 2, t = *a.pos;
+    float* kc = a.kc + ((int64_t)bl * a.N) * dh;
+    float* vc = a.vc + ((int64_t)bl * a.N) * dh;
+    if (tid < dh) {
+        const float* qr = a.q + (int64_t)b * a.q_stride + a.q_off + l * dh;
+        const float* kr = a.k + (int64_t)b * a.k_stride + a.k_off + l * dh;
+        const float cs = a.cosb[t * dh + tid], sn = a.sinb[t * dh + tid];
+        const float qrot = tid < half ? -qr[tid + half] : qr[tid - half];
+        const float krot = tid < half ? -kr[tid + half] : kr[tid - half];
+        const float kv = kr[tid] * cs + krot * sn, vv = a.v[(int64_t)b * a.v_stride + a.v_off + l * dh + tid];
+        sq[tid] = (qr[tid] * cs + qrot * sn) * rsqrtf((float)dh);
+        skt[tid] = kv;
+        svt[tid] = vv;
+        if (sp == 0) {
+            kc[(int64_t)t * dh + tid] = kv;
+            vc[(int64_t)t * dh + tid] = vv;
+        }
+    }
+    __syncthreads();
+    const int w = t / a.W, lo = (w > 0 ? w - 1 : 0) * a.W, nk = t - lo + 1;
+    const int per = (nk + LSPLIT - 1) / LSPLIT, j0 = sp * per, j1 = min(nk, j0 + per);      // per <= 2 W / 4 <= 256 (checked by the launcher)
+    const int cnt = max(0, j1 - j0);
+    float d = -INFINITY;
+    if (tid < cnt) {
+        const int j = lo + j0 + tid;
+        const float4* kj = j == t ? (const float4*)skt : (const float4*)(kc + (int64_t)j * dh);
+        float4 kv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) kv[e] = kj[e];
+        d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float4 qv = *(const float4*)(sq + 4 * e);
+            d = fmaf(qv.x, kv[e].x, fmaf(qv.y, kv[e].y, fmaf(qv.z, kv[e].z, fmaf(qv.w, kv[e].w, d))));
+        }
+    }
+    float mx = d;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float pj = tid < cnt ? __expf(d - mx) : 0.f;
+    sc[tid] = pj;
+    float sum = pj;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    __syncthreads();          // red is reused; sc complete
+    if (lane == 0) red[wv] = sum;
+    __syncthreads();
+    sum = (red[0] + red[1]) + (red[2] + red[3]);
+    float acc = 0.f;          // thread = (key slice wv, value dim lane)
+    int j = wv;
+    for (; j + 28 < cnt; j += 32) {
+        float vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int jj = lo + j0 + j + 4 * u;
+            vv[u] = jj == t ? svt[lane] : vc[(int64_t)jj * dh + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(sc[j + 4 * u], vv[u], acc);
+    }
+    for (; j < cnt; j += 4) {
+        const int jj = lo + j0 + j;
+        acc = fmaf(sc[j], jj == t ? svt[lane] : vc[(int64_t)jj * dh + lane], acc);
+    }
+    sacc[wv][lane] = acc;
+    __syncthreads();
+    float* pr = part + (int64_t)blk * LPART;
+    if (tid < dh) pr[2 + tid] = (sacc[0][tid] + sacc[1][tid]) + (sacc[2][tid] + sacc[3][tid]);
+    if (tid == 0) {
+        pr[0] = cnt > 0 ? mx : -INFINITY;
+        pr[1] = cnt > 0 ? sum : 0.f;
+    }
+}
+
+__device__ __forceinline__ void local_step_combine_body(const LocalStepArgs& a, const float* __restrict__ part, const int bl) {
+    const int b = bl / a.L, l = bl % a.L, tid = threadIdx.x;
+    if (tid >= a.dh) return;
+    const float* pr = part + (int64_t)bl * LSPLIT * LPART;
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < LSPLIT; ++s) M = fmaxf(M, pr[s * LPART]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int s = 0; s < LSPLIT; ++s) {
+        const float ms = pr[s * LPART];
+        const float w = ms == -INFINITY ? 0.f : __expf(ms - M);
+        num = fmaf(w, pr[s * LPART + 2 + tid], num);
+        den = fmaf(w, pr[s * LPART + 1], den);
+    }
+    a.out[(int64_t)b * a.out_stride + a.out_off + l * a.dh + tid] = num / den;
+}
+
+__global__ __launch_bounds__(256) void attn_step_a_kernel(const FavorProjArgs pa, const LocalStepArgs la, float* __restrict__ part, const int nproj) {
+    if ((int)blockIdx.x < nproj) favor_step_proj_body(pa, (int)blockIdx.x);
+    else local_step_partial_body(la, part, (int)blockIdx.x - nproj);
+}
+__global__ __launch_bounds__(1024) void attn_step_b_kernel(const FavorStepArgs fa, const LocalStepArgs la, const float* __restrict__ part, const int nfav) {
+    if ((int)blockIdx.x < nfav) favor_step_body(fa, (int)blockIdx.x);
+    else local_step_combine_body(la, part, (int)blockIdx.x - nfav);
 }
 
 
@@ -2083,7 +2215,10 @@ extern "C" int sa_favor_step(const float* q, int q_stride, int q_off, const floa
                              const int* pos, float* out, int out_stride, int out_off, void* stream) {
     if (!q || !k || !v || !proj || !smax || !kmax || !dd || !E || !Ez || !V1 || !pos || !out) return SA_EINVAL;
     if (dh != 64 || m > 272 || B <= 0 || G <= 0) return SA_EUNSUPPORTED;   // 16 waves x 17 features
-    SA_LAUNCH(favor_step_proj_kernel, dim3(B * G), dim3(256), 0, ST(stream), q, q_stride, q_off, k, k_stride, k_off, proj, G, dh, m, LDF, dd, kmax, pos);
+    FavorProjArgs pa;
+    pa.q = q; pa.k = k; pa.proj = proj; pa.q_stride = q_stride; pa.q_off = q_off; pa.k_stride = k_stride; pa.k_off = k_off; pa.G = G; pa.dh = dh; pa.m = m; pa.LDF = LDF;
+    pa.dd = dd; pa.kmax = kmax; pa.pos = pos; pa.rows = B * G;
+    SA_LAUNCH(favor_step_proj_kernel, dim3(B * G), dim3(256), 0, ST(stream), pa);
     SA_CHECK_LAUNCH();
     FavorStepArgs a;
     a.ddq = dd; a.ddk = dd + (int64_t)B * G * LDF; a.q = q; a.k = k; a.v = v;
@@ -2108,6 +2243,34 @@ extern "C" int sa_local_attn_step(const float* q, int q_stride, int q_off, const
     a.cosb = cosb; a.sinb = sinb; a.kc = kcache; a.vc = vcache; a.pos = pos; a.N = N; a.W = W; a.L = L; a.dh = dh;
     a.out = out; a.out_stride = out_stride; a.out_off = out_off;
     SA_LAUNCH(local_attn_step_kernel, dim3(B * L), dim3(1024), 2 * (size_t)W * sizeof(float), ST(stream), a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+// global + local heads of one layer's decode step in two launches (attn_step_a_kernel / attn_step_b_kernel): arguments of sa_favor_step and sa_local_attn_step,
+// plus `part`: B * L * 4 * 66 floats of scratch.  Same results as the two calls up to the summation order of the local heads' softmax (keys in four segments).
+extern "C" int sa_attn_step(const float* qkv, int stride, int inner, const float* proj, int B, int G, int L, int dh, int m, int LDF, float* smax, int* kmax, float* dd,
+                            float* E, float* Ez, float* V1, const float* cosb, const float* sinb, float* kcache, float* vcache, int N, int W, float* part,
+                            const int* pos, float* out, int out_stride, void* stream) {
+    if (!qkv || !proj || !smax || !kmax || !dd || !E || !Ez || !V1 || !cosb || !sinb || !kcache || !vcache || !part || !pos || !out) return SA_EINVAL;
+    if (dh != 64 || m > 272 || B <= 0 || G <= 0 || L <= 0 || W <= 0 || (2 * W + LSPLIT - 1) / LSPLIT > 256 || inner != (G + L) * dh) return SA_EUNSUPPORTED;
+    FavorProjArgs pa;
+    pa.q = qkv; pa.k = qkv; pa.proj = proj; pa.q_stride = stride; pa.q_off = 0; pa.k_stride = stride; pa.k_off = inner; pa.G = G; pa.dh = dh; pa.m = m; pa.LDF = LDF;
+    pa.dd = dd; pa.kmax = kmax; pa.pos = pos; pa.rows = B * G;
+    LocalStepArgs la;
+    la.q = qkv; la.k = qkv; la.v = qkv; la.q_stride = stride; la.q_off = G * dh; la.k_stride = stride; la.k_off = inner + G * dh; la.v_stride = stride;
+    la.v_off = 2 * inner + G * dh; la.cosb = cosb; la.sinb = sinb; la.kc = kcache; la.vc = vcache; la.pos = pos; la.N = N; la.W = W; la.L = L; la.dh = dh;
+    la.out = out; la.out_stride = out_stride; la.out_off = G * dh;
+    SA_LAUNCH(attn_step_a_kernel, dim3(B * G + B * L * LSPLIT), dim3(256), 0, ST(stream), pa, la, part, B * G);
+    SA_CHECK_LAUNCH();
+    FavorStepArgs a;
+    a.ddq = dd; a.ddk = dd + (int64_t)B * G * LDF; a.q = qkv; a.k = qkv; a.v = qkv;
+    a.q_stride = stride; a.q_off = 0; a.k_stride = stride; a.k_off = inner; a.v_stride = stride; a.v_off = 2 * inner;
+    a.G = G; a.dh = dh; a.m = m; a.LDF = LDF; a.smax = smax; a.kmax = kmax; a.E = E; a.Ez = Ez; a.V1 = V1; a.pos = pos;
+    a.out = out; a.out_stride = out_stride; a.out_off = 0;
+    a.eps_feat = 1e-4f;
+    a.eps_den = 1e-6f;
+    SA_LAUNCH(attn_step_b_kernel, dim3(B * G + B * L), dim3(1024), 0, ST(stream), a, la, (const float*)part, B * G);
     SA_CHECK_LAUNCH();
     return 0;
 }

@@ -543,7 +543,8 @@ class _LayerEngine:
                    dd=torch.zeros(2, max(B * G, 1), LDF, dtype=f32, device=dev),
                    E=torch.empty(max(B * G, 1), LDF * dh, dtype=f32, device=dev), Ez=torch.empty(max(B * G, 1), LDF, dtype=f32, device=dev),
                    V1=torch.empty(max(B * G, 1), dh, dtype=f32, device=dev), kc=torch.empty(B, max(L, 1), N, dh, dtype=f32, device=dev),
-                   vc=torch.empty(B, max(L, 1), N, dh, dtype=f32, device=dev))
+                   vc=torch.empty(B, max(L, 1), N, dh, dtype=f32, device=dev),
+                   lpart=torch.empty(B * max(L, 1) * 4 * 66, dtype=f32, device=dev))      # sa_attn_step: partial softmax of the local heads (4 key segments)
         self.reset_state(stt)
         return stt
 
@@ -589,7 +590,7 @@ class _LayerEngine:
         return ent[1]
 
     def step(self, x, B, N, pos, stt):
-        """x [B, dim] fp32 = the block input at position *pos (device int32) -> block output; updates `stt`.  Seven launches, no host
+        """x [B, dim] fp32 = the block input at position *pos (device int32) -> block output; updates `stt`.  Six launches (seven without sa_attn_step), no host
         synchronisation and no host-side dependence on the position, so a whole token step can be captured in a HIP graph."""
         lib, st, dev = _ffi.lib(), _ffi.stream(), x.device
         sa, ff = self.sa, self.ff
@@ -600,13 +601,21 @@ class _LayerEngine:
         qkv = torch.empty(B, 3 * inner, dtype=f32, device=dev)
         self._gemv(xa, [sa.to_q, sa.to_k, sa.to_v], qkv)
         attn = torch.empty(B, inner, dtype=f32, device=dev)
-        if G > 0:
+        merged = G > 0 and L > 0 and dh == 64 and (2 * self.W + 3) // 4 <= 256 and not debug.host("no_attn_step_merge")
+        if merged:
+            # both kinds of heads in TWO launches: [projections | local heads over four key segments], [FAVOR+ update | combine of the segments]
+            self._proj_op()
+            cosb, sinb = self._rot_tables(N, dev)
+            _ck(lib.sa_attn_step(_ffi.ptr(qkv), 3 * inner, inner, _ffi.ptr(self._pop[2]), B, G, L, dh, m, LDF, _ffi.ptr(stt["smax"]), _ffi.ptr(stt["kmax"]),
+                                 _ffi.ptr(stt["dd"]), _ffi.ptr(stt["E"]), _ffi.ptr(stt["Ez"]), _ffi.ptr(stt["V1"]), _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(stt["kc"]),
+                                 _ffi.ptr(stt["vc"]), N, self.W, _ffi.ptr(stt["lpart"]), _ffi.ptr(pos), _ffi.ptr(attn), inner, st), "sa_attn_step")
+        if G > 0 and not merged:
             self._proj_op()
             ps = self._pop[2]    # projection matrix with the data normaliser folded in
             _ck(lib.sa_favor_step(_ffi.ptr(qkv), 3 * inner, 0, _ffi.ptr(qkv), 3 * inner, inner, _ffi.ptr(qkv), 3 * inner, 2 * inner, _ffi.ptr(ps), B, G, dh, m, LDF,
                                   _ffi.ptr(stt["smax"]), _ffi.ptr(stt["kmax"]), _ffi.ptr(stt["dd"]), _ffi.ptr(stt["E"]), _ffi.ptr(stt["Ez"]), _ffi.ptr(stt["V1"]),
                                   _ffi.ptr(pos), _ffi.ptr(attn), inner, 0, st), "sa_favor_step")
-        if L > 0:
+        if L > 0 and not merged:
             cosb, sinb = self._rot_tables(N, dev)
             _ck(lib.sa_local_attn_step(_ffi.ptr(qkv), 3 * inner, G * dh, _ffi.ptr(qkv), 3 * inner, inner + G * dh, _ffi.ptr(qkv), 3 * inner, 2 * inner + G * dh,
                                        _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(stt["kc"]), _ffi.ptr(stt["vc"]), _ffi.ptr(pos), B, N, L, self.W, dh, _ffi.ptr(attn),
