@@ -754,3 +754,52 @@ def test_stateful_sampler_with_bos_replacement_conditioning():
         x = torch.cat((x, P.forward(st, cfg, x, seqs, conds, "bos_replacement")[:, -1].argmax(-1, keepdim=True)), 1)
     ref = x[:, 1:][:, o.get_revert_sequence_ordering()].reshape(B, *shape)
     assert torch.equal(fast.cpu(), ref)
+
+
+@pytest.mark.parametrize("B,G,L,N,W", [(2, 2, 2, 60, 7), (3, 1, 3, 1000, 420), (1, 3, 1, 300, 64)])
+def test_two_launch_attention_step_equals_the_separate_steps(B, G, L, N, W):
+    """sa_attn_step ([projections | local heads over four key segments], [FAVOR+ update | combine]) against sa_favor_step + sa_local_attn_step on the same
+    random q | k | v rows, position by position over N steps (window fills, window boundaries, the second window sliding): attention rows <= 1e-5, key / value
+    caches and the FAVOR+ state identical."""
+    from synthanatomy_amd import _ffi
+    lib, st = _ffi.lib(), _ffi.stream()
+    torch.manual_seed(B * 100 + W)
+    dh, m, LDF = 64, 266, 272
+    H = G + L
+    inner = H * dh
+    proj = (torch.randn(m, dh) * dh ** -0.25).cuda()
+    fr = torch.einsum("i,j->ij", torch.arange(N, dtype=torch.float32), 1.0 / (10000 ** (torch.arange(0, dh, 2).float() / dh)))
+    fr = torch.cat((fr, fr), -1).cuda()
+    cosb, sinb = fr.cos().contiguous(), fr.sin().contiguous()
+
+    def state():
+        s = dict(smax=torch.full((2,), float("-inf"), device="cuda"), kmax=torch.full((2,), -2139095041, dtype=torch.int32, device="cuda"),
+                 dd=torch.zeros(2, B * G, LDF, device="cuda"), E=torch.zeros(B * G, LDF * dh, device="cuda"), Ez=torch.zeros(B * G, LDF, device="cuda"),
+                 V1=torch.zeros(B * G, dh, device="cuda"), kc=torch.zeros(B, L, N, dh, device="cuda"), vc=torch.zeros(B, L, N, dh, device="cuda"),
+                 part=torch.zeros(B * L * 4 * 66, device="cuda"))
+        return s
+    sa_, sb_ = state(), state()
+    pos = torch.zeros(1, dtype=torch.int32, device="cuda")
+    worst = 0.0
+    qkv_all = torch.randn(N, B, 3 * inner, device="cuda")
+    for t in range(N):
+        pos.fill_(t)
+        qkv = qkv_all[t]
+        a1 = torch.zeros(B, inner, device="cuda")
+        a2 = torch.zeros(B, inner, device="cuda")
+        _ffi.check(lib.sa_attn_step(_ffi.ptr(qkv), 3 * inner, inner, _ffi.ptr(proj), B, G, L, dh, m, LDF, _ffi.ptr(sa_["smax"]), _ffi.ptr(sa_["kmax"]), _ffi.ptr(sa_["dd"]),
+                                    _ffi.ptr(sa_["E"]), _ffi.ptr(sa_["Ez"]), _ffi.ptr(sa_["V1"]), _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(sa_["kc"]), _ffi.ptr(sa_["vc"]), N, W,
+                                    _ffi.ptr(sa_["part"]), _ffi.ptr(pos), _ffi.ptr(a1), inner, st))
+        _ffi.check(lib.sa_favor_step(_ffi.ptr(qkv), 3 * inner, 0, _ffi.ptr(qkv), 3 * inner, inner, _ffi.ptr(qkv), 3 * inner, 2 * inner, _ffi.ptr(proj), B, G, dh, m, LDF,
+                                     _ffi.ptr(sb_["smax"]), _ffi.ptr(sb_["kmax"]), _ffi.ptr(sb_["dd"]), _ffi.ptr(sb_["E"]), _ffi.ptr(sb_["Ez"]), _ffi.ptr(sb_["V1"]),
+                                     _ffi.ptr(pos), _ffi.ptr(a2), inner, 0, st))
+        _ffi.check(lib.sa_local_attn_step(_ffi.ptr(qkv), 3 * inner, G * dh, _ffi.ptr(qkv), 3 * inner, inner + G * dh, _ffi.ptr(qkv), 3 * inner, 2 * inner + G * dh,
+                                          _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(sb_["kc"]), _ffi.ptr(sb_["vc"]), _ffi.ptr(pos), B, N, L, W, dh, _ffi.ptr(a2),
+                                          inner, G * dh, st))
+        if t % 37 == 0 or t in (W - 1, W, 2 * W - 1, 2 * W, N - 1):
+            assert torch.equal(a1[:, :G * dh], a2[:, :G * dh])                      # global heads: the same code on the same state
+            worst = max(worst, _rel(a1[:, G * dh:], a2[:, G * dh:]))
+    torch.cuda.synchronize()
+    assert worst < 1e-5, worst
+    for k in ("E", "Ez", "V1", "kc", "vc", "smax"):
+        assert torch.equal(sa_[k], sb_[k]), k
