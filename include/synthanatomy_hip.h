@@ -93,8 +93,8 @@ int sa_kernel_log_read(char *buf, int cap, int stop);
 #define SA_DBG_IM2COL_DIRECT     (1u << 7)   /* sa_convt1_im2col without the LDS gather */
 #define SA_DBG_SCAN_VALU         (1u << 8)   /* FAVOR+ scans on the VALU segment kernels */
 #define SA_DBG_LOCAL_ATTN_EXACT  (1u << 9)   /* local attention on the exact-fp32 MFMA kernels */
-#define SA_DBG_HALO256_4W        (1u << 13)  /* bf16 forward / data- / weight-gradient kernels with four waves per block instead of eight */
-#define SA_DBG_TILE256           (1u << 14)  /* A/B: 256 x 128 tiles for the im2col-order forward / data-gradient kernel (measured slower) */
+#define SA_DBG_HALO256_4W        (1u << 13)  /* bf16 im2col-order forward / data-gradient and weight-gradient kernels with four waves per block instead of eight */
+#define SA_DBG_RESERVED_14       (1u << 14)  /* (was SA_DBG_TILE256: 256 x 128 tiles for the im2col-order kernel -- measured slower, instance removed) */
 #define SA_DBG_DENSE_NARROW      (1u << 15)  /* A/B: 128 x 64 tiles for every small dense grid (the round-2 rule) */
 #define SA_DBG_DENSE_RING        (1u << 17)  /* A/B instance: dense layers with few wide tiles on the three-stage 128x256 ring of csrc/dense_ring.hip (measured slower) */
 #define SA_DBG_DETERMINISTIC     (1u << 16)  /* fixed-order reductions where the library itself chooses (BatchNorm sums); see the deterministic-mode section */

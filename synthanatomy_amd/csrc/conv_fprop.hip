@@ -935,14 +935,15 @@ static int launch_fprop_halo256(FpropArgs a, hipStream_t st) {
     const size_t lds = 41 * 1024 + 2 * 128 * 128;   // 73 KiB (>= the 64 KiB hidden tile of the fused variant)
     // bf16: eight waves per block (two blocks = four waves per SIMD): fused block 4.76 -> 4.51 ms, data gradient 4.73 -> 4.29 ms on the C = 128 /
     // 80 x 112 x 80 layer.  fp32 keeps four (its 128 accumulators + wider fragments do not fit 128 VGPRs).  SA_DBG_HALO256_4W selects four for A/B runs.
+    // (the four-wave bf16 instances of THIS kernel -- 1 MB of device code each -- left the build after the measurement; SA_DBG_HALO256_4W still selects the
+    //  four-wave forms of the im2col-order and weight-gradient kernels)
     if constexpr (sizeof(T) == 2) {
-        if (!dbg(SA_DBG_HALO256_4W)) {
-            (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo256_kernel<%s, %s, 8>", tname<T>(), FUSE ? "true" : "false"), note_kernel(g_last_conv_kernel));
-            return launch_fprop_halo256_impl<T, FUSE, 8>(a, nbn, lds, st);
-        }
+        (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo256_kernel<%s, %s, 8>", tname<T>(), FUSE ? "true" : "false"), note_kernel(g_last_conv_kernel));
+        return launch_fprop_halo256_impl<T, FUSE, 8>(a, nbn, lds, st);
+    } else {
+        (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo256_kernel<%s, %s, 4>", tname<T>(), FUSE ? "true" : "false"), note_kernel(g_last_conv_kernel));
+        return launch_fprop_halo256_impl<T, FUSE, 4>(a, nbn, lds, st);
     }
-    (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo256_kernel<%s, %s, 4>", tname<T>(), FUSE ? "true" : "false"), note_kernel(g_last_conv_kernel));
-    return launch_fprop_halo256_impl<T, FUSE, 4>(a, nbn, lds, st);
 }
 
 template <typename T>
@@ -950,7 +951,7 @@ static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
     const int cv = a.g.cout_valid;
     if (a.ep.out_pre || a.ep.out_lp) {
         // the extra outputs exist in the LDS-staged epilogue of the im2col-order kernels (dense layers): whole 4-channel groups only
-        if (halo256_eligible(a, (int)sizeof(T)) || halo_eligible(a, (int)sizeof(T)) || (cv & 3) || (a.g.Cout & 3) || dbg(SA_DBG_TILE256)) return SA_EUNSUPPORTED;
+        if (halo256_eligible(a, (int)sizeof(T)) || halo_eligible(a, (int)sizeof(T)) || (cv & 3) || (a.g.Cout & 3)) return SA_EUNSUPPORTED;
     }
     if (halo256_eligible(a, (int)sizeof(T))) return launch_fprop_halo256<T>(a, st);
     if (halo_eligible(a, (int)sizeof(T))) return launch_fprop_halo<T, false>(a, st);
@@ -966,17 +967,9 @@ static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
         // 4x4x4 conv forward 1.83 -> 1.73 ms, its 8-parity data gradient 2.64 -> 2.17 ms, transposed conv forward 2.73 -> 2.15 ms at batch 8
         // (tools/microbench.py); SA_DBG_HALO256_4W keeps four waves for A/B runs
         const bool w8 = sizeof(T) == 2 && a.in_bytes != 0 && !dbg(SA_DBG_HALO256_4W);
-        // A/B instance only (SA_TILE256=1): 256 x 128 tiles (eight waves of 64 x 64 outputs, 96 KiB of LDS: ONE block per CU) move 87 FLOP per staged byte
-        // instead of 64 (128 x 128) or 43 (128 x 64), but MEASURED SLOWER in round 3: Performer step 40.2 vs 37.7 ms, VQ-VAE step 62.1 vs 63.3 volumes/s --
-        // again two or three independent blocks per CU beat the better operand reuse of one big block
-        if constexpr (sizeof(T) == 2) {
-            const uint64_t blocks256 = (uint64_t)((a.M + 255u) / 256u) * (((uint32_t)cv + 127u) / 128u);
-            if (w8 && dbg(SA_DBG_TILE256) && (uint32_t)cv % 128u == 0 && blocks256 >= 200) {
-                FpropArgs b = a;
-                b.nblk_m = (a.M + 255u) / 256u;
-                return launch_fprop<T, 4, 2, 4, 4>(b, st);
-            }
-        }
+        // (256 x 128 tiles -- eight waves of 64 x 64 outputs, 96 KiB of LDS: ONE block per CU, 87 FLOP per staged byte instead of 64 / 43 -- were MEASURED SLOWER in
+        // round 3: Performer step 40.2 vs 37.7 ms, VQ-VAE step 62.1 vs 63.3 volumes/s; the instance <T, 4, 2, 4, 4> and its SA_TILE256 switch left the build again:
+        // 1.1 MB of device code and a minute of compile time.  The kernel template still accepts BM = 256.)
         // Round 3, per shape (tools/bench_dense_tiles.py, M = 8 400): the narrow tile only pays for SHORT reductions over few output columns
         // (K <= 512 and N <= 2 048: 51.9 vs 51.2, 31.0 vs 31.8 us); with K >= 1 024 the wide tile wins by 14-32 % (w2 forward 52.7 -> 39.3 us,
         // q|k|v data gradient 76.3 -> 51.6 us) and q|k|v forward (N = 3 072) by 15 %.  SA_DENSE_NARROW=1 restores the round-2 rule for A/B runs.

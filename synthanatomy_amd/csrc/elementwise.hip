@@ -36,7 +36,6 @@ static uint32_t flags_from_env() {
     if (getenv("SA_WGRAD_HALO9") && num("SA_WGRAD_HALO9", 1) == 0) f |= SA_DBG_NO_WGRAD_HALO9;
     if (on("SA_IM2COL_DIRECT")) f |= SA_DBG_IM2COL_DIRECT;
     if (on("SA_HALO256_4W")) f |= SA_DBG_HALO256_4W;
-    if (on("SA_TILE256")) f |= SA_DBG_TILE256;
     if (on("SA_DENSE_NARROW")) f |= SA_DBG_DENSE_NARROW;
     if (on("SA_DETERMINISTIC")) f |= SA_DBG_DETERMINISTIC;
     if (on("SA_DENSE_RING")) f |= SA_DBG_DENSE_RING;
