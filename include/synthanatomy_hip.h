@@ -400,6 +400,12 @@ int sa_colsum_det(const void *g, int dtype, int64_t M, int C, int cstride, float
 int sa_vq_stats_det(const float *rows, const float *codebook, const int64_t *idx, int64_t M, int K, int D, float *counts, float *dw, float *sqerr,
                     float *err_ws, void *stream);
 int sa_embed_scatter_det(const float *dy, float *dtable, const int64_t *idx, int per_position, int dim, int N, int64_t R, int nrows, void *stream);
+/* Performer sums in a fixed order: out[0] (+)= sum x (one block); out[0] (+)= a . b (b fp32 / bf16; ws = 1 024 floats); sa_cross_entropy with per-row losses
+ * (row_loss[R], summed by sa_sum_det); the summand matrix of the LayerNorm weight gradient (column sums through sa_colsum_det). */
+int sa_sum_det(const float *x, int64_t n, float *out, int accumulate, void *stream);
+int sa_dot_det(const float *a, const void *b, int b_dtype, int64_t n, float *out, int accumulate, float *ws, void *stream);
+int sa_cross_entropy_rows(const float *logits, const int64_t *target, int64_t R, int V, float *row_loss, void *dlogits, int d_dtype, float gscale, void *stream);
+int sa_layernorm_dwprod(const float *dy, const float *x, const float *stats, float *prod, int64_t R, int C, void *stream);
 
 #ifdef __cplusplus
 }

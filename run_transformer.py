@@ -169,11 +169,11 @@ def run(argv):
     np.random.seed(cfg["seed"])
     if cfg.get("deterministic"):
         # upstream: torch.backends.cudnn.deterministic (src/utils/general.py:336-338).  The forward, the FAVOR+ / local-attention / dense kernels and the weight
-        # gradients are deterministic already; the flag adds the fixed-order embedding gradient.  The LayerNorm / ReZero gate gradients and the loss sum still
-        # use fp32 atomics
+        # gradients are deterministic already; the flag replaces the remaining fp32 atomics by fixed-order sums: embedding gradients, ReZero gate gradients,
+        # LayerNorm weight / bias gradients, bias gradients and the loss (csrc/deterministic.hip; tests/test_deterministic_gpu.py: bit-identical steps)
         from synthanatomy_amd import debug
         debug.set_deterministic(True)
-        log(rank, "--deterministic: fixed-order embedding gradients; the LayerNorm / ReZero-gate gradient sums keep fp32 atomics (last-bit differences remain)")
+        log(rank, "--deterministic: fixed-order reductions (csrc/deterministic.hip); slower than the default path")
     create_folder_structure(cfg)
     dev = torch.device("cuda", local)
     (training if cfg["mode"] == "training" else inference)(cfg, rank, local, world, dev)

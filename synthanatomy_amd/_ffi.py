@@ -142,6 +142,10 @@ _SIGS = {
     "sa_favor_fused_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
+    "sa_sum_det": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p]),
+    "sa_dot_det": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
+    "sa_cross_entropy_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p]),
+    "sa_layernorm_dwprod": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "sa_colsum_det_workspace_bytes": (c_int64, [c_int]),
     "sa_colsum_det": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "sa_vq_stats_det": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -100,9 +100,116 @@ __global__ __launch_bounds__(256) void embed_scatter_det_kernel(const float* __r
     }
 }
 
+// ---- Performer: the sums its backward pass accumulates with fp32 atomics (ReZero gate gradient, CE loss, LayerNorm weight gradient), in a fixed order
+// x[0 .. n) summed by ONE block: thread t adds elements t, t + 1024, ... in order, then a fixed tree over the 1 024 partials
+__global__ __launch_bounds__(1024) void sum_det_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out, int accumulate) {
+    __shared__ float red[1024];
+    float s = 0.f;
+    for (int64_t e = threadIdx.x; e < n; e += 1024) s += x[e];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + red[0];
+}
+
+// stage 1 of a dot product: block b owns the contiguous range [b * per, (b + 1) * per) and leaves ONE partial (same thread order and tree as above)
+__global__ __launch_bounds__(256) void dot_det_stage1_kernel(const float* __restrict__ a, const void* __restrict__ b, int b_dtype, int64_t n, int64_t per,
+                                                             float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    float s = 0.f;
+    for (int64_t e = lo + threadIdx.x; e < hi; e += 256) s += a[e] * load_as_f32(b, b_dtype, e);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// per-row cross entropy (the row losses are summed afterwards by sum_det_kernel); gradient as ce_kernel
+__global__ void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, int64_t R, int V, float* __restrict__ row_loss, void* dlogits,
+                               int d_dtype, float gscale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* lr = logits + r * V;
+    float mx = -INFINITY;
+    for (int c = lane; c < V; c += 64) mx = fmaxf(mx, lr[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float s = 0.f;
+    for (int c = lane; c < V; c += 64) s += expf(lr[c] - mx);
+    s = wave_sum(s);
+    const float lse = mx + logf(s);
+    const int64_t tg = target[r];
+    const bool valid = tg >= 0 && tg < (int64_t)V, ignored = tg == -100;   // as ce_kernel: ignore_index contributes nothing, any other bad id poisons the loss
+    if (lane == 0) row_loss[r] = valid ? lse - lr[tg] : (ignored ? 0.f : __uint_as_float(0x7fc00000u));
+    if (dlogits) {
+        for (int c = lane; c < V; c += 64) {
+            const float p = expf(lr[c] - lse);
+            store_from_f32(dlogits, d_dtype, r * V + c, valid ? (p - (c == tg ? 1.f : 0.f)) * gscale : 0.f);
+        }
+    }
+}
+
+// prod[r][c] = dy[r][c] * (x[r][c] - mean_r) * rstd_r: the summand of the LayerNorm weight gradient (its column sum goes through sa_colsum_det)
+__global__ void layernorm_dwprod_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats, float* __restrict__ prod, int64_t R,
+                                        int C) {
+    const int64_t total = R * C;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / C;
+        prod[e] = dy[e] * (x[e] - stats[2 * r]) * stats[2 * r + 1];
+    }
+}
+
 }  // namespace sa
 
 using namespace sa;
+
+// out[0] (+)= sum of x[0 .. n) in a fixed order (one block)
+extern "C" int sa_sum_det(const float* x, int64_t n, float* out, int accumulate, void* stream) {
+    if (!x || !out || n <= 0) return SA_EINVAL;
+    SA_LAUNCH(sum_det_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, out, accumulate);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+// out[0] (+)= sum_e a[e] * b[e] in a fixed order (b fp32 or bf16): 1 024 contiguous ranges, then one block over the partials; ws: 1 024 floats
+extern "C" int sa_dot_det(const float* a, const void* b, int b_dtype, int64_t n, float* out, int accumulate, float* ws, void* stream) {
+    if (!a || !b || !out || !ws || n <= 0) return SA_EINVAL;
+    if (b_dtype != SA_F32 && b_dtype != SA_BF16) return SA_EUNSUPPORTED;
+    const int64_t per = (n + 1023) / 1024;
+    const int nblk = (int)((n + per - 1) / per);
+    SA_LAUNCH(dot_det_stage1_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a, b, b_dtype, n, per, ws);
+    SA_CHECK_LAUNCH();
+    SA_LAUNCH(sum_det_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)ws, (int64_t)nblk, out, accumulate);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+// sa_cross_entropy with the row losses written to row_loss[R] instead of accumulated atomically (sum them with sa_sum_det)
+extern "C" int sa_cross_entropy_rows(const float* logits, const int64_t* target, int64_t R, int V, float* row_loss, void* dlogits, int d_dtype, float gscale,
+                                     void* stream) {
+    if (!logits || !target || !row_loss || R <= 0 || V <= 0) return SA_EINVAL;
+    SA_LAUNCH(ce_rows_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, target, R, V, row_loss, dlogits, d_dtype, gscale);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+// summand matrix of the LayerNorm weight gradient (stats = mean, rstd pairs of sa_layernorm_fwd); its column sums = d weight
+extern "C" int sa_layernorm_dwprod(const float* dy, const float* x, const float* stats, float* prod, int64_t R, int C, void* stream) {
+    if (!dy || !x || !stats || !prod || R <= 0 || C <= 0) return SA_EINVAL;
+    const int64_t total = R * C;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    SA_LAUNCH(layernorm_dwprod_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, stats, prod, R, C);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int64_t sa_colsum_det_workspace_bytes(int C) { return (int64_t)CD_BLOCKS * (C > 0 ? C : 1) * 4; }
 

@@ -7,7 +7,7 @@ from typing import Dict
 
 import torch
 
-from .. import _ffi
+from .. import _ffi, debug
 
 
 class _CEFn(torch.autograd.Function):
@@ -21,7 +21,13 @@ class _CEFn(torch.autograd.Function):
         acc = torch.zeros(1, dtype=torch.float32, device=rows.device)
         d = torch.empty_like(rows) if logits_bvn.requires_grad else None
         scale = (1.0 / R) if mean else 1.0
-        _ffi.check(_ffi.lib().sa_cross_entropy(_ffi.ptr(rows), _ffi.ptr(tgt), R, V, _ffi.ptr(acc), _ffi.ptr(d), _ffi.SA_F32, scale, _ffi.stream()), "sa_cross_entropy")
+        if debug.deterministic():   # --deterministic: per-row losses, then ONE block adds them in a fixed order (the default kernel adds them with fp32 atomics)
+            row_loss = torch.empty(R, dtype=torch.float32, device=rows.device)
+            _ffi.check(_ffi.lib().sa_cross_entropy_rows(_ffi.ptr(rows), _ffi.ptr(tgt), R, V, _ffi.ptr(row_loss), _ffi.ptr(d), _ffi.SA_F32, scale, _ffi.stream()),
+                       "sa_cross_entropy_rows")
+            _ffi.check(_ffi.lib().sa_sum_det(_ffi.ptr(row_loss), R, _ffi.ptr(acc), 0, _ffi.stream()), "sa_sum_det")
+        else:
+            _ffi.check(_ffi.lib().sa_cross_entropy(_ffi.ptr(rows), _ffi.ptr(tgt), R, V, _ffi.ptr(acc), _ffi.ptr(d), _ffi.SA_F32, scale, _ffi.stream()), "sa_cross_entropy")
         ctx.d = d
         return (acc * scale).reshape(())
 

@@ -636,6 +636,14 @@ class _LayerEngine:
         dF = torch.empty(dy.shape, dtype=self.dtype, device=dev)
         g = self._gate(wrap, dev)
         dg = gc.buf(wrap.g) if self.rezero else torch.zeros((), device=dev)
+        if self.rezero and debug.deterministic():
+            # --deterministic: d g = <dy, F> in a fixed order (sa_dot_det) instead of one atomic per block; the elementwise half of the kernel runs as usual
+            scratch = torch.zeros(1 + 1024, dtype=torch.float32, device=dev)
+            _ck(lib.sa_rezero_bwd(_ffi.ptr(dy), _ffi.ptr(Fout), _ffi.dtype_id(Fout.dtype), _ffi.ptr(g), _ffi.ptr(dF), _ffi.dtype_id(dF.dtype), _ffi.ptr(scratch),
+                                  dy.numel(), st), "sa_rezero_bwd")
+            _ck(lib.sa_dot_det(_ffi.ptr(dy), _ffi.ptr(Fout), _ffi.dtype_id(Fout.dtype), dy.numel(), _ffi.ptr(dg), 1, _ffi.ptr(scratch[1:]), st), "sa_dot_det")
+            gc.done(wrap.g)
+            return dF
         _ck(lib.sa_rezero_bwd(_ffi.ptr(dy), _ffi.ptr(Fout), _ffi.dtype_id(Fout.dtype), _ffi.ptr(g), _ffi.ptr(dF), _ffi.dtype_id(dF.dtype), _ffi.ptr(dg),
                               dy.numel(), st), "sa_rezero_bwd")
         if self.rezero:
@@ -648,8 +656,18 @@ class _LayerEngine:
             return dxin  # the dgrad epilogues already added dres
         lib, st = _ffi.lib(), _ffi.stream()
         dx = torch.empty_like(dres)
-        _ck(lib.sa_layernorm_bwd(_ffi.ptr(dxin), _ffi.ptr(xres), _ffi.ptr(wrap.norm.weight), _ffi.ptr(stats), _ffi.ptr(dx), _ffi.ptr(gc.buf(wrap.norm.weight)),
-                                 _ffi.ptr(gc.buf(wrap.norm.bias)), R, self.dim, st), "sa_layernorm_bwd")
+        if debug.deterministic():   # the weight / bias gradients as fixed-order column sums (see _LayerNormFn.backward)
+            from ...engine import colsum_det
+            junk = torch.zeros(2, self.dim, dtype=torch.float32, device=dres.device)
+            _ck(lib.sa_layernorm_bwd(_ffi.ptr(dxin), _ffi.ptr(xres), _ffi.ptr(wrap.norm.weight), _ffi.ptr(stats), _ffi.ptr(dx), _ffi.ptr(junk[0]), _ffi.ptr(junk[1]), R,
+                                     self.dim, st), "sa_layernorm_bwd")
+            prod = torch.empty_like(dxin)
+            _ck(lib.sa_layernorm_dwprod(_ffi.ptr(dxin), _ffi.ptr(xres), _ffi.ptr(stats), _ffi.ptr(prod), R, self.dim, st), "sa_layernorm_dwprod")
+            colsum_det(prod.view(R, self.dim), self.dim, gc.buf(wrap.norm.weight))
+            colsum_det(dxin.view(R, self.dim), self.dim, gc.buf(wrap.norm.bias))
+        else:
+            _ck(lib.sa_layernorm_bwd(_ffi.ptr(dxin), _ffi.ptr(xres), _ffi.ptr(wrap.norm.weight), _ffi.ptr(stats), _ffi.ptr(dx), _ffi.ptr(gc.buf(wrap.norm.weight)),
+                                     _ffi.ptr(gc.buf(wrap.norm.bias)), R, self.dim, st), "sa_layernorm_bwd")
         gc.done(wrap.norm.weight, wrap.norm.bias)
         _ck(lib.sa_axpy(_ffi.ptr(dx), _ffi.ptr(dres), 1.0, dx.numel(), st), "sa_axpy")
         return dx
@@ -903,6 +921,14 @@ class _LayerNormFn(torch.autograd.Function):
         dx, dw, db = torch.empty_like(x2), torch.zeros_like(w), torch.zeros_like(w)
         _ck(_ffi.lib().sa_layernorm_bwd(_ffi.ptr(d), _ffi.ptr(x2), _ffi.ptr(w), _ffi.ptr(stats), _ffi.ptr(dx), _ffi.ptr(dw), _ffi.ptr(db), R, C, _ffi.stream()),
             "sa_layernorm_bwd")
+        if debug.deterministic():
+            # --deterministic: the weight / bias gradients again as fixed-order column sums (the kernel above accumulated them with one atomic per column and block)
+            from ...engine import colsum_det
+            prod = torch.empty_like(x2)
+            _ck(_ffi.lib().sa_layernorm_dwprod(_ffi.ptr(d), _ffi.ptr(x2), _ffi.ptr(stats), _ffi.ptr(prod), R, C, _ffi.stream()), "sa_layernorm_dwprod")
+            dw, db = torch.zeros_like(w), torch.zeros_like(w)
+            colsum_det(prod, C, dw)
+            colsum_det(d, C, db)
         return dx.view(dy.shape), dw, db, None
 
 

@@ -165,3 +165,44 @@ def test_performer_embedding_gradients_are_bit_reproducible_in_deterministic_mod
     for k in a:
         assert torch.equal(a[k], b[k]), k
         assert _rel(a[k], c[k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("rezero", [True, False])
+def test_performer_step_is_bit_reproducible_in_deterministic_mode(rezero):
+    """Loss and EVERY parameter gradient of a Performer step (production width, N = 1 400, W = 420; ReZero and pre-LayerNorm forms) are bit-identical between two
+    runs in deterministic mode: ReZero gate gradients through sa_dot_det, LayerNorm weight / bias gradients through sa_layernorm_dwprod + sa_colsum_det, the loss
+    through sa_cross_entropy_rows + sa_sum_det, embedding gradients through sa_embed_scatter_det; everything else (dense layers, FAVOR+, local attention) has no
+    atomics.  Against the default mode the results agree to rounding."""
+    from synthanatomy_amd import debug
+    from synthanatomy_amd.losses.transformer import CELoss
+    from synthanatomy_amd.networks.transformers.img2seq_ordering import Ordering
+    from synthanatomy_amd.networks.transformers.performer import Performer
+    shape, n = (10, 14, 10), 1400
+    g = torch.Generator().manual_seed(4)
+    tok = torch.randint(0, 2049, (2, n), generator=g).cuda()
+    tgt = torch.randint(0, 2048, (2, n), generator=g).cuda()
+
+    def run(det):
+        torch.manual_seed(3)
+        o = Ordering("raster_scan", 3, (1,) + shape, (False,) * 3, (), ())
+        net = Performer(num_tokens=2049, max_seq_len=n, dim=512, depth=2, heads=16, ordering=o, dim_head=64, local_attn_heads=8, local_window_size=420,
+                        use_rezero=rezero, spatial_position_emb="absolute", spatial_shape=shape, feature_redraw_interval=None, compute_dtype=torch.bfloat16).cuda().train()
+        if rezero:
+            with torch.no_grad():
+                for k, p in net.named_parameters():
+                    if k.endswith(".g"):
+                        p.fill_(0.2)
+        with debug.override(deterministic=det):
+            loss = CELoss()(net(tok).transpose(1, 2), tgt)
+            loss.backward()
+            torch.cuda.synchronize()
+        return float(loss.detach()), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    (la, a), (lb, b), (lc, c) = run(True), run(True), run(False)
+    assert la == lb
+    assert len(a) >= 20
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert abs(la - lc) < 1e-5 * abs(lc)
+    worst = max(_rel(a[k], c[k]) for k in a if float(c[k].abs().max()) > 0)
+    assert worst < 1e-3, worst
