@@ -30,6 +30,8 @@ def _digest(path):
     hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     if not path.endswith(("conv_fprop.hip", "dense_ring.hip")):
         hdrs = [h for h in hdrs if not h.endswith("conv_fprop_common.h")]     # only its two includers depend on it
+    if not path.endswith(("local_attn.hip", "favor_fused.hip")):
+        hdrs = [h for h in hdrs if not h.endswith("local_attn_split.h")]
     for dep in [path, *hdrs, os.path.join(HERE, "..", "include", "synthanatomy_hip.h")]:
         with open(dep, "rb") as f:
             h.update(f.read())
