@@ -380,13 +380,27 @@ int64_t sa_favor_fused_state_bytes(int B, int N, int G, int m);
 int sa_favor_fused_proj_tiles(const float *ps, int m, void *tiles, void *stream);
 int sa_favor_fused_prepass(const float *q, const float *k, int stride, int G, const void *tiles, float *offq, int32_t *amq, float *offk, void *gmax_ws,
                            int64_t rows, int m, int dh, void *stream);
+/* Local-window heads co-launched with the FAVOR+ heads (last argument of sa_favor_fused_fwd / _bwd; NULL = none): the arguments of sa_local_attn_fwd
+ * (q, k rotated; o, lse, o_lp) or sa_local_attn_bwd (out, dout, lse_in, dq, dk, dv, Dbuf, dv_lp) for the same B, N.  Their blocks are appended to the FAVOR+
+ * launches they do not depend on ([scan A | local forward]; [scan B dq | reversed states | local dq], [scan B dk | scan A dv | local dk dv]) and fill those
+ * launches' tails; results are identical to separate calls.  SA_EUNSUPPORTED (nothing launched) with SA_DBG_LOCAL_ATTN_EXACT or, backward, without state_fwd. */
+typedef struct sa_local_attn_args {
+    const float *q, *k, *v;
+    int32_t q_stride, q_off, k_stride, k_off, v_stride, v_off, o_stride, o_off;
+    float *o, *lse;            /* forward */
+    void *o_lp;
+    const float *out, *dout, *lse_in;   /* backward */
+    float *dq, *dk, *dv, *Dbuf;
+    void *dv_lp;
+    int32_t L, W;
+} sa_local_attn_args;
 int sa_favor_fused_fwd(const float *q, const float *k, const float *v, int stride, const void *tiles, const float *ps, const float *offq, const float *offk,
                        const void *gmax_ws, float *attn, int attn_stride, float *inv_out, float den_eps, int B, int N, int G, int m, float *state,
-                       void *attn_lp, void *stream);
+                       void *attn_lp, const sa_local_attn_args *la, void *stream);
 int sa_favor_fused_bwd(const float *q, const float *k, const float *v, int stride, const void *tiles, const float *ps, const float *offq, const int32_t *amq,
                        const float *offk, const void *gmax_ws, const float *dattn, const float *attn, int attn_stride, const float *inv, float *dq, float *dk,
                        float *dv, int B, int N, int G, int m, const float *state_fwd, float *state_ws, float *dden_ws, float *tsum_ws, void *dq_lp,
-                       void *dk_lp, void *dv_lp, void *stream);
+                       void *dk_lp, void *dv_lp, const sa_local_attn_args *la, void *stream);
 
 /* ---- deterministic mode (the reference's --deterministic flag: torch.backends.cudnn.deterministic, src/utils/general.py:336-338) -------------------
  * Fixed-order forms of the reductions the throughput path accumulates with fp32 atomics (csrc/deterministic.hip); the host calls them INSTEAD of the

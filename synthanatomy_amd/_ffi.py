@@ -48,6 +48,17 @@ class Epilogue(Structure):
     ]
 
 
+class LocalAttnArgs(Structure):
+    """sa_local_attn_args (include/synthanatomy_hip.h): local-window heads co-launched with the FAVOR+ heads."""
+    _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p),
+                ("q_stride", c_int32), ("q_off", c_int32), ("k_stride", c_int32), ("k_off", c_int32), ("v_stride", c_int32), ("v_off", c_int32),
+                ("o_stride", c_int32), ("o_off", c_int32),
+                ("o", c_void_p), ("lse", c_void_p), ("o_lp", c_void_p),
+                ("out", c_void_p), ("dout", c_void_p), ("lse_in", c_void_p),
+                ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p), ("Dbuf", c_void_p), ("dv_lp", c_void_p),
+                ("L", c_int32), ("W", c_int32)]
+
+
 _SIGS = {
     "sa_abi_version": (c_int, []),
     "sa_last_error": (c_char_p, []),
@@ -138,10 +149,10 @@ _SIGS = {
     "sa_favor_fused_proj_tiles": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "sa_favor_fused_prepass": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "sa_favor_fused_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float,
-                                   c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+                                   c_int, c_int, c_int, c_int, c_void_p, c_void_p, POINTER(LocalAttnArgs), c_void_p]),
     "sa_favor_fused_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p]),
+                                   POINTER(LocalAttnArgs), c_void_p]),
     "sa_sum_det": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p]),
     "sa_dot_det": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "sa_cross_entropy_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p]),

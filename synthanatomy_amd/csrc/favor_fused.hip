@@ -16,6 +16,7 @@
 
 #include "sa_common.h"
 #include "split_bf16.h"
+#include "local_attn_split.h"
 
 namespace sa {
 
@@ -730,6 +731,28 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fpair_b_a_kernel(const F
     else favor_fout_a_body(sa, (int)blockIdx.x - nb, lds);
 }
 
+// The same launches with the LOCAL-WINDOW heads' blocks appended (sa_local_attn_args): they depend on q | k | v (or d attn) only, like the FAVOR+ chain, and
+// each of their launches ends in a tail of its own; here their blocks fill the FAVOR+ launches' tails instead.  [scan A | local forward],
+// [scan B dq | reversed states | local dq], [scan B dk | scan A dv | local dk dv].
+static_assert(LA_SPLIT_LDS <= FUSED_LDS, "the local-attention bodies run in the FAVOR+ kernels' LDS buffer");
+__global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_a_la_kernel(const FusedArgs sa, const LAArgs la, const int nfav) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
+    if ((int)blockIdx.x < nfav) favor_fout_a_body(sa, (int)blockIdx.x, lds);
+    else local_attn_q_split_body<0>(la, (int)blockIdx.x - nfav, lds);
+}
+__global__ __launch_bounds__(256, FUSED_WPS) void favor_fpair_b_state_la_kernel(const FusedArgs sb, const FusedArgs ss, const LAArgs la, const int nb) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
+    if ((int)blockIdx.x < nb) favor_fout_b_body(sb, (int)blockIdx.x, lds);
+    else if ((int)blockIdx.x < 2 * nb) favor_fstate_body(ss, (int)blockIdx.x - nb, lds);
+    else local_attn_q_split_body<1>(la, (int)blockIdx.x - 2 * nb, lds);
+}
+__global__ __launch_bounds__(256, FUSED_WPS) void favor_fpair_b_a_la_kernel(const FusedArgs sb, const FusedArgs sa, const LAArgs la, const int nb) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
+    if ((int)blockIdx.x < nb) favor_fout_b_body(sb, (int)blockIdx.x, lds);
+    else if ((int)blockIdx.x < 2 * nb) favor_fout_a_body(sa, (int)blockIdx.x - nb, lds);
+    else local_attn_kv_split_body(la, (int)blockIdx.x - 2 * nb, lds);
+}
+
 // keys: the global-max element (head row r*, feature f*) takes -(sum of all t): dk[r*] -= T P[f*];  T = the per-block partials in a fixed order (deterministic)
 __global__ __launch_bounds__(64) void favor_fkey_fix_kernel(float* __restrict__ dx, unsigned short* __restrict__ dx_lp, int x_stride, int heads,
                                                             const unsigned long long* __restrict__ gmax, const float* __restrict__ partial, int nblk,
@@ -810,6 +833,25 @@ extern "C" int sa_favor_fused_prepass(const float* q, const float* k, int stride
     return 0;
 }
 
+// sa_local_attn_args -> the local-attention launch arguments (split-bf16 path only); nblk = its grid
+static int la_from_args(const sa_local_attn_args* p, int B, int N, bool backward, LAArgs& a, unsigned& nblk) {
+    if (!p->q || !p->k || !p->v || p->L <= 0 || p->W <= 0) return SA_EINVAL;
+    if (la_exact()) return SA_EUNSUPPORTED;            // the exact-fp32 kernels live in local_attn.hip: call sa_local_attn_* separately
+    a = LAArgs{};
+    if (int rc = fill_la(a, p->q_stride, p->q_off, p->k_stride, p->k_off, p->v_stride, p->v_off, p->o_stride, p->o_off, B, N, p->L, p->W, 64)) return rc;
+    a.q = p->q; a.k = p->k; a.v = p->v;
+    if (!backward) {
+        if (!p->o || !p->lse) return SA_EINVAL;
+        a.o = p->o; a.lse_out = p->lse; a.o_lp = (unsigned short*)p->o_lp;
+    } else {
+        if (!p->out || !p->dout || !p->lse_in || !p->dq || !p->dk || !p->dv || !p->Dbuf) return SA_EINVAL;
+        a.out = p->out; a.dout = p->dout; a.lse_in = p->lse_in; a.dq = p->dq; a.dk = p->dk; a.dv = p->dv; a.Dbuf_out = p->Dbuf; a.Dbuf_in = p->Dbuf;
+        a.dv_lp = (unsigned short*)p->dv_lp;
+    }
+    nblk = (unsigned)(B * p->L * ((N + LT - 1) / LT));
+    return 0;
+}
+
 static void fused_common(FusedArgs& s, const void* tiles, const float* ps, const void* gmax, int B, int N, int G, int m, int stride) {
     s.ptiles = (const unsigned char*)tiles; s.ps = ps; s.gmax = (const unsigned long long*)gmax;
     s.B = B; s.N = N; s.G = G; s.m = m; s.LDF = ldf_of(m); s.S = (N + 63) / 64; s.stride = stride;
@@ -827,8 +869,13 @@ static int fused_prefix(float* state, int B, int G, int S, int LDF, hipStream_t 
 // (sum phi_k (x) v | sum phi_k) for the dq' scan of the backward pass
 extern "C" int sa_favor_fused_fwd(const float* q, const float* k, const float* v, int stride, const void* tiles, const float* ps, const float* offq,
                                   const float* offk, const void* gmax_ws, float* attn, int attn_stride, float* inv_out, float den_eps, int B, int N, int G, int m,
-                                  float* state, void* attn_lp, void* stream) {
+                                  float* state, void* attn_lp, const sa_local_attn_args* la, void* stream) {
     if (!q || !k || !v || !tiles || !ps || !offq || !offk || !gmax_ws || !attn || !inv_out || !state) return SA_EINVAL;
+    LAArgs laa;
+    unsigned nla = 0;
+    if (la) {
+        if (int rc = la_from_args(la, B, N, false, laa, nla)) return rc;
+    }
     if (int rc = fused_check(B, N, G, m, 64, stride)) return rc;
     if ((attn_stride & 3) || (int64_t)N * attn_stride * 4 >= ((int64_t)1 << 31)) return SA_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -842,7 +889,8 @@ extern "C" int sa_favor_fused_fwd(const float* q, const float* k, const float* v
     SA_LAUNCH(favor_fstate_kernel, dim3(nblk), dim3(256), 0, st, s);
     SA_CHECK_LAUNCH();
     if (int rc = fused_prefix(state, B, G, s.S, s.LDF, st)) return rc;
-    SA_LAUNCH(favor_fout_a_kernel, dim3(nblk), dim3(256), 0, st, s);
+    if (la) SA_LAUNCH(favor_fout_a_la_kernel, dim3(nblk + nla), dim3(256), 0, st, s, laa, (int)nblk);
+    else SA_LAUNCH(favor_fout_a_kernel, dim3(nblk), dim3(256), 0, st, s);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -852,12 +900,19 @@ extern "C" int sa_favor_fused_fwd(const float* q, const float* k, const float* v
 extern "C" int sa_favor_fused_bwd(const float* q, const float* k, const float* v, int stride, const void* tiles, const float* ps, const float* offq,
                                   const int32_t* amq, const float* offk, const void* gmax_ws, const float* dattn, const float* attn, int attn_stride,
                                   const float* inv, float* dq, float* dk, float* dv, int B, int N, int G, int m, const float* state_fwd, float* state_ws,
-                                  float* dden_ws, float* tsum_ws, void* dq_lp, void* dk_lp, void* dv_lp, void* stream) {
+                                  float* dden_ws, float* tsum_ws, void* dq_lp, void* dk_lp, void* dv_lp, const sa_local_attn_args* la,
+                                  void* stream) {
     if (!q || !k || !v || !tiles || !ps || !offq || !amq || !offk || !gmax_ws || !dattn || !attn || !inv || !dq || !dk || !dv || !state_ws || !dden_ws || !tsum_ws)
         return SA_EINVAL;
     if (int rc = fused_check(B, N, G, m, 64, stride)) return rc;
     if ((attn_stride & 3) || (int64_t)N * attn_stride * 4 >= ((int64_t)1 << 31)) return SA_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    LAArgs laa;
+    unsigned nla = 0;
+    if (la) {   // (checked before the first launch: SA_EUNSUPPORTED leaves nothing behind)
+        if ((g_tunables.pp_dbg & 512u) || !state_fwd) return SA_EUNSUPPORTED;   // the co-launch rides on the paired launches (forward states kept): otherwise call sa_local_attn_bwd
+        if (int rc = la_from_args(la, B, N, true, laa, nla)) return rc;
+    }
     const int64_t rows = (int64_t)B * N * G;
     SA_LAUNCH(favor_fdden_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, dattn, attn, attn_stride, G, inv, dden_ws, rows);
     SA_CHECK_LAUNCH();
@@ -891,7 +946,8 @@ extern "C" int sa_favor_fused_bwd(const float* q, const float* k, const float* v
     s.dx_lp = (unsigned short*)dk_lp;
     const FusedArgs sk = s;
     if (pair && state_fwd) {
-        SA_LAUNCH(favor_fpair_b_state_kernel, dim3(2 * nblk), dim3(256), 0, st, sq, sk, (int)nblk);
+        if (la) SA_LAUNCH(favor_fpair_b_state_la_kernel, dim3(2 * nblk + nla), dim3(256), 0, st, sq, sk, laa, (int)nblk);
+        else SA_LAUNCH(favor_fpair_b_state_kernel, dim3(2 * nblk), dim3(256), 0, st, sq, sk, (int)nblk);
         SA_CHECK_LAUNCH();
     } else {
         SA_LAUNCH(favor_fout_b_kernel, dim3(nblk), dim3(256), 0, st, sq);
@@ -904,7 +960,8 @@ extern "C" int sa_favor_fused_bwd(const float* q, const float* k, const float* v
     s.zmode = 0; s.y = dv; s.y_stride = stride; s.inv_out = nullptr; s.accumulate = 0;
     s.y_lp = (unsigned short*)dv_lp;
     if (pair) {
-        SA_LAUNCH(favor_fpair_b_a_kernel, dim3(2 * nblk), dim3(256), 0, st, sk, s, (int)nblk);
+        if (la) SA_LAUNCH(favor_fpair_b_a_la_kernel, dim3(2 * nblk + nla), dim3(256), 0, st, sk, s, laa, (int)nblk);
+        else SA_LAUNCH(favor_fpair_b_a_kernel, dim3(2 * nblk), dim3(256), 0, st, sk, s, (int)nblk);
         SA_CHECK_LAUNCH();
     } else {
         SA_LAUNCH(favor_fout_b_kernel, dim3(nblk), dim3(256), 0, st, sk);

@@ -420,6 +420,10 @@ class _LayerEngine:
         attn_lp = (torch.empty(R, inner, dtype=T, device=dev)
                    if (T == torch.bfloat16 and (G == 0 or self._fused_favor()) and not debug.host("no_lp_mirrors")) else None)
         sv = dict(x=x, xa=xa, xaT=xaT, st_a=st_a, q=q, k=k, v=v, attn=attn)
+        # throughput mode with both kinds of heads: the local-window heads' blocks ride in the FAVOR+ launches (sa_local_attn_args): rotary first, no launch of their own
+        la_args = None
+        if G > 0 and L > 0 and self._fused_favor() and not debug.host("no_attn_colaunch"):
+            la_args = self._local_fwd_prep(q, k, v, qs, attn, attn_lp, B, N, R, dev, sv)
         if G > 0 and self._fused_favor():
             tiles, ps = self._proj_tiles()
             offq = torch.empty(R * G, dtype=f32, device=dev)
@@ -437,7 +441,12 @@ class _LayerEngine:
             _ck(lib.sa_favor_fused_prepass(_ffi.ptr(q), _ffi.ptr(k), qs, G, _ffi.ptr(tiles), _ffi.ptr(offq), _ffi.ptr(amq), _ffi.ptr(offk), _ffi.ptr(gws), R * G, m, dh, st),
                 "sa_favor_fused_prepass")
             rc = lib.sa_favor_fused_fwd(_ffi.ptr(q), _ffi.ptr(k), _ffi.ptr(v), qs, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(offk), _ffi.ptr(gws),
-                                        _ffi.ptr(attn), inner, _ffi.ptr(inv), 1e-6, B, N, G, m, _ffi.ptr(state), _ffi.ptr(attn_lp), st)
+                                        _ffi.ptr(attn), inner, _ffi.ptr(inv), 1e-6, B, N, G, m, _ffi.ptr(state), _ffi.ptr(attn_lp),
+                                        ctypes.byref(la_args) if la_args is not None else None, st)
+            if rc == _ffi.SA_EUNSUPPORTED and la_args is not None:      # (exact-fp32 local attention: its kernels cannot share the launch) -> separate launches
+                la_args = None
+                rc = lib.sa_favor_fused_fwd(_ffi.ptr(q), _ffi.ptr(k), _ffi.ptr(v), qs, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(offk), _ffi.ptr(gws),
+                                            _ffi.ptr(attn), inner, _ffi.ptr(inv), 1e-6, B, N, G, m, _ffi.ptr(state), _ffi.ptr(attn_lp), None, st)
             _ck(rc, "sa_favor_fused_fwd")
             sv.update(fused=True, offq=offq, offk=offk, amq=amq, gws=gws, inv=inv, scan_state=state if tape is not None else None)
         elif G > 0:
@@ -481,20 +490,12 @@ class _LayerEngine:
             else:
                 _ck(rc, "sa_favor_scan_a_norm")
             sv.update(qg=qg, kg=kg, ddq=ddq, ddk=ddk, qf=qf, kf=kf, gws=gws, Z=Z, inv=inv, scan_state=ws if (Z is None and tape is not None) else None)
-        if L > 0:
-            cosb, sinb = self._rot_tables(N, dev)
-            qkr = torch.empty(2, R, L * dh, dtype=f32, device=dev)
-            qr, kr = qkr[0], qkr[1]
-            if k.data_ptr() - q.data_ptr() == inner * 4 and q.stride(0) == k.stride(0):   # q | k are column blocks of one matrix: one launch rotates both
-                _ck(lib.sa_rotary_groups(_ffi.ptr(q), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(qkr), L * dh, 0, N, R, 0, 0, 2, inner, R * L * dh, None, st),
-                    "sa_rotary_groups(q|k)")
-            else:
-                _ck(lib.sa_rotary(_ffi.ptr(q), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(qr), L * dh, 0, N, R, 0, 0, st), "sa_rotary(q)")
-                _ck(lib.sa_rotary(_ffi.ptr(k), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(kr), L * dh, 0, N, R, 0, 0, st), "sa_rotary(k)")
-            lse = torch.empty(R * L, dtype=f32, device=dev)
+        if L > 0 and "lse" not in sv:          # (not prepared for the co-launch)
+            self._local_fwd_prep(q, k, v, qs, attn, attn_lp, B, N, R, dev, sv)
+        if L > 0 and la_args is None:
+            qr, kr, lse = sv["qr"], sv["kr"], sv["lse"]
             _ck(lib.sa_local_attn_fwd(_ffi.ptr(qr), L * dh, 0, _ffi.ptr(kr), L * dh, 0, _ffi.ptr(v), qs, G * dh, _ffi.ptr(attn), inner, G * dh, _ffi.ptr(lse),
                                       B, N, L, self.W, dh, _ffi.ptr(attn_lp), st), "sa_local_attn_fwd")
-            sv.update(qr=qr, kr=kr, lse=lse)
         attnT = attn_lp if attn_lp is not None else _cast(attn, T)
         ga = self._gate(self.aw, dev)
         gf = self._gate(self.fw, dev)
@@ -534,6 +535,30 @@ class _LayerEngine:
         return x2
 
     # ---------------------------------------------------------------------------------------------- stateful decoding (one position)
+    def _local_fwd_prep(self, q, k, v, qs, attn, attn_lp, B, N, R, dev, sv):
+        """Rotated q | k of the local heads + the log-sum-exp buffer (kept in `sv` for the backward pass); returns the sa_local_attn_args of the forward launch."""
+        lib, st = _ffi.lib(), _ffi.stream()
+        G, L, dh = self.G, self.L, self.dh
+        inner = self.H * dh
+        f32 = torch.float32
+        cosb, sinb = self._rot_tables(N, dev)
+        qkr = torch.empty(2, R, L * dh, dtype=f32, device=dev)
+        qr, kr = qkr[0], qkr[1]
+        if k.data_ptr() - q.data_ptr() == inner * 4 and q.stride(0) == k.stride(0):   # q | k are column blocks of one matrix: one launch rotates both
+            _ck(lib.sa_rotary_groups(_ffi.ptr(q), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(qkr), L * dh, 0, N, R, 0, 0, 2, inner, R * L * dh, None, st),
+                "sa_rotary_groups(q|k)")
+        else:
+            _ck(lib.sa_rotary(_ffi.ptr(q), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(qr), L * dh, 0, N, R, 0, 0, st), "sa_rotary(q)")
+            _ck(lib.sa_rotary(_ffi.ptr(k), qs, G * dh, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(kr), L * dh, 0, N, R, 0, 0, st), "sa_rotary(k)")
+        lse = torch.empty(R * L, dtype=f32, device=dev)
+        sv.update(qr=qr, kr=kr, lse=lse)
+        a = _ffi.LocalAttnArgs()
+        a.q, a.k, a.v = qr.data_ptr(), kr.data_ptr(), v.data_ptr()
+        a.q_stride, a.q_off, a.k_stride, a.k_off, a.v_stride, a.v_off, a.o_stride, a.o_off = L * dh, 0, L * dh, 0, qs, G * dh, inner, G * dh
+        a.o, a.lse, a.o_lp = attn.data_ptr(), lse.data_ptr(), (attn_lp.data_ptr() if attn_lp is not None else None)
+        a.L, a.W = L, self.W
+        return a
+
     def new_state(self, B, N, dev):
         """Per-layer decoding state: FAVOR+ running sums of the global heads (rescalable, see csrc/performer.hip) and the rotated-key /
         value caches of the local heads."""
@@ -700,6 +725,7 @@ class _LayerEngine:
         q, k, v, attn = sv["q"], sv["k"], sv["v"], sv["attn"]
         fused_qkv = "to_qkv" in ops and q.stride(0) == 3 * inner
         dqkv_lp = None
+        local_done = False
         if fused_qkv:   # gradients as column blocks of one matrix, like q / k / v themselves: one cast, one wgrad, one dgrad below
             dqkv = torch.empty(R, 3 * inner, dtype=f32, device=dev)
             dq, dk, dv = dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:]
@@ -721,11 +747,32 @@ class _LayerEngine:
                 self._ws = torch.empty(nst, dtype=f32, device=dev)
             dden = torch.empty(R * G, dtype=f32, device=dev)
             tsum = torch.empty(B * G * ((N + 63) // 64), dtype=f32, device=dev)
-            _ck(lib.sa_favor_fused_bwd(_ffi.ptr(q), _ffi.ptr(k), _ffi.ptr(v), qs, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(sv["offq"]), _ffi.ptr(sv["amq"]),
-                                       _ffi.ptr(sv["offk"]), _ffi.ptr(sv["gws"]), _ffi.ptr(dattn), _ffi.ptr(attn), inner, _ffi.ptr(sv["inv"]), _ffi.ptr(dq),
-                                       _ffi.ptr(dk), _ffi.ptr(dv), B, N, G, m, _ffi.ptr(sv.get("scan_state")), _ffi.ptr(self._ws), _ffi.ptr(dden), _ffi.ptr(tsum),
-                                       _ffi.ptr(dq_lp), _ffi.ptr(dk_lp), _ffi.ptr(dv_lp), st),
-                "sa_favor_fused_bwd")
+            la_args = None
+            if L > 0 and sv.get("scan_state") is not None and not debug.host("no_attn_colaunch"):
+                # the local-window heads' backward blocks ride in the FAVOR+ launches (as in the forward pass); dq / dk of the local heads come out in ROTATED
+                # space (dqkr) and are rotated back below
+                dqkr = torch.empty(2, R, L * dh, dtype=f32, device=dev)
+                Db = torch.empty(R * L, dtype=f32, device=dev)
+                la_args = _ffi.LocalAttnArgs()
+                la_args.q, la_args.k, la_args.v = sv["qr"].data_ptr(), sv["kr"].data_ptr(), v.data_ptr()
+                (la_args.q_stride, la_args.q_off, la_args.k_stride, la_args.k_off, la_args.v_stride, la_args.v_off, la_args.o_stride,
+                 la_args.o_off) = L * dh, 0, L * dh, 0, qs, G * dh, inner, G * dh
+                la_args.out, la_args.dout, la_args.lse_in = attn.data_ptr(), dattn.data_ptr(), sv["lse"].data_ptr()
+                la_args.dq, la_args.dk, la_args.dv, la_args.Dbuf = dqkr[0].data_ptr(), dqkr[1].data_ptr(), dv.data_ptr(), Db.data_ptr()
+                la_args.dv_lp = dv_lp.data_ptr() if dv_lp is not None else None
+                la_args.L, la_args.W = L, self.W
+
+            def favor_bwd(la):
+                return lib.sa_favor_fused_bwd(_ffi.ptr(q), _ffi.ptr(k), _ffi.ptr(v), qs, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(sv["offq"]), _ffi.ptr(sv["amq"]),
+                                              _ffi.ptr(sv["offk"]), _ffi.ptr(sv["gws"]), _ffi.ptr(dattn), _ffi.ptr(attn), inner, _ffi.ptr(sv["inv"]), _ffi.ptr(dq),
+                                              _ffi.ptr(dk), _ffi.ptr(dv), B, N, G, m, _ffi.ptr(sv.get("scan_state")), _ffi.ptr(self._ws), _ffi.ptr(dden), _ffi.ptr(tsum),
+                                              _ffi.ptr(dq_lp), _ffi.ptr(dk_lp), _ffi.ptr(dv_lp), ctypes.byref(la) if la is not None else None, st)
+            rc = favor_bwd(la_args)
+            if rc == _ffi.SA_EUNSUPPORTED and la_args is not None:   # exact-fp32 local attention / unpaired launches: separate launches below
+                la_args = None
+                rc = favor_bwd(None)
+            _ck(rc, "sa_favor_fused_bwd")
+            local_done = la_args is not None
             sv["scan_state"] = None
         elif G > 0:
             qf, kf, Z, inv = sv["qf"], sv["kf"], sv["Z"], sv["inv"]
@@ -780,12 +827,13 @@ class _LayerEngine:
                                                       _ffi.ptr(sv["gws"]), _ffi.ptr(tsum), R * G, m, LDF, dh, st), "sa_favor_features_project_bwd(k)")
         if L > 0:
             cosb, sinb = self._rot_tables(N, dev)
-            dqkr = torch.empty(2, R, L * dh, dtype=f32, device=dev)
+            if not local_done:
+                dqkr = torch.empty(2, R, L * dh, dtype=f32, device=dev)
+                Db = torch.empty(R * L, dtype=f32, device=dev)
+                _ck(lib.sa_local_attn_bwd(_ffi.ptr(sv["qr"]), L * dh, 0, _ffi.ptr(sv["kr"]), L * dh, 0, _ffi.ptr(v), qs, G * dh, _ffi.ptr(attn), _ffi.ptr(dattn),
+                                          inner, G * dh, _ffi.ptr(sv["lse"]), _ffi.ptr(dqkr[0]), _ffi.ptr(dqkr[1]), _ffi.ptr(dv), _ffi.ptr(Db), B, N, L, self.W, dh,
+                                          _ffi.ptr(dv_lp), st), "sa_local_attn_bwd")
             dqr, dkr = dqkr[0], dqkr[1]
-            Db = torch.empty(R * L, dtype=f32, device=dev)
-            _ck(lib.sa_local_attn_bwd(_ffi.ptr(sv["qr"]), L * dh, 0, _ffi.ptr(sv["kr"]), L * dh, 0, _ffi.ptr(v), qs, G * dh, _ffi.ptr(attn), _ffi.ptr(dattn),
-                                      inner, G * dh, _ffi.ptr(sv["lse"]), _ffi.ptr(dqr), _ffi.ptr(dkr), _ffi.ptr(dv), _ffi.ptr(Db), B, N, L, self.W, dh, _ffi.ptr(dv_lp), st),
-                "sa_local_attn_bwd")
             if fused_qkv:   # dq | dk are column blocks of one matrix: one launch
                 _ck(lib.sa_rotary_groups(_ffi.ptr(dqkr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dq), qs, G * dh, N, R, 1, 0, 2, R * L * dh, inner, _ffi.ptr(dq_lp), st),
                     "sa_rotary_groups^T(q|k)")

@@ -33,6 +33,7 @@ def test_ctypes_struct_layout_matches_header():
     assert ctypes.sizeof(_ffi.ConvGeom) == 4 * (14 + 18 + 2)
     assert ctypes.sizeof(_ffi.Epilogue) == 4 * 8 + 6 * 4 + 4 + 4 + 2 * 8  # 4 pointers, 6 ints, slope, padding, 2 extra-output pointers
     assert _ffi.Epilogue.out_pre.offset == 64 and _ffi.Epilogue.out_lp.offset == 72
+    assert ctypes.sizeof(_ffi.LocalAttnArgs) == 3 * 8 + 8 * 4 + 11 * 8 + 2 * 4 and _ffi.LocalAttnArgs.o.offset == 56 and _ffi.LocalAttnArgs.L.offset == 144   # sa_local_attn_args
     assert ctypes.sizeof(_ffi.PackDesc) == 2 * 8 + 64 * 4 + 2 * 8 + 8 * 4  # 2 pointers, tap table, 2 strides, 8 ints
 
 

@@ -58,7 +58,7 @@ def _fused(q, k, v, proj, dattn, local_cols=64):
     attn_lp = torch.full((R, inner), 7.0, device="cuda", dtype=torch.bfloat16)     # bf16 mirrors of the fp32 outputs (operands of the next dense layers)
     inv = torch.empty(R * G, device="cuda")
     _ffi.check(lib.sa_favor_fused_fwd(_ffi.ptr(qd), _ffi.ptr(kd), _ffi.ptr(vd), stride, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(offk), _ffi.ptr(gws),
-                                      _ffi.ptr(attn), inner, _ffi.ptr(inv), 1e-6, B, N, G, m, _ffi.ptr(state), _ffi.ptr(attn_lp), st))
+                                      _ffi.ptr(attn), inner, _ffi.ptr(inv), 1e-6, B, N, G, m, _ffi.ptr(state), _ffi.ptr(attn_lp), None, st))
     da = torch.zeros(R, inner)
     da[:, :G * dh] = pack(dattn)
     da = da.cuda()
@@ -70,7 +70,7 @@ def _fused(q, k, v, proj, dattn, local_cols=64):
     tsum = torch.zeros(B * G * ((N + 63) // 64), device="cuda")
     _ffi.check(lib.sa_favor_fused_bwd(_ffi.ptr(qd), _ffi.ptr(kd), _ffi.ptr(vd), stride, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(amq), _ffi.ptr(offk),
                                       _ffi.ptr(gws), _ffi.ptr(da), _ffi.ptr(attn), inner, _ffi.ptr(inv), _ffi.ptr(dq), _ffi.ptr(dk), _ffi.ptr(dv), B, N, G, m,
-                                      _ffi.ptr(state), _ffi.ptr(state2), _ffi.ptr(dden), _ffi.ptr(tsum), _ffi.ptr(dq_lp), _ffi.ptr(dk_lp), _ffi.ptr(dv_lp), st))
+                                      _ffi.ptr(state), _ffi.ptr(state2), _ffi.ptr(dden), _ffi.ptr(tsum), _ffi.ptr(dq_lp), _ffi.ptr(dk_lp), _ffi.ptr(dv_lp), None, st))
     torch.cuda.synchronize()
     # the mirrors hold exactly the fp32 outputs rounded to bf16 (incl. the key row the fix-up launch touches), and nothing outside the written columns
     assert torch.equal(attn_lp, attn.to(torch.bfloat16)) and torch.equal(dqkv_lp, dqkv.to(torch.bfloat16))

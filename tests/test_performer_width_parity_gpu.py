@@ -160,8 +160,9 @@ def test_bf16_engine_follows_oracle_at_production_width(case):
     joined = "\n".join(names)
     # FAVOR+ with the feature maps recomputed on chip (csrc/favor_fused.hip), flash-style local attention, bf16 dense layers
     # (backward: the independent chunk kernels share launches -- [scan B dq | reversed states], [scan B dk | scan A dv])
-    for need in ("favor_prepass_kernel", "favor_fstate_kernel", "favor_fout_a_kernel", "favor_fpair_b_state_kernel", "favor_fpair_b_a_kernel", "local_attn_q_split_kernel",
-                 "local_attn_kv_split_kernel", "conv_fprop_dma_kernel<unsigned short"):
+    #  and the local-window heads' split-bf16 blocks ride in the FAVOR+ launches: the *_la_kernel instances)
+    for need in ("favor_prepass_kernel", "favor_fstate_kernel", "favor_fout_a_la_kernel", "favor_fpair_b_state_la_kernel", "favor_fpair_b_a_la_kernel",
+                 "conv_fprop_dma_kernel<unsigned short"):
         assert need in joined, (need, names)
     for gone in ("favor_project_fwd_kernel", "favor_feat_fwd_kernel", "favor_feat_proj_bwd_kernel", "favor_chunk_out_b_split_kernel"):
         assert gone not in joined, (gone, names)     # nothing writes dd / phi / d phi to HBM any more
@@ -177,7 +178,7 @@ def test_fused_and_unfused_favor_agree_at_production_width(case):
     ju = "\n".join(names_u)
     for need in ("favor_chunk_state_split_kernel", "favor_chunk_out_a_split_kernel", "favor_chunk_out_b_split_kernel", "favor_feat_proj_bwd_kernel"):
         assert need in ju, (need, names_u)
-    assert "favor_fout_b_kernel" not in ju and "favor_fpair_b_a_kernel" not in ju
+    assert "favor_fout_b_kernel" not in ju and "favor_fpair_b_a" not in ju
     e = _rel_fro(out_f, out_u)
     num = sum(float((grads_f[k].double() - grads_u[k].double()).pow(2).sum()) for k in grads_u)
     den = sum(float(grads_u[k].double().pow(2).sum()) for k in grads_u)
