@@ -119,3 +119,65 @@ def test_fused_favor_is_deterministic_and_ignores_the_future():
     v2[:, :, 130:] += 5.0
     c = _fused(q, k, v2, proj, dattn)
     assert torch.equal(c[0][:, :, :130], a[0][:, :, :130])      # values of later positions never reach earlier outputs (keys would, through the global maximum)
+
+
+@pytest.mark.parametrize("B,G,L,N,W", [(2, 2, 2, 333, 64), (1, 3, 1, 1000, 420), (6, 8, 8, 1400, 420)])
+def test_colaunched_local_heads_equal_separate_launches(B, G, L, N, W):
+    """sa_favor_fused_fwd / _bwd with sa_local_attn_args (the local-window heads' blocks appended to the FAVOR+ launches) against the same calls without it
+    followed by sa_local_attn_fwd / _bwd: every output (attention rows and their bf16 mirror, lse, dq / dk in rotated space, dv and its mirror, D, the FAVOR+
+    gradients) bit-identical."""
+    import ctypes
+    from synthanatomy_amd import _ffi
+    lib, st = _ffi.lib(), _ffi.stream()
+    torch.manual_seed(N + W)
+    dh, m = 64, 266
+    H = G + L
+    inner, R = H * dh, B * N
+    stride = 3 * inner
+    qkv = torch.randn(R, stride, device="cuda")
+    qd, kd, vd = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
+    qkr = torch.randn(2, R, L * dh, device="cuda")            # "rotated" q | k of the local heads
+    ps = (torch.randn(m, dh) * dh ** -0.25).cuda()
+    tiles = torch.empty(5 * 16384, dtype=torch.uint8, device="cuda")
+    _ffi.check(lib.sa_favor_fused_proj_tiles(_ffi.ptr(ps), m, _ffi.ptr(tiles), st))
+    offq, offk = torch.empty(R * G, device="cuda"), torch.empty(R * G, device="cuda")
+    amq, gws = torch.empty(R * G, dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+    _ffi.check(lib.sa_favor_fused_prepass(_ffi.ptr(qd), _ffi.ptr(kd), stride, G, _ffi.ptr(tiles), _ffi.ptr(offq), _ffi.ptr(amq), _ffi.ptr(offk), _ffi.ptr(gws), R * G, m, dh, st))
+    nst = lib.sa_favor_fused_state_bytes(B, N, G, m) // 4
+    da = torch.randn(R, inner, device="cuda")
+
+    def run(co):
+        state, ws = torch.empty(nst, device="cuda"), torch.empty(nst, device="cuda")
+        attn, attn_lp = torch.zeros(R, inner, device="cuda"), torch.zeros(R, inner, device="cuda", dtype=torch.bfloat16)
+        inv, lse = torch.empty(R * G, device="cuda"), torch.empty(R * L, device="cuda")
+        a = _ffi.LocalAttnArgs()
+        a.q, a.k, a.v = qkr[0].data_ptr(), qkr[1].data_ptr(), vd.data_ptr()
+        a.q_stride, a.q_off, a.k_stride, a.k_off, a.v_stride, a.v_off, a.o_stride, a.o_off = L * dh, 0, L * dh, 0, stride, G * dh, inner, G * dh
+        a.o, a.lse, a.o_lp, a.L, a.W = attn.data_ptr(), lse.data_ptr(), attn_lp.data_ptr(), L, W
+        _ffi.check(lib.sa_favor_fused_fwd(_ffi.ptr(qd), _ffi.ptr(kd), _ffi.ptr(vd), stride, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(offk), _ffi.ptr(gws),
+                                          _ffi.ptr(attn), inner, _ffi.ptr(inv), 1e-6, B, N, G, m, _ffi.ptr(state), _ffi.ptr(attn_lp), ctypes.byref(a) if co else None, st))
+        if not co:
+            _ffi.check(lib.sa_local_attn_fwd(_ffi.ptr(qkr[0]), L * dh, 0, _ffi.ptr(qkr[1]), L * dh, 0, _ffi.ptr(vd), stride, G * dh, _ffi.ptr(attn), inner, G * dh,
+                                             _ffi.ptr(lse), B, N, L, W, dh, _ffi.ptr(attn_lp), st))
+        dqkv = torch.zeros(R, stride, device="cuda")
+        dqkv_lp = torch.zeros(R, stride, device="cuda", dtype=torch.bfloat16)
+        dq, dk, dv = dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:]
+        dq_lp, dk_lp, dv_lp = dqkv_lp[:, :inner], dqkv_lp[:, inner:2 * inner], dqkv_lp[:, 2 * inner:]
+        dqkr, Db = torch.zeros(2, R, L * dh, device="cuda"), torch.zeros(R * L, device="cuda")
+        dden, tsum = torch.empty(R * G, device="cuda"), torch.zeros(B * G * ((N + 63) // 64), device="cuda")
+        a.out, a.dout, a.lse_in = attn.data_ptr(), da.data_ptr(), lse.data_ptr()
+        a.dq, a.dk, a.dv, a.Dbuf, a.dv_lp = dqkr[0].data_ptr(), dqkr[1].data_ptr(), dv.data_ptr(), Db.data_ptr(), dv_lp.data_ptr()
+        _ffi.check(lib.sa_favor_fused_bwd(_ffi.ptr(qd), _ffi.ptr(kd), _ffi.ptr(vd), stride, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(amq), _ffi.ptr(offk),
+                                          _ffi.ptr(gws), _ffi.ptr(da), _ffi.ptr(attn), inner, _ffi.ptr(inv), _ffi.ptr(dq), _ffi.ptr(dk), _ffi.ptr(dv), B, N, G, m,
+                                          _ffi.ptr(state), _ffi.ptr(ws), _ffi.ptr(dden), _ffi.ptr(tsum), _ffi.ptr(dq_lp), _ffi.ptr(dk_lp), _ffi.ptr(dv_lp),
+                                          ctypes.byref(a) if co else None, st))
+        if not co:
+            _ffi.check(lib.sa_local_attn_bwd(_ffi.ptr(qkr[0]), L * dh, 0, _ffi.ptr(qkr[1]), L * dh, 0, _ffi.ptr(vd), stride, G * dh, _ffi.ptr(attn), _ffi.ptr(da), inner,
+                                             G * dh, _ffi.ptr(lse), _ffi.ptr(dqkr[0]), _ffi.ptr(dqkr[1]), _ffi.ptr(dv), _ffi.ptr(Db), B, N, L, W, dh, _ffi.ptr(dv_lp), st))
+        torch.cuda.synchronize()
+        return dict(attn=attn, attn_lp=attn_lp, lse=lse, dqkv=dqkv, dqkv_lp=dqkv_lp, dqkr=dqkr, Db=Db)
+
+    a, b = run(True), run(False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert float(a["attn"][:, G * dh:].abs().max()) > 0 and float(a["dqkr"].abs().max()) > 0
