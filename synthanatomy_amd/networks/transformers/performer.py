@@ -251,9 +251,46 @@ def _cast(t, dtype):
     return cast_pad(t, dtype, t.shape[-1])
 
 
+_SIDE_STREAMS = {}
+
+
+class _SideWgrad:
+    """Weight gradients on a second HIP stream.  They are leaves of the backward pass: nothing on the main chain reads a dW before the optimizer, and the dense
+    data-gradient launches they sit between run one block per CU (§4.4 (iii)) -- the weight-gradient blocks of the other queue share those CUs.  Every launch is
+    ordered behind an event of the main stream (its operands are complete), its operands are handed to the side stream with record_stream (the allocator must not
+    recycle them while the side launch still reads), and the main stream joins once at the end of the backward pass."""
+
+    def __init__(self, dev):
+        self.main = torch.cuda.current_stream(dev)
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+        self.side = _SIDE_STREAMS[key]
+
+    def run(self, fn, *operands):
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        for t in operands:
+            if t is not None:
+                t.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            fn()
+
+    def join(self):
+        self.main.wait_stream(self.side)
+
+
 class _GradCtx:
-    def __init__(self, sink=None):
-        self.sink, self.grads = sink, {}
+    def __init__(self, sink=None, side=None):
+        self.sink, self.grads, self.side = sink, {}, side
+
+    def wgrad(self, op, x, g, dw, db):
+        """op.wgrad(x, g, dw, db), on the side stream when there is one"""
+        if self.side is None:
+            op.wgrad(x, g, dw, db)
+        else:
+            self.side.run(lambda: op.wgrad(x, g, dw, db), x, g, dw, db)
 
     def buf(self, p):
         if p is None:
@@ -707,10 +744,10 @@ class _LayerEngine:
         r5 = (1, 1, R)
         # ---- feed-forward block
         dFf = self._post_bwd(self.fw, dx2, sv["Ff"], gc, dev)
-        ops["w2"].wgrad(_as5(sv["h"]), _as5(dFf), gc.buf(ff.w2.weight), gc.buf(ff.w2.bias))
+        gc.wgrad(ops["w2"], _as5(sv["h"]), _as5(dFf), gc.buf(ff.w2.weight), gc.buf(ff.w2.bias))
         gc.done(ff.w2.weight, ff.w2.bias)
         du = ops["w2"].dgrad(_as5(dFf), r5, mask=_as5(sv["u"]), mask_mode=MASK_GELU)
-        ops["w1"].wgrad(_as5(sv["xfT"]), du, gc.buf(ff.w1.weight), gc.buf(ff.w1.bias))
+        gc.wgrad(ops["w1"], _as5(sv["xfT"]), du, gc.buf(ff.w1.weight), gc.buf(ff.w1.bias))
         gc.done(ff.w1.weight, ff.w1.bias)
         if self.rezero:
             dx1 = ops["w1"].dgrad(du, r5, addend=_as5(dx2), out_dtype=f32).view(R, self.dim)
@@ -719,7 +756,7 @@ class _LayerEngine:
             dx1 = self._pre_bwd(self.fw, dxf, dx2, sv["x1"], sv["st_f"], R, gc)
         # ---- attention block
         dFa = self._post_bwd(self.aw, dx1, sv["Fa"], gc, dev)
-        ops["to_out"].wgrad(_as5(sv["attnT"]), _as5(dFa), gc.buf(sa.to_out.weight), gc.buf(sa.to_out.bias))
+        gc.wgrad(ops["to_out"], _as5(sv["attnT"]), _as5(dFa), gc.buf(sa.to_out.weight), gc.buf(sa.to_out.bias))
         gc.done(sa.to_out.weight, sa.to_out.bias)
         dattn = ops["to_out"].dgrad(_as5(dFa), r5, out_dtype=f32).view(R, inner)
         q, k, v, attn = sv["q"], sv["k"], sv["v"], sv["attn"]
@@ -847,7 +884,7 @@ class _LayerEngine:
             gbufs = [gc.buf(sa.to_q.weight), gc.buf(sa.to_k.weight), gc.buf(sa.to_v.weight)]
             gw = self._stacked([t.view(inner, self.dim) for t in gbufs])
             if gw is not None:
-                ops["to_qkv"].wgrad(xaT, dqkvT, gw.view(3 * inner, self.dim, 1, 1, 1), None)
+                gc.wgrad(ops["to_qkv"], xaT, dqkvT, gw.view(3 * inner, self.dim, 1, 1, 1), None)
             else:   # gradient buffers are not adjacent: through a scratch matrix
                 tmp = torch.zeros(3 * inner, self.dim, 1, 1, 1, dtype=f32, device=dev)
                 ops["to_qkv"].wgrad(xaT, dqkvT, tmp, None)
@@ -892,10 +929,18 @@ class _StackChain:
 
     def backward(self, dy, tape):
         B, N, D = dy.shape
-        gc = _GradCtx(self.grad_sink)
+        # single-process training in throughput mode: weight gradients on a second stream (with a gradient sink -- DDP buckets -- they stay in stream order: the
+        # sink all-reduces a bucket as soon as its gradients are marked ready)
+        side = None
+        if ((self.grad_sink is None or getattr(self.grad_sink, "world", 2) == 1) and self.dtype != torch.float32 and not debug.host("no_side_wgrad") and not debug.deterministic()
+                and not torch.cuda.is_current_stream_capturing()):
+            side = _SideWgrad(dy.device)
+        gc = _GradCtx(self.grad_sink, side)
         g = dy.reshape(B * N, D).float().contiguous()
         for l, sv in zip(reversed(self.layers), reversed(tape)):
             g = l.bwd(g, sv, B, N, gc)
+        if side is not None:
+            side.join()
         return g.view(B, N, D), gc.grads
 
 
