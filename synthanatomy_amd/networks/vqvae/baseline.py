@@ -240,7 +240,7 @@ class _ConvStage:
         if G.shape[-1] % vec or G.dtype != self.dtype:
             G = cast_pad(G, self.dtype, (G.shape[-1] + vec - 1) // vec * vec)
         dw, db = grads.buf(self.mod.weight), grads.buf(self.mod.bias)
-        self.op.wgrad(x, G, dw, db)
+        grads.wgrad(self.op, x, G, dw, db)
         grads.done(self.mod.weight, self.mod.bias)
         if not self.need_dx or wgrad_only:
             return None
@@ -466,7 +466,7 @@ class _ResStage:
             self.c1.wgrad(h, G, grads.buf(self.c1m.weight), grads.buf(self.c1m.bias))
             dp = self.c1.dgrad(G, dims, mask=h, mask_mode=MASK_POS)
         grads.done(self.c1m.weight, self.c1m.bias)
-        self.c3.wgrad(x, dp, grads.buf(self.c3m.weight), grads.buf(self.c3m.bias))
+        grads.wgrad(self.c3, x, dp, grads.buf(self.c3m.weight), grads.buf(self.c3m.bias))
         grads.done(self.c3m.weight, self.c3m.bias)
         return self.c3.dgrad(dp, dims, addend=G, mask=x if self.in_act else None, mask_mode=MASK_POS)
 
@@ -476,8 +476,15 @@ class _GradCtx:
     sink (runtime.ddp.GradReducer): views of the flat gradient buffer, and the sink is told as soon as a parameter's
     gradient kernels are queued so that its bucket's all-reduce can start while backward continues."""
 
-    def __init__(self, sink=None):
-        self.sink, self.grads = sink, {}
+    def __init__(self, sink=None, side=None):
+        self.sink, self.grads, self.side = sink, {}, side
+
+    def wgrad(self, op, x, g, dw, db):
+        """op.wgrad(x, g, dw, db); on the second stream when there is one (networks/transformers/performer._SideWgrad: weight gradients are leaves of the pass)"""
+        if self.side is None:
+            op.wgrad(x, g, dw, db)
+        else:
+            self.side.run(lambda: op.wgrad(x, g, dw, db), x, g, dw, db)
 
     def buf(self, p):
         if self.sink is not None:
@@ -542,9 +549,16 @@ class _Chain:
         return gc.grads[st.params()[0]]
 
     def backward(self, G: torch.Tensor, tape):
-        gc = _GradCtx(self.grad_sink)
+        side = None
+        if ((self.grad_sink is None or getattr(self.grad_sink, "world", 2) == 1) and self.dtype != torch.float32 and not debug.host("no_side_wgrad")
+                and not debug.deterministic() and G.is_cuda):
+            from ..transformers.performer import _SideWgrad
+            side = _SideWgrad(G.device)
+        gc = _GradCtx(self.grad_sink, side)
         for s, saved in zip(reversed(self.stages), reversed(tape)):
             G = s.bwd(G, saved, gc)
+        if side is not None:
+            side.join()
         return G, gc.grads
 
 
