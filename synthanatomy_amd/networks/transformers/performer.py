@@ -306,10 +306,20 @@ class _GradCtx:
         return t
 
     def done(self, *params):
-        if self.sink is not None:
-            for p in params:
-                if p is not None:
-                    self.sink.ready(p)
+        if self.sink is None:
+            return
+        if self.side is not None and getattr(self.sink, "world", 2) > 1:
+            # DDP: a bucket's all-reduce is ordered behind an event of the CURRENT stream (runtime/ddp.GradReducer._launch); the gradients of these parameters
+            # were queued on the main stream (bias / gate gradients) and on the weight-gradient stream, so report them from the latter after it has caught up
+            self.side.side.wait_stream(self.side.main)
+            with torch.cuda.stream(self.side.side):
+                for p in params:
+                    if p is not None:
+                        self.sink.ready(p)
+            return
+        for p in params:
+            if p is not None:
+                self.sink.ready(p)
 
 
 class _LayerEngine:
@@ -929,10 +939,9 @@ class _StackChain:
 
     def backward(self, dy, tape):
         B, N, D = dy.shape
-        # single-process training in throughput mode: weight gradients on a second stream (with a gradient sink -- DDP buckets -- they stay in stream order: the
-        # sink all-reduces a bucket as soon as its gradients are marked ready)
+        # throughput mode: weight gradients on a second stream (DDP: _GradCtx.done reports a bucket's parameters from that stream)
         side = None
-        if ((self.grad_sink is None or getattr(self.grad_sink, "world", 2) == 1) and self.dtype != torch.float32 and not debug.host("no_side_wgrad") and not debug.deterministic()
+        if (self.dtype != torch.float32 and not debug.host("no_side_wgrad") and not debug.deterministic()
                 and not torch.cuda.is_current_stream_capturing()):
             side = _SideWgrad(dy.device)
         gc = _GradCtx(self.grad_sink, side)

@@ -496,9 +496,17 @@ class _GradCtx:
         return t
 
     def done(self, *params):
-        if self.sink is not None:
-            for p in params:
-                self.sink.ready(p)
+        if self.sink is None:
+            return
+        if self.side is not None and getattr(self.sink, "world", 2) > 1:
+            # DDP: the bucket's all-reduce waits for an event of the CURRENT stream; these gradients were queued on the main and on the weight-gradient stream
+            self.side.side.wait_stream(self.side.main)
+            with torch.cuda.stream(self.side.side):
+                for p in params:
+                    self.sink.ready(p)
+            return
+        for p in params:
+            self.sink.ready(p)
 
 
 class _Chain:
@@ -550,7 +558,7 @@ class _Chain:
 
     def backward(self, G: torch.Tensor, tape):
         side = None
-        if ((self.grad_sink is None or getattr(self.grad_sink, "world", 2) == 1) and self.dtype != torch.float32 and not debug.host("no_side_wgrad")
+        if (self.dtype != torch.float32 and not debug.host("no_side_wgrad")
                 and not debug.deterministic() and G.is_cuda):
             from ..transformers.performer import _SideWgrad
             side = _SideWgrad(G.device)
