@@ -558,7 +558,9 @@ class _Chain:
 
     def backward(self, G: torch.Tensor, tape):
         side = None
-        if (self.dtype != torch.float32 and not debug.host("no_side_wgrad")
+        # (opt-in here, SA_SIDE_WGRAD_VQVAE=1: +0.9 % on the step -- the big kernels fill the CUs by themselves -- but overlapping launches inflate every per-kernel
+        #  duration, and bench.py's roofline record is per kernel; the Performer, whose dense data-gradient launches leave the CUs half empty, runs it by default)
+        if (self.dtype != torch.float32 and debug.host("side_wgrad_vqvae") and not debug.host("no_side_wgrad")
                 and not debug.deterministic() and G.is_cuda):
             from ..transformers.performer import _SideWgrad
             side = _SideWgrad(G.device)
