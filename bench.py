@@ -232,18 +232,18 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     dtm = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dtm], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dtm = float(t.item())
@@ -259,7 +259,7 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
             out = net.sample(prefix, sample=True, top_k=None, temperature=1.0)
             torch.cuda.synchronize()
             dts = time.perf_counter() - t1
-        if world > 1:
+        if dist.is_initialized():
             t = torch.tensor([dts], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dts = float(t.item())
@@ -541,7 +541,7 @@ def main():
         res = bench_performer(args, rank, world, dev)
         if rank == 0:
             print(json.dumps(res), flush=True)
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -571,26 +571,26 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     timer = None
     if not args.no_kernel_timer:
         timer = engine.KernelTimer()
         engine.TIMER = timer
-    reducer.timing = world > 1
+    reducer.timing = dist.is_initialized()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     engine.TIMER = None
     reducer.timing = False
     comm = reducer.comm_stats()
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -637,6 +637,7 @@ def main():
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         }
         if comm is not None:
+            comm["backend"] = dist.get_backend()
             line["comm"] = comm   # gradient all-reduce on the side stream, rank 0: total / exposed after backward / hidden under backward
         if roof is not None:
             line["roofline"] = roof
@@ -652,16 +653,16 @@ def main():
         for _ in range(max(1, args.warmup)):
             rec = net.decode_samples(net.index_quantize(x))
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         t1 = time.perf_counter()
         for _ in range(args.steps):
             rec = net.decode_samples(net.index_quantize(x))
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         dti = time.perf_counter() - t1
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dti], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dti = float(t.item())
@@ -696,7 +697,7 @@ def main():
         if secondary_14k is not None:
             line["secondary_14k"] = secondary_14k
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

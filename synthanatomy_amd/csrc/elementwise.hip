@@ -94,6 +94,48 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const sa_pack_d
     const int tr = (a.rows_pad + 63) >> 6, tk = (a.Kpad + 63) >> 6;
     const bool row_fast = a.s_row < a.s_red;   // consecutive rows are adjacent in the parameter: read with the row index on the lanes
     const int lo6 = threadIdx.x & 63, hi2 = threadIdx.x >> 6;
+    // Linear / 1x1x1 operands (one tap, unit stride along one side, everything a multiple of four): 16-byte reads and 8 / 16-byte writes.
+    // Same values and the same rounding as the element-wise walk below, which every other operand keeps.
+    const bool lin = a.ntaps == 1 && a.tap_lut[0] == 0 && a.red_stride >= a.red && (a.Kpad & 3) == 0 && (((uintptr_t)a.w | (uintptr_t)a.wpk) & 15) == 0 &&
+                     ((a.s_red == 1 && (a.s_row & 3) == 0 && (a.red & 3) == 0) || (a.s_row == 1 && (a.s_red & 3) == 0 && (a.rows & 3) == 0));
+    if (lin) {
+        const int q4 = (threadIdx.x & 15) << 2, hi4 = threadIdx.x >> 4;
+        for (int t = (int)blockIdx.x - b0; t < tr * tk; t += nb) {
+            const int r0 = (t / tk) << 6, k0 = (t % tk) << 6;
+            __syncthreads();
+            float4 v[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int o = hi4 + 16 * p;
+                const int r = r0 + (row_fast ? q4 : o), k = k0 + (row_fast ? o : q4);
+                v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < a.rows && k < a.red) v[p] = *reinterpret_cast<const float4*>(a.w + r * a.s_row + k * a.s_red);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int o = hi4 + 16 * p;
+                if (row_fast) {
+                    tile[q4][o] = v[p].x, tile[q4 + 1][o] = v[p].y, tile[q4 + 2][o] = v[p].z, tile[q4 + 3][o] = v[p].w;
+                } else {
+                    tile[o][q4] = v[p].x, tile[o][q4 + 1] = v[p].y, tile[o][q4 + 2] = v[p].z, tile[o][q4 + 3] = v[p].w;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int rl = hi4 + 16 * p, r = r0 + rl, k = k0 + q4;
+                if (r < a.rows_pad && k < a.Kpad) {
+                    const float x0 = tile[rl][q4], x1 = tile[rl][q4 + 1], x2 = tile[rl][q4 + 2], x3 = tile[rl][q4 + 3];
+                    const int64_t e = (int64_t)r * a.Kpad + k;
+                    if (a.dtype == SA_F32) *reinterpret_cast<float4*>((float*)a.wpk + e) = make_float4(x0, x1, x2, x3);
+                    else
+                        *reinterpret_cast<uint2*>((bf16_t*)a.wpk + e) =
+                            make_uint2((uint32_t)f32_to_bf16(x0) | ((uint32_t)f32_to_bf16(x1) << 16), (uint32_t)f32_to_bf16(x2) | ((uint32_t)f32_to_bf16(x3) << 16));
+                }
+            }
+        }
+        return;
+    }
     for (int t = (int)blockIdx.x - b0; t < tr * tk; t += nb) {
         const int r0 = (t / tk) << 6, k0 = (t % tk) << 6;
         __syncthreads();

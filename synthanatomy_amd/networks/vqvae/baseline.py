@@ -118,7 +118,7 @@ class _VQFn(torch.autograd.Function):
         if training:
             # EMA update (baseline.py:66-80).  The statistics are SUMMED over ranks; the all-reduce and the update run on a
             # side stream because nothing downstream in this step reads the new codebook.
-            use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(q.process_group) > 1
+            use_dist = dist.is_available() and dist.is_initialized() and (dist.get_world_size(q.process_group) > 1 or debug.host("ddp_single_rank"))
             if q._side is None:
                 q._side = torch.cuda.Stream(device=dev)
             ready = torch.cuda.Event()

@@ -16,6 +16,7 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+from .. import debug
 from .optim import FlatParams
 
 
@@ -25,7 +26,8 @@ def init_distributed(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    single = world == 1 and "RANK" in os.environ and "MASTER_PORT" in os.environ and debug.host("ddp_single_rank")   # one-GPU box: RCCL on a one-rank group
+    if (world > 1 or single) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -113,7 +115,7 @@ class GradReducer:
             self._launch(b)
 
     def _launch(self, b: int):
-        if self.world == 1:
+        if self.world == 1 and not (dist.is_initialized() and debug.host("ddp_single_rank")):
             return
         lo, hi = self.buckets[b][0], self.buckets[b][1]
         view = self.flat.grad[lo:hi]

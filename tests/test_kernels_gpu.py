@@ -187,7 +187,8 @@ def test_batched_weight_repack_matches_single_launches():
     torch.manual_seed(6)
     mk = lambda *shp: (torch.randn(*shp) * 0.1).cuda()
     specs = [("conv", 16, 24, 3, 1, 1, torch.bfloat16), ("conv", 8, 136, 4, 2, 1, torch.float32), ("convT", 24, 16, 4, 2, 1, torch.bfloat16),
-             ("conv", 512, 96, 1, 1, 0, torch.bfloat16)]
+             ("conv", 512, 96, 1, 1, 0, torch.bfloat16), ("conv", 64, 40, 1, 1, 0, torch.float32), ("conv", 6, 16, 1, 1, 0, torch.bfloat16)]
+    # (the 1x1x1 / Linear operands with multiple-of-four sides take the 16-byte-vector walk of the batched kernel; 6 -> 16 channels does not)
     ops = []
     for kind, cin, cout, k, st, pad, dt in specs:
         w = mk(cout, cin, k, k, k) if kind == "conv" else mk(cin, cout, k, k, k)
