@@ -17,6 +17,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC: RCCL between processes needs this before the runtime loads
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

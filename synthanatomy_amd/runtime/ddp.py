@@ -23,6 +23,7 @@ from .optim import FlatParams
 def init_distributed(backend: Optional[str] = None):
     """torchrun-style bootstrap (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); replaces deepspeed.init_distributed
     (run_vqvae.py:831-842).  Returns (rank, local_rank, world_size)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver; read when the HIP runtime starts (first device call)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
