@@ -242,8 +242,8 @@ __device__ __forceinline__ int64_t head_row_off(int64_t r, int heads, int stride
 __global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs a) {
     // PERSISTENT blocks (two per CU: the projection matrix, 80 KiB of pre-split slab tiles, is staged once per block) walk tiles of 64 head rows
     // (wave = 16 of them) of q (tiles [0, ntq)) and k (tiles [ntq, 2 ntq)): fine-grained tiles keep the last round of the walk short
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ unsigned long long sbest[4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // exactly 80 KiB and NO static LDS beside it: two blocks fill the CU's 160 KiB (32 static bytes
+                                                                           // for the block maximum made it 81 952 B = ONE block per CU and two rounds of the "persistent" grid)
     const int nfr = a.LDF >> 4;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), qi = lane & 15, g = lane >> 4;
     {
@@ -322,6 +322,8 @@ __global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs
         const unsigned long long ot = __shfl_xor(best, o, 64);
         best = ot > best ? ot : best;
     }
+    __syncthreads();   // every wave is done with the projection tiles: their first bytes carry the four wave maxima
+    unsigned long long* sbest = (unsigned long long*)smem;
     if (lane == 0) sbest[w] = best;
     __syncthreads();
     if (tid == 0) {
