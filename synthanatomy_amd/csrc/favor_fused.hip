@@ -256,17 +256,32 @@ __global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs
     }
     __syncthreads();
     unsigned long long best = 0ull;
+    // the rows of a block's NEXT tile are fetched before the products of the current one (a block walks four or five tiles: each fetch used to be exposed)
+    auto tile_row = [&](int tile) __attribute__((always_inline)) { return (int64_t)(tile < a.nbq ? tile : tile - a.nbq) * 64 + w * 16 + qi; };
+    auto fetch = [&](int tile, float4 (&v)[4]) __attribute__((always_inline)) {
+        const int64_t r = tile_row(tile);
+        const float* xr = (tile < a.nbq ? a.q : a.k) + head_row_off(r < a.rows ? r : a.rows - 1, a.heads, a.stride);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v[2 * ks] = *(const float4*)(xr + ks * 32 + g * 8);
+            v[2 * ks + 1] = *(const float4*)(xr + ks * 32 + g * 8 + 4);
+        }
+    };
+    float4 nxt[4];
+    if ((int)blockIdx.x < 2 * a.nbq) fetch(blockIdx.x, nxt);
     for (int tile = blockIdx.x; tile < 2 * a.nbq; tile += gridDim.x) {
         const bool isq = tile < a.nbq;
-        const float* X = isq ? a.q : a.k;
-        const int64_t r = (int64_t)(isq ? tile : tile - a.nbq) * 64 + w * 16 + qi;
+        const int64_t r = tile_row(tile);
         const bool ok = r < a.rows;
-        const float* xr = X + head_row_off(ok ? r : a.rows - 1, a.heads, a.stride);
+        float4 cur[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
+        if (tile + (int)gridDim.x < 2 * a.nbq) fetch(tile + gridDim.x, nxt);
         short8_t xh[2], xl[2];
         float ss = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            float4 v0 = *(const float4*)(xr + ks * 32 + g * 8), v1 = *(const float4*)(xr + ks * 32 + g * 8 + 4);
+            float4 v0 = cur[2 * ks], v1 = cur[2 * ks + 1];
             if (!ok) v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
             const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
@@ -275,20 +290,18 @@ __global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs
         }
         float mx = -INFINITY;
         int am = 0x7fffffff;
-#pragma unroll 2
-        for (int f = 0; f < nfr; ++f) {
+        // per accumulator the product order of tile_rows_gemm (hi*lo, lo*hi, hi*hi over ks = 0, 1), so the chunk kernels rebuild bit-identical dd values; FOUR feature
+        // fragments at a time keep four independent MFMA chains in flight (one chain of six dependent MFMAs per fragment left the pipe idle between issues)
+        auto products = [&](int f, int ks, float4_t& c) __attribute__((always_inline)) {
             const unsigned char* sPh = smem + (f >> 2) * (2 * FT_BYTES);
             const unsigned char* sPl = sPh + FT_BYTES;
-            float4_t c = (float4_t){0.f, 0.f, 0.f, 0.f};
-            // per accumulator the product order of tile_rows_gemm (hi*lo, lo*hi, hi*hi), so the chunk kernels rebuild bit-identical dd values
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const uint32_t o = lroff((f & 3) * 16 + qi, ks * 32 + g * 8);
-                const short8_t ah = *(const short8_t*)(sPh + o), al = *(const short8_t*)(sPl + o);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[ks], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[ks], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[ks], c, 0, 0, 0);
-            }
+            const uint32_t o = lroff((f & 3) * 16 + qi, ks * 32 + g * 8);
+            const short8_t ah = *(const short8_t*)(sPh + o), al = *(const short8_t*)(sPl + o);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[ks], c, 0, 0, 0);
+        };
+        auto take = [&](int f, const float4_t& c) __attribute__((always_inline)) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int col = f * 16 + g * 4 + rr;
@@ -296,6 +309,24 @@ __global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs
                 mx = t0 ? c[rr] : mx;
                 am = t0 ? col : am;
             }
+        };
+        int f = 0;
+        for (; f + 4 <= nfr; f += 4) {
+            float4_t c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) products(f + u, ks, c[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) take(f + u, c[u]);
+        }
+        for (; f < nfr; ++f) {
+            float4_t c = (float4_t){0.f, 0.f, 0.f, 0.f};
+            products(f, 0, c);
+            products(f, 1, c);
+            take(f, c);
         }
         // a row lives in the four lanes qi, qi + 16, qi + 32, qi + 48
 #pragma unroll
