@@ -256,32 +256,17 @@ __global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs
     }
     __syncthreads();
     unsigned long long best = 0ull;
-    // the rows of a block's NEXT tile are fetched before the products of the current one (a block walks four or five tiles: each fetch used to be exposed)
-    auto tile_row = [&](int tile) __attribute__((always_inline)) { return (int64_t)(tile < a.nbq ? tile : tile - a.nbq) * 64 + w * 16 + qi; };
-    auto fetch = [&](int tile, float4 (&v)[4]) __attribute__((always_inline)) {
-        const int64_t r = tile_row(tile);
-        const float* xr = (tile < a.nbq ? a.q : a.k) + head_row_off(r < a.rows ? r : a.rows - 1, a.heads, a.stride);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            v[2 * ks] = *(const float4*)(xr + ks * 32 + g * 8);
-            v[2 * ks + 1] = *(const float4*)(xr + ks * 32 + g * 8 + 4);
-        }
-    };
-    float4 nxt[4];
-    if ((int)blockIdx.x < 2 * a.nbq) fetch(blockIdx.x, nxt);
     for (int tile = blockIdx.x; tile < 2 * a.nbq; tile += gridDim.x) {
         const bool isq = tile < a.nbq;
-        const int64_t r = tile_row(tile);
+        const float* X = isq ? a.q : a.k;
+        const int64_t r = (int64_t)(isq ? tile : tile - a.nbq) * 64 + w * 16 + qi;
         const bool ok = r < a.rows;
-        float4 cur[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
-        if (tile + (int)gridDim.x < 2 * a.nbq) fetch(tile + gridDim.x, nxt);
+        const float* xr = X + head_row_off(ok ? r : a.rows - 1, a.heads, a.stride);
         short8_t xh[2], xl[2];
         float ss = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            float4 v0 = cur[2 * ks], v1 = cur[2 * ks + 1];
+            float4 v0 = *(const float4*)(xr + ks * 32 + g * 8), v1 = *(const float4*)(xr + ks * 32 + g * 8 + 4);
             if (!ok) v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
             const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
