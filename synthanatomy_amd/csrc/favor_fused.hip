@@ -775,8 +775,18 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fpair_b_a_la_kernel(cons
 __global__ __launch_bounds__(64) void favor_fkey_fix_kernel(float* __restrict__ dx, unsigned short* __restrict__ dx_lp, int x_stride, int heads,
                                                             const unsigned long long* __restrict__ gmax, const float* __restrict__ partial, int nblk,
                                                             const float* __restrict__ ps, int LDF) {
+    // one wave, up to ~30 partials per lane: the loads of eight trips are issued together (the additions keep their order: bit-identical to the plain loop,
+    // whose every trip waited for its own load)
     float t = 0.f;
-    for (int i = threadIdx.x; i < nblk; i += 64) t += partial[i];
+    int i = threadIdx.x;
+    for (; i + 7 * 64 < nblk; i += 8 * 64) {
+        float p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = partial[i + u * 64];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += p[u];
+    }
+    for (; i < nblk; i += 64) t += partial[i];
     t = wave_sum(t);
     const uint32_t idx = 0xffffffffu - (uint32_t)(*gmax & 0xffffffffull);
     const int64_t r = idx / (uint32_t)LDF;
