@@ -213,7 +213,7 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
     flat = FlatParams(net.parameters())
     opt = FusedAdam(flat, lr=1e-3)
     opt.on_step.append(net.invalidate_packed_weights)
-    reducer = GradReducer(flat)
+    reducer = GradReducer(flat, mode=args.ddp_mode, transport=args.grad_transport)
     net.set_grad_sink(reducer)
     loss_fn = CELoss()
     gen = torch.Generator(device=dev).manual_seed(4 + rank)
@@ -316,17 +316,22 @@ def _respawn(args):
 
 
 def dry_run(args):
-    """Launch plumbing without a GPU (CPU, gloo): rendezvous, the bucketed gradient reducer over a flat host buffer, barrier-bracketed timing,
-    MAX over ranks and the one JSON line -- what `tests/test_bench_spawn_cpu.py` exercises.  No kernel runs, so the line says dry_run."""
-    from synthanatomy_amd.runtime.ddp import GradReducer, init_distributed
+    """Launch plumbing without a GPU (CPU, gloo): rendezvous, the bucketed gradient reducer over the flat buffer of the REAL config-2 parameter list
+    (28.1 M trainable parameters, 32 MiB buckets in backward order; `--ddp-mode` / `--grad-transport` select the collective), the packed
+    [counts | dw] EMA statistics exchange, the file sharding of the CLIs, barrier-bracketed timing, MAX over ranks and the one JSON line --
+    what `tests/test_bench_spawn_cpu.py` exercises with 2 and 8 ranks.  No kernel runs, so the line says dry_run."""
+    from synthanatomy_amd.networks.vqvae.baseline import BaselineVQVAE
+    from synthanatomy_amd.runtime.ddp import GradReducer, all_reduce_sum, init_distributed
     from synthanatomy_amd.runtime.optim import FlatParams
+    from synthanatomy_amd.utils.general import shard_for_rank
 
     rank, local, world = init_distributed(backend="gloo")
     assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     torch.manual_seed(4)
-    ps = [torch.nn.Parameter(torch.randn(256, 64)) for _ in range(6)]
+    net = BaselineVQVAE(**NET, compute_dtype=torch.bfloat16)     # host parameters only: nothing is launched
+    ps = [p for p in net.parameters() if p.requires_grad]
     flat = FlatParams(ps)
-    red = GradReducer(flat, bucket_bytes=128 << 10)
+    red = GradReducer(flat, mode=args.ddp_mode, transport=args.grad_transport)
 
     def step():
         flat.zero_grad()
@@ -350,15 +355,47 @@ def dry_run(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     want = world * (world + 1) / 2.0
-    assert abs(float(flat.grad[0]) - want) < 1e-6 and abs(scale - 1.0 / world) < 1e-12, (float(flat.grad[0]), want, scale)
+    for p in ps:   # every parameter's gradient view carries the sum over ranks (and nothing else moved)
+        v = red.buffer(p)
+        assert float(v.min()) == want == float(v.max()), (tuple(p.shape), float(v.min()), float(v.max()), want)
+    assert abs(scale - 1.0 / world) < 1e-12
+    # EMA statistics: the packed [counts(K) | dw(K, D)] buffer summed over ranks (baseline.py:70-72), 270 KB
+    K, D = NET["n_embed"], NET["embed_dim"]
+    packed = torch.full((K + K * D,), float(rank + 1))
+    if world > 1:
+        all_reduce_sum(packed)
+    assert float(packed[0]) == want and float(packed[-1]) == want
+    # the CLIs' file sharding at this world size: every sample appears, every rank runs the same number of steps
+    n_files = 8 * world + 3
+    shards = [shard_for_rank(n_files, r, world, epoch=1, seed=4) for r in range(world)]
+    assert len({len(sh) for sh in shards}) == 1 and set(i for sh in shards for i in sh) == set(range(n_files))
     if rank == 0:
         print(json.dumps({"metric": "vqvae_train_volumes_per_sec", "value": None, "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "dry_run": True,
-                          "config": {"workload": "launch plumbing only (CPU, gloo): no kernel ran", "parallelism": f"dp{world}"}}), flush=True)
+                          "config": {"workload": "launch plumbing only (CPU, gloo): no kernel ran", "parallelism": f"dp{world}"},
+                          "comm": {"buckets": len(red.buckets), "bytes_per_step": int(flat.numel * (2 if red.transport == "bf16" else 4)),
+                                   "mode": red.mode, "transport": red.transport, "backend": dist.get_backend() if world > 1 else None}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_end_to_end():
+    """BASELINE.json configs[4] on this GPU, production size, through the CLIs (tools/end_to_end.py): wall seconds per stage, file IO and network
+    construction included -- a pipeline check with a clock on it, not a throughput figure."""
+    import shutil
+    import tempfile
+
+    from tools import end_to_end
+    tmp = tempfile.mkdtemp(prefix="sa_e2e_")
+    try:
+        res = end_to_end.run_chain(tmp, volumes=4, extract=4, samples=2)
+        return {"workload": res["workload"], "seconds": res["seconds"], "total_s": res["total_s"], "codes": len(res["codes"]),
+                "samples": len(res["samples"]), "decoded_volumes": len(res["decoded"]), "bos_tokens_clamped": res["bos_tokens_clamped"]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+        torch.cuda.empty_cache()
 
 
 def bench_fp32_mode(dev, batch=2, steps=2):
@@ -510,6 +547,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the measured-peak probes and the fp32-mode sub-record")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the configs[4] chain through the CLIs (tools/end_to_end.py)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--performer-batch", type=int, default=6, help="sequences per GPU per step (README.md:119)")
     ap.add_argument("--no-performer", action="store_true", help="skip the secondary Performer tokens/s measurement")
@@ -517,6 +555,9 @@ def main():
     ap.add_argument("--only-performer", action="store_true", help="dev/profiling: measure only the Performer workload")
     ap.add_argument("--performer-shape", default="10,14,10", help="latent grid of the Performer workload (20,28,25 = the 14 000-token variant)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: exercise the launch + reduction plumbing only (no GPU, no kernels)")
+    ap.add_argument("--ddp-mode", default=None, choices=["all_reduce", "reduce_scatter"],
+                    help="gradient collective per bucket: one all-reduce (default, what DDP issues) or reduce-scatter + all-gather (runtime/ddp.GradReducer)")
+    ap.add_argument("--grad-transport", default=None, choices=["fp32", "bf16"], help="gradient bytes on the links (default fp32)")
     ap.add_argument("--share-device", action="store_true",
                     help="test aid: all ranks on cuda:0 with the gloo backend (RCCL refuses two ranks per device) -- the N > 1 code path on real kernels, not a number")
     args = ap.parse_args()
@@ -553,7 +594,7 @@ def main():
     opt = FusedAdam(flat, lr=1.65e-4)
     opt.on_step.append(net.invalidate_packed_weights)
     sched = ExponentialLR(opt, gamma=0.99999)
-    reducer = GradReducer(flat)
+    reducer = GradReducer(flat, mode=args.ddp_mode, transport=args.grad_transport)
     net.set_grad_sink(reducer)
     loss_fn = MSELoss()
     gen = torch.Generator(device=dev).manual_seed(4 + rank)
@@ -692,6 +733,8 @@ def main():
         torch.cuda.empty_cache()
         if args.performer_shape == "10,14,10":   # BASELINE.json configs[3] says "~14k-token" latents: also the 20x28x25 grid, one sequence per GPU
             secondary_14k = bench_performer(args, rank, world, dev, shape=(20, 28, 25), batch=1)
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_end_to_end:
+        line["end_to_end"] = bench_end_to_end()
     if rank == 0:
         if secondary is not None:
             line["secondary"] = secondary

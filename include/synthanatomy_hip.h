@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 1
+#define SA_ABI_VERSION 2   /* 2 (round 4): sa_local_attn_fwd/bwd + sa_epilogue grew trailing pointers in round 3, SA_F16 operand type, sa_mse partials; a caller built against 1 must not load this library */
 enum { SA_F32 = 0, SA_BF16 = 1 };
 enum { SA_ACT_NONE = 0, SA_ACT_RELU = 1, SA_ACT_LRELU = 2, SA_ACT_GELU = 3 };
 enum { SA_MASK_NONE = 0, SA_MASK_POS = 1 /* out *= (mask > 0) */, SA_MASK_LRELU = 2 /* out *= mask>0 ? 1 : slope */,
@@ -329,7 +329,9 @@ int sa_cross_entropy(const float *logits, const int64_t *target, int64_t R, int 
 
 /* ==== discriminator normalisation (reference src/networks/discriminator/baseline.py:52-79: nn.BatchNorm3d + LeakyReLU) ====
  * x, y, g, dx: channels-last [M, C] of dtype.  training: batch statistics (+ running-stat update, momentum, unbiased variance);
- * eval: running statistics.  mean/rstd [C] are outputs kept for the backward; sums_ws is 2*C floats of scratch. */
+ * eval: running statistics.  mean/rstd [C] are outputs kept for the backward; sums_ws is scratch: 2*C floats, and (1 + 64)*2*C floats when the
+ * SA_DBG_DETERMINISTIC flag is set (64 per-block partial sums per statistic, added in block order: sa_bn_sums_ws_floats(C) returns the size). */
+int64_t sa_bn_sums_ws_floats(int C);
 int sa_bn_forward(const void *x, int dtype, int64_t M, int C, const float *w, const float *b, float *running_mean, float *running_var,
                   float momentum, float eps, int training, float slope, void *y, float *mean, float *rstd, float *sums_ws, void *stream);
 int sa_bn_backward(const void *x, const void *g, int dtype, int64_t M, int C, const float *w, const float *mean, const float *rstd,
@@ -417,6 +419,9 @@ int sa_embed_scatter_det(const float *dy, float *dtable, const int64_t *idx, int
 /* Performer sums in a fixed order: out[0] (+)= sum x (one block); out[0] (+)= a . b (b fp32 / bf16; ws = 1 024 floats); sa_cross_entropy with per-row losses
  * (row_loss[R], summed by sa_sum_det); the summand matrix of the LayerNorm weight gradient (column sums through sa_colsum_det). */
 int sa_sum_det(const float *x, int64_t n, float *out, int accumulate, void *stream);
+/* sa_mse with the squared errors summed in a fixed order (2 048 contiguous ranges, then one block): loss_sum += sum; ws: 2 048 floats.  The logged
+ * loss and the validation MSE (the key metric that selects checkpoint_key_metric=*.pt) are then bit-reproducible too. */
+int sa_mse_det(const float *a, const float *b, int64_t n, float *loss_sum, float *grad, float gscale, float *ws, void *stream);
 int sa_dot_det(const float *a, const void *b, int b_dtype, int64_t n, float *out, int accumulate, float *ws, void *stream);
 int sa_cross_entropy_rows(const float *logits, const int64_t *target, int64_t R, int V, float *row_loss, void *dlogits, int d_dtype, float gscale, void *stream);
 int sa_layernorm_dwprod(const float *dy, const float *x, const float *stats, float *prod, int64_t R, int C, void *stream);

@@ -94,6 +94,8 @@ _SIGS = {
     "sa_vq_embed": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "sa_cast_pad": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "sa_mse": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p]),
+    "sa_mse_det": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "sa_bn_sums_ws_floats": (c_int64, [c_int]),
     "sa_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
     "sa_embed_sum": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), c_int, c_int, c_int64, c_void_p, c_void_p]),
     "sa_embed_step": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), c_int, c_void_p, c_int, c_void_p, c_void_p]),
@@ -188,12 +190,14 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.sa_abi_version() != 1:
-            raise HipLibraryError("ABI version mismatch")
+        if l.sa_abi_version() != ABI_VERSION:
+            raise HipLibraryError(f"ABI version mismatch: {LIB_PATH} reports {l.sa_abi_version()}, this package binds version {ABI_VERSION} "
+                                  "(include/synthanatomy_hip.h: SA_ABI_VERSION) -- rebuild with `python -m synthanatomy_amd.build`")
         _lib = l
     return _lib
 
 
+ABI_VERSION = 2   # include/synthanatomy_hip.h: SA_ABI_VERSION
 SA_EINVAL, SA_EUNSUPPORTED, SA_ENOGPU = -1, -2, -3   # include/synthanatomy_hip.h
 
 

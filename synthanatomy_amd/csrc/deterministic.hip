@@ -115,6 +115,26 @@ __global__ __launch_bounds__(1024) void sum_det_kernel(const float* __restrict__
     if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + red[0];
 }
 
+// squared-error partials: block b owns the contiguous range [b * per, (b + 1) * per) and leaves ONE partial; gradient written as mse_kernel does
+__global__ __launch_bounds__(256) void mse_det_stage1_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, int64_t per,
+                                                             float* __restrict__ partial, float* __restrict__ grad, float gcoef) {
+    __shared__ float red[256];
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    float s = 0.f;
+    for (int64_t e = lo + threadIdx.x; e < hi; e += 256) {
+        const float d = a[e] - b[e];
+        s += d * d;
+        if (grad) grad[e] = d * gcoef;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 // stage 1 of a dot product: block b owns the contiguous range [b * per, (b + 1) * per) and leaves ONE partial (same thread order and tree as above)
 __global__ __launch_bounds__(256) void dot_det_stage1_kernel(const float* __restrict__ a, const void* __restrict__ b, int b_dtype, int64_t n, int64_t per,
                                                              float* __restrict__ partial) {
@@ -188,6 +208,18 @@ extern "C" int sa_dot_det(const float* a, const void* b, int b_dtype, int64_t n,
     SA_LAUNCH(dot_det_stage1_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a, b, b_dtype, n, per, ws);
     SA_CHECK_LAUNCH();
     SA_LAUNCH(sum_det_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)ws, (int64_t)nblk, out, accumulate);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+// sa_mse in a fixed order (the logged loss / validation MSE decide the key-metric checkpoint): 2 048 contiguous ranges, then one block; ws: 2 048 floats
+extern "C" int sa_mse_det(const float* a, const float* b, int64_t n, float* loss_sum, float* grad, float gscale, float* ws, void* stream) {
+    if (!a || !b || !loss_sum || !ws || n <= 0) return SA_EINVAL;
+    const int64_t per = (n + 2047) / 2048;
+    const int nblk = (int)((n + per - 1) / per);
+    SA_LAUNCH(mse_det_stage1_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, a, b, n, per, ws, grad, 2.f * gscale / (float)n);
+    SA_CHECK_LAUNCH();
+    SA_LAUNCH(sum_det_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)ws, (int64_t)nblk, loss_sum, 1);
     SA_CHECK_LAUNCH();
     return 0;
 }

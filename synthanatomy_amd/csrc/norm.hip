@@ -132,6 +132,9 @@ static inline unsigned grid_e(int64_t n) {
 
 using namespace sa;
 
+// floats of scratch sa_bn_forward / sa_bn_backward need in sums_ws under the CURRENT debug flags (deterministic mode keeps 64 per-block partials per statistic)
+extern "C" int64_t sa_bn_sums_ws_floats(int C) { return (int64_t)(dbg(SA_DBG_DETERMINISTIC) ? 65 : 1) * 2 * (C > 0 ? C : 1); }
+
 extern "C" int sa_bn_forward(const void* x, int dtype, int64_t M, int C, const float* w, const float* b, float* running_mean, float* running_var,
                              float momentum, float eps, int training, float slope, void* y, float* mean, float* rstd, float* sums_ws, void* stream) {
     if (!x || !w || !b || !y || !mean || !rstd || !sums_ws || M <= 0 || C <= 0) return SA_EINVAL;

@@ -7,7 +7,7 @@ from typing import Dict, List
 
 import torch
 
-from .. import _ffi
+from .. import _ffi, debug
 
 
 class _MSEFn(torch.autograd.Function):
@@ -19,7 +19,11 @@ class _MSEFn(torch.autograd.Function):
         n = a.numel()
         acc = torch.zeros(1, dtype=torch.float32, device=a.device)
         grad = torch.empty_like(a) if pred.requires_grad else None
-        _ffi.check(_ffi.lib().sa_mse(_ffi.ptr(a), _ffi.ptr(b), n, _ffi.ptr(acc), _ffi.ptr(grad), 1.0, _ffi.stream()), "sa_mse")
+        if debug.deterministic():   # --deterministic: the squared errors are summed in a fixed order (the loss value decides the key-metric checkpoint)
+            ws = torch.empty(2048, dtype=torch.float32, device=a.device)
+            _ffi.check(_ffi.lib().sa_mse_det(_ffi.ptr(a), _ffi.ptr(b), n, _ffi.ptr(acc), _ffi.ptr(grad), 1.0, _ffi.ptr(ws), _ffi.stream()), "sa_mse_det")
+        else:
+            _ffi.check(_ffi.lib().sa_mse(_ffi.ptr(a), _ffi.ptr(b), n, _ffi.ptr(acc), _ffi.ptr(grad), 1.0, _ffi.stream()), "sa_mse")
         ctx.grad = grad
         return (acc / n).reshape(())
 

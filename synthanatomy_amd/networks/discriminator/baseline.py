@@ -69,7 +69,7 @@ class _Stage:
         bn = self.bn
         mean = torch.empty(C, dtype=torch.float32, device=c.device)
         rstd = torch.empty_like(mean)
-        ws = torch.empty(65 * 2 * C, dtype=torch.float32, device=c.device)   # totals + 64 per-block partials (deterministic mode)
+        ws = torch.empty(int(lib.sa_bn_sums_ws_floats(C)), dtype=torch.float32, device=c.device)   # 2 C totals (+ 64 per-block partials each in deterministic mode)
         y = torch.empty_like(c)
         use_batch = training or bn.running_mean is None
         _ffi.check(lib.sa_bn_forward(_ffi.ptr(c), _ffi.dtype_id(c.dtype), M, C, _ffi.ptr(bn.weight), _ffi.ptr(bn.bias), _ffi.ptr(bn.running_mean),
@@ -95,7 +95,7 @@ class _Stage:
             C = self.op.cout
             M = c.numel() // C
             dc = torch.empty_like(c)
-            ws = torch.empty(65 * 2 * C, dtype=torch.float32, device=c.device)   # totals + 64 per-block partials (deterministic mode)
+            ws = torch.empty(int(lib.sa_bn_sums_ws_floats(C)), dtype=torch.float32, device=c.device)   # 2 C totals (+ 64 per-block partials each in deterministic mode)
             _ffi.check(lib.sa_bn_backward(_ffi.ptr(c), _ffi.ptr(G), _ffi.dtype_id(c.dtype), M, C, _ffi.ptr(self.bn.weight), _ffi.ptr(stats[0]), _ffi.ptr(stats[1]),
                                           int(use_batch), _ffi.ptr(dc), _ffi.ptr(gc.buf(self.bn.weight)), _ffi.ptr(gc.buf(self.bn.bias)), _ffi.ptr(ws), st),
                        "sa_bn_backward")

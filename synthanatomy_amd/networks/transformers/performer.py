@@ -308,7 +308,7 @@ class _GradCtx:
     def done(self, *params):
         if self.sink is None:
             return
-        if self.side is not None and getattr(self.sink, "world", 2) > 1:
+        if self.side is not None and getattr(self.sink, "active", True):
             # DDP: a bucket's all-reduce is ordered behind an event of the CURRENT stream (runtime/ddp.GradReducer._launch); the gradients of these parameters
             # were queued on the main stream (bias / gate gradients) and on the weight-gradient stream, so report them from the latter after it has caught up
             self.side.side.wait_stream(self.side.main)

@@ -498,7 +498,7 @@ class _GradCtx:
     def done(self, *params):
         if self.sink is None:
             return
-        if self.side is not None and getattr(self.sink, "world", 2) > 1:
+        if self.side is not None and getattr(self.sink, "active", True):
             # DDP: the bucket's all-reduce waits for an event of the CURRENT stream; these gradients were queued on the main and on the weight-gradient stream
             self.side.side.wait_stream(self.side.main)
             with torch.cuda.stream(self.side.side):

@@ -20,13 +20,32 @@ from .. import debug
 from .optim import FlatParams
 
 
+def ipc_mode_default(env=None, verbose: bool = True) -> bool:
+    """RCCL between processes exchanges device-memory handles; the MI355X hosts this build targets only support dmabuf IPC, which the HIP runtime
+    selects when ``HSA_ENABLE_IPC_MODE_LEGACY=0`` is in the environment BEFORE its first device call (without it: ``hipIpcGetMemHandle: invalid
+    argument`` in the first collective).  Applied only when the variable is unset and ``SA_KEEP_IPC_MODE`` is not given, and said so once on rank 0
+    -- a host whose driver wants legacy IPC exports ``HSA_ENABLE_IPC_MODE_LEGACY=1`` (respected) or ``SA_KEEP_IPC_MODE=1``.  Returns whether the
+    default was applied.  Documented in INTEGRATION.md ("Multi-process environment")."""
+    env = os.environ if env is None else env
+    if "HSA_ENABLE_IPC_MODE_LEGACY" in env or debug.host("keep_ipc_mode"):
+        return False
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if verbose and int(env.get("WORLD_SIZE", "1")) > 1 and int(env.get("RANK", "0")) == 0:
+        print("[synthanatomy_amd] HSA_ENABLE_IPC_MODE_LEGACY was unset: defaulting to 0 (dmabuf IPC) for RCCL; SA_KEEP_IPC_MODE=1 leaves it alone", flush=True)
+    return True
+
+
 def init_distributed(backend: Optional[str] = None):
     """torchrun-style bootstrap (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); replaces deepspeed.init_distributed
-    (run_vqvae.py:831-842).  Returns (rank, local_rank, world_size)."""
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver; read when the HIP runtime starts (first device call)
+    (run_vqvae.py:831-842).  Returns (rank, local_rank, world_size).  ``SA_SHARE_DEVICE=1`` (test aid) puts every rank on cuda:0 over gloo:
+    the N > 1 code path of the CLIs on a one-GPU box (RCCL refuses two ranks per device)."""
+    ipc_mode_default()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if debug.host("share_device"):
+        local = 0
+        backend = backend or "gloo"
     single = world == 1 and "RANK" in os.environ and "MASTER_PORT" in os.environ and debug.host("ddp_single_rank")   # one-GPU box: RCCL on a one-rank group
     if (world > 1 or single) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -68,10 +87,55 @@ def all_reduce_sum(t: torch.Tensor, group=None):
     t.copy_(h)
 
 
+def _reduce_scatter_sum(out: torch.Tensor, inp: torch.Tensor, group=None):
+    """``out`` = this rank's 1/world slice of the SUM of ``inp`` over ranks (``out`` may alias that slice of ``inp``: the in-place form RCCL
+    reduces without a staging copy).  gloo has no reduce-scatter: the CPU / shared-device tests get the same result from an all-reduce."""
+    if dist.get_backend(group) == "gloo":
+        all_reduce_sum(inp, group)
+        if out.data_ptr() != inp.data_ptr() + dist.get_rank(group) * out.numel() * out.element_size():
+            r = dist.get_rank(group)
+            out.copy_(inp[r * out.numel():(r + 1) * out.numel()])
+        return
+    dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group)
+
+
+def _all_gather(out: torch.Tensor, inp: torch.Tensor, group=None):
+    """``out`` = the ranks' ``inp`` slices in rank order (``inp`` may alias this rank's slice of ``out``)."""
+    if dist.get_backend(group) == "gloo":
+        if out.is_cuda and _HOST_STAGED.get("gloo"):
+            h = [torch.empty(inp.numel(), dtype=inp.dtype) for _ in range(dist.get_world_size(group))]
+            dist.all_gather(h, inp.detach().cpu(), group=group)
+            out.copy_(torch.cat(h))
+            return
+        parts = [torch.empty_like(inp) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, inp.clone(), group=group)
+        out.copy_(torch.cat(parts))
+        return
+    dist.all_gather_into_tensor(out, inp, group=group)
+
+
+MODES = ("all_reduce", "reduce_scatter")
+TRANSPORTS = ("fp32", "bf16")
+
+
 class GradReducer:
-    def __init__(self, flat: FlatParams, bucket_bytes: int = 32 << 20, process_group=None):
+    """Gradient sink of the backward chains + the bucketed reduction over ranks.
+
+    ``mode``      ``"all_reduce"`` (default; what DDP issues, run_vqvae.py:72-77): one SUM all-reduce per bucket.
+                  ``"reduce_scatter"``: every bucket is reduce-scattered (each rank receives the sum of its 1/world slice) and the reduced slices are
+                  all-gathered back -- on the fully connected xGMI mesh both halves are direct peer-to-peer exchanges over all 7 links at once instead
+                  of a ring bound by one link; the flat buffer ends up with the same sums, so the optimizer is unchanged.
+    ``transport`` ``"fp32"`` (default) or ``"bf16"``: the bucket crosses the links as bf16 (half the bytes; the sum is formed in bf16, so gradients carry
+                  bf16 rounding -- opt-in).
+    Environment defaults: ``SA_DDP_MODE``, ``SA_DDP_TRANSPORT`` (read at construction)."""
+
+    def __init__(self, flat: FlatParams, bucket_bytes: int = 32 << 20, process_group=None, mode: Optional[str] = None, transport: Optional[str] = None):
         self.flat, self.group = flat, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.mode = mode or os.environ.get("SA_DDP_MODE", "all_reduce")
+        self.transport = transport or os.environ.get("SA_DDP_TRANSPORT", "fp32")
+        if self.mode not in MODES or self.transport not in TRANSPORTS:
+            raise ValueError(f"GradReducer: mode {self.mode!r} / transport {self.transport!r}; choices are {MODES} / {TRANSPORTS}")
         # buckets are contiguous [lo, hi) ranges of the flat buffer, built from the END (backward produces the last
         # parameters first)
         n = len(flat.params)
@@ -91,10 +155,17 @@ class GradReducer:
         self._pending = None
         self._side = None
         self._works = []
+        self._lp = None          # bf16 transport: one staging buffer of the largest bucket's size (buckets are reduced one after the other on the side stream)
         self.timing = False      # bench.py: record HIP events around every bucket's collective and around the wait in finish()
         self._ev = []            # per finished step: (bucket (start, end) events on the side stream, main-stream arrival, side-stream end)
         self._bucket_ev = []
         self.reset()
+
+    @property
+    def active(self) -> bool:
+        """True when a reported bucket launches a collective (more than one rank, or the one-rank RCCL test mode): the backward chains ask this to
+        decide from which stream a bucket's parameters are reported."""
+        return self.world > 1 or (dist.is_initialized() and debug.host("ddp_single_rank"))
 
     def reset(self):
         self._pending = [hi - lo + 1 for (_, _, lo, hi) in self.buckets]
@@ -115,8 +186,32 @@ class GradReducer:
         if self._pending[b] == 0:
             self._launch(b)
 
+    def _collective(self, view: torch.Tensor):
+        """The bucket's reduction on the CURRENT stream (device) or synchronously (host tensors of the gloo tests)."""
+        buf = view
+        if self.transport == "bf16":
+            if self._lp is None or self._lp.device != view.device:
+                self._lp = torch.empty(max(hi - lo for lo, hi, _, _ in self.buckets), dtype=torch.bfloat16, device=view.device)
+            buf = self._lp[:view.numel()]
+            buf.copy_(view)
+        if self.mode == "all_reduce" or self.world == 1:
+            all_reduce_sum(buf, self.group)
+        else:
+            w = self.world
+            c = buf.numel() // w
+            if c:
+                r = dist.get_rank(self.group)
+                body = buf[:c * w]
+                mine = body[r * c:(r + 1) * c]
+                _reduce_scatter_sum(mine, body, self.group)
+                _all_gather(body, mine, self.group)
+            if buf.numel() > c * w:            # fewer than `world` trailing elements
+                all_reduce_sum(buf[c * w:], self.group)
+        if buf is not view:
+            view.copy_(buf)
+
     def _launch(self, b: int):
-        if self.world == 1 and not (dist.is_initialized() and debug.host("ddp_single_rank")):
+        if not self.active:
             return
         lo, hi = self.buckets[b][0], self.buckets[b][1]
         view = self.flat.grad[lo:hi]
@@ -130,13 +225,15 @@ class GradReducer:
                 if self.timing:
                     e0 = torch.cuda.Event(enable_timing=True)
                     e0.record()
-                all_reduce_sum(view, self.group)
+                self._collective(view)
                 if self.timing:
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record()
                     self._bucket_ev.append((e0, e1))
-        else:
+        elif self.mode == "all_reduce" and self.transport == "fp32":
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._collective(view)
 
     def finish(self) -> float:
         """Wait for every bucket (launching any bucket whose parameters never reported, e.g. unused ones) and return the
@@ -170,4 +267,5 @@ class GradReducer:
         self._ev = []
         exp = min(exp, tot)
         return {"steps": n, "comm_ms": round(tot / n, 3), "exposed_ms": round(exp / n, 3), "hidden_ms": round((tot - exp) / n, 3),
-                "buckets": len(self.buckets), "bytes_per_step": int(self.flat.numel * 4)}
+                "buckets": len(self.buckets), "bytes_per_step": int(self.flat.numel * (2 if self.transport == "bf16" else 4)),
+                "mode": self.mode, "transport": self.transport}

@@ -112,36 +112,50 @@ def _state(obj):
 
 
 _BEST_SCORE = {}   # checkpoint directory -> (file, unrounded score) of the key-metric checkpoint this process wrote or read
+_SIDECAR = "checkpoint_key_metric.json"   # {"file": <basename>, "score": <unrounded float>} next to the key-metric checkpoint
 
 
 def _best_key_metric(ck, files):
-    """Unrounded score of the existing key-metric checkpoint: from this process' memory, else from the file's payload, else (files written by
-    the reference, which stores no score) parsed back from the file name."""
+    """Unrounded score of the existing key-metric checkpoint: from this process' memory, else from the small sidecar file this build writes next to
+    it, else (files written by the reference, which stores no score; or a lost sidecar) parsed back from the file name.  The checkpoint itself is
+    never opened for this -- it holds the network, optimizer and discriminator states."""
     if not files:
         return None
     hit = _BEST_SCORE.get(os.path.abspath(ck))
     if hit is not None and hit[0] in files:
         return hit[1]
+    side = None
+    try:
+        import json
+        with open(os.path.join(ck, _SIDECAR)) as f:
+            side = json.load(f)
+    except (OSError, ValueError):
+        side = None
     best = None
     for f in files:
         score = None
-        try:
-            score = torch.load(f, map_location="cpu", weights_only=False).get("key_metric")
-        except Exception:   # unreadable / foreign file: fall back to the name
-            score = None
+        if side and side.get("file") == os.path.basename(f):
+            score = side.get("score")
         if score is None:
-            score = float(re.search(r"key_metric=(-?[0-9.eE+-]+)\.pt$", f).group(1))
+            m = re.search(r"key_metric=(-?[0-9.]+(?:[eE][+-]?[0-9]+)?)\.pt$", f)
+            if m is None:      # a foreign file name: not a candidate
+                continue
+            score = float(m.group(1))
         if best is None or score > best[1]:
             best = (f, float(score))
+    if best is None:
+        return None
     _BEST_SCORE[os.path.abspath(ck)] = best
     return best[1]
 
 
 def save_checkpoint(config, epoch, to_save: dict, key_metric: float = None, key_metric_name: str = None):
-    """One ``.pt`` whose top-level keys are those of the reference's ``to_save`` (run_vqvae.py:312-326: ``network``, ``optimizer``,
+    """One ``.pt`` whose top-level keys are EXACTLY those of the reference's ``to_save`` (run_vqvae.py:312-326: ``network``, ``optimizer``,
     ``lr_scheduler``, ``trainer`` and, with the adversarial component, ``d_network``, ``d_optimizer``, ``d_lr_scheduler``), each the
     object's ``state_dict()``.  Periodic checkpoints are ``checkpoint_epoch=<e>.pt`` with ``n_saved=1``; with ``key_metric`` the file is the
-    evaluator's ``checkpoint_key_metric=<value>.pt`` (``key_metric_n_saved=1``: kept only while it is the best so far)."""
+    evaluator's ``checkpoint_key_metric=<value>.pt`` (``key_metric_n_saved=1``: kept only while it is the best so far); its unrounded score goes
+    to the sidecar ``checkpoint_key_metric.json`` (ignite compares the score it keeps in memory; the file name only carries a rounded copy, and
+    validation MSEs below 1e-4 must still order correctly after a restart)."""
     if not isinstance(to_save, dict):   # round-1 call form: save_checkpoint(cfg, epoch, network, optimizer)
         raise TypeError("to_save must be a dict of name -> object with state_dict()")
     obj = {k: _state(v) for k, v in to_save.items() if v is not None}
@@ -157,11 +171,11 @@ def save_checkpoint(config, epoch, to_save: dict, key_metric: float = None, key_
     best = _best_key_metric(ck, old)
     if best is not None and key_metric <= best:
         return None
-    # ignite compares the UNROUNDED score it keeps in memory; the file name only carries a rounded copy.  The exact score rides in the payload
-    # (and in a per-directory cache), so metrics below 1e-4 (validation MSE) still order correctly after a restart.
-    obj["key_metric"] = float(key_metric)
     path = os.path.join(ck, f"checkpoint_key_metric={key_metric:.4f}.pt")
     torch.save(obj, path)
+    import json
+    with open(os.path.join(ck, _SIDECAR), "w") as f:
+        json.dump({"file": os.path.basename(path), "score": float(key_metric)}, f)
     _BEST_SCORE[os.path.abspath(ck)] = (path, float(key_metric))
     for f in old:
         if f != path:

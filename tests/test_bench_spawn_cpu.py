@@ -34,3 +34,16 @@ def test_bench_under_torchrun():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _json_lines(r.stdout)
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2
+
+
+def test_bench_dry_run_with_eight_ranks_and_reduce_scatter():
+    """The launch form of the 8-GPU scaling run, on CPU: 8 ranks, the flat gradient buffer of the real config-2 parameter list in 32 MiB buckets,
+    reduce-scatter + all-gather per bucket, the packed EMA statistics exchange and the CLIs' file sharding at world 8 (bench.py: dry_run)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--dry-run", "--ddp-mode",
+                        "reduce_scatter"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8 and lines[0]["dry_run"] is True
+    assert lines[0]["comm"]["mode"] == "reduce_scatter" and lines[0]["comm"]["buckets"] >= 3 and lines[0]["comm"]["bytes_per_step"] > 100e6

@@ -1,4 +1,5 @@
 """CPU: CLI plumbing -- flag parsing in the reference's style, folder layout, checkpoint naming, uint16 .npy code files."""
+import json
 import os
 
 import numpy as np
@@ -84,16 +85,21 @@ def test_best_checkpoint_is_chosen_by_the_unrounded_metric(tmp_path):
     a = G.save_checkpoint(cfg, 1, {"network": net}, key_metric=-0.00054)
     assert os.path.basename(a) == "checkpoint_key_metric=-0.0005.pt"
     b = G.save_checkpoint(cfg, 2, {"network": net}, key_metric=-0.00052)          # better, same rounded name
-    assert b is not None and torch.load(b, weights_only=False)["key_metric"] == -0.00052
+    assert b is not None and sorted(torch.load(b, weights_only=False)) == ["network"]          # exactly the reference's to_save keys
+    assert json.load(open(os.path.join(cfg["checkpoint_directory"], G._SIDECAR))) == {"file": os.path.basename(b), "score": -0.00052}
     assert G.save_checkpoint(cfg, 3, {"network": net}, key_metric=-0.00053) is None
     c = G.save_checkpoint(cfg, 4, {"network": net}, key_metric=-3e-5)
     assert os.path.basename(c) == "checkpoint_key_metric=-0.0000.pt" and not os.path.exists(b)
-    G._BEST_SCORE.clear()                                                          # a restarted process: the score comes back from the payload
+    G._BEST_SCORE.clear()                                                          # a restarted process: the score comes back from the sidecar file
     assert G.save_checkpoint(cfg, 5, {"network": net}, key_metric=-4e-5) is None
     d = G.save_checkpoint(cfg, 6, {"network": net}, key_metric=-1e-5)
-    assert d is not None and torch.load(d, weights_only=False)["key_metric"] == -1e-5
-    assert len(os.listdir(cfg["checkpoint_directory"])) == 1
-    G.load_checkpoint(d, {"network": net})                                         # the extra payload key does not disturb loading
+    assert d is not None and json.load(open(os.path.join(cfg["checkpoint_directory"], G._SIDECAR)))["score"] == -1e-5
+    assert sorted(os.listdir(cfg["checkpoint_directory"])) == sorted([os.path.basename(d), G._SIDECAR])
+    G.load_checkpoint(d, {"network": net})
+    # a lost sidecar / a reference-written file: the score is parsed back from the name; a foreign name is skipped, not an AttributeError
+    os.remove(os.path.join(cfg["checkpoint_directory"], G._SIDECAR))
+    G._BEST_SCORE.clear()
+    assert G._best_key_metric(cfg["checkpoint_directory"], [d, os.path.join(cfg["checkpoint_directory"], "checkpoint_key_metric_foreign.pt")]) == 0.0
 
 
 def test_resume_uses_the_checkpoints_epoch_length():

@@ -36,6 +36,28 @@ def _worker(rank, world, port, q):
     scale = red.finish()
     ok_grad = bool(torch.allclose(flat.grad[: ps[0].numel()], torch.full((ps[0].numel(),), 3.0))) and scale == 0.5
 
+    # the other collectives behind the same sink (reduce-scatter + all-gather, bf16 transport) against the all-reduce path:
+    # seeded, rank-dependent gradients; fp32 transport must agree to rounding (a different summation tree), bf16 to bf16 rounding
+    def reduced(mode, transport):
+        f = FlatParams([torch.nn.Parameter(p.detach().clone()) for p in ps])
+        rd = GradReducer(f, bucket_bytes=300, mode=mode, transport=transport)
+        gg = torch.Generator().manual_seed(100 + rank)
+        for p in reversed(f.params):
+            rd.buffer(p).copy_(torch.randn(p.shape, generator=gg))
+            rd.ready(p)
+        assert rd.finish() == 0.5
+        return f.grad.clone(), rd
+    base, rd0 = reduced("all_reduce", "fp32")
+    rs, rd1 = reduced("reduce_scatter", "fp32")
+    lp, _ = reduced("all_reduce", "bf16")
+    rslp, _ = reduced("reduce_scatter", "bf16")
+    assert rd0.buckets == rd1.buckets and len(rd1.buckets) >= 2   # (views are 16-byte aligned, so only world sizes that do not divide 4 see a tail: the 8-rank dry run)
+    ok_grad = ok_grad and bool(torch.allclose(rs, base, rtol=1e-6, atol=1e-6)) and bool(torch.allclose(lp, base, rtol=2e-2, atol=2e-2)) \
+        and bool(torch.allclose(rslp, lp, rtol=2e-2, atol=2e-2)) and not torch.equal(lp, base)
+    both = [torch.empty_like(base) for _ in range(world)]
+    dist.all_gather(both, rs)
+    ok_grad = ok_grad and all(torch.equal(b, both[0]) for b in both)      # replicas hold identical sums after the all-gather
+
     # EMA statistics: each rank quantizes its half of the batch; the packed [counts | dw] buffer is summed
     from oracle import vqvae_ref
     cfg = vqvae_ref.VQVAEConfig(n_embed=32, embed_dim=8, vq_decay=0.5)
@@ -62,7 +84,7 @@ def test_two_rank_reducer_and_ema_statistics():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=240) for _ in range(2))
+    res = sorted(q.get(timeout=120) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
