@@ -280,21 +280,51 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
     return res
 
 
-PMC_FILE = "r03_pmc_traffic.json"   # profiles/: HBM bytes per launch from the committed PMC passes (its `_provenance` names the command and commit)
+PMC_FILE = "r04_pmc_traffic.json"   # profiles/: HBM bytes per launch from the committed PMC passes (its `_provenance` names the command and commit)
+
+
+def csrc_digest():
+    """SHA-1 over the kernel sources (synthanatomy_amd/csrc/*.hip, *.h, in name order): `tools/rocpd_tools.py traffic` stores it next to the counters
+    it summarises, and `roofline.traffic` is only reported while the sources are the ones that were profiled."""
+    import hashlib
+    d = os.path.join(ROOT, "synthanatomy_amd", "csrc")
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
+_PMC_STATE = {}
 
 
 def _pmc_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from the PMC passes of this same command (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3
-    --pmc runs; counters cannot be read from inside the process).  Recorded in profiles/r01_pmc_traffic.json with its provenance; only
-    reported for the configuration it was collected on (default batch, bf16), else null."""
+    --pmc runs; counters cannot be read from inside the process).  Recorded in profiles/<PMC_FILE> with its provenance and the digest of the
+    kernel sources it was collected on; reported only for the configuration it was collected on (default batch, bf16) and only while that
+    digest matches the sources of this tree -- a stale file gives null (and `traffic_source` says so), never an old number."""
     if args.batch != 8 or args.dtype != "bf16":
         return None
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_FILE)) as f:
-            rec = json.load(f)["kernels"].get(kernel)
+        if "rec" not in _PMC_STATE:
+            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
+                rec = json.load(f)
+            _PMC_STATE["rec"] = rec
+            _PMC_STATE["fresh"] = rec.get("csrc_sha1") == csrc_digest()
+        if not _PMC_STATE["fresh"]:
+            return None
+        rec = _PMC_STATE["rec"]["kernels"].get(kernel)
         return int(rec["hbm_bytes_per_launch"]) if rec else None
     except (OSError, ValueError, KeyError):
+        _PMC_STATE.setdefault("fresh", False)
         return None
+
+
+def _pmc_source():
+    if _PMC_STATE.get("fresh"):
+        return f"profiles/{PMC_FILE} (separate rocprofv3 --pmc passes of this command on these kernel sources; not sampled in this run)"
+    return f"null: profiles/{PMC_FILE} is missing or was collected on other kernel sources (csrc digest mismatch) -- re-run the PMC passes (tools/rocpd_tools.py traffic)"
 
 
 def _respawn(args):
@@ -440,16 +470,23 @@ def bench_bf16_vs_fp32(dev, batch=2):
     low = BaselineVQVAE(**NET, compute_dtype=torch.bfloat16)
     low.load_state_dict(ref.state_dict())
     low = low.to(dev).eval()
+    old = BaselineVQVAE(**NET, compute_dtype=torch.bfloat16, encoder_forward_dtype=torch.bfloat16)   # bf16 forward operands too (the round-3 mode)
+    old.load_state_dict(ref.state_dict())
+    old = old.to(dev).eval()
     x = torch.rand(batch, 1, *VOL, generator=torch.Generator(device=dev).manual_seed(4), device=dev)
     with torch.no_grad():
-        i32, i16 = ref.index_quantize(x)[0], low.index_quantize(x)[0]
-        z32, z16 = ref.encode(x)[0].double(), low.encode(x)[0].double()
+        i32, i16, ibf = ref.index_quantize(x)[0], low.index_quantize(x)[0], old.index_quantize(x)[0]
+        z32, z16, zbf = ref.encode(x)[0].double(), low.encode(x)[0].double(), old.encode(x)[0].double()
         r32, r16 = ref.decode_samples([i32]).double(), low.decode_samples([i32]).double()
     res = {"index_agreement_vs_fp32": round(float((i32 == i16).float().mean()), 5), "positions": int(i32.numel()),
            "z_max_rel": float(f"{float((z16 - z32).abs().max() / z32.abs().max()):.3e}"),
            "recon_max_rel_same_indices": float(f"{float((r16 - r32).abs().max() / r32.abs().max()):.3e}"),
-           "what": f"bf16 product path vs fp32 product path, same random-init weights, {batch} volumes {VOL[0]}x{VOL[1]}x{VOL[2]}, eval"}
-    del ref, low, x
+           "encoder_forward_dtype": str(low.encoder_forward_dtype).replace("torch.", ""),
+           "bf16_forward_operands": {"index_agreement_vs_fp32": round(float((i32 == ibf).float().mean()), 5),
+                                     "z_max_rel": float(f"{float((zbf - z32).abs().max() / z32.abs().max()):.3e}")},
+           "what": f"benchmarked mode (bf16 MFMA, encoder forward on float16 operands) vs fp32 product path, same random-init weights, {batch} volumes "
+                   f"{VOL[0]}x{VOL[1]}x{VOL[2]}, eval"}
+    del ref, low, old, x
     torch.cuda.empty_cache()
     return res
 
@@ -649,7 +686,7 @@ def main():
         ach = flops / (ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "traffic": _pmc_traffic(name, args), "traffic_source": f"profiles/{PMC_FILE} (separate rocprofv3 --pmc passes of this command; not sampled in this run)",
+                "traffic": _pmc_traffic(name, args), "traffic_source": _pmc_source(),
                 "kernel": name, "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                 "kernels": {k: {"launches": v[0], "ms": round(v[2], 3), "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2) if v[2] > 0 else None}
                             for k, v in sorted(stats.items(), key=lambda kv: -kv[1][2])}}
@@ -663,7 +700,10 @@ def main():
             k, v = max(hb.items(), key=lambda kv: kv[1][2])
             gbs = v[3] / (v[2] * 1e-3) / 1e9
             roof_hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
-                        "traffic": _pmc_traffic(k.split("+")[0], args), "kernel": k, "launches": v[0], "avg_launch_us": round(v[2] * 1e3 / v[0], 2)}
+                        "traffic": _pmc_traffic(k.split("+")[0], args), "kernel": k, "launches": v[0], "avg_launch_us": round(v[2] * 1e3 / v[0], 2),
+                        # every launch the step reports against bandwidth (the one-channel first / last layers, the fused 1x1x1 backward)
+                        "kernels": {kk: {"launches": vv[0], "avg_launch_us": round(vv[2] * 1e3 / vv[0], 2), "gbs": round(vv[3] / (vv[2] * 1e-3) / 1e9, 1),
+                                         "frac": round(vv[3] / (vv[2] * 1e-3) / 1e9 / 8000.0, 4)} for kk, vv in sorted(hb.items(), key=lambda kv: -kv[1][2])}}
     if rank == 0:
         vols = args.batch * world * args.steps
         value = vols / dt

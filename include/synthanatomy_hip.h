@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 #define SA_ABI_VERSION 2   /* 2 (round 4): sa_local_attn_fwd/bwd + sa_epilogue grew trailing pointers in round 3, SA_F16 operand type, sa_mse partials; a caller built against 1 must not load this library */
-enum { SA_F32 = 0, SA_BF16 = 1 };
+enum { SA_F32 = 0, SA_BF16 = 1, SA_F16 = 2 /* IEEE half: FORWARD operand / activation type only (the reference's AMP dtype, src/engines/trainer.py:161-163); see sa_conv_fprop */ };
 enum { SA_ACT_NONE = 0, SA_ACT_RELU = 1, SA_ACT_LRELU = 2, SA_ACT_GELU = 3 };
 enum { SA_MASK_NONE = 0, SA_MASK_POS = 1 /* out *= (mask > 0) */, SA_MASK_LRELU = 2 /* out *= mask>0 ? 1 : slope */,
        SA_MASK_GELU = 3 /* out *= gelu'(mask) */ };
@@ -57,8 +57,8 @@ typedef struct sa_epilogue {
     int32_t add_before_act;
     int32_t out_dtype, add_dtype, mask_dtype;
     float slope;          /* LeakyReLU slope */
-    /* optional extra outputs of the same launch (bf16, laid out like out; the LDS-staged epilogue of the im2col-order kernels only -- a launch that
-     * would take another epilogue returns SA_EUNSUPPORTED):
+    /* optional extra outputs of the same launch (bf16, laid out like out; the LDS-staged epilogue of the im2col-order kernels only, and out_lp also
+     * in the register epilogue of SA_F16 launches -- a launch that would take another epilogue returns SA_EUNSUPPORTED):
      *   out_pre: the value BEFORE activation / alpha / addend (acc + bias): the pre-activation a GELU backward needs (nn.Linear -> GELU in one launch),
      *            or the branch output F of a ReZero block x + g F
      *   out_lp : a bf16 copy of the final value (the operand of the next dense layer when out itself is the fp32 residual stream) */
@@ -96,7 +96,7 @@ int sa_kernel_log_read(char *buf, int cap, int stop);
 #define SA_DBG_HALO256_4W        (1u << 13)  /* bf16 im2col-order forward / data-gradient and weight-gradient kernels with four waves per block instead of eight */
 #define SA_DBG_RESERVED_14       (1u << 14)  /* (was SA_DBG_TILE256: 256 x 128 tiles for the im2col-order kernel -- measured slower, instance removed) */
 #define SA_DBG_DENSE_NARROW      (1u << 15)  /* A/B: 128 x 64 tiles for every small dense grid (the round-2 rule) */
-#define SA_DBG_DENSE_RING        (1u << 17)  /* A/B instance: dense layers with few wide tiles on the three-stage 128x256 ring of csrc/dense_ring.hip (measured slower) */
+#define SA_DBG_RESERVED_17       (1u << 17)  /* (was SA_DBG_DENSE_RING: three-stage 128x256 ring for dense layers -- measured 15 % slower in round 3, removed in round 4) */
 #define SA_DBG_DETERMINISTIC     (1u << 16)  /* fixed-order reductions where the library itself chooses (BatchNorm sums); see the deterministic-mode section */
 #define SA_DBG_SCAN_EXACT_SHIFT  10          /* 3 bits: chunk states | scan A outputs | scan B outputs on the exact-fp32 MFMA kernels */
 /* measurement aid (bench.py `roofline.peak_measured`): `blocks` x 4 waves each issue iters x 8 independent v_mfma_f32_32x32x16_bf16;
@@ -129,11 +129,16 @@ int sa_pack_weights_batch(const sa_pack_desc *table, const int32_t *block_first,
 
 /* ---- convolution forward / data gradient (implicit GEMM on MFMA) -- replaces cuDNN behind nn.Conv3d /
  * nn.ConvTranspose3d / nn.Linear at baseline.py:153-160,218-244,258-293; discriminator/baseline.py:41-80;
- * performer_pytorch to_q/to_k/to_v/to_out/FeedForward (performer.py:194-219) and performer.py:221 to_out. */
+ * performer_pytorch to_q/to_k/to_v/to_out/FeedForward (performer.py:194-219) and performer.py:221 to_out.
+ * dtype = the operand type of `in` and `wpk`: SA_F32 (exact-f32 MFMA), SA_BF16, or SA_F16 -- IEEE halves, the reference's AMP forward dtype
+ * (src/engines/trainer.py:161-163), for FORWARD launches with DMA-addressable operands (< 4 GiB each): 16-bit addends / outputs of an SA_F16
+ * launch are halves too (ep->add_dtype / out_dtype = SA_F16, or SA_F32), masks are never halves, and ep->out_lp receives a bf16 copy of the
+ * output from either epilogue (what the bf16 backward pass of the next layer reads).  Mixing 16-bit types otherwise -> SA_EUNSUPPORTED. */
 int sa_conv_fprop(const sa_conv_geom *g, int dtype, const void *in, const void *wpk, void *out, const sa_epilogue *ep,
                   void *stream);
 
-/* ---- ResidualLayer forward in ONE launch (baseline.py:150-160), bf16, 128 channels, k3 s1 p1 geometry `g`:
+/* ---- ResidualLayer forward in ONE launch (baseline.py:150-160), bf16 or f16 (dtype = type of x, the packed weights and y; addend / out dtypes of
+ * ep must equal it; h_out is ALWAYS bf16 -- it is an operand of the bf16 backward pass -- and ep->out_lp takes a bf16 copy of an f16 y), 128 channels, k3 s1 p1 geometry `g`:
  *   h = relu(conv3x3x3(x) + bias1)  (stored to h_out when non-NULL: the backward pass needs it)
  *   y = epilogue(h . w1pk^T)  with ep = {bias = b2, addend = x, add_before_act = 1, act = RELU} for the reference block.
  * w3pk / w1pk are sa_pack_weights operands ([128][27*128] and [128][128]).  SA_EUNSUPPORTED for other shapes: use two sa_conv_fprop. */
@@ -346,6 +351,9 @@ int sa_lrelu_mask(const void *dy, const void *y, int dtype, void *g, int64_t n, 
  * sa_conv1_wgrad: dw [128][64] += g^T x_taps, db [128] += sum g  (g [N,D,H,W,128] bf16; accumulated with fp32 atomics: zero them first).
  * cout != 128 -> SA_EUNSUPPORTED: use sa_convt1_im2col + sa_conv_fprop / sa_conv_wgrad on the [cells][64] matrix. */
 int sa_conv1_fwd(const float *x, const void *wpk, const float *bias, void *y, int N, int D, int H, int W, int cout, int act, void *stream);
+/* sa_conv1_fwd_f16: the same with IEEE-half taps, weights (wpk packed as SA_F16) and output y -- the first layer of an f16 forward chain -- and an
+ * optional bf16 copy y_lp of y (what the bf16 backward pass of the NEXT layer reads). */
+int sa_conv1_fwd_f16(const float *x, const void *wpk, const float *bias, void *y, void *y_lp, int N, int D, int H, int W, int cout, int act, void *stream);
 int sa_conv1_wgrad(const float *x, const void *g, float *dw, float *db, int N, int D, int H, int W, int cout, void *stream);
 /* Backward of the last decoder layer nn.ConvTranspose3d(128 -> 1, k4 s2 p1) (baseline.py:283-293, last level), bf16, on the two kernels above:
  * g = d loss / d output [N,2D,2H,2W] fp32, x = the layer input [N,D,H,W,128] bf16, wpk = the transposed-convolution weight [128][64 taps] as bf16

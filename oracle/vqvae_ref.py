@@ -19,7 +19,8 @@ here against fixtures produced by importing the reference itself
 (``tests/golden/make_goldens.py``).
 
 A ``round_dtype`` knob emulates the product's reduced-precision storage (activations
-and weights rounded to bf16 between layers, fp32 accumulation) so the bf16 HIP path
+and weights rounded to bf16 -- or float16, the encoder's forward operand type in the
+product's throughput mode -- between layers, fp32 accumulation) so the 16-bit HIP paths
 can be compared at tight tolerance; with ``round_dtype=None`` it is the fp32 reference.
 """
 from __future__ import annotations
@@ -198,9 +199,10 @@ def decode(st, cfg: VQVAEConfig, zq: torch.Tensor, round_dtype=None) -> torch.Te
     return x
 
 
-def forward(st, cfg: VQVAEConfig, images, training: bool, round_dtype=None, world_stats=None):
-    """baseline.py:354-362."""
-    z = encode(st, cfg, images, round_dtype)
+def forward(st, cfg: VQVAEConfig, images, training: bool, round_dtype=None, world_stats=None, enc_round_dtype="same"):
+    """baseline.py:354-362.  ``enc_round_dtype`` (default: ``round_dtype``): storage rounding of the ENCODER half alone -- the product's throughput
+    mode runs the encoder's forward on float16 operands (the reference's AMP dtype) and everything else on bf16."""
+    z = encode(st, cfg, images, round_dtype if isinstance(enc_round_dtype, str) else enc_round_dtype)
     zq, qloss, idx, aux = quantize(st, cfg, z, training, world_stats)
     recon = decode(st, cfg, zq, round_dtype)
     return {"reconstruction": [recon], "quantization_losses": [qloss], "indices": idx, "z": z, "aux": aux}

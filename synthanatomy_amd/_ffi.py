@@ -13,7 +13,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SA_HIP_LIB") or os.path.join(HERE, "libsynthanatomy_hip.so")   # (SA_HIP_LIB: dev A/B builds)
 
-SA_F32, SA_BF16 = 0, 1
+SA_F32, SA_BF16, SA_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU = 0, 1, 2, 3
 MASK_NONE, MASK_POS, MASK_LRELU, MASK_GELU = 0, 1, 2, 3
 MAX_TAPS = 64
@@ -70,6 +70,7 @@ _SIGS = {
     "sa_get_debug_flags": (ctypes.c_uint32, []),
     "sa_set_debug_flags": (ctypes.c_uint32, [ctypes.c_uint32]),
     "sa_conv1_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "sa_conv1_fwd_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "sa_conv1_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "sa_convt1_fused_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sa_convt1_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -212,6 +213,8 @@ def dtype_id(dt: torch.dtype) -> int:
         return SA_F32
     if dt == torch.bfloat16:
         return SA_BF16
+    if dt == torch.float16:
+        return SA_F16      # forward operand / activation type of an f16 forward chain only
     raise TypeError(f"unsupported dtype {dt}")
 
 

@@ -28,8 +28,8 @@ def _sources():
 def _digest(path):
     h = hashlib.sha1()
     hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
-    if not path.endswith(("conv_fprop.hip", "dense_ring.hip")):
-        hdrs = [h for h in hdrs if not h.endswith("conv_fprop_common.h")]     # only its two includers depend on it
+    if not path.endswith(("conv_fprop.hip", "conv_fprop_f16.hip")):
+        hdrs = [h for h in hdrs if not h.endswith(("conv_fprop_common.h", "conv_fprop_kernels.h"))]     # only the two forward translation units depend on them
     if not path.endswith(("local_attn.hip", "favor_fused.hip")):
         hdrs = [h for h in hdrs if not h.endswith("local_attn_split.h")]
     for dep in [path, *hdrs, os.path.join(HERE, "..", "include", "synthanatomy_hip.h")]:

@@ -23,6 +23,7 @@ struct C1Args {
     int32_t act;
     const bf16_t* mask;    // forward, optional [cells][128]: outputs are zeroed where mask <= 0 (the ReLU mask of a data gradient)
     float* sum_out;        // forward, optional: += sum of the whole volume x (every voxel is the centre tap of exactly one cell)
+    bf16_t* y_lp;          // f16 forward (conv1_fwd_f16_kernel), optional: a bf16 copy of y for the backward pass
     uint32_t cells;        // N*D*H*W
     FastDiv dW_, dH_, dD_;
 };
@@ -32,7 +33,7 @@ typedef float float4u_t __attribute__((ext_vector_type(4), aligned(4)));   // 16
 // taps (kd, kh, kw = 0..3) of NCELL consecutive cells starting at cell0 -> tile[cell][64] bf16; cells >= a.cells give zero rows.
 // Lanes run along the cells (thread = one cell, 256 / NCELL threads share its 16 (kd, kh) rows): consecutive lanes read overlapping 16-byte
 // windows 8 bytes apart of the same input row, i.e. a wave reads one contiguous 0.5 KiB stretch per (kd, kh).
-template <int NCELL>
+template <int NCELL, bool F16 = false>
 __device__ __forceinline__ void c1_gather(unsigned char* tile, const C1Args& a, uint32_t cell0, int tid, float* centre_sum = nullptr) {
     constexpr int PARTS = 256 / NCELL, PER = 16 / PARTS;
     const uint32_t cl = (uint32_t)tid % NCELL, part = (uint32_t)tid / NCELL;
@@ -68,15 +69,16 @@ __device__ __forceinline__ void c1_gather(unsigned char* tile, const C1Args& a, 
         // every input voxel is covered exactly once by the taps {1,2}^3 of its cell
         if (centre_sum && ok && (kd == 1u || kd == 2u) && (kh == 1u || kh == 2u)) *centre_sum += v[1] + v[2];
         uint2 pk;
-        pk.x = ok ? pack_bf16x2(v[0], v[1]) : 0u;
-        pk.y = ok ? pack_bf16x2(v[2], v[3]) : 0u;
+        pk.x = ok ? (F16 ? pack2<f16_t>(v[0], v[1]) : pack_bf16x2(v[0], v[1])) : 0u;
+        pk.y = ok ? (F16 ? pack2<f16_t>(v[2], v[3]) : pack_bf16x2(v[2], v[3])) : 0u;
         *(uint2*)(tile + lroff(cl, kk * 4u)) = pk;
     }
 }
 
 // forward: block = 256 consecutive cells, wave = 64 of them (four MFMA column sets); D[i = channel][j = cell]
-__global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const C1Args a) {
-    __shared__ __attribute__((aligned(16))) unsigned char sX[256 * 128];
+// F16: taps, weights and the output are IEEE halves (the forward operand type of an f16 encoder chain), + an optional bf16 copy of the output
+template <bool F16>
+__device__ __forceinline__ void conv1_fwd_body(const C1Args& a, unsigned char* sX) {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g = lane >> 4;
     const uint32_t cell0 = blockIdx.x * 256u;   // (a persistent variant that fetches the weight operands once per block measured 7 % slower)
     short8_t wf[8][2];   // W[co = f*16 + fr][taps ks*32 + g*8 .. +7]
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const C1Args a) {
 #pragma unroll
     for (int f = 0; f < 8; ++f) bv[f] = a.bias ? *(const float4_t*)(a.bias + f * 16 + g * 4) : (float4_t){0.f, 0.f, 0.f, 0.f};
     float csum = 0.f;
-    c1_gather<256>(sX, a, cell0, tid, a.sum_out ? &csum : nullptr);
+    c1_gather<256, F16>(sX, a, cell0, tid, a.sum_out ? &csum : nullptr);
     if (a.sum_out) {   // block-uniform
         __shared__ float red[4];
         csum = wave_sum(csum);
@@ -108,7 +110,10 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const C1Args a) {
         for (int f = 0; f < 8; ++f) {
             acc[f] = bv[f];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f][ks], xb[ks], acc[f], 0, 0, 0);
+            for (int ks = 0; ks < 2; ++ks) {
+                if constexpr (F16) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8_t*)&wf[f][ks], *(const half8_t*)&xb[ks], acc[f], 0, 0, 0);
+                else acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f][ks], xb[ks], acc[f], 0, 0, 0);
+            }
         }
         const uint32_t cell = cell0 + cl;
 #pragma unroll
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const C1Args a) {
                 v[r] = t0; v[4 + r] = t1; v[8 + r] = t2; v[12 + r] = t3;
             }
             if (cell < a.cells) {
-                uint32_t pk[8];
+                uint32_t pk[8], pl[8];
                 u32x4 mk[2] = {(u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}};
                 if (a.mask) {
                     const u32x4* mp = (const u32x4*)(a.mask + (int64_t)cell * 128 + half * 64 + g * 16);
@@ -135,14 +140,30 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const C1Args a) {
                     const uint32_t mw = mk[e >> 2][e & 3];
                     x0 = __uint_as_float(mw << 16) > 0.f ? x0 : 0.f;
                     x1 = __uint_as_float(mw & 0xffff0000u) > 0.f ? x1 : 0.f;
-                    pk[e] = pack_bf16x2(x0, x1);
+                    pk[e] = F16 ? pack2<f16_t>(x0, x1) : pack_bf16x2(x0, x1);
+                    if constexpr (F16) pl[e] = pack_bf16x2(x0, x1);
                 }
                 u32x4* o = (u32x4*)(a.y + (int64_t)cell * 128 + half * 64 + g * 16);
                 o[0] = (u32x4){pk[0], pk[1], pk[2], pk[3]};
                 o[1] = (u32x4){pk[4], pk[5], pk[6], pk[7]};
+                if constexpr (F16) {
+                    if (a.y_lp) {
+                        u32x4* ol = (u32x4*)(a.y_lp + (int64_t)cell * 128 + half * 64 + g * 16);
+                        ol[0] = (u32x4){pl[0], pl[1], pl[2], pl[3]};
+                        ol[1] = (u32x4){pl[4], pl[5], pl[6], pl[7]};
+                    }
+                }
             }
         }
     }
+}
+__global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const C1Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char sX[256 * 128];
+    conv1_fwd_body<false>(a, sX);
+}
+__global__ __launch_bounds__(256, 3) void conv1_fwd_f16_kernel(const C1Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char sX[256 * 128];
+    conv1_fwd_body<true>(a, sX);
 }
 
 // gradient tile [128 cells][128 channels] bf16, 256-byte rows; 32-byte chunks XOR-swizzled with the row for the transposing reads
@@ -288,6 +309,19 @@ extern "C" int sa_conv1_fwd(const float* x, const void* wpk, const float* bias, 
     if (rc) return rc;
     a.x = x; a.wpk = (const bf16_t*)wpk; a.bias = bias; a.y = (bf16_t*)y; a.act = act;
     SA_LAUNCH(conv1_fwd_kernel, dim3((a.cells + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+// the same with f16 operands and output (wpk = the weight packed as SA_F16), + an optional bf16 copy y_lp of the output for the backward pass
+extern "C" int sa_conv1_fwd_f16(const float* x, const void* wpk, const float* bias, void* y, void* y_lp, int N, int D, int H, int W, int cout, int act, void* stream) {
+    if (!x || !wpk || !y) return SA_EINVAL;
+    if (act != SA_ACT_NONE && act != SA_ACT_RELU) return SA_EUNSUPPORTED;
+    C1Args a = {};
+    const int rc = c1_fill(a, N, D, H, W, cout);
+    if (rc) return rc;
+    a.x = x; a.wpk = (const bf16_t*)wpk; a.bias = bias; a.y = (bf16_t*)y; a.y_lp = (bf16_t*)y_lp; a.act = act;
+    SA_LAUNCH(conv1_fwd_f16_kernel, dim3((a.cells + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();
     return 0;
 }

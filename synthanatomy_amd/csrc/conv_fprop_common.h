@@ -1,4 +1,4 @@
-// Shared by the implicit-GEMM forward / data-gradient translation units (conv_fprop.hip, dense_ring.hip): the launch arguments, the MFMA slab product,
+// Shared by the implicit-GEMM forward / data-gradient translation units (conv_fprop.hip, conv_fprop_f16.hip): the launch arguments, the MFMA slab product,
 // the swizzled tile addressing and the epilogues (LDS-staged and register forms).  Everything here is a template or __device__ __forceinline__.
 #pragma once
 #include <stdlib.h>
@@ -43,6 +43,10 @@ __device__ __forceinline__ void mma_slab(float4_t& acc, const u32x4& wa, const u
 template <>
 __device__ __forceinline__ void mma_slab<bf16_t>(float4_t& acc, const u32x4& wa, const u32x4& xb) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const short8_t*)&wa, *(const short8_t*)&xb, acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_slab<f16_t>(float4_t& acc, const u32x4& wa, const u32x4& xb) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8_t*)&wa, *(const half8_t*)&xb, acc, 0, 0, 0);
 }
 template <>
 __device__ __forceinline__ void mma_slab<float>(float4_t& acc, const u32x4& wa, const u32x4& xb) {
@@ -128,8 +132,8 @@ __device__ __forceinline__ void fprop_epilogue_ov(const FpropArgs& a, float4_t (
                         ad[0] = t4[0]; ad[1] = t4[1]; ad[2] = t4[2]; ad[3] = t4[3];
                     } else {
                         const uint2 t2 = *(const uint2*)((const bf16_t*)ep.addend + o);
-                        ad[0] = __uint_as_float(t2.x << 16); ad[1] = __uint_as_float(t2.x & 0xffff0000u);
-                        ad[2] = __uint_as_float(t2.y << 16); ad[3] = __uint_as_float(t2.y & 0xffff0000u);
+                        unpack2_dt(ep.add_dtype, t2.x, ad[0], ad[1]);
+                        unpack2_dt(ep.add_dtype, t2.y, ad[2], ad[3]);
                     }
                 }
                 if (ep.mask_mode != SA_MASK_NONE) {
@@ -169,8 +173,8 @@ __device__ __forceinline__ void fprop_epilogue_ov(const FpropArgs& a, float4_t (
                     *(float4_t*)((float*)a.out + o) = (float4_t){v[0], v[1], v[2], v[3]};
                 } else {
                     uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    pk.x = pack2_dt(ep.out_dtype, v[0], v[1]);
+                    pk.y = pack2_dt(ep.out_dtype, v[2], v[3]);
                     *(uint2*)((bf16_t*)a.out + o) = pk;
                 }
                 if (ep.out_lp) {        // bf16 copy of the final value
@@ -225,13 +229,21 @@ constexpr int epi_batch_size() {
     return regs * 4 <= BUDGET ? 4 : regs * 2 <= BUDGET ? 2 : 1;
 }
 
-template <int W>
+template <int W, bool F16 = false>
 __device__ __forceinline__ void epi_unpack16(const u32x4 (&p)[W], float (&v)[16]) {
     if constexpr (W == 4) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[4 * k + e] = __uint_as_float(p[k][e]);
+    } else if constexpr (F16) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[8 * k + 2 * e] = f16_to_f32((unsigned short)(p[k][e] & 0xffffu));
+                v[8 * k + 2 * e + 1] = f16_to_f32((unsigned short)(p[k][e] >> 16));
+            }
     } else {
 #pragma unroll
         for (int k = 0; k < 2; ++k)
@@ -244,7 +256,9 @@ __device__ __forceinline__ void epi_unpack16(const u32x4 (&p)[W], float (&v)[16]
 }
 
 // one batch: row groups JB .. JB + EPI_BATCH - 1 (compile-time indices: a run-time index would demote the accumulators to scratch memory)
-template <int MI, int NI, int JB, bool ADD, bool MASK, bool ADD32, bool MASK32, int BUDGET, typename RowOv>
+// F16IO (the kernels of an f16 forward chain): 16-bit addends and outputs are IEEE halves, and the launch may ask for a bf16 copy of its output
+// (sa_epilogue.out_lp); compile-time, because the eight-wave bf16 kernels sit exactly at the 128-VGPR line and must not carry the extra paths
+template <int MI, int NI, int JB, bool ADD, bool MASK, bool ADD32, bool MASK32, int BUDGET, bool F16IO, typename RowOv>
 __device__ __forceinline__ void epi_batch(const FpropArgs& a, float4_t (&acc)[NI][MI], uint32_t wm, uint32_t frow, uint32_t c0, RowOv row_ov, float alpha) {
     const sa_conv_geom& g = a.g;
     const sa_epilogue& ep = a.ep;
@@ -283,8 +297,8 @@ __device__ __forceinline__ void epi_batch(const FpropArgs& a, float4_t (&acc)[NI
             v[r] = t0; v[4 + r] = t1; v[8 + r] = t2; v[12 + r] = t3;
         }
         float ad[16], mk[16];
-        if constexpr (ADD) epi_unpack16<AW>(adp[jj], ad);
-        if constexpr (MASK) epi_unpack16<MW>(mkp[jj], mk);
+        if constexpr (ADD) epi_unpack16<AW, F16IO>(adp[jj], ad);
+        if constexpr (MASK) epi_unpack16<MW>(mkp[jj], mk);      // (16-bit masks are bf16: data gradients only)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             float x = v[e];
@@ -305,12 +319,26 @@ __device__ __forceinline__ void epi_batch(const FpropArgs& a, float4_t (&acc)[NI
             if (ep.out_dtype == SA_F32) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) *(float4_t*)((float*)a.out + o[jj] + 4 * k) = (float4_t){v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+            } else if constexpr (F16IO) {
+                // the f16 value for the next forward launch and (training) its bf16 copy for the backward pass, packed pair by pair so that the fp32
+                // values die as they are consumed
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    u32x4 pk, pl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pk[e] = pack2<f16_t>(v[8 * k + 2 * e], v[8 * k + 2 * e + 1]);
+                        pl[e] = pack2<bf16_t>(v[8 * k + 2 * e], v[8 * k + 2 * e + 1]);
+                    }
+                    *(u32x4*)((bf16_t*)a.out + o[jj] + 8 * k) = pk;
+                    if (ep.out_lp) *(u32x4*)((bf16_t*)ep.out_lp + o[jj] + 8 * k) = pl;
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     u32x4 pk;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = (uint32_t)f32_to_bf16(v[8 * k + 2 * e]) | ((uint32_t)f32_to_bf16(v[8 * k + 2 * e + 1]) << 16);
+                    for (int e = 0; e < 4; ++e) pk[e] = pack2<bf16_t>(v[8 * k + 2 * e], v[8 * k + 2 * e + 1]);
                     *(u32x4*)((bf16_t*)a.out + o[jj] + 8 * k) = pk;
                 }
             }
@@ -331,20 +359,20 @@ __device__ __forceinline__ void epi_add_bias(const FpropArgs& a, float4_t (&acc)
 }
 
 // all batches of one (ADD, MASK, widths) specialisation
-template <int MI, int NI, int JB, bool ADD, bool MASK, bool ADD32, bool MASK32, int BUDGET, typename RowOv>
+template <int MI, int NI, int JB, bool ADD, bool MASK, bool ADD32, bool MASK32, int BUDGET, bool F16IO, typename RowOv>
 __device__ __forceinline__ void epi_run_from(const FpropArgs& a, float4_t (&acc)[NI][MI], uint32_t wm, uint32_t frow, uint32_t c0, RowOv row_ov, float alpha) {
     if constexpr (JB < MI) {
-        epi_batch<MI, NI, JB, ADD, MASK, ADD32, MASK32, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
-        epi_run_from<MI, NI, JB + epi_batch_size<ADD, MASK, ADD32, MASK32, BUDGET>(), ADD, MASK, ADD32, MASK32, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+        epi_batch<MI, NI, JB, ADD, MASK, ADD32, MASK32, BUDGET, F16IO>(a, acc, wm, frow, c0, row_ov, alpha);
+        epi_run_from<MI, NI, JB + epi_batch_size<ADD, MASK, ADD32, MASK32, BUDGET>(), ADD, MASK, ADD32, MASK32, BUDGET, F16IO>(a, acc, wm, frow, c0, row_ov, alpha);
     }
 }
-template <int MI, int NI, bool ADD, bool MASK, bool ADD32, bool MASK32, int BUDGET, typename RowOv>
+template <int MI, int NI, bool ADD, bool MASK, bool ADD32, bool MASK32, int BUDGET, bool F16IO, typename RowOv>
 __device__ __forceinline__ void epi_run(const FpropArgs& a, float4_t (&acc)[NI][MI], uint32_t wm, uint32_t frow, uint32_t c0, RowOv row_ov, float alpha) {
     static_assert(MI % 4 == 0, "row groups per wave must be a multiple of the largest batch");
-    epi_run_from<MI, NI, 0, ADD, MASK, ADD32, MASK32, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+    epi_run_from<MI, NI, 0, ADD, MASK, ADD32, MASK32, BUDGET, F16IO>(a, acc, wm, frow, c0, row_ov, alpha);
 }
 
-template <int MI, int NI, int BUDGET = 64, typename RowOv>
+template <int MI, int NI, int BUDGET = 64, bool F16IO = false, typename RowOv>
 __device__ __forceinline__ void fprop_epilogue_regs(const FpropArgs& a, float4_t (&acc)[NI][MI], uint32_t wm, uint32_t wn, uint32_t frow, uint32_t fq,
                                                     uint32_t n_base, RowOv row_ov, bool bias_done = false) {
     static_assert(NI == 4, "4 column fragments per wave");
@@ -355,18 +383,18 @@ __device__ __forceinline__ void fprop_epilogue_regs(const FpropArgs& a, float4_t
     const bool add = ep.addend != nullptr, mask = ep.mask_mode != SA_MASK_NONE;
     const bool a32 = ep.add_dtype == SA_F32, m32 = ep.mask_dtype == SA_F32;
     // block-uniform dispatch to a straight-line specialisation (loads of a batch back to back)
-    if (!add && !mask) epi_run<MI, NI, false, false, false, false, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+    if (!add && !mask) epi_run<MI, NI, false, false, false, false, BUDGET, F16IO>(a, acc, wm, frow, c0, row_ov, alpha);
     else if (add && !mask) {
-        if (a32) epi_run<MI, NI, true, false, true, false, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
-        else epi_run<MI, NI, true, false, false, false, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+        if (a32) epi_run<MI, NI, true, false, true, false, BUDGET, F16IO>(a, acc, wm, frow, c0, row_ov, alpha);
+        else epi_run<MI, NI, true, false, false, false, BUDGET, F16IO>(a, acc, wm, frow, c0, row_ov, alpha);
     } else if (!add && mask) {
-        if (m32) epi_run<MI, NI, false, true, false, true, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
-        else epi_run<MI, NI, false, true, false, false, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+        if (m32) epi_run<MI, NI, false, true, false, true, BUDGET, F16IO>(a, acc, wm, frow, c0, row_ov, alpha);
+        else epi_run<MI, NI, false, true, false, false, BUDGET, F16IO>(a, acc, wm, frow, c0, row_ov, alpha);
     } else {
-        if (a32 && m32) epi_run<MI, NI, true, true, true, true, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
-        else if (!a32 && !m32) epi_run<MI, NI, true, true, false, false, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
-        else if (a32) epi_run<MI, NI, true, true, true, false, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
-        else epi_run<MI, NI, true, true, false, true, BUDGET>(a, acc, wm, frow, c0, row_ov, alpha);
+        if (a32 && m32) epi_run<MI, NI, true, true, true, true, BUDGET, F16IO>(a, acc, wm, frow, c0, row_ov, alpha);
+        else if (!a32 && !m32) epi_run<MI, NI, true, true, false, false, BUDGET, F16IO>(a, acc, wm, frow, c0, row_ov, alpha);
+        else if (a32) epi_run<MI, NI, true, true, true, false, BUDGET, F16IO>(a, acc, wm, frow, c0, row_ov, alpha);
+        else epi_run<MI, NI, true, true, false, true, BUDGET, F16IO>(a, acc, wm, frow, c0, row_ov, alpha);
     }
 }
 
@@ -381,8 +409,5 @@ __device__ __forceinline__ void fprop_epilogue(const FpropArgs& a, float4_t (&ac
 
 // 32-bit buffer offset that is out of bounds for every operand: LDS-DMA loads from it deliver zeros (padding taps, rows beyond M)
 constexpr uint32_t OOB_OFF = 0xfffffff0u;
-
-// dense (1x1x1) layers with few, wide tiles: three-stage LDS-DMA ring on 128 x 256 tiles (dense_ring.hip); SA_EUNSUPPORTED when the shape does not qualify
-int launch_dense_ring(const FpropArgs& a, hipStream_t st);
 
 }  // namespace sa

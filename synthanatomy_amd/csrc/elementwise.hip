@@ -38,7 +38,6 @@ static uint32_t flags_from_env() {
     if (on("SA_HALO256_4W")) f |= SA_DBG_HALO256_4W;
     if (on("SA_DENSE_NARROW")) f |= SA_DBG_DENSE_NARROW;
     if (on("SA_DETERMINISTIC")) f |= SA_DBG_DETERMINISTIC;
-    if (on("SA_DENSE_RING")) f |= SA_DBG_DENSE_RING;
     if (on("SA_SCAN_VALU")) f |= SA_DBG_SCAN_VALU;
     if (num("SA_LOCAL_ATTN_EXACT", 0) == 1) f |= SA_DBG_LOCAL_ATTN_EXACT;
     f |= ((uint32_t)num("SA_SCAN_EXACT", 0) & 7u) << SA_DBG_SCAN_EXACT_SHIFT;
@@ -128,9 +127,7 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const sa_pack_d
                     const float x0 = tile[rl][q4], x1 = tile[rl][q4 + 1], x2 = tile[rl][q4 + 2], x3 = tile[rl][q4 + 3];
                     const int64_t e = (int64_t)r * a.Kpad + k;
                     if (a.dtype == SA_F32) *reinterpret_cast<float4*>((float*)a.wpk + e) = make_float4(x0, x1, x2, x3);
-                    else
-                        *reinterpret_cast<uint2*>((bf16_t*)a.wpk + e) =
-                            make_uint2((uint32_t)f32_to_bf16(x0) | ((uint32_t)f32_to_bf16(x1) << 16), (uint32_t)f32_to_bf16(x2) | ((uint32_t)f32_to_bf16(x3) << 16));
+                    else *reinterpret_cast<uint2*>((bf16_t*)a.wpk + e) = make_uint2(pack2_dt(a.dtype, x0, x1), pack2_dt(a.dtype, x2, x3));
                 }
             }
         }
@@ -330,7 +327,7 @@ extern "C" int sa_pack_weights(const float* w, void* wpk, int dtype, int rows, i
     if (!w || !wpk || rows <= 0 || red <= 0 || ntaps <= 0 || ntaps > SA_MAX_TAPS || rows_pad < rows || red_stride < red ||
         Kpad < ntaps * red_stride)
         return SA_EINVAL;
-    if (dtype != SA_F32 && dtype != SA_BF16) return SA_EUNSUPPORTED;
+    if (dtype != SA_F32 && dtype != SA_BF16 && dtype != SA_F16) return SA_EUNSUPPORTED;
     PackArgs a;
     a.w = w;
     a.wpk = wpk;

@@ -10,6 +10,10 @@
 namespace sa {
 
 typedef unsigned short bf16_t;  // raw storage
+// IEEE half, raw storage.  A distinct type (not a typedef of unsigned short) so that kernel templates select the f16 MFMA and the f16 conversions
+// by overload; only the FORWARD operand type of a chain (the reference's AMP dtype, src/engines/trainer.py:161-163): gradients stay bf16.
+struct f16_t { unsigned short v; };
+typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
 typedef __attribute__((ext_vector_type(8))) short short8_t;
 typedef __attribute__((ext_vector_type(4))) float float4_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -48,6 +52,7 @@ inline void note_kernel(const char* name) {
         hipLaunchKernelGGL(kern, __VA_ARGS__);   \
     } while (0)
 template <typename T> inline const char* tname() { return sizeof(T) == 4 ? "float" : "unsigned short"; }
+template <> inline const char* tname<f16_t>() { return "f16_t"; }
 
 #define SA_CHECK_LAUNCH()                         \
     do {                                          \
@@ -67,6 +72,30 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return (bf16_t)(u >> 16);
 }
 
+// round-to-nearest-even; finite values beyond the half range saturate to +-65504 instead of becoming infinities (the un-normalised residual stream)
+__device__ __forceinline__ unsigned short f32_to_f16(float f) {
+    const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f);
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float f16_to_f32(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }
+// two values -> one packed 32-bit word of 16-bit storage type T (bf16_t / f16_t)
+template <typename T> __device__ __forceinline__ uint32_t pack2(float a, float b);
+// (gfx950 v_cvt_pk_bf16_f32: one VALU op, round to nearest even like f32_to_bf16(), which costs ~6 per value)
+typedef __attribute__((ext_vector_type(2))) float sa_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 sa_bf16x2_t;
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float a, float b) {
+    const sa_f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sa_bf16x2_t));
+}
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float a, float b) { return (uint32_t)f32_to_f16(a) | ((uint32_t)f32_to_f16(b) << 16); }
+// the same by run-time dtype (SA_BF16 / SA_F16)
+__device__ __forceinline__ uint32_t pack2_dt(int dtype, float a, float b) { return dtype == SA_F16 ? pack2<f16_t>(a, b) : pack2<bf16_t>(a, b); }
+// packed word -> two floats
+__device__ __forceinline__ void unpack2_dt(int dtype, uint32_t w, float& a, float& b) {
+    if (dtype == SA_F16) { a = f16_to_f32((unsigned short)(w & 0xffffu)); b = f16_to_f32((unsigned short)(w >> 16)); }
+    else { a = __uint_as_float(w << 16); b = __uint_as_float(w & 0xffff0000u); }
+}
+
 template <typename T> struct DT;
 template <> struct DT<float> {
     static constexpr int id = SA_F32;
@@ -81,11 +110,19 @@ template <> struct DT<bf16_t> {
     __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
+template <> struct DT<f16_t> {
+    static constexpr int id = SA_F16;
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float ld(const f16_t* p) { return f16_to_f32(p->v); }
+    __device__ static __forceinline__ void st(f16_t* p, float v) { p->v = f32_to_f16(v); }
+};
+
 __device__ __forceinline__ float load_as_f32(const void* base, int dtype, int64_t off) {
-    return dtype == SA_F32 ? ((const float*)base)[off] : bf16_to_f32(((const bf16_t*)base)[off]);
+    return dtype == SA_F32 ? ((const float*)base)[off] : dtype == SA_F16 ? f16_to_f32(((const unsigned short*)base)[off]) : bf16_to_f32(((const bf16_t*)base)[off]);
 }
 __device__ __forceinline__ void store_from_f32(void* base, int dtype, int64_t off, float v) {
     if (dtype == SA_F32) ((float*)base)[off] = v;
+    else if (dtype == SA_F16) ((unsigned short*)base)[off] = f32_to_f16(v);
     else ((bf16_t*)base)[off] = f32_to_bf16(v);
 }
 

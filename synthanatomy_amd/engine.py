@@ -119,9 +119,11 @@ class ConvOp:
     """kind="conv": weight [Cout, Cin, k,k,k];  kind="convT": weight [Cin, Cout, k,k,k] (k4 s2 p1 only)."""
 
     def __init__(self, kind: str, cin: int, cout: int, k: int, stride: int, pad: int, weight: torch.Tensor, bias: Optional[torch.Tensor],
-                 dtype: torch.dtype, w_strides: Optional[Tuple[int, int]] = None):
+                 dtype: torch.dtype, w_strides: Optional[Tuple[int, int]] = None, fwd_dtype: Optional[torch.dtype] = None):
         """`w_strides` = (stride of cout, stride of cin) in elements of `weight` for a 1x1x1 "conv" whose weight is stored transposed
-        (the 64 taps of the final ConvTranspose3d as output channels): forward and wgrad only."""
+        (the 64 taps of the final ConvTranspose3d as output channels): forward and wgrad only.
+        `fwd_dtype` (torch.float16 with dtype = torch.bfloat16): the FORWARD launches take f16 activations and an f16-packed operand and write f16
+        (+ a bf16 copy on request, `want_lp`); data and weight gradients stay in `dtype` -- the reference's AMP forward (src/engines/trainer.py:161-163)."""
         assert kind in ("conv", "convT")
         assert w_strides is None or (kind == "conv" and k == 1)
         self.w_strides = w_strides
@@ -130,6 +132,8 @@ class ConvOp:
         self.kind, self.cin, self.cout, self.k, self.stride, self.pad = kind, cin, cout, k, stride, pad
         self.weight, self.bias = weight, bias
         self.dtype = dtype
+        self.fwd_dtype = fwd_dtype or dtype
+        assert self.fwd_dtype == dtype or (self.fwd_dtype == torch.float16 and dtype == torch.bfloat16), (self.fwd_dtype, dtype)
         self.vec = vec_of(dtype)
         self.T = k ** 3
         self._plans = {}
@@ -193,19 +197,20 @@ class ConvOp:
         return plans
 
     # ------------------------------------------------------------------ weight packing
-    def _pack(self, plan: _Plan, ver):
+    def _pack(self, plan: _Plan, ver, dtype=None):
         # packed operands are shared by every launch geometry that needs the same layout (e.g. a Linear applied to
-        # sequences of different lengths), keyed by the pack description
+        # sequences of different lengths), keyed by the pack description (the operand type last: PackSet reads it from there)
         g = plan.geom
-        key = (plan.rows, plan.red, plan.ntaps, tuple(plan.lut) if plan.lut is not None else None, plan.s_row, plan.s_red, g.CoutPad, g.Cin, g.Kpad)
+        dtype = dtype or self.dtype
+        key = (plan.rows, plan.red, plan.ntaps, tuple(plan.lut) if plan.lut is not None else None, plan.s_row, plan.s_red, g.CoutPad, g.Cin, g.Kpad, dtype)
         ent = self._packs.get(key)
         if ent is None or ent[0].device != self.weight.device:
-            ent = [torch.empty(g.CoutPad * g.Kpad, dtype=self.dtype, device=self.weight.device), None]
+            ent = [torch.empty(g.CoutPad * g.Kpad, dtype=dtype, device=self.weight.device), None]
             self._packs[key] = ent
         plan.wpk = ent[0]
         if ent[1] == ver:
             return
-        _ffi.check(_ffi.lib().sa_pack_weights(_ffi.ptr(self.weight), _ffi.ptr(plan.wpk), _ffi.dtype_id(self.dtype), plan.rows, plan.red,
+        _ffi.check(_ffi.lib().sa_pack_weights(_ffi.ptr(self.weight), _ffi.ptr(plan.wpk), _ffi.dtype_id(dtype), plan.rows, plan.red,
                                               plan.ntaps, plan.lut_c, plan.s_row, plan.s_red, g.CoutPad, g.Cin, g.Kpad, _ffi.stream()),
                    "sa_pack_weights")
         ent[1] = ver
@@ -217,16 +222,16 @@ class ConvOp:
     def _pack_version(self):
         return (self.weight._version, self.weight.data_ptr(), self._epoch)
 
-    def _ensure_packed(self, plans: Sequence[_Plan]):
+    def _ensure_packed(self, plans: Sequence[_Plan], dtype=None):
         ver = self._pack_version()
         for pl in plans:
-            self._pack(pl, ver)
+            self._pack(pl, ver, dtype)
 
     def packed_fwd_operand(self, N: int, idims: Tuple[int, int, int]) -> torch.Tensor:
         """The forward GEMM operand [CoutPad][Kpad] (compute dtype) for this launch geometry, packed and current -- for kernels outside the
         generic launchers that consume the same layout (csrc/conv1.hip)."""
         plans = self._get_plans(N, idims, self.cout, _ru(self.cout, self.vec))
-        self._ensure_packed(plans["fwd"])
+        self._ensure_packed(plans["fwd"], self.fwd_dtype)
         return plans["fwd"][0].wpk
 
     def _bias_padded(self):
@@ -266,11 +271,11 @@ class ConvOp:
         """want_pre / want_lp (dense layers, bf16 extras of the same launch, sa_epilogue.out_pre / out_lp): returns (out, pre, lp) where pre = acc + bias
         before activation / alpha / addend and lp = a bf16 copy of out."""
         N, D, H, W, C = x.shape
-        assert x.dtype == self.dtype and x.is_contiguous() and C == self.cs_in(), (x.dtype, x.shape, self.cs_in())
-        out_dtype = out_dtype or self.dtype
+        assert x.dtype == self.fwd_dtype and x.is_contiguous() and C == self.cs_in(), (x.dtype, x.shape, self.cs_in())
+        out_dtype = out_dtype or self.fwd_dtype
         cout_s = out_channels_stride or self.cout
         plans = self._get_plans(N, (D, H, W), cout_s, _ru(self.cout, self.vec))
-        self._ensure_packed(plans["fwd"])
+        self._ensure_packed(plans["fwd"], self.fwd_dtype)
         od = plans["odims"]
         out = torch.empty((N, *od, cout_s), dtype=out_dtype, device=x.device)
         if cout_s != self.cout:
@@ -278,7 +283,7 @@ class ConvOp:
         pre = torch.empty((N, *od, cout_s), dtype=torch.bfloat16, device=x.device) if want_pre else None
         lp = torch.empty((N, *od, cout_s), dtype=torch.bfloat16, device=x.device) if want_lp else None
         ep = self._epilogue(self._bias_padded() if use_bias else None, addend, mask, alpha, act, mask_mode, add_before_act, out_dtype, slope, pre, lp)
-        lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
+        lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.fwd_dtype)
         for pl in plans["fwd"]:
             _launch(None, _geom_flops(pl.geom),
                     lambda pl=pl: _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(x), _ffi.ptr(pl.wpk), _ffi.ptr(out), ctypes.byref(ep), st),
@@ -359,11 +364,11 @@ class PackSet:
             table = (_ffi.PackDesc * len(items))()
             first = [0]
             for d, (op, key, ent) in zip(table, items):
-                rows, red, ntaps, lut, s_row, s_red, rows_pad, red_stride, kpad = key
+                rows, red, ntaps, lut, s_row, s_red, rows_pad, red_stride, kpad, pdt = key
                 d.w, d.wpk = op.weight.data_ptr(), ent[0].data_ptr()
                 for t in range(ntaps):
                     d.tap_lut[t] = lut[t] if lut is not None else t
-                d.s_row, d.s_red, d.dtype, d.rows, d.red, d.ntaps = s_row, s_red, _ffi.dtype_id(op.dtype), rows, red, ntaps
+                d.s_row, d.s_red, d.dtype, d.rows, d.red, d.ntaps = s_row, s_red, _ffi.dtype_id(pdt), rows, red, ntaps
                 d.rows_pad, d.red_stride, d.Kpad = rows_pad, red_stride, kpad
                 first.append(first[-1] + max(1, min(256, ((rows_pad + 63) // 64) * ((kpad + 63) // 64))))   # one block per 64 x 64 tile, capped
             dev = items[0][0].weight.device

@@ -15,7 +15,7 @@ masks and residual adds fused into the GEMM epilogues.
 from __future__ import annotations
 
 import os
-from typing import Dict, List, Sequence, Tuple, Union
+from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import torch
 import torch.distributed as dist
@@ -209,15 +209,29 @@ class ResidualLayer(nn.Sequential):
 
 
 # ------------------------------------------------------------------------------------------------ chain stages
+class _Act:
+    """An activation of an f16 FORWARD chain (the encoder in throughput mode): ``f`` (float16) feeds the next forward launch, ``s`` (bfloat16, written
+    by the same launch: ``sa_epilogue.out_lp``) is what the bf16 backward pass reads -- None when nothing is recorded (eval)."""
+    __slots__ = ("f", "s")
+
+    def __init__(self, f, s):
+        self.f, self.s = f, s
+
+
+def _fs(x):
+    return (x.f, x.s) if isinstance(x, _Act) else (x, x)
+
+
 class _ConvStage:
     """conv / convT (+ReLU).  ``in_act``: the stage's input is a post-ReLU tensor, so the data gradient it hands back is
     masked with (x > 0) in the dgrad epilogue."""
 
-    def __init__(self, mod: nn.Module, kind, act, in_act, dtype, out_f32=False, need_dx=True):
+    def __init__(self, mod: nn.Module, kind, act, in_act, dtype, out_f32=False, need_dx=True, fwd_dtype=None):
         k, s, p = mod.kernel_size[0], mod.stride[0], mod.padding[0]
         self.mod, self.act, self.in_act, self.out_f32, self.need_dx = mod, act, in_act, out_f32, need_dx
-        self.op = ConvOp(kind, mod.in_channels, mod.out_channels, k, s, p, mod.weight, mod.bias, dtype)
+        self.op = ConvOp(kind, mod.in_channels, mod.out_channels, k, s, p, mod.weight, mod.bias, dtype, fwd_dtype=fwd_dtype)
         self.dtype = dtype
+        self.mixed = self.op.fwd_dtype != dtype
 
     def params(self):
         return [self.mod.weight, self.mod.bias]
@@ -228,10 +242,15 @@ class _ConvStage:
     def fwd(self, x, tape):
         self._sync()
         cout = self.op.cout
-        y = self.op.fprop(x, act=self.act, out_dtype=torch.float32 if self.out_f32 else self.dtype, out_channels_stride=cout)
+        xf, xs = _fs(x)
         if tape is not None:
-            tape.append((x,))
-        return y
+            tape.append((xs,))
+        if self.mixed and not self.out_f32:
+            if tape is None:
+                return _Act(self.op.fprop(xf, act=self.act, out_channels_stride=cout), None)
+            y, _, ys = self.op.fprop(xf, act=self.act, out_channels_stride=cout, want_lp=True)
+            return _Act(y, ys)
+        return self.op.fprop(xf, act=self.act, out_dtype=torch.float32 if self.out_f32 else self.op.fwd_dtype, out_channels_stride=cout)
 
     def bwd(self, G, saved, grads, wgrad_only=False):
         (x,) = saved
@@ -258,10 +277,11 @@ class _Conv1Stage:
 
     GEMM_MIN_CELLS = 4096
 
-    def __init__(self, mod: nn.Conv3d, act, dtype):
+    def __init__(self, mod: nn.Conv3d, act, dtype, fwd_dtype=None):
         self.mod, self.act, self.dtype = mod, act, dtype
-        self.op = ConvOp("conv", 64, mod.out_channels, 1, 1, 0, mod.weight.view(mod.out_channels, 64, 1, 1, 1), mod.bias, dtype)
-        self.fallback = _ConvStage(mod, "conv", act, in_act=False, dtype=dtype, need_dx=False)
+        self.op = ConvOp("conv", 64, mod.out_channels, 1, 1, 0, mod.weight.view(mod.out_channels, 64, 1, 1, 1), mod.bias, dtype, fwd_dtype=fwd_dtype)
+        self.mixed = self.op.fwd_dtype != dtype
+        self.fallback = _ConvStage(mod, "conv", act, in_act=False, dtype=dtype, need_dx=False, fwd_dtype=fwd_dtype)
         self.fallback_op = self.fallback.op
 
     @staticmethod
@@ -278,22 +298,31 @@ class _Conv1Stage:
     def fwd(self, x, tape):
         """x: the raw fp32 volume [N, D, H, W]."""
         N, D, H, W = x.shape
-        if D % 2 or H % 2 or W % 2 or N * (D // 2) * (H // 2) * (W // 2) < self.GEMM_MIN_CELLS or debug.host("no_conv1_gemm"):   # generic stage
+        Do, Ho, Wo, cout = D // 2, H // 2, W // 2, self.op.cout
+        fused = (self.dtype == torch.bfloat16 and cout == 128 and not debug.host("no_conv1_fused") and not debug.deterministic())   # (its weight gradient ends in fp32 atomics)
+        if (D % 2 or H % 2 or W % 2 or N * Do * Ho * Wo < self.GEMM_MIN_CELLS or debug.host("no_conv1_gemm")   # generic stage
+                or (self.mixed and not fused)):      # (an f16 forward chain has the fused kernel and the generic stage, not the im2col route)
             vec = vec_of(self.dtype)
-            return self.fallback.fwd(cast_pad(x.unsqueeze(-1), self.dtype, vec), tape)
+            xc = cast_pad(x.unsqueeze(-1), self.op.fwd_dtype, vec)
+            return self.fallback.fwd(_Act(xc, cast_pad(x.unsqueeze(-1), self.dtype, vec) if tape is not None else None) if self.mixed else xc, tape)
         self._sync()
         lib, st = _ffi.lib(), _ffi.stream()
-        Do, Ho, Wo, cout = D // 2, H // 2, W // 2, self.op.cout
-        if self.dtype == torch.bfloat16 and cout == 128 and not debug.host("no_conv1_fused") and not debug.deterministic():   # (its weight gradient ends in fp32 atomics)
+        if fused:
             # csrc/conv1.hip: taps gathered into LDS straight from the volume; nothing but the output touches HBM
             wpk = self.op.packed_fwd_operand(N, (Do, Ho, Wo))
-            y = torch.empty((N, Do, Ho, Wo, cout), dtype=self.dtype, device=x.device)
-            _launch("conv1_fwd_kernel", 2.0 * y.numel() * 64,
-                    lambda: _ffi.check(lib.sa_conv1_fwd(_ffi.ptr(x), _ffi.ptr(wpk), _ffi.ptr(self.mod.bias), _ffi.ptr(y), N, Do, Ho, Wo, cout, self.act, st),
-                                       "sa_conv1_fwd"))
+            y = torch.empty((N, Do, Ho, Wo, cout), dtype=self.op.fwd_dtype, device=x.device)
+            if self.mixed:   # f16 taps / weights / output + the bf16 copy the first residual block's backward reads
+                ys = torch.empty((N, Do, Ho, Wo, cout), dtype=self.dtype, device=x.device) if tape is not None else None
+                _launch("conv1_fwd_f16_kernel", 2.0 * y.numel() * 64, nbytes=y.numel() * 2.0 * (2 if ys is not None else 1) + x.numel() * 4.0,
+                        fn=lambda: _ffi.check(lib.sa_conv1_fwd_f16(_ffi.ptr(x), _ffi.ptr(wpk), _ffi.ptr(self.mod.bias), _ffi.ptr(y), _ffi.ptr(ys), N, Do, Ho, Wo, cout,
+                                                                  self.act, st), "sa_conv1_fwd_f16"))
+            else:
+                _launch("conv1_fwd_kernel", 2.0 * y.numel() * 64, nbytes=y.numel() * 2.0 + x.numel() * 4.0,
+                        fn=lambda: _ffi.check(lib.sa_conv1_fwd(_ffi.ptr(x), _ffi.ptr(wpk), _ffi.ptr(self.mod.bias), _ffi.ptr(y), N, Do, Ho, Wo, cout, self.act, st),
+                                              "sa_conv1_fwd"))
             if tape is not None:
                 tape.append((x, "fused"))
-            return y
+            return _Act(y, ys) if self.mixed else y
         Xc = torch.empty((N, Do, Ho, Wo, 64), dtype=self.dtype, device=x.device)
         _ffi.check(lib.sa_convt1_im2col(_ffi.ptr(x), _ffi.dtype_id(self.dtype), _ffi.ptr(Xc), None, N, Do, Ho, Wo, st), "sa_convt1_im2col")
         y = self.op.fprop(Xc, act=self.act, out_dtype=self.dtype, out_channels_stride=cout)
@@ -356,8 +385,8 @@ class _ConvT1Stage:
             # one launch: the per-cell tap products stay in LDS (csrc/convt1.hip: convt1_fused_fwd_kernel)
             self._sync()
             wpk = self.taps_fwd.packed_fwd_operand(N, (D, H, W))      # [taps (padded to 128 rows)][128 channels] bf16
-            _launch("convt1_fused_fwd_kernel", 2.0 * x.numel() * 64,
-                    lambda: _ffi.check(lib.sa_convt1_fused_fwd(_ffi.ptr(x), _ffi.ptr(wpk), _ffi.ptr(self.mod.bias), _ffi.ptr(out), N, D, H, W, st), "sa_convt1_fused_fwd"))
+            _launch("convt1_fused_fwd_kernel", 2.0 * x.numel() * 64, nbytes=x.numel() * 2.0 + out.numel() * 4.0,   # algorithmic bytes: input once, output once
+                    fn=lambda: _ffi.check(lib.sa_convt1_fused_fwd(_ffi.ptr(x), _ffi.ptr(wpk), _ffi.ptr(self.mod.bias), _ffi.ptr(out), N, D, H, W, st), "sa_convt1_fused_fwd"))
         elif self._gemm(x):
             self._sync()
             P = self.taps_fwd.fprop(x, out_dtype=torch.float32, use_bias=False)          # [N, D, H, W, 64]
@@ -408,11 +437,12 @@ class _ConvT1Stage:
 
 
 class _ResStage:
-    def __init__(self, mod: ResidualLayer, in_act, dtype):
+    def __init__(self, mod: ResidualLayer, in_act, dtype, fwd_dtype=None):
         c3, c1 = mod[0], mod[3]
         self.c3m, self.c1m, self.in_act, self.dtype = c3, c1, in_act, dtype
-        self.c3 = ConvOp("conv", c3.in_channels, c3.out_channels, 3, 1, 1, c3.weight, c3.bias, dtype)
-        self.c1 = ConvOp("conv", c1.in_channels, c1.out_channels, 1, 1, 0, c1.weight, c1.bias, dtype)
+        self.c3 = ConvOp("conv", c3.in_channels, c3.out_channels, 3, 1, 1, c3.weight, c3.bias, dtype, fwd_dtype=fwd_dtype)
+        self.c1 = ConvOp("conv", c1.in_channels, c1.out_channels, 1, 1, 0, c1.weight, c1.bias, dtype, fwd_dtype=fwd_dtype)
+        self.mixed = self.c3.fwd_dtype != dtype
 
     def params(self):
         return [self.c3m.weight, self.c3m.bias, self.c1m.weight, self.c1m.bias]
@@ -431,29 +461,41 @@ class _ResStage:
         N, D, H, W, C = x.shape
         p3 = self.c3._get_plans(N, (D, H, W), 128, 128)
         p1 = self.c1._get_plans(N, (D, H, W), 128, 128)
-        self.c3._ensure_packed(p3["fwd"])
-        self.c1._ensure_packed(p1["fwd"])
+        fdt = self.c3.fwd_dtype      # == self.dtype, or float16 in an f16 forward chain (x, y f16; h and the copy of y for the backward pass bf16)
+        self.c3._ensure_packed(p3["fwd"], fdt)
+        self.c1._ensure_packed(p1["fwd"], fdt)
         y = torch.empty_like(x)
-        h = torch.empty_like(x) if need_h else None
-        ep = ConvOp._epilogue(self.c1._bias_padded(), x, None, None, ACT_RELU, 0, True, self.dtype, 0.2)
+        h = torch.empty(x.shape, dtype=self.dtype, device=x.device) if need_h else None
+        ys = torch.empty(x.shape, dtype=self.dtype, device=x.device) if (need_h and self.mixed) else None
+        ep = ConvOp._epilogue(self.c1._bias_padded(), x, None, None, ACT_RELU, 0, True, fdt, 0.2, None, ys)
         from ... import engine
         b1 = self.c3._bias_padded()
         st = _ffi.stream()
         engine._launch(None, engine._geom_flops(p3["fwd"][0].geom) + engine._geom_flops(p1["fwd"][0].geom),
-                       lambda: _ffi.check(_ffi.lib().sa_resblock_fprop(ctypes.byref(p3["fwd"][0].geom), _ffi.dtype_id(self.dtype), _ffi.ptr(x),
+                       lambda: _ffi.check(_ffi.lib().sa_resblock_fprop(ctypes.byref(p3["fwd"][0].geom), _ffi.dtype_id(fdt), _ffi.ptr(x),
                                                                        _ffi.ptr(p3["fwd"][0].wpk), _ffi.ptr(b1), _ffi.ptr(p1["fwd"][0].wpk), _ffi.ptr(h), _ffi.ptr(y),
                                                                        ctypes.byref(ep), st), "sa_resblock_fprop"))
-        return y, h
+        return (_Act(y, ys) if self.mixed else y), h
 
     def fwd(self, x, tape):
         self._sync()
-        if self._fused_ok(x):
-            y, h = self._fwd_fused(x, tape is not None)
+        xf, xs = _fs(x)
+        rec = tape is not None
+        if self._fused_ok(xf):
+            y, h = self._fwd_fused(xf, rec)
+        elif self.mixed:     # two launches; each writes its f16 output and, when recording, the bf16 copy the backward pass reads
+            if rec:
+                hf, _, h = self.c3.fprop(xf, act=ACT_RELU, want_lp=True)
+                yf, _, ys = self.c1.fprop(hf, act=ACT_RELU, addend=xf, add_before_act=True, want_lp=True)
+            else:
+                hf, h, ys = self.c3.fprop(xf, act=ACT_RELU), None, None
+                yf = self.c1.fprop(hf, act=ACT_RELU, addend=xf, add_before_act=True)
+            y = _Act(yf, ys)
         else:
-            h = self.c3.fprop(x, act=ACT_RELU)
-            y = self.c1.fprop(h, act=ACT_RELU, addend=x, add_before_act=True)
-        if tape is not None:
-            tape.append((x, h))
+            h = self.c3.fprop(xf, act=ACT_RELU)
+            y = self.c1.fprop(h, act=ACT_RELU, addend=xf, add_before_act=True)
+        if rec:
+            tape.append((xs, h))
         return y
 
     def bwd(self, G, saved, grads):
@@ -510,8 +552,9 @@ class _GradCtx:
 
 
 class _Chain:
-    def __init__(self, stages, dtype, in_channels):
+    def __init__(self, stages, dtype, in_channels, fwd_dtype=None):
         self.stages, self.dtype, self.in_channels = stages, dtype, in_channels
+        self.fwd_dtype = fwd_dtype or dtype     # float16 with dtype = bfloat16: the forward launches run on f16 operands (_Act)
         self.grad_sink = None
         self.last_tape = None
 
@@ -536,10 +579,16 @@ class _Chain:
             x = x_ncdhw.float().contiguous().view(x_ncdhw.shape[0], *x_ncdhw.shape[2:])   # the first stage reads the fp32 volume itself
         else:
             x = x_ncdhw.float().permute(0, 2, 3, 4, 1).contiguous()
-            x = cast_pad(x, self.dtype, (self.in_channels + vec - 1) // vec * vec)
+            cs = (self.in_channels + vec - 1) // vec * vec
+            if self.fwd_dtype != self.dtype:
+                x = _Act(cast_pad(x, self.fwd_dtype, cs), cast_pad(x, self.dtype, cs) if record else None)
+            else:
+                x = cast_pad(x, self.dtype, cs)
         tape = [] if record else None
         for s in self.stages:
             x = s.fwd(x, tape)
+        if isinstance(x, _Act):
+            x = x.f
         self.last_tape = tape     # for last_stage_wgrad (adaptive adversarial weight); dropped when the backward pass consumes the tape
         return x, tape
 
@@ -611,6 +660,7 @@ class BaselineVQVAE(VQVAEBase, nn.Module):
         vq_decay: float = 0.5,
         use_subpixel_conv: bool = False,
         compute_dtype: torch.dtype = torch.bfloat16,
+        encoder_forward_dtype: Optional[torch.dtype] = None,
     ):
         super().__init__()
         assert n_levels == len(downsample_parameters) and n_levels == len(upsample_parameters), (
@@ -632,6 +682,14 @@ class BaselineVQVAE(VQVAEBase, nn.Module):
         self.n_channels, self.n_res_channels, self.n_res_layers, self.p_dropout = n_channels, n_res_channels, n_res_layers, p_dropout
         self.commitment_cost, self.vq_decay = commitment_cost, vq_decay
         self.compute_dtype = compute_dtype
+        # Throughput mode (bf16 MFMA): the ENCODER's forward launches run on float16 activations and weights -- the reference's AMP dtype
+        # (src/engines/trainer.py:161-163; three more mantissa bits than bf16 at the same MFMA rate), so the code indices follow the fp32 path; every
+        # gradient, the decoder and the saved activations stay bf16.  SA_NO_F16_FORWARD=1 / encoder_forward_dtype=torch.bfloat16: bf16 forward too.
+        if encoder_forward_dtype is None:
+            encoder_forward_dtype = torch.float16 if (compute_dtype == torch.bfloat16 and not debug.host("no_f16_forward")) else compute_dtype
+        if encoder_forward_dtype != compute_dtype and not (encoder_forward_dtype == torch.float16 and compute_dtype == torch.bfloat16):
+            raise ValueError("encoder_forward_dtype: torch.float16 with compute_dtype=torch.bfloat16, or the compute dtype itself")
+        self.encoder_forward_dtype = encoder_forward_dtype
         if (n_channels // 2) % 8 or embed_dim % 8:
             raise NotImplementedError("channel counts must be multiples of 8 (16-byte channels-last vectors): n_channels//2 and embed_dim")
 
@@ -675,18 +733,18 @@ class BaselineVQVAE(VQVAEBase, nn.Module):
 
     # ---------------------------------------------------------------- launch chains over those parameters
     def _build_encoder_chain(self) -> _Chain:
-        dt = self.compute_dtype
+        dt, fdt = self.compute_dtype, self.encoder_forward_dtype
         mods = list(self.encoder[0])
         stages = []
         for lvl in range(self.n_levels):
             conv, res = mods[3 * lvl], mods[3 * lvl + 2]
             if lvl == 0 and _Conv1Stage.applicable(conv):
-                stages.append(_Conv1Stage(conv, ACT_RELU, dt))
+                stages.append(_Conv1Stage(conv, ACT_RELU, dt, fwd_dtype=fdt))
             else:
-                stages.append(_ConvStage(conv, "conv", ACT_RELU, in_act=lvl > 0, dtype=dt, need_dx=lvl > 0))
-            stages += [_ResStage(r, in_act=True, dtype=dt) for r in res]
-        stages.append(_ConvStage(mods[3 * self.n_levels], "conv", ACT_NONE, in_act=True, dtype=dt, out_f32=True))
-        return _Chain(stages, dt, in_channels=1)
+                stages.append(_ConvStage(conv, "conv", ACT_RELU, in_act=lvl > 0, dtype=dt, need_dx=lvl > 0, fwd_dtype=fdt))
+            stages += [_ResStage(r, in_act=True, dtype=dt, fwd_dtype=fdt) for r in res]
+        stages.append(_ConvStage(mods[3 * self.n_levels], "conv", ACT_NONE, in_act=True, dtype=dt, out_f32=True, fwd_dtype=fdt))
+        return _Chain(stages, dt, in_channels=1, fwd_dtype=fdt)
 
     def _build_decoder_chain(self) -> _Chain:
         dt = self.compute_dtype

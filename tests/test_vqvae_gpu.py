@@ -98,7 +98,8 @@ def test_against_oracle_fresh_inputs(dtype):
     x = torch.rand(3, 1, 24, 40, 16)
     rd = None if dtype == torch.float32 else torch.bfloat16
     with torch.no_grad():
-        ref = vqvae_ref.forward({k: v.clone() for k, v in st.items()}, cfg, x, training=False, round_dtype=rd)
+        ref = vqvae_ref.forward({k: v.clone() for k, v in st.items()}, cfg, x, training=False, round_dtype=rd,
+                                enc_round_dtype=torch.float16 if rd is not None else None)   # throughput mode: encoder forward on float16 operands
         z = net.encode(x.cuda())[0]
         idx = net.index_quantize(x.cuda())[0]
         rec = net.decode_samples([ref["indices"].cuda()])
@@ -144,7 +145,7 @@ def test_training_step_bf16_decreases_loss_and_matches_oracle_grads():
     leaf = {k: v.clone().requires_grad_(True) for k, v in st.items() if "quantizer" not in k}
     stt = {k: v.clone() for k, v in st.items()}
     stt.update(leaf)
-    ref = vqvae_ref.forward(stt, cfg, x, training=True, round_dtype=torch.bfloat16)
+    ref = vqvae_ref.forward(stt, cfg, x, training=True, round_dtype=torch.bfloat16, enc_round_dtype=torch.float16)
     vqvae_ref.mse_loss(ref, x).backward()
     out = net(x.cuda())
     loss = torch.nn.functional.mse_loss(out["reconstruction"][0], x.cuda()) + out["quantization_losses"][0]

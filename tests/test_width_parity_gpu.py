@@ -19,6 +19,11 @@ def _rel(got, ref):
     return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
 
 
+def _enc_rd(rd):
+    """storage rounding of the oracle's ENCODER half: the product's throughput mode (bf16 MFMA) runs the encoder forward on float16 operands"""
+    return torch.float16 if rd == torch.bfloat16 else rd
+
+
 def _fro(got, ref):
     got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
     return float((got - ref).norm() / (ref.norm() + 1e-30))
@@ -46,8 +51,8 @@ def _oracle_step(vqvae_ref, cfg, st, x, rd):
     stt = {k: v.clone() for k, v in st.items()}
     stt.update(leaf)
     with torch.no_grad():
-        ev = vqvae_ref.forward({k: v.clone() for k, v in st.items()}, cfg, x, training=False, round_dtype=rd)
-    ref = vqvae_ref.forward(stt, cfg, x, training=True, round_dtype=rd)
+        ev = vqvae_ref.forward({k: v.clone() for k, v in st.items()}, cfg, x, training=False, round_dtype=rd, enc_round_dtype=_enc_rd(rd))
+    ref = vqvae_ref.forward(stt, cfg, x, training=True, round_dtype=rd, enc_round_dtype=_enc_rd(rd))
     loss = vqvae_ref.mse_loss(ref, x)
     loss.backward()
     return ev, ref, float(loss), {k: v.grad for k, v in leaf.items()}, stt
@@ -107,11 +112,12 @@ def test_bf16_mode_runs_the_production_kernels_and_tracks_the_rounded_oracle(set
     ev, ref, ref_loss, ref_grads, _ = _oracle_step(vqvae_ref, cfg, st, x, torch.bfloat16)
     net = _product(st, torch.bfloat16)
     z, idx, rec, loss, grads, kernels = _product_step(net, x)
-    want = ["conv_fprop_halo256_kernel<unsigned short, true, 8>",   # fused residual block (forward)
+    want = ["conv_fprop_halo256_kernel<f16_t, true, 8>",            # fused residual block, encoder (f16 forward operands)
+            "conv_fprop_halo256_kernel<unsigned short, true, 8>",   # fused residual block, decoder
             "conv_fprop_halo256_kernel<unsigned short, false, 8>",  # its 3x3x3 data gradient
             "conv_wgrad_halo9_kernel",                              # nine-tap weight gradient
             "conv_wgrad_dma_kernel<unsigned short, true, 4>",       # fused 1x1x1 backward
-            "conv1_fwd_kernel", "conv1_wgrad_kernel"]               # one-channel first layer
+            "conv1_fwd_f16_kernel", "conv1_wgrad_kernel"]           # one-channel first layer
     for w in want:
         assert any(k.startswith(w) for k in kernels), (w, sorted(kernels))
     agree = float((idx == ev["indices"]).float().mean())
@@ -136,14 +142,14 @@ def test_decoder_and_encoder_halves_against_oracle_at_config2_widths(setup, dtyp
     vqvae_ref, cfg, st, x = setup
     rd = None if dtype == torch.float32 else torch.bfloat16
     with torch.no_grad():
-        ev = vqvae_ref.forward({k: v.clone() for k, v in st.items()}, cfg, x, training=False, round_dtype=rd)
+        ev = vqvae_ref.forward({k: v.clone() for k, v in st.items()}, cfg, x, training=False, round_dtype=rd, enc_round_dtype=_enc_rd(rd))
         zq = vqvae_ref.embed(st, ev["indices"])
     leaf = {k: v.clone().requires_grad_(True) for k, v in st.items() if "quantizer" not in k}
     stt = {k: v.clone() for k, v in st.items()}
     stt.update(leaf)
     rec_ref = vqvae_ref.decode(stt, cfg, zq, round_dtype=rd)
     torch.nn.functional.mse_loss(rec_ref, x).backward()
-    z_ref = vqvae_ref.encode(stt, cfg, x, round_dtype=rd)
+    z_ref = vqvae_ref.encode(stt, cfg, x, round_dtype=_enc_rd(rd))
     torch.nn.functional.mse_loss(z_ref, zq).backward()      # the commitment term's gradient (baseline.py:82) with the codes held fixed
     net = _product(st, dtype).train()
     rec = net.decode([zq.cuda()])

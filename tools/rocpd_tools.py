@@ -98,8 +98,11 @@ def traffic(fetch_db, write_db, out=None, provenance="", by_grid=False):
         rec[k] = {"launches": n, "fetch_size_kib": round(fs, 1), "write_size_kib": round(ws, 1), "hbm_bytes_per_launch": int(b)}
         print(f"{k[:84]:84s} {n:8d} {fs:15.1f} {ws:15.1f} {b / 1e9:14.3f}")
     if out:
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import csrc_digest      # the digest of the kernel sources the counters were collected on: bench.py reports the traffic only while it matches
         with open(out, "w") as fh:
-            json.dump({"_provenance": provenance, "kernels": rec}, fh, indent=1)
+            json.dump({"_provenance": provenance, "csrc_sha1": csrc_digest(), "kernels": rec}, fh, indent=1)
 
 
 if __name__ == "__main__":
