@@ -249,6 +249,30 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dtm = float(t.item())
     toks = B * N * world * args.steps / dtm
+    roof = None
+    if rank == 0 and world == 1 and not args.no_kernel_timer and shape is None:
+        # per-kernel pass for the roofline record: two more steps on ONE stream (the timed steps above overlap the weight gradients with the data-gradient
+        # chain on a second stream, which inflates every per-kernel duration) with HIP events around every dense launch and the FAVOR+ launch groups
+        from synthanatomy_amd import debug, engine
+        with debug.override(no_side_wgrad=True):
+            step()
+            torch.cuda.synchronize()
+            timer = engine.KernelTimer()
+            engine.TIMER = timer
+            for _ in range(2):
+                step()
+            stats = timer.collect()
+            engine.TIMER = None
+        single = {k: v for k, v in stats.items() if "+" not in k and v[1] > 0} or stats
+        name, (n, flops, ms, _nb) = max(single.items(), key=lambda kv: kv[1][2])
+        ach = flops / (ms * 1e-3) / 1e12
+        peak = PEAK_BF16_TFLOPS if dt == torch.bfloat16 else PEAK_F32_TFLOPS
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "kernel": name,
+                "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
+                "note": "one-stream pass (weight gradients not overlapped) of 2 steps; dense layers (nn.Linear) on the im2col-order MFMA kernel; brackets with '+' "
+                        "cover several launches (FAVOR+ groups: algorithmic FLOPs, the kernels execute ~3x on split-bf16 products)",
+                "kernels": {k: {"launches": v[0], "ms": round(v[2], 3), "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2) if v[2] > 0 and v[1] > 0 else None}
+                            for k, v in sorted(stats.items(), key=lambda kv: -kv[1][2])[:10]}}
     sampling = None
     if args.sampling and shape is None:
         # "also report sampling tokens/s (B10)": autoregressive sample() of full N-token sequences, stateful O(N) path
@@ -273,6 +297,8 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
            "config": {"workload": f"performer n_embd=512 n_layers=24 n_head=16 local_attn_heads=8 local_window=420 vocab=2048, N={N} raster-ordered "
                                   f"{'x'.join(map(str, spatial))} latents, training step = fwd + CE + bwd + Adam, projections redrawn every other step", "batch_per_gpu": B,
                       "global_batch": B * world, "seq_len": N, "parallelism": f"dp{world}"}}
+    if roof is not None:
+        res["roofline"] = roof
     if sampling is not None:
         res["sampling"] = sampling
     del net, flat, opt, reducer

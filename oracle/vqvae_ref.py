@@ -108,6 +108,10 @@ def init_state(cfg: VQVAEConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
 def _rd(t: torch.Tensor, round_dtype: Optional[torch.dtype]) -> torch.Tensor:
     if round_dtype is None:
         return t
+    if round_dtype == torch.float16:
+        # float16 is a FORWARD storage type only (the product keeps every gradient in bf16 / fp32): round the value, pass the gradient straight through --
+        # autograd through .to(float16) would push the (tiny, un-scaled) gradients through half precision and flush them
+        return t + (t.detach().to(round_dtype).to(torch.float32) - t.detach())
     return t.to(round_dtype).to(torch.float32)
 
 

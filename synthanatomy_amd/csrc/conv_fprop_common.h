@@ -75,9 +75,10 @@ __device__ __forceinline__ long long linear_row_voxel(const FpropArgs& a, uint32
 }
 
 // `row_ov(row)` -> output voxel of tile row `row` (or -1): the linear launch grid, or the 2-D patch of the halo mainloop
+// `parks`: whether this thread holds accumulators of the tile (false for the second K group of a KG = 2 block, which only helps with the write-back)
 template <int BM, int BN, int WM, int WN, int MI, int NI, int NT, typename RowOv>
 __device__ __forceinline__ void fprop_epilogue_ov(const FpropArgs& a, float4_t (&acc)[NI][MI], unsigned char* smem, uint32_t tid, uint32_t wm, uint32_t wn,
-                                                  uint32_t frow, uint32_t fq, uint32_t n_base, RowOv row_ov) {
+                                                  uint32_t frow, uint32_t fq, uint32_t n_base, RowOv row_ov, bool parks = true) {
     const sa_conv_geom& g = a.g;
     //  A) every lane parks its 4x(acc + bias) for one voxel in an fp32 tile [BM][BN+4] (stride padded: conflict-free b128)
     //  B) the block re-reads the tile voxel-row-wise, 4 channels per thread: addend / activation / mask are applied with
@@ -86,18 +87,20 @@ __device__ __forceinline__ void fprop_epilogue_ov(const FpropArgs& a, float4_t (
     float* sT = (float*)smem;
     long long* sOv = (long long*)(smem + BM * LDT * 4);
     const sa_epilogue& ep = a.ep;
+    if (parks) {
 #pragma unroll
-    for (int j = 0; j < MI; ++j) {
-        const uint32_t row = wm * (MI * 16) + j * 16 + frow;
+        for (int j = 0; j < MI; ++j) {
+            const uint32_t row = wm * (MI * 16) + j * 16 + frow;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const uint32_t col = wn * (NI * 16) + i * 16 + fq * 4;
-            float4_t v = acc[i][j];
-            if (ep.bias) {
-                const float4_t bv = *(const float4_t*)(ep.bias + n_base + col);
-                v += bv;
+            for (int i = 0; i < NI; ++i) {
+                const uint32_t col = wn * (NI * 16) + i * 16 + fq * 4;
+                float4_t v = acc[i][j];
+                if (ep.bias) {
+                    const float4_t bv = *(const float4_t*)(ep.bias + n_base + col);
+                    v += bv;
+                }
+                *(float4_t*)(sT + row * LDT + col) = v;
             }
-            *(float4_t*)(sT + row * LDT + col) = v;
         }
     }
     if (tid < BM) sOv[tid] = row_ov(tid);

@@ -230,23 +230,32 @@ __device__ __forceinline__ void resblock_second_gemm(const FpropArgs& a, float4_
 // two slabs in flight (counted s_waitcnt vmcnt + raw barrier) was 25-35 % SLOWER (512 -> 512 layer 25 -> 33 us, Performer step +10 %): the
 // third buffer costs a resident block per CU (72 KiB against 48 KiB), and co-resident blocks hide the DMA round trip better than depth does.
 
-template <typename T, int WM, int WN, int MI, int NI, bool UNIFORM, bool FUSE = false>
-__global__ __launch_bounds__(WM * WN * 64) void conv_fprop_dma_kernel(const FpropArgs a) {
+// KG = 2 ("two K groups", round 4): TWICE the waves on the same tile -- waves [0, NW) reduce the first half of the K-slabs, waves [NW, 2 NW) the second half,
+// each group through its own pair of stage buffers; group 1 then hands its accumulators to group 0 through LDS and all 2 NW waves write the tile back.
+// For launches with about ONE tile per CU and a long reduction (the 512-column dense layers of the Performer at M = 8 400: 264 tiles, K = 1 024 .. 3 072), where a
+// lone eight-wave block waits out every DMA round trip: sixteen waves per CU without needing more tiles (128 KiB of LDS: one block per CU).
+template <typename T, int WM, int WN, int MI, int NI, bool UNIFORM, bool FUSE = false, int KG = 1>
+__global__ __launch_bounds__(WM * WN * 64 * KG) void conv_fprop_dma_kernel(const FpropArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins only exist in the device pass; the host pass needs just the stub
     constexpr int BM = WM * MI * 16;
     constexpr int BN = WN * NI * 16;
     constexpr int NW = WM * WN;                           // 4 waves, or 8 (half-size wave tiles: twice the waves per SIMD to cover DMA / LDS latency)
     static_assert((BM == 128 || (BM == 256 && NW == 8 && MI == 4 && NI == 4)) && (NW == 4 || NW == 8) && (!FUSE || NW == 4), "tile");
+    static_assert(KG == 1 || (KG == 2 && !FUSE && BM == 128), "two K groups: plain 128-row tiles");
+    constexpr int STAGE = 2 * (BM + BN) * 128;            // one group's two stage buffers
     constexpr int A_PER_WAVE = (BM / 8) / NW;              // 1 KiB pieces (8 rows) of the activation tile per wave
     constexpr int SZ = sizeof(T);
     constexpr int BKE = 128 / SZ;
     constexpr int B_PIECES = BN / 8;                       // 1 KiB pieces (8 rows) of the weight tile
     constexpr int B_PER_WAVE = (B_PIECES + NW - 1) / NW;
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t kg = KG == 1 ? 0u : wave_all / NW;     // K group of this wave
+    const uint32_t wave = KG == 1 ? wave_all : wave_all - kg * NW;
+    unsigned char* const smem = smem_all + kg * STAGE;
     const uint32_t wm = wave / WN, wn = wave % WN;
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
     uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
@@ -356,27 +365,55 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fprop_dma_kernel(const Fpro
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-    issue(0, 0);
+    // K-slabs [s0, s1) of this wave's group; every wave runs `trips` barrier intervals (group 1 may idle through the last one when nk is odd)
+    const uint32_t nk0 = KG == 1 ? a.nk : (a.nk + 1u) / 2u;
+    const uint32_t s0 = kg ? nk0 : 0u, s1 = kg ? a.nk : nk0, trips = nk0;
+    if (s0 < s1) issue(s0, 0);
     __syncthreads();
     const uint32_t frow = lane & 15u, fq = lane >> 4;
-    for (uint32_t s = 0; s < a.nk; ++s) {
-        const uint32_t buf = s & 1u;
-        if (s + 1 < a.nk) issue(s + 1, buf ^ 1u);
+    for (uint32_t it = 0; it < trips; ++it) {
+        const uint32_t s = s0 + it;
+        const uint32_t buf = it & 1u;
+        if (s + 1 < s1) issue(s + 1, buf ^ 1u);
         const unsigned char* pa = smem + buf * (BM * 128);
         const unsigned char* pb = smem + 2 * BM * 128 + buf * (BN * 128);
+        if (KG == 1 || s < s1) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            u32x4 xf[MI], wf[NI];
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 xf[MI], wf[NI];
 #pragma unroll
-            for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(pa + tile_off(wm * (MI * 16) + j * 16 + frow, ks * 4 + fq));
+                for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(pa + tile_off(wm * (MI * 16) + j * 16 + frow, ks * 4 + fq));
 #pragma unroll
-            for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + tile_off(wn * (NI * 16) + i * 16 + frow, ks * 4 + fq));
+                for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + tile_off(wn * (NI * 16) + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
+            }
+        }
+        __syncthreads();  // (the DMA in flight makes hipcc drain vmcnt(0) here: next slab landed, this one free)
+    }
+    if constexpr (KG == 2) {
+        // group 1 -> group 0: accumulator fragments through group 1's (now idle) stage buffers, one 16-byte slot per (wave, fragment, lane): both groups
+        // hold the same fragment of the tile in the same (wave, lane), so the hand-over is a straight copy + add
+        float4_t* const xch = (float4_t*)(smem_all + STAGE);
+        if (kg == 1) {
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
+                for (int j = 0; j < MI; ++j) xch[((wave * NI + i) * MI + j) * 64 + lane] = acc[i][j];
         }
-        __syncthreads();  // (the DMA in flight makes hipcc drain vmcnt(0) here: next slab landed, this one free)
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) acc[i][j] += xch[((wave * NI + i) * MI + j) * 64 + lane];
+        }
+        __syncthreads();   // (the epilogue's staging tile reaches into group 1's buffers)
+        fprop_epilogue_ov<BM, BN, WM, WN, MI, NI, NW * 64 * KG>(a, acc, smem_all, tid, wm, wn, frow, fq, n_base,
+                                                                [&](uint32_t row) __attribute__((always_inline)) { return linear_row_voxel(a, m_base + row); }, kg == 0);
+        return;
     }
     if constexpr (FUSE) {
         static_assert(!FUSE || (sizeof(T) == 2 && BM == 128 && BN == 128), "fused residual block: bf16, 128 x 128 tile");
@@ -848,6 +885,20 @@ extern "C" int sa_debug_timing(unsigned long long* out, int reset) {
 namespace sa {
 #endif
 
+// compute units of the current device (queried once per device ordinal)
+static inline int device_cu_count() {
+    static std::atomic<int> cu_count[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int cus = cu_count[dev & 63].load(std::memory_order_relaxed);
+    if (cus <= 0) {
+        cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        cu_count[dev & 63].store(cus, std::memory_order_relaxed);
+    }
+    return cus;
+}
+
 template <typename T, int WM, int WN, int MI, int NI>
 static int launch_fprop(const FpropArgs& a, hipStream_t st) {
     constexpr int BM = WM * MI * 16, BN = WN * NI * 16;
@@ -867,13 +918,30 @@ static int launch_fprop(const FpropArgs& a, hipStream_t st) {
                 (void)hipFuncSetAttribute((const void*)conv_fprop_dma_kernel<T, WM, WN, MI, NI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             });
         }
-        (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma_kernel<%s, %d, %d, %d, %d, %s, false>", tname<T>(), WM, WN, MI, NI, uniform ? "true" : "false"), note_kernel(g_last_conv_kernel));
         FpropArgs b = a;
         // Dense layers with >= 8 channel tiles (M = 8 400 rows, tools/bench_dense_tiles.py; FETCH_SIZE per launch 203 -> 65 MB for q|k|v): q|k|v forward 77.1 -> 68.0 us,
         // w1 forward 52.8 -> 45.0, w2 data gradient 52.1 -> 43.1, to_out data gradient 30.5 -> 26.3.  With 4 channel tiles (N = 512, one block per CU) the fetch
         // bytes halve as well (139 -> 65 MB) but the time does not move (52.1 -> 54.7 us): those launches wait on the per-slab DMA round trip, not on the fabric.
         // SA_PP_DBG bits 16-23: group size override for A/B runs (255 = off).
         if (b.ntaps == 1 && nbn_valid > 1) b.group_m = (g_tunables.pp_dbg >> 16) ? ((g_tunables.pp_dbg >> 16) & 255u) % 255u : (nbn_valid >= 8 ? 8u : 0u);
+        if constexpr (std::is_same<T, bf16_t>::value && WM == 4 && WN == 2 && MI == 2 && NI == 4) {
+            // At most one 128 x 128 tile per CU and a long reduction: a lone eight-wave block per CU waits out every DMA round trip with nothing else resident.
+            // Two K groups = sixteen waves on the same tile (KG = 2 above), 128 KiB of LDS, i.e. ONE block per CU -- so only grids that fit one round.
+            // Measured (tools/bench_dense_tiles.py, K = 1 024 / 2 048 / 3 072 -> 512 columns): M = 8 192 (256 tiles) 25.1 / 37.3 / 48.3 -> 21.7 / 31.6 / 40.9 us;
+            // M = 8 400 (264 tiles: a second round of 8) 26.9 / 39.6 / 52.0 -> 34.2 / 50.2 / 70.4 us, which is why the README batch stays on the one-group kernel.
+            // SA_NO_KGROUPS / SA_DBG_NO_KGROUPS keeps the one-group kernel everywhere (A/B runs and the equality test).
+            if (uniform && b.ntaps == 1 && b.nk >= 8 && (int)grid.x <= device_cu_count() && !dbg(SA_DBG_NO_KGROUPS)) {
+                static std::atomic<uint64_t> attr2_done{0};
+                configure_once_per_device(attr2_done, [] {
+                    (void)hipFuncSetAttribute((const void*)conv_fprop_dma_kernel<T, WM, WN, MI, NI, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                });
+                (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma_kernel<%s, %d, %d, %d, %d, true, false, 2>", tname<T>(), WM, WN, MI, NI), note_kernel(g_last_conv_kernel));
+                hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, true, false, 2>), grid, dim3(WM * WN * 64 * 2), 2 * pipe, st, b);
+                SA_CHECK_LAUNCH();
+                return 0;
+            }
+        }
+        (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma_kernel<%s, %d, %d, %d, %d, %s, false>", tname<T>(), WM, WN, MI, NI, uniform ? "true" : "false"), note_kernel(g_last_conv_kernel));
         if (uniform) hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, true>), grid, dim3(WM * WN * 64), lds, st, b);
         else hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, false>), grid, dim3(WM * WN * 64), lds, st, b);
         SA_CHECK_LAUNCH();

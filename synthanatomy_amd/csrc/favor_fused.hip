@@ -20,6 +20,17 @@
 
 namespace sa {
 
+#ifdef SA_TIMING_FAVOR
+// dev instrumentation (-DSA_TIMING_FAVOR): s_memtime sums of wave 0 of every block, read back by sa_debug_timing_favor
+// scan B body: [0] prologue, [1] feature maps, [2] wait + tile writes, [3] barrier 2, [4] two GEMMs, [5] VALU + operand split, [6] dx GEMM, [7] epilogue, [8] blocks;
+// scan A body: [10] prologue, [11] slab loop, [12] epilogue, [13] blocks;   state body: [15] prologue, [16] slab loop, [17] blocks
+__device__ unsigned long long g_ftime[24];
+#define FT_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define FT_ACC(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_ftime[i], (unsigned long long)(v)); } while (0)
+#else
+#define FT_T(var)
+#define FT_ACC(i, v)
+#endif
 constexpr int FT_BYTES = 64 * 128;   // one [64 rows][64 bf16] tile
 constexpr int FSLAB = 64;
 #ifndef FUSED_WPS
@@ -81,57 +92,85 @@ __device__ __forceinline__ void load_x_operand(XOperand& xo, const FeatSrc& f, c
 }
 
 // features [slab0, slab0 + 64) of this lane's position (column lane & 15 of the wave): F[f][r] = feature slab0 + f*16 + g4*4 + r
+// nf = 16-feature fragments of the slab that hold features at all (the last slab of m = 266 has ONE: its other three fragments stay zero and cost neither
+// MFMAs nor exponentials; block-uniform)
+__device__ __forceinline__ int slab_frags(const FusedArgs& s, int slab0) { return min(4, (s.LDF - slab0 + 15) >> 4); }
+
 __device__ __forceinline__ void feat_slab(float4_t (&F)[4], const unsigned char* sPh, const unsigned char* sPl, const XOperand& xo, bool valid, int slab0,
                                           const FusedArgs& s, int fr, int g4) {
+    const int nf = slab_frags(s, slab0);
 #pragma unroll
     for (int f = 0; f < 4; ++f) F[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
-    tile_rows_gemm(F, sPh, sPl, xo.h, xo.l, fr, g4);
+    tile_rows_gemm(F, sPh, sPl, xo.h, xo.l, fr, g4, nf);
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < 4; ++f) {
+        if (f >= nf) break;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int mi = slab0 + f * 16 + g4 * 4 + r;
             const float e = fmaf(s.ratio, __expf(F[f][r] - xo.off), s.reps);
             F[f][r] = (valid && mi < s.m) ? e : 0.f;
         }
+    }
 }
 
 // two feature maps of the same positions from ONE walk over the projection fragments (half the ds_read_b128 traffic of two feat_slab calls)
 __device__ __forceinline__ void feat_slab2(float4_t (&F0)[4], float4_t (&F1)[4], const unsigned char* sPh, const unsigned char* sPl, const XOperand& x0, const XOperand& x1,
                                            bool valid, int slab0, const FusedArgs& s, int fr, int g4) {
+    const int nf = slab_frags(s, slab0);
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
         F0[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
         F1[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
     }
+    // per accumulator the product order of tile_rows_gemm (hi*lo, lo*hi, hi*hi over ks = 0, 1): bit-identical dd to the pre-pass
+    auto frag = [&](const int f, const int ks, short8_t& ah, short8_t& al) __attribute__((always_inline)) {
+        const uint32_t o = lroff(f * 16 + fr, ks * 32 + g4 * 8);
+        ah = *(const short8_t*)(sPh + o);
+        al = *(const short8_t*)(sPl + o);
+    };
+    if (nf == 4) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        short8_t ah[4], al[4];
+        for (int ks = 0; ks < 2; ++ks) {
+            short8_t ah[4], al[4];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const uint32_t o = lroff(f * 16 + fr, ks * 32 + g4 * 8);
-            ah[f] = *(const short8_t*)(sPh + o);
-            al[f] = *(const short8_t*)(sPl + o);
+            for (int f = 0; f < 4; ++f) frag(f, ks, ah[f], al[f]);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], x0.l[ks], F0[f], 0, 0, 0);
+                F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], x1.l[ks], F1[f], 0, 0, 0);
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], x0.h[ks], F0[f], 0, 0, 0);
+                F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], x1.h[ks], F1[f], 0, 0, 0);
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], x0.h[ks], F0[f], 0, 0, 0);
+                F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], x1.h[ks], F1[f], 0, 0, 0);
+            }
         }
-        // per accumulator the product order of tile_rows_gemm (hi*lo, lo*hi, hi*hi): bit-identical dd to the pre-pass
+    } else {   // partial (last) slab: fragment by fragment, the same per-accumulator order
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], x0.l[ks], F0[f], 0, 0, 0);
-            F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], x1.l[ks], F1[f], 0, 0, 0);
-        }
+        for (int f = 0; f < 3; ++f) {
+            if (f >= nf) break;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], x0.h[ks], F0[f], 0, 0, 0);
-            F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], x1.h[ks], F1[f], 0, 0, 0);
-        }
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], x0.h[ks], F0[f], 0, 0, 0);
-            F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], x1.h[ks], F1[f], 0, 0, 0);
+            for (int ks = 0; ks < 2; ++ks) {
+                short8_t ah, al;
+                frag(f, ks, ah, al);
+                F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, x0.l[ks], F0[f], 0, 0, 0);
+                F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, x1.l[ks], F1[f], 0, 0, 0);
+                F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, x0.h[ks], F0[f], 0, 0, 0);
+                F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, x1.h[ks], F1[f], 0, 0, 0);
+                F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, x0.h[ks], F0[f], 0, 0, 0);
+                F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, x1.h[ks], F1[f], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < 4; ++f) {
+        if (f >= nf) break;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int mi = slab0 + f * 16 + g4 * 4 + r;
@@ -140,6 +179,7 @@ __device__ __forceinline__ void feat_slab2(float4_t (&F0)[4], float4_t (&F1)[4],
             F0[f][r] = in ? e0 : 0.f;
             F1[f][r] = in ? e1 : 0.f;
         }
+    }
 }
 
 // this wave's 16 positions x 64 features -> rows w*16 + fr of a [64 positions][64 features] hi / lo tile
@@ -411,7 +451,7 @@ __device__ __forceinline__ void favor_fstate_body(const FusedArgs& s, const int 
         float4_t acc[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) acc[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
-        tile_cols_gemm(acc, sAh, sAl, bh, bl, lane);      // acc[f][r]: feature slab0 + f*16 + g4*4 + r, value column w*16 + fr
+        tile_cols_gemm(acc, sAh, sAl, bh, bl, lane, 2, slab_frags(s, slab0));      // acc[f][r]: feature slab0 + f*16 + g4*4 + r, value column w*16 + fr
         float4_t accz = (float4_t){0.f, 0.f, 0.f, 0.f};  // feature tile w of the slab
         if (s.zmode) {
 #pragma unroll
@@ -584,6 +624,7 @@ __device__ __forceinline__ void favor_fout_b_body(const FusedArgs& s, const int 
     unsigned char* const sBl = sT[0] + FT_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
     const int chunk = bid % s.S, g = (bid / s.S) % s.G, b = bid / (s.S * s.G);
+    FT_T(ft_start);
     const float kmax = unpack_max(*s.gmax);
     const __amdgpu_buffer_rsrc_t rc = f_rsrc(s.c + (int64_t)b * s.N * s.c_stride, (int64_t)s.N * s.c_stride * 4);
     const __amdgpu_buffer_rsrc_t rcs = f_rsrc((s.c_scale ? s.c_scale : s.c) + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G * 4);
@@ -648,11 +689,14 @@ __device__ __forceinline__ void favor_fout_b_body(const FusedArgs& s, const int 
     tile_stage(sT[0], sT[0] + FT_BYTES, pt, tid);
     pslab_store(sP[0], pre, tid);
     __syncthreads();
+    FT_T(ft_loop);
+    FT_ACC(0, ft_loop - ft_start);
     for (int sl = 0; sl < nslab; ++sl) {
         const int slab0 = sl * FSLAB;
         const unsigned char* sPc = sP[sl & 1];
         const unsigned char* sTh = sT[sl & 1];
         const unsigned char* sTl = sTh + FT_BYTES;
+        FT_T(ft0);
         if (sl + 1 < nslab) {
             pslab_load(pre, s.ptiles, sl + 1, tid);
             tslab_load(pt, rt, slab0 + FSLAB, tid);
@@ -662,18 +706,28 @@ __device__ __forceinline__ void favor_fout_b_body(const FusedArgs& s, const int 
         for (int q = 0; q < 4; ++q) zc[q] = f_ld4(rz, (uint32_t)(slab0 + q * 16 + g4 * 4) * 4u);
         float4_t F[4], Fx[4];
         feat_slab2(F, Fx, sPc, sPc + FT_BYTES, xa, xx, vi, slab0, s, fr, g4);
+        FT_T(ft1);
         if (sl) __syncthreads();   // the previous slab's GEMMs are done with the feature tile (and with the other slab buffers)
         feat_to_tile(sAh, sAl, F, w, fr, g4);
         if (sl + 1 < nslab) {      // next slab's operands into the other buffers while this slab's GEMMs run
             tile_stage(sT[(sl + 1) & 1], sT[(sl + 1) & 1] + FT_BYTES, pt, tid);
             pslab_store(sP[(sl + 1) & 1], pre, tid);
         }
+        FT_T(ft2);
         __syncthreads();
+        FT_T(ft3);
+        FT_ACC(1, ft1 - ft0); FT_ACC(2, ft2 - ft1); FT_ACC(3, ft3 - ft2);
         float4_t acc[4];
 #pragma unroll
         for (int f = 0; f < 4; ++f) acc[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
-        tile_rows_gemm(acc, sTh, sTl, Ch, Cl, fr, g4);   // inter-chunk: T_prev c_i
-        tile_cols_gemm(acc, sAh, sAl, Ph, Pl, lane);     // intra-chunk: sum_j phi_a(j)[m] P[j][i]
+        const int nf = slab_frags(s, slab0);
+        tile_rows_gemm(acc, sTh, sTl, Ch, Cl, fr, g4, nf);   // inter-chunk: T_prev c_i
+        tile_cols_gemm(acc, sAh, sAl, Ph, Pl, lane, 2, nf);  // intra-chunk: sum_j phi_a(j)[m] P[j][i]
+#ifdef SA_TIMING_FAVOR
+        asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));
+#endif
+        FT_T(ft4);
+        FT_ACC(4, ft4 - ft3);
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
@@ -686,8 +740,15 @@ __device__ __forceinline__ void favor_fout_b_body(const FusedArgs& s, const int 
             }
         short8_t Dh[2], Dl[2];
         acc_to_operand(Dh, Dl, acc);
-        tile_cols_gemm(dxa, sPc, sPc + FT_BYTES, Dh, Dl, lane);   // dx^T[d][i] += sum_m P[m][d] v[m][i]
+        FT_T(ft5);
+        tile_cols_gemm(dxa, sPc, sPc + FT_BYTES, Dh, Dl, lane, (min(64, s.LDF - slab0) + 31) >> 5);   // dx^T[d][i] += sum_m P[m][d] v[m][i]
+#ifdef SA_TIMING_FAVOR
+        asm volatile("s_nop 0" ::"v"(dxa[0][0]), "v"(dxa[1][0]), "v"(dxa[2][0]), "v"(dxa[3][0]));
+#endif
+        FT_T(ft6);
+        FT_ACC(5, ft5 - ft4); FT_ACC(6, ft6 - ft5);
     }
+    FT_T(ft_ep);
     float t = tp;
     t += __shfl_xor(t, 16, 64);
     t += __shfl_xor(t, 32, 64);
@@ -721,6 +782,11 @@ __device__ __forceinline__ void favor_fout_b_body(const FusedArgs& s, const int 
         __syncthreads();
         if (tid == 0) s.tsum[bid] = (sred[0] + sred[1]) + (sred[2] + sred[3]);   // one partial per block, summed in a fixed order by the fix-up launch
     }
+#ifdef SA_TIMING_FAVOR
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FT_T(ft_end);
+    FT_ACC(7, ft_end - ft_ep); FT_ACC(8, 1); FT_ACC(9, ft_end - ft_start);
+#endif
 }
 
 __global__ __launch_bounds__(256, 2) void favor_fstate_kernel(const FusedArgs s) {
@@ -839,6 +905,14 @@ __global__ __launch_bounds__(256) void favor_fdden_v4_kernel(const float* __rest
 }
 
 }  // namespace sa
+
+#ifdef SA_TIMING_FAVOR
+extern "C" int sa_debug_timing_favor(unsigned long long* out, int reset) {
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(sa::g_ftime), 24 * 8);
+    if (reset) { unsigned long long z[24] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(sa::g_ftime), z, 24 * 8); }
+    return 0;
+}
+#endif
 
 using namespace sa;
 

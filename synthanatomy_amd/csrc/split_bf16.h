@@ -69,22 +69,38 @@ __device__ __forceinline__ void acc_to_operand(short8_t (&hi)[2], short8_t (&lo)
 // acc[f] += rows (f*16 + lane&15) of the tile . B operand; reduction over the 64 tile columns in natural order: B operand word e of lane
 // (n, g) is column ks*32 + g*8 + e.  Fragments via ds_read_b128.
 __device__ __forceinline__ void tile_rows_gemm(float4_t (&acc)[4], const unsigned char* tHi, const unsigned char* tLo, const short8_t (&bh)[2],
-                                               const short8_t (&bl)[2], int i16, int g) {
+                                               const short8_t (&bl)[2], int i16, int g, int nf = 4) {
+    if (nf == 4) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        short8_t ah[4], al[4];
+        for (int ks = 0; ks < 2; ++ks) {
+            short8_t ah[4], al[4];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const uint32_t o = lroff(f * 16 + i16, ks * 32 + g * 8);
-            ah[f] = *(const short8_t*)(tHi + o);
-            al[f] = *(const short8_t*)(tLo + o);
+            for (int f = 0; f < 4; ++f) {
+                const uint32_t o = lroff(f * 16 + i16, ks * 32 + g * 8);
+                ah[f] = *(const short8_t*)(tHi + o);
+                al[f] = *(const short8_t*)(tLo + o);
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bl[ks], acc[f], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], bh[ks], acc[f], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bh[ks], acc[f], 0, 0, 0);
         }
+        return;
+    }
+    // only the first nf output fragments (block-uniform nf < 4): the same per-accumulator product order
 #pragma unroll
-        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bl[ks], acc[f], 0, 0, 0);
+    for (int f = 0; f < 3; ++f) {
+        if (f >= nf) break;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], bh[ks], acc[f], 0, 0, 0);
-#pragma unroll
-        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bh[ks], acc[f], 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint32_t o = lroff(f * 16 + i16, ks * 32 + g * 8);
+            const short8_t ah = *(const short8_t*)(tHi + o), al = *(const short8_t*)(tLo + o);
+            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ks], acc[f], 0, 0, 0);
+            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ks], acc[f], 0, 0, 0);
+            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ks], acc[f], 0, 0, 0);
+        }
     }
 }
 
@@ -113,24 +129,42 @@ __device__ __forceinline__ void tile_rows_gemm_perm(float4_t (&acc)[4], const un
 
 // acc[f] += tile^T (tile columns f*16 + lane&15) . B operand; reduction over the 64 tile ROWS in accumulator-row order (transposing reads)
 __device__ __forceinline__ void tile_cols_gemm(float4_t (&acc)[4], const unsigned char* tHi, const unsigned char* tLo, const short8_t (&bh)[2],
-                                               const short8_t (&bl)[2], int lane, int nks = 2) {
+                                               const short8_t (&bl)[2], int lane, int nks = 2, int nf = 4) {
     const uint32_t trow = (uint32_t)(lane >> 4) * 4u + ((uint32_t)(lane & 15) >> 2), tcol = (uint32_t)(lane & 3) * 4u;
+    if (nf == 4) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        if (ks >= nks) break;
-        short8_t ah[4], al[4];
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks >= nks) break;
+            short8_t ah[4], al[4];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const uint32_t o0 = lroff(ks * 32 + trow, f * 16 + tcol), o1 = lroff(ks * 32 + 16 + trow, f * 16 + tcol);
-            ah[f] = __builtin_shufflevector(lds_tr16_b64(tHi + o0), lds_tr16_b64(tHi + o1), 0, 1, 2, 3, 4, 5, 6, 7);
-            al[f] = __builtin_shufflevector(lds_tr16_b64(tLo + o0), lds_tr16_b64(tLo + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+            for (int f = 0; f < 4; ++f) {
+                const uint32_t o0 = lroff(ks * 32 + trow, f * 16 + tcol), o1 = lroff(ks * 32 + 16 + trow, f * 16 + tcol);
+                ah[f] = __builtin_shufflevector(lds_tr16_b64(tHi + o0), lds_tr16_b64(tHi + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+                al[f] = __builtin_shufflevector(lds_tr16_b64(tLo + o0), lds_tr16_b64(tLo + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bl[ks], acc[f], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], bh[ks], acc[f], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bh[ks], acc[f], 0, 0, 0);
         }
+        return;
+    }
+    // only the first nf output fragments (tile columns [0, 16 nf)); block-uniform nf < 4, the same per-accumulator product order
 #pragma unroll
-        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bl[ks], acc[f], 0, 0, 0);
+    for (int f = 0; f < 3; ++f) {
+        if (f >= nf) break;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], bh[ks], acc[f], 0, 0, 0);
-#pragma unroll
-        for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bh[ks], acc[f], 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks >= nks) break;
+            const uint32_t o0 = lroff(ks * 32 + trow, f * 16 + tcol), o1 = lroff(ks * 32 + 16 + trow, f * 16 + tcol);
+            const short8_t ah = __builtin_shufflevector(lds_tr16_b64(tHi + o0), lds_tr16_b64(tHi + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+            const short8_t al = __builtin_shufflevector(lds_tr16_b64(tLo + o0), lds_tr16_b64(tLo + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ks], acc[f], 0, 0, 0);
+            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ks], acc[f], 0, 0, 0);
+            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ks], acc[f], 0, 0, 0);
+        }
     }
 }
 

@@ -25,6 +25,7 @@ import torch.nn as nn
 
 from ... import _ffi, debug
 from ..._ffi import MASK_GELU
+from ... import engine as _engine
 from ...engine import ConvOp, PackSet
 from .img2seq_ordering import Ordering
 from .transformer import TransformerBase
@@ -252,6 +253,30 @@ def _cast(t, dtype):
 
 
 _SIDE_STREAMS = {}
+
+
+def FAVOR_FWD_FLOP_PER_HEAD_ROW(m: int, dh: int) -> float:
+    """ALGORITHMIC forward FLOPs of causal FAVOR+ per (batch, position, head): two feature maps 2 x 2 dh m, the state update k' (x) v and
+    the read-out q' . S 2 x 2 m dh, the normaliser 2 x 2 m.  (The kernels execute about 3 x that on the matrix cores: split-bf16 products, and the key
+    features are rebuilt by the state AND the output launch.)"""
+    return 2.0 * 2 * dh * m + 2.0 * 2 * m * dh + 2.0 * 2 * m
+
+
+def _favor_bracket_begin():
+    """bench.py's live kernel timer (engine.TIMER): HIP events around the FAVOR+ launch groups of a layer; None when no timer is attached"""
+    if _engine.TIMER is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _favor_bracket_end(e0, key, flops):
+    if e0 is None or _engine.TIMER is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    _engine.TIMER.pending.append((key, flops, e0, e1, 0.0))
 
 
 class _SideWgrad:
@@ -485,6 +510,7 @@ class _LayerEngine:
                 if self._ws is None or self._ws.numel() < nst or self._ws.device != dev:
                     self._ws = torch.empty(nst, dtype=f32, device=dev)
                 state = self._ws
+            t0 = _favor_bracket_begin()
             _ck(lib.sa_favor_fused_prepass(_ffi.ptr(q), _ffi.ptr(k), qs, G, _ffi.ptr(tiles), _ffi.ptr(offq), _ffi.ptr(amq), _ffi.ptr(offk), _ffi.ptr(gws), R * G, m, dh, st),
                 "sa_favor_fused_prepass")
             rc = lib.sa_favor_fused_fwd(_ffi.ptr(q), _ffi.ptr(k), _ffi.ptr(v), qs, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(offk), _ffi.ptr(gws),
@@ -495,6 +521,7 @@ class _LayerEngine:
                 rc = lib.sa_favor_fused_fwd(_ffi.ptr(q), _ffi.ptr(k), _ffi.ptr(v), qs, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(offk), _ffi.ptr(gws),
                                             _ffi.ptr(attn), inner, _ffi.ptr(inv), 1e-6, B, N, G, m, _ffi.ptr(state), _ffi.ptr(attn_lp), None, st)
             _ck(rc, "sa_favor_fused_fwd")
+            _favor_bracket_end(t0, "favor_prepass+fstate+fprefix+fout_a" + ("_la" if la_args is not None else ""), B * N * G * FAVOR_FWD_FLOP_PER_HEAD_ROW(m, dh))
             sv.update(fused=True, offq=offq, offk=offk, amq=amq, gws=gws, inv=inv, scan_state=state if tape is not None else None)
         elif G > 0:
             pop = self._proj_op()
@@ -814,11 +841,14 @@ class _LayerEngine:
                                               _ffi.ptr(sv["offk"]), _ffi.ptr(sv["gws"]), _ffi.ptr(dattn), _ffi.ptr(attn), inner, _ffi.ptr(sv["inv"]), _ffi.ptr(dq),
                                               _ffi.ptr(dk), _ffi.ptr(dv), B, N, G, m, _ffi.ptr(sv.get("scan_state")), _ffi.ptr(self._ws), _ffi.ptr(dden), _ffi.ptr(tsum),
                                               _ffi.ptr(dq_lp), _ffi.ptr(dk_lp), _ffi.ptr(dv_lp), ctypes.byref(la) if la is not None else None, st)
+            t0 = _favor_bracket_begin()
             rc = favor_bwd(la_args)
             if rc == _ffi.SA_EUNSUPPORTED and la_args is not None:   # exact-fp32 local attention / unpaired launches: separate launches below
                 la_args = None
                 rc = favor_bwd(None)
             _ck(rc, "sa_favor_fused_bwd")
+            _favor_bracket_end(t0, "favor_fdden+fpair_b_state+fprefix+fpair_b_a+fkey_fix" + ("_la" if la_args is not None else ""),
+                               2.0 * B * N * G * FAVOR_FWD_FLOP_PER_HEAD_ROW(m, dh))
             local_done = la_args is not None
             sv["scan_state"] = None
         elif G > 0:

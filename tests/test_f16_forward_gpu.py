@@ -142,11 +142,12 @@ def test_encoder_chain_f16_forward_tracks_fp32_and_trains_like_bf16():
     e16, ebf = _rel(z16, z32), _rel(zbf, z32)
     print(f"[f16 forward] z vs fp32 encoder: f16 {e16:.2e}, bf16 {ebf:.2e}")
     assert e16 < 1.5e-3 and e16 < 0.35 * ebf, (e16, ebf)
-    # encoder backward under a FIXED upstream gradient (no quantizer in between: a flipped code would replace a decoder input outright): the f16-forward chain
-    # saves bf16 copies and runs the same bf16 backward kernels, so its gradients agree with the bf16-forward chain to bf16 noise
+    # encoder backward under a FIXED random upstream gradient (no quantizer in between), against the fp32 product path: thirty layers of ReLU masks make this a
+    # harsh comparison for any 16-bit forward (measured: bf16 forward operands 0.13-0.17 Frobenius-relative on the first level, f16 forward operands 0.05) --
+    # the f16-forward chain saves bf16 copies and runs the SAME bf16 backward kernels, and must be the closer of the two on every parameter group
     gz = torch.randn(z16.shape, generator=torch.Generator().manual_seed(3)).cuda()
     grads = {}
-    for name, net in (("f16", n16), ("bf16", nbf)):
+    for name, net in (("fp32", ref), ("f16", n16), ("bf16", nbf)):
         net.train()
         z = net.encode(x)[0]
         if name == "f16":
@@ -155,10 +156,16 @@ def test_encoder_chain_f16_forward_tracks_fp32_and_trains_like_bf16():
         torch.cuda.synchronize()
         grads[name] = {k: p.grad.detach().float().clone() for k, p in net.named_parameters() if p.grad is not None}
         net.zero_grad(set_to_none=True)
-    assert grads["f16"].keys() == grads["bf16"].keys() and len(grads["f16"]) >= 55
-    worst = max((float((grads["f16"][k] - grads["bf16"][k]).norm() / (grads["bf16"][k].norm() + 1e-20)), k) for k in grads["f16"])
-    print(f"[f16 forward] worst encoder-gradient deviation from the bf16-forward chain: {worst[0]:.2e} ({worst[1]})")
-    assert worst[0] < 4e-2, worst
+    assert grads["f16"].keys() == grads["bf16"].keys() == grads["fp32"].keys() and len(grads["f16"]) >= 55
+
+    def fro(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-20))
+    d16 = {k: fro(grads["f16"][k], grads["fp32"][k]) for k in grads["fp32"]}
+    dbf = {k: fro(grads["bf16"][k], grads["fp32"][k]) for k in grads["fp32"]}
+    w16, wbf = max(d16.values()), max(dbf.values())
+    print(f"[f16 forward] worst encoder-gradient deviation from the fp32 path: f16 forward {w16:.2e}, bf16 forward {wbf:.2e}")
+    assert w16 < 8e-2 and w16 < 0.6 * wbf, (w16, wbf)
+    assert sum(d16[k] <= dbf[k] * 1.05 + 1e-3 for k in d16) >= len(d16) - 2
     # and one whole training step runs (quantizer + decoder behind the f16 encoder): finite loss, every parameter receives a gradient
     out = n16(x)
     loss = F.mse_loss(out["reconstruction"][0].float(), x) + out["quantization_losses"][0]

@@ -540,3 +540,33 @@ def test_last_layer_backward_on_the_first_layer_kernels(shape, in_act):
     gc = _GradCtx(None)
     assert st.bwd(G, (x,), gc, wgrad_only=True) is None
     assert _rel_t(gc.grads[mod.weight], res[0][1]) < 1e-5
+
+
+@pytest.mark.parametrize("K,N,R", [(2048, 512, 8192), (1024, 512, 8100), (3072, 512, 8192), (1088, 512, 4100)])
+def test_dense_layer_two_k_groups_equal_one_group(K, N, R):
+    """conv_fprop_dma_kernel<..., 2> (round 4: about one 128 x 128 tile per CU and a long reduction -> two groups of eight waves reduce the two halves of K and
+    group 1 hands its accumulators over through LDS) against the one-group kernel on the same operands -- same products, one fp32 addition in a different
+    place -- and against torch; with the dense-layer epilogue extras (bias, GELU, pre-activation copy, bf16 copy, fp32 residual, ReZero gate)."""
+    from synthanatomy_amd import _ffi, debug, engine
+    torch.manual_seed(K + N)
+    w = (torch.randn(N, K, 1, 1, 1) * K ** -0.5).to(torch.bfloat16).float().cuda()
+    b = (torch.randn(N) * 0.1).cuda()
+    op = engine.ConvOp("conv", K, N, 1, 1, 0, w, b, torch.bfloat16)
+    x = torch.randn(1, 1, 1, R, K).to(torch.bfloat16).cuda()
+    res = torch.randn(1, 1, 1, R, N).cuda()
+    gate = torch.tensor([0.37], device="cuda")
+    outs = {}
+    for one_group in (False, True):
+        with debug.override(no_kgroups=one_group):
+            y = op.fprop(x, out_dtype=torch.float32)
+            kern = _ffi.lib().sa_last_conv_kernel().decode()
+            y2, pre, lp = op.fprop(x, act=_ffi.ACT_GELU, alpha=gate, addend=res, out_dtype=torch.float32, want_pre=True, want_lp=True)
+        outs[one_group] = (y, y2, pre, lp, kern)
+    assert outs[False][4].endswith("true, false, 2>") and outs[True][4].endswith("true, false>"), (outs[False][4], outs[True][4])
+    ref = torch.nn.functional.linear(x.view(R, K).float().cpu(), w.view(N, K).cpu(), b.cpu())
+    for a_, b_ in zip(outs[False][:4], outs[True][:4]):
+        assert float((a_.float() - b_.float()).abs().max()) <= 2e-5 * float(b_.float().abs().max()) + (8e-3 * float(b_.float().abs().max()) if a_.dtype == torch.bfloat16 else 0.0)
+    _close(outs[False][0].view(R, N).cpu(), ref, torch.bfloat16, "two K groups vs torch")
+    ref2 = torch.nn.functional.gelu(ref) * 0.37 + res.view(R, N).cpu()
+    _close(outs[False][1].view(R, N).cpu(), ref2, torch.bfloat16, "two K groups + epilogue vs torch")
+    _close(outs[False][2].float().view(R, N).cpu(), ref, torch.bfloat16, "pre-activation copy")

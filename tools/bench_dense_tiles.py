@@ -33,13 +33,15 @@ def main():
         fl = 2.0 * R * K * N
         res = []
         for wide in (False, True):
-            with debug.override(no_small_tiles=wide):
+            with debug.override(no_small_tiles=wide, no_kgroups=True):
                 t = timeit(lambda: op.fprop(x, out_dtype=torch.float32))
                 res.append((t, _ffi.lib().sa_last_conv_kernel().decode()))
+        tk = timeit(lambda: op.fprop(x, out_dtype=torch.float32))      # the product's dispatch (two K groups where the rule selects them)
+        kk = _ffi.lib().sa_last_conv_kernel().decode()
         xt, wt = x.view(R, K), w.view(N, K).to(torch.bfloat16)
         tb = timeit(lambda: torch.nn.functional.linear(xt, wt))
         print(f"{name:13s} K={K:5d} N={N:5d}  narrow {res[0][0]:6.1f} us {fl / res[0][0] / 1e6:6.1f} TF | wide {res[1][0]:6.1f} us {fl / res[1][0] / 1e6:6.1f} TF | "
-              f"hipBLASLt {tb:6.1f} us {fl / tb / 1e6:6.1f} TF   [{res[0][1]} / {res[1][1]}]", flush=True)
+              f"product {tk:6.1f} us {fl / tk / 1e6:6.1f} TF | hipBLASLt {tb:6.1f} us {fl / tb / 1e6:6.1f} TF   [{res[0][1]} / {res[1][1]} / {kk}]", flush=True)
 
 
 if __name__ == "__main__":
