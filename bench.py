@@ -211,10 +211,16 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
                     local_attn_heads=PERF["local_heads"], local_window_size=PERF["window"], feature_redraw_interval=1, use_rezero=True,
                     spatial_position_emb="absolute", spatial_shape=spatial, compute_dtype=dt).to(dev).train()
     flat = FlatParams(net.parameters())
-    opt = FusedAdam(flat, lr=1e-3)
-    opt.on_step.append(net.invalidate_packed_weights)
     reducer = GradReducer(flat, mode=args.ddp_mode, transport=args.grad_transport)
     net.set_grad_sink(reducer)
+    if not args.opt_in_backward:
+        opt = FusedAdam(flat, lr=1e-3)
+        opt.on_step.append(net.invalidate_packed_weights)
+    else:   # the optimizer slice + operand re-pack of a bucket run behind its gradients, in the shadow of the backward pass (runtime/optim.FusedAdam)
+        opt = FusedAdam(flat, lr=1e-3, in_backward=reducer)
+        rp = net.range_repacker(flat)
+        opt.on_range.append(rp)
+        opt.on_step.append(rp.finish)
     loss_fn = CELoss()
     gen = torch.Generator(device=dev).manual_seed(4 + rank)
     codes = torch.randint(0, PERF["vocab"], (B, N), generator=gen, device=dev)
@@ -621,6 +627,7 @@ def main():
     ap.add_argument("--ddp-mode", default=None, choices=["all_reduce", "reduce_scatter"],
                     help="gradient collective per bucket: one all-reduce (default, what DDP issues) or reduce-scatter + all-gather (runtime/ddp.GradReducer)")
     ap.add_argument("--grad-transport", default=None, choices=["fp32", "bf16"], help="gradient bytes on the links (default fp32)")
+    ap.add_argument("--opt-in-backward", action="store_true", help="A/B: per-bucket Adam slices + re-packs behind the gradients (FusedAdam in_backward) instead of one launch each after backward")
     ap.add_argument("--share-device", action="store_true",
                     help="test aid: all ranks on cuda:0 with the gloo backend (RCCL refuses two ranks per device) -- the N > 1 code path on real kernels, not a number")
     args = ap.parse_args()
@@ -654,11 +661,17 @@ def main():
     torch.manual_seed(4)
     net = BaselineVQVAE(**NET, compute_dtype=dtype).to(dev).train()
     flat = FlatParams(net.parameters())
-    opt = FusedAdam(flat, lr=1.65e-4)
-    opt.on_step.append(net.invalidate_packed_weights)
-    sched = ExponentialLR(opt, gamma=0.99999)
     reducer = GradReducer(flat, mode=args.ddp_mode, transport=args.grad_transport)
     net.set_grad_sink(reducer)
+    if not args.opt_in_backward:
+        opt = FusedAdam(flat, lr=1.65e-4)
+        opt.on_step.append(net.invalidate_packed_weights)
+    else:
+        opt = FusedAdam(flat, lr=1.65e-4, in_backward=reducer)
+        rp = net.range_repacker(flat)
+        opt.on_range.append(rp)
+        opt.on_step.append(rp.finish)
+    sched = ExponentialLR(opt, gamma=0.99999)
     loss_fn = MSELoss()
     gen = torch.Generator(device=dev).manual_seed(4 + rank)
     x = torch.rand(args.batch, 1, *VOL, generator=gen, device=dev, dtype=torch.float32)

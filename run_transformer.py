@@ -94,11 +94,18 @@ def training(cfg, rank, local, world, dev):
     net, ordering = build(cfg, dims, dev)
     net.train()
     flat = FlatParams(net.parameters())
-    opt = FusedAdam(flat, lr=cfg["learning_rate"])
-    opt.on_step.append(net.invalidate_packed_weights)
-    sched = ExponentialLR(opt, gamma=float(cfg["gamma"]) if cfg["gamma"] != "auto" else 0.99999)
     red = GradReducer(flat)
     net.set_grad_sink(red)
+    from synthanatomy_amd import debug
+    if debug.host("opt_in_backward"):     # SA_OPT_IN_BACKWARD=1: a bucket's Adam slice + operand re-pack run behind its gradients (runtime/optim.py)
+        opt = FusedAdam(flat, lr=cfg["learning_rate"], in_backward=red)
+        repacker = net.range_repacker(flat)
+        opt.on_range.append(repacker)
+        opt.on_step.append(repacker.finish)
+    else:
+        opt = FusedAdam(flat, lr=cfg["learning_rate"])
+        opt.on_step.append(net.invalidate_packed_weights)
+    sched = ExponentialLR(opt, gamma=float(cfg["gamma"]) if cfg["gamma"] != "auto" else 0.99999)
     loss_fn = CELoss()
     per_rank = (len(files) + world - 1) // world
     epoch_length = cfg["training_epoch_length"] or (per_rank + cfg["batch_size"] - 1) // cfg["batch_size"]

@@ -96,12 +96,19 @@ def training(cfg, rank, local, world, dev):
     loss_fn = get_vqvae_loss(cfg)
     net = build_network(cfg, dev).train()
     flat = FlatParams(net.parameters())
-    opt = FusedAdam(flat, lr=cfg["learning_rate"])
-    opt.on_step.append(net.invalidate_packed_weights)
-    gamma = float(cfg["gamma"]) if cfg["gamma"] != "auto" else 0.99999
-    sched = ExponentialLR(opt, gamma=gamma)
     red = GradReducer(flat)
     net.set_grad_sink(red)
+    from synthanatomy_amd import debug
+    if cfg["adversarial_component"] or not debug.host("opt_in_backward"):      # (the adversarial iteration runs several backward passes per optimizer step)
+        opt = FusedAdam(flat, lr=cfg["learning_rate"])
+        opt.on_step.append(net.invalidate_packed_weights)
+    else:                                 # SA_OPT_IN_BACKWARD=1: a bucket's Adam slice + operand re-pack run behind its gradients (runtime/optim.py)
+        opt = FusedAdam(flat, lr=cfg["learning_rate"], in_backward=red)
+        repacker = net.range_repacker(flat)
+        opt.on_range.append(repacker)
+        opt.on_step.append(repacker.finish)
+    gamma = float(cfg["gamma"]) if cfg["gamma"] != "auto" else 0.99999
+    sched = ExponentialLR(opt, gamma=gamma)
     files = list_inputs(cfg["training_subjects"])
     val_files = list_inputs(cfg["validation_subjects"])
     per_rank = (len(files) + world - 1) // world

@@ -383,6 +383,62 @@ class PackSet:
             ent[1] = op._pack_version()
 
 
+class RangeRepacker:
+    """``FusedAdam(in_backward=...)`` callback pair: ``repacker(lo, hi)`` (``on_range``) re-packs the GEMM operands of every op whose parameter lies wholly
+    inside the ranges of the flat buffer stepped so far in this step -- on the stream the optimizer slice ran on, right behind it -- and ``finish()``
+    (``on_step``) covers the rest (ops whose parameters are not in the flat buffer) and closes the step.  One PackSet (device descriptor table) per group of
+    ops that becomes ready together: the buckets report in the same order every step, so the tables are built once."""
+
+    def __init__(self, flat, ops_fn):
+        self.flat, self.ops_fn = flat, ops_fn
+        self._ranges, self._done, self._sets = [], set(), {}
+
+    def _span(self, op):
+        base = self.flat.data.data_ptr()
+        a = (op.weight.data_ptr() - base) // 4
+        if a < 0 or a >= self.flat.numel:
+            return None
+        return a, a + op.weight.numel()
+
+    def _covered(self, span):
+        a, b = span
+        for lo, hi in sorted(self._ranges):
+            if lo > a:
+                return False
+            if hi > a:
+                a = hi
+                if a >= b:
+                    return True
+        return a >= b
+
+    def _repack(self, ops):
+        if not ops:
+            return
+        for op in ops:
+            op.invalidate()
+            self._done.add(id(op))
+        key = tuple(id(op) for op in ops)
+        ps = self._sets.get(key)
+        if ps is None:
+            ps = self._sets[key] = PackSet()
+        ps.repack(ops)
+
+    def __call__(self, lo: int, hi: int):
+        self._ranges.append((lo, hi))
+        ready = []
+        for op in self.ops_fn():
+            if id(op) in self._done:
+                continue
+            sp = self._span(op)
+            if sp is not None and self._covered(sp):
+                ready.append(op)
+        self._repack(ready)
+
+    def finish(self):
+        self._repack([op for op in self.ops_fn() if id(op) not in self._done])
+        self._ranges, self._done = [], set()
+
+
 def colsum_det(g: torch.Tensor, C: int, db: torch.Tensor):
     """db[c] += sum over all rows of g[..., c] in a fixed order (sa_colsum_det)."""
     lib = _ffi.lib()

@@ -338,10 +338,14 @@ class _GradCtx:
             # were queued on the main stream (bias / gate gradients) and on the weight-gradient stream, so report them from the latter after it has caught up
             self.side.side.wait_stream(self.side.main)
             with torch.cuda.stream(self.side.side):
+                if hasattr(self.sink, "flush"):
+                    self.sink.flush()     # optimizer slices deferred by EARLIER reports: everything that reads their parameters is queued (runtime/ddp.GradReducer.flush)
                 for p in params:
                     if p is not None:
                         self.sink.ready(p)
             return
+        if hasattr(self.sink, "flush"):
+            self.sink.flush()
         for p in params:
             if p is not None:
                 self.sink.ready(p)
@@ -1203,6 +1207,12 @@ class Performer(TransformerBase):
         if getattr(self, "_packset", None) is None:
             self._packset = PackSet()
         self._packset.repack([op for l in self._chain.layers for op in l.ops.values()] + [self._out_op])
+
+    def range_repacker(self, flat):
+        """For ``FusedAdam(in_backward=reducer)``: ``opt.on_range.append(r); opt.on_step.append(r.finish)`` INSTEAD of ``invalidate_packed_weights`` --
+        a layer's operands are re-packed right behind the optimizer slice of its bucket, in the shadow of the backward pass."""
+        from ...engine import RangeRepacker
+        return RangeRepacker(flat, lambda: [op for l in self._chain.layers for op in l.ops.values()] + [self._out_op])
 
     # ------------------------------------------------------------------------------------------------ sampling
     @torch.no_grad()

@@ -544,9 +544,13 @@ class _GradCtx:
             # DDP: the bucket's all-reduce waits for an event of the CURRENT stream; these gradients were queued on the main and on the weight-gradient stream
             self.side.side.wait_stream(self.side.main)
             with torch.cuda.stream(self.side.side):
+                if hasattr(self.sink, "flush"):
+                    self.sink.flush()     # optimizer slices deferred by EARLIER reports: everything that reads their parameters is queued (runtime/ddp.GradReducer.flush)
                 for p in params:
                     self.sink.ready(p)
             return
+        if hasattr(self.sink, "flush"):
+            self.sink.flush()
         for p in params:
             self.sink.ready(p)
 
@@ -775,6 +779,11 @@ class BaselineVQVAE(VQVAEBase, nn.Module):
         if getattr(self, "_packset", None) is None:
             self._packset = PackSet()
         self._packset.repack(self._enc_chain.ops() + self._dec_chain.ops())   # all packed operands again, in one launch
+
+    def range_repacker(self, flat):
+        """For ``FusedAdam(in_backward=reducer)`` (see networks/transformers/performer.Performer.range_repacker)."""
+        from ...engine import RangeRepacker
+        return RangeRepacker(flat, lambda: self._enc_chain.ops() + self._dec_chain.ops())
 
     # ---------------------------------------------------------------- accessors (baseline.py:301-327)
     def get_ema_decay(self) -> Sequence[float]:

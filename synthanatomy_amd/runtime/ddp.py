@@ -156,6 +156,12 @@ class GradReducer:
         self._side = None
         self._works = []
         self._lp = None          # bf16 transport: one staging buffer of the largest bucket's size (buckets are reduced one after the other on the side stream)
+        self.on_bucket = None    # optional callback(lo, hi, scale) run on the side stream after a bucket's gradients are final (reduced): the optimizer's
+                                 # slice for that range (runtime/optim.FusedAdam in_backward mode), so that nothing but the last bucket is serial after backward.
+                                 # It WRITES parameters and packed operands, which the data-gradient launches of the bucket's last layer still read -- and a chain
+                                 # reports a layer's parameters before it queues that layer's data gradient -- so the call is deferred to the next ready() /
+                                 # finish(): by then everything that reads the bucket's parameters has been queued, and the side stream waits for it
+        self._deferred = []
         self.timing = False      # bench.py: record HIP events around every bucket's collective and around the wait in finish()
         self._ev = []            # per finished step: (bucket (start, end) events on the side stream, main-stream arrival, side-stream end)
         self._bucket_ev = []
@@ -165,7 +171,7 @@ class GradReducer:
     def active(self) -> bool:
         """True when a reported bucket launches a collective (more than one rank, or the one-rank RCCL test mode): the backward chains ask this to
         decide from which stream a bucket's parameters are reported."""
-        return self.world > 1 or (dist.is_initialized() and debug.host("ddp_single_rank"))
+        return self.world > 1 or (dist.is_initialized() and debug.host("ddp_single_rank")) or self.on_bucket is not None
 
     def reset(self):
         self._pending = [hi - lo + 1 for (_, _, lo, hi) in self.buckets]
@@ -176,6 +182,30 @@ class GradReducer:
         if id(p) not in self.flat.index:
             return None
         return self.flat.grad_view(p)
+
+    def _flush_deferred(self):
+        if not self._deferred:
+            return
+        todo, self._deferred = self._deferred, []
+        cuda = self.flat.grad.is_cuda
+        if cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.flat.grad.device)
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                for lo, hi, scale in todo:
+                    self.on_bucket(lo, hi, scale)
+        else:
+            for lo, hi, scale in todo:
+                self.on_bucket(lo, hi, scale)
+
+    def flush(self):
+        """Called by a backward chain at the START of a layer's report (before its ready() calls): everything queued so far belongs to layers whose launches
+        are complete, so the optimizer slices deferred by earlier reports may go.  (A bucket boundary can fall between the weight and the bias of ONE layer:
+        flushing inside ready() would step that layer's weight before its data-gradient launch, which reads the packed weight, has been queued.)"""
+        self._flush_deferred()
 
     def ready(self, p: torch.nn.Parameter):
         i = self.flat.index.get(id(p))
@@ -210,11 +240,17 @@ class GradReducer:
         if buf is not view:
             view.copy_(buf)
 
+    def _collects(self) -> bool:
+        return self.world > 1 or (dist.is_initialized() and debug.host("ddp_single_rank"))
+
     def _launch(self, b: int):
         if not self.active:
             return
         lo, hi = self.buckets[b][0], self.buckets[b][1]
         view = self.flat.grad[lo:hi]
+        if not self._collects():          # one rank, optimizer in backward: no collective, only the bucket's (deferred) optimizer slice
+            self._deferred.append((lo, hi, 1.0))
+            return
         if view.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=view.device)
@@ -230,10 +266,14 @@ class GradReducer:
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record()
                     self._bucket_ev.append((e0, e1))
-        elif self.mode == "all_reduce" and self.transport == "fp32":
+            if self.on_bucket is not None:
+                self._deferred.append((lo, hi, 1.0 / self.world))
+        elif self.mode == "all_reduce" and self.transport == "fp32" and self.on_bucket is None:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self._collective(view)
+            if self.on_bucket is not None:
+                self._deferred.append((lo, hi, 1.0 / self.world))
 
     def finish(self) -> float:
         """Wait for every bucket (launching any bucket whose parameters never reported, e.g. unused ones) and return the
@@ -242,6 +282,7 @@ class GradReducer:
             if left > 0:
                 self._pending[b] = 0
                 self._launch(b)
+        self._flush_deferred()
         if self._side is not None:
             if self.timing and self._bucket_ev:
                 arrive = torch.cuda.Event(enable_timing=True)

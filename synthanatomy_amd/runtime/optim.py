@@ -54,20 +54,56 @@ class FlatParams:
 
 
 class FusedAdam:
-    """torch.optim.Adam semantics (no amsgrad) in one launch over the flat buffer."""
+    """torch.optim.Adam semantics (no amsgrad) in one launch over the flat buffer.
 
-    def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    ``in_backward=<GradReducer>`` ("optimizer in the shadow of the backward pass"): the reducer calls back as soon as a bucket's gradients are final (all
+    its weight-gradient kernels queued and, with several ranks, its collective done) and THAT range is stepped right there, on the reducer's side stream,
+    followed by the ``on_range`` callbacks (re-packing the GEMM operands of the layers in the range); ``step()`` then only covers what no bucket reported,
+    waits for the side stream and runs ``on_step``.  Same arithmetic per element as the one-launch step (Adam is element-wise), so parameters and moments
+    are bit-identical; only the last bucket's slice is still serial after backward (Performer: Adam 0.55 ms + re-pack 0.53 ms = 3.5 % of the step before)."""
+
+    def __init__(self, flat: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, in_backward=None):
         self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, lr, betas, eps, weight_decay
         self.m = torch.zeros_like(flat.data)
         self.v = torch.zeros_like(flat.data)
         self.step_count = 0
-        self.on_step = []  # callbacks, e.g. network.invalidate_packed_weights
+        self.on_step = []   # callbacks, e.g. network.invalidate_packed_weights
+        self.on_range = []  # in_backward mode: callbacks(lo, hi) after a range of the flat buffer was stepped (element offsets)
+        self._reducer = in_backward
+        self._stepped = []  # ranges stepped since the last step()
+        if in_backward is not None:
+            assert in_backward.flat is flat
+            in_backward.on_bucket = self._bucket_step
+
+    def _adam(self, lo: int, hi: int, grad_scale: float):
+        f = self.flat
+        _ffi.check(_ffi.lib().sa_adam(_ffi.ptr(f.data[lo:hi]), _ffi.ptr(f.grad[lo:hi]), _ffi.ptr(self.m[lo:hi]), _ffi.ptr(self.v[lo:hi]), hi - lo, self.lr,
+                                      self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale, _ffi.stream()), "sa_adam")
+
+    def _bucket_step(self, lo: int, hi: int, grad_scale: float):
+        if not self._stepped:
+            self.step_count += 1        # the first range of a step opens it (bias correction uses the step number)
+        self._adam(lo, hi, grad_scale)
+        self._stepped.append((lo, hi))
+        for cb in self.on_range:
+            cb(lo, hi)
 
     def step(self, grad_scale: float = 1.0):
-        self.step_count += 1
         f = self.flat
-        _ffi.check(_ffi.lib().sa_adam(_ffi.ptr(f.data), _ffi.ptr(f.grad), _ffi.ptr(self.m), _ffi.ptr(self.v), f.numel, self.lr, self.betas[0],
-                                      self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale, _ffi.stream()), "sa_adam")
+        if self._reducer is None:
+            self.step_count += 1
+            self._adam(0, f.numel, grad_scale)
+        else:
+            if not self._stepped:
+                self.step_count += 1
+            covered, pos = sorted(self._stepped), 0
+            for lo, hi in covered + [(f.numel, f.numel)]:      # whatever no bucket reported (normally nothing: GradReducer.finish() launches every bucket)
+                if lo > pos:
+                    self._adam(pos, lo, grad_scale)
+                    for cb in self.on_range:
+                        cb(pos, lo)
+                pos = max(pos, hi)
+            self._stepped = []
         for cb in self.on_step:
             cb()
 

@@ -6,7 +6,7 @@ from synthanatomy_amd import _ffi
 import bench, argparse
 lib = ctypes.CDLL(_ffi.LIB_PATH)
 buf = (ctypes.c_ulonglong * 24)()
-args = argparse.Namespace(dtype="bf16", performer_shape="10,14,10", performer_batch=6, warmup=2, steps=3, sampling=False, ddp_mode=None, grad_transport=None, no_kernel_timer=True)
+args = argparse.Namespace(dtype="bf16", performer_shape="10,14,10", performer_batch=6, warmup=2, steps=3, sampling=False, ddp_mode=None, grad_transport=None, no_kernel_timer=True, opt_in_backward=False)
 torch.zeros(1, device="cuda")
 lib.sa_debug_timing_favor(None, 1)
 res = bench.bench_performer(args, 0, 1, torch.device("cuda", 0))
