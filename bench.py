@@ -315,16 +315,20 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
 PMC_FILE = "r04_pmc_traffic.json"   # profiles/: HBM bytes per launch from the committed PMC passes (its `_provenance` names the command and commit)
 
 
+VQVAE_KERNEL_SOURCES = ("conv1.hip", "conv_fprop.hip", "conv_fprop_f16.hip", "conv_fprop_kernels.h", "conv_fprop_common.h", "conv_wgrad.hip", "convt1.hip",
+                        "elementwise.hip", "norm.hip", "vq.hip", "sa_common.h", "split_bf16.h")
+
+
 def csrc_digest():
-    """SHA-1 over the kernel sources (synthanatomy_amd/csrc/*.hip, *.h, in name order): `tools/rocpd_tools.py traffic` stores it next to the counters
-    it summarises, and `roofline.traffic` is only reported while the sources are the ones that were profiled."""
+    """SHA-1 over the sources of the kernels the VQ-VAE step launches (synthanatomy_amd/csrc/: VQVAE_KERNEL_SOURCES, in that order):
+    `tools/rocpd_tools.py traffic` stores it next to the counters it summarises, and `roofline.traffic` is only reported while the sources are the ones that
+    were profiled."""
     import hashlib
     d = os.path.join(ROOT, "synthanatomy_amd", "csrc")
     h = hashlib.sha1()
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            with open(os.path.join(d, f), "rb") as fh:
-                h.update(f.encode() + b"\0" + fh.read())
+    for f in VQVAE_KERNEL_SOURCES:
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()
 
 
