@@ -941,7 +941,7 @@ static int launch_fprop(const FpropArgs& a, hipStream_t st) {
                 return 0;
             }
         }
-        (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma_kernel<%s, %d, %d, %d, %d, %s, false>", tname<T>(), WM, WN, MI, NI, uniform ? "true" : "false"), note_kernel(g_last_conv_kernel));
+        (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma_kernel<%s, %d, %d, %d, %d, %s, false, 1>", tname<T>(), WM, WN, MI, NI, uniform ? "true" : "false"), note_kernel(g_last_conv_kernel));
         if (uniform) hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, true>), grid, dim3(WM * WN * 64), lds, st, b);
         else hipLaunchKernelGGL((conv_fprop_dma_kernel<T, WM, WN, MI, NI, false>), grid, dim3(WM * WN * 64), lds, st, b);
         SA_CHECK_LAUNCH();
@@ -1076,7 +1076,7 @@ static int launch_resblock(const FpropArgs& a, hipStream_t st) {
     if (halo256_eligible(a, 2) && !dbg(SA_DBG_NO_HALO256_FUSE)) return launch_fprop_halo256<T, true>(a, st);
     if (halo_eligible(a, 2)) return launch_fprop_halo<T, true>(a, st);
     const size_t pipe = 2 * (128 + 128) * 128, epi = (size_t)128 * (128 + 4) * 4 + 128 * 8;
-    (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma_kernel<%s, 2, 2, 4, 4, true, true>", tname<T>()), note_kernel(g_last_conv_kernel));
+    (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_dma_kernel<%s, 2, 2, 4, 4, true, true, 1>", tname<T>()), note_kernel(g_last_conv_kernel));
     hipLaunchKernelGGL((conv_fprop_dma_kernel<T, 2, 2, 4, 4, true, true>), dim3(a.nblk_m), dim3(256), pipe > epi ? pipe : epi, st, a);
     SA_CHECK_LAUNCH();
     return 0;
