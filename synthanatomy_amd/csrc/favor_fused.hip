@@ -477,6 +477,130 @@ __device__ __forceinline__ void favor_fstate_body(const FusedArgs& s, const int 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ chunk states, sequential form (round 4)
+// The chunk-state launch above leaves U_c per chunk and a second launch (favor_fprefix_kernel) turns them into exclusive prefixes: 74 MB written, 148 MB through the
+// prefix pass and 1 056 blocks that each stage the whole projection matrix.  Here a block owns ONE 64-feature slab of one (batch, head) and walks the chunks
+// in scan order with the running sum in its accumulators: before chunk c's contribution is added the accumulators ARE the exclusive prefix of chunk c and are
+// stored as such -- no prefix launch, one projection slab per block, the next chunk's rows fetched while the current one is multiplied.  B G ceil(m / 64)
+// blocks (240 at the README shape); what the consumers read (state[b, g, chunk]) keeps its layout.
+struct FSeqStep {
+    u32x4 xv[4], vv[4];
+    float off, sc[4], wv;
+};
+__device__ __forceinline__ void fseq_load(FSeqStep& r, const FusedArgs& s, int b, int g, int c, int tid, int w, int fr, int g4, float kmax,
+                                          __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t ro, __amdgpu_buffer_rsrc_t rv, __amdgpu_buffer_rsrc_t rsc,
+                                          __amdgpu_buffer_rsrc_t rex) {
+    const int ri = f_row(s, c * 64 + w * 16 + fr);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        r.xv[2 * ks] = f_ld4(rx, (uint32_t)(ri * s.stride + g * 64 + ks * 32 + g4 * 8) * 4u);
+        r.xv[2 * ks + 1] = f_ld4(rx, (uint32_t)(ri * s.stride + g * 64 + ks * 32 + g4 * 8 + 4) * 4u);
+    }
+    r.off = f_ld1(ro, (uint32_t)(ri * s.G + g) * 4u) + (s.fa.use_kmax ? kmax : 0.f);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = f_row(s, c * 64 + (tid >> 4) + 16 * it);
+        r.vv[it] = f_ld4(rv, (uint32_t)(i * s.b_stride + g * 64 + (tid & 15) * 4) * 4u);
+        r.sc[it] = s.b_scale ? f_ld1(rsc, (uint32_t)(i * s.G + g) * 4u) : 1.f;
+    }
+    const int pj = c * 64 + (tid & 63);
+    r.wv = pj < s.N ? 1.f : 0.f;
+    if (s.zmode == 2) r.wv = f_ld1(rex, (uint32_t)(f_row(s, pj) * s.G + g) * 4u);   // (rows outside [0, N) read as zero)
+}
+
+__device__ __forceinline__ void favor_fstate_seq_body(const FusedArgs& s, const int bid, unsigned char* const lds) {
+    unsigned char* const sBh = lds, * const sBl = lds + FT_BYTES, * const sAh = lds + 2 * FT_BYTES, * const sAl = lds + 3 * FT_BYTES;
+    unsigned char* const sPh = lds + 4 * FT_BYTES, * const sPl = lds + 5 * FT_BYTES;
+    float* const sW = (float*)(lds + 6 * FT_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
+    const int nslab = (s.LDF + FSLAB - 1) / FSLAB;
+    const int sl = bid % nslab, g = (bid / nslab) % s.G, b = bid / (nslab * s.G);
+    const int slab0 = sl * FSLAB, nf = slab_frags(s, slab0);
+    const float kmax = unpack_max(*s.gmax);
+    const __amdgpu_buffer_rsrc_t rx = f_rsrc(s.fa.x + (int64_t)b * s.N * s.stride, (int64_t)s.N * s.stride * 4);
+    const __amdgpu_buffer_rsrc_t ro = f_rsrc(s.fa.rowoff + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G * 4);
+    const __amdgpu_buffer_rsrc_t rv = f_rsrc(s.b + (int64_t)b * s.N * s.b_stride, (int64_t)s.N * s.b_stride * 4);
+    const __amdgpu_buffer_rsrc_t rsc = f_rsrc((s.b_scale ? s.b_scale : s.b) + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G * 4);
+    const __amdgpu_buffer_rsrc_t rex = f_rsrc((s.zmode == 2 ? s.ex_scale : s.b) + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G * 4);
+    FSeqStep nxt;
+    fseq_load(nxt, s, b, g, 0, tid, w, fr, g4, kmax, rx, ro, rv, rsc, rex);
+    {
+        PSlabRegs pre;
+        pslab_load(pre, s.ptiles, sl, tid);
+        pslab_store(sPh, pre, tid);     // (hi tile | lo tile, contiguous)
+    }
+    float4_t acc[4], accz = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    const uint32_t trow = (uint32_t)g4 * 4u + ((uint32_t)fr >> 2), tcol = (uint32_t)(fr & 3) * 4u;
+    const int64_t zs = (int64_t)s.LDF * 64 + s.LDF;
+    float* const st0 = s.state + (((int64_t)b * s.G + g) * s.S) * zs;
+    for (int c = 0; c < s.S; ++c) {
+        const FSeqStep cur = nxt;
+        if (c + 1 < s.S) fseq_load(nxt, s, b, g, c + 1, tid, w, fr, g4, kmax, rx, ro, rv, rsc, rex);
+        // the running sums before this chunk = its exclusive prefix
+        float* const st = st0 + (int64_t)c * zs;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            if (f >= nf) break;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[(slab0 + f * 16 + g4 * 4 + r) * 64 + w * 16 + fr] = acc[f][r];
+        }
+        if (s.zmode && fr == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = slab0 + w * 16 + g4 * 4 + r;
+                if (m < s.LDF) st[(int64_t)s.LDF * 64 + m] = accz[r];
+            }
+        }
+        // this chunk's operands: key / query rows -> MFMA operand, value rows (times their scale) -> hi / lo tile, weights of the running sums
+        XOperand xa;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float xs[8] = {__uint_as_float(cur.xv[2 * ks][0]), __uint_as_float(cur.xv[2 * ks][1]), __uint_as_float(cur.xv[2 * ks][2]), __uint_as_float(cur.xv[2 * ks][3]),
+                                 __uint_as_float(cur.xv[2 * ks + 1][0]), __uint_as_float(cur.xv[2 * ks + 1][1]), __uint_as_float(cur.xv[2 * ks + 1][2]),
+                                 __uint_as_float(cur.xv[2 * ks + 1][3])};
+            split8(xs, xa.h[ks], xa.l[ks]);
+        }
+        xa.off = cur.off;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const uint32_t o = lroff((tid >> 4) + 16 * it, (tid & 15) * 4);
+            uint2 h, l;
+            split_pair(__uint_as_float(cur.vv[it][0]) * cur.sc[it], __uint_as_float(cur.vv[it][1]) * cur.sc[it], h.x, l.x);
+            split_pair(__uint_as_float(cur.vv[it][2]) * cur.sc[it], __uint_as_float(cur.vv[it][3]) * cur.sc[it], h.y, l.y);
+            *(uint2*)(sBh + o) = h;
+            *(uint2*)(sBl + o) = l;
+        }
+        if (tid < 64) sW[tid] = cur.wv;
+        const bool valid = c * 64 + w * 16 + fr < s.N;
+        float4_t F[4];
+        feat_slab(F, sPh, sPl, xa, valid, slab0, s, fr, g4);
+        feat_to_tile(sAh, sAl, F, w, fr, g4);
+        __syncthreads();
+        short8_t bh[2], bl[2], wh[2], wl[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint32_t o0 = lroff(ks * 32 + trow, w * 16 + tcol), o1 = lroff(ks * 32 + 16 + trow, w * 16 + tcol);
+            bh[ks] = f_tr_operand(sBh, o0, o1);
+            bl[ks] = f_tr_operand(sBl, o0, o1);
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = fr == 0 ? sW[ks * 32 + (e >> 2) * 16 + g4 * 4 + (e & 3)] : 0.f;
+            split8(x, wh[ks], wl[ks]);
+        }
+        tile_cols_gemm(acc, sAh, sAl, bh, bl, lane, 2, nf);      // acc[f][r] += sum_j phi(j)[slab0 + f*16 + g4*4 + r] b_j[w*16 + fr]
+        if (s.zmode) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint32_t o0 = lroff(ks * 32 + trow, w * 16 + tcol), o1 = lroff(ks * 32 + 16 + trow, w * 16 + tcol);
+                accz = mfma3(f_tr_operand(sAh, o0, o1), f_tr_operand(sAl, o0, o1), wh[ks], wl[ks], accz);
+            }
+        }
+        __syncthreads();   // the next chunk overwrites the feature / value tiles
+    }
+}
+
 // state[b, g, chunk] <- sum of the states of the chunks before it (exclusive prefix), four elements per thread.  Loads go out in batches of eight
 // before the dependent stores (the array aliases itself, so the compiler would otherwise keep every load behind the previous store: S round trips).
 __global__ void favor_fprefix_kernel(float* __restrict__ state, int64_t BG, int S, int64_t elems4) {
@@ -793,6 +917,10 @@ __global__ __launch_bounds__(256, 2) void favor_fstate_kernel(const FusedArgs s)
     __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
     favor_fstate_body(s, (int)blockIdx.x, lds);
 }
+__global__ __launch_bounds__(256, 2) void favor_fstate_seq_kernel(const FusedArgs s) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
+    favor_fstate_seq_body(s, (int)blockIdx.x, lds);
+}
 __global__ __launch_bounds__(256, FUSED_WPS) void favor_fout_a_kernel(const FusedArgs s) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
     favor_fout_a_body(s, (int)blockIdx.x, lds);
@@ -829,6 +957,24 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fpair_b_state_la_kernel(
     if ((int)blockIdx.x < nb) favor_fout_b_body(sb, (int)blockIdx.x, lds);
     else if ((int)blockIdx.x < 2 * nb) favor_fstate_body(ss, (int)blockIdx.x - nb, lds);
     else local_attn_q_split_body<1>(la, (int)blockIdx.x - 2 * nb, lds);
+}
+// with the sequential chunk states (favor_fstate_seq_body: B G ceil(m / 64) long-running blocks): they come FIRST in the grid so that they start at once and the
+// short blocks of the other bodies fill the slots beside them
+__global__ __launch_bounds__(256, FUSED_WPS) void favor_fseq_la_kernel(const FusedArgs ss, const LAArgs la, const int nst) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
+    if ((int)blockIdx.x < nst) favor_fstate_seq_body(ss, (int)blockIdx.x, lds);
+    else local_attn_q_split_body<0>(la, (int)blockIdx.x - nst, lds);
+}
+__global__ __launch_bounds__(256, FUSED_WPS) void favor_fpair_seq_b_kernel(const FusedArgs ss, const FusedArgs sb, const int nst, const int nb) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
+    if ((int)blockIdx.x < nst) favor_fstate_seq_body(ss, (int)blockIdx.x, lds);
+    else favor_fout_b_body(sb, (int)blockIdx.x - nst, lds);
+}
+__global__ __launch_bounds__(256, FUSED_WPS) void favor_fpair_seq_b_la_kernel(const FusedArgs ss, const FusedArgs sb, const LAArgs la, const int nst, const int nb) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
+    if ((int)blockIdx.x < nst) favor_fstate_seq_body(ss, (int)blockIdx.x, lds);
+    else if ((int)blockIdx.x < nst + nb) favor_fout_b_body(sb, (int)blockIdx.x - nst, lds);
+    else local_attn_q_split_body<1>(la, (int)blockIdx.x - nst - nb, lds);
 }
 __global__ __launch_bounds__(256, FUSED_WPS) void favor_fpair_b_a_la_kernel(const FusedArgs sb, const FusedArgs sa, const LAArgs la, const int nb) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
@@ -988,6 +1134,8 @@ static void fused_common(FusedArgs& s, const void* tiles, const float* ps, const
     const float c = powf(64.f, -0.25f);
     s.ratio = 1.f / sqrtf((float)m); s.reps = s.ratio * 1e-4f; s.c2 = c * c;
 }
+// SA_PP_DBG bit 11 keeps the parallel chunk-state launch + prefix launch (A/B runs; the two forms differ in the association of the fp32 sums only)
+static inline bool fused_seq_states() { return !(g_tunables.pp_dbg & 2048u); }
 static int fused_prefix(float* state, int B, int G, int S, int LDF, hipStream_t st) {
     const int64_t bg = (int64_t)B * G, e4 = ((int64_t)LDF * 65) / 4;   // LDF % 16 == 0
     SA_LAUNCH(favor_fprefix_kernel, dim3((unsigned)((bg * e4 + 255) / 256)), dim3(256), 0, st, state, bg, S, e4);
@@ -1016,6 +1164,16 @@ extern "C" int sa_favor_fused_fwd(const float* q, const float* k, const float* v
     s.b = v; s.b_stride = stride; s.state = state; s.zmode = 1; s.den_eps = den_eps; s.inv_out = inv_out; s.y = attn; s.y_stride = attn_stride;
     s.y_lp = (unsigned short*)attn_lp;
     const unsigned nblk = (unsigned)((int64_t)B * G * s.S);
+    if (fused_seq_states()) {
+        // sequential chunk states (exclusive prefixes written directly: no prefix launch), the local-window heads' forward beside them; then scan A
+        const unsigned nst = (unsigned)((int64_t)B * G * ((s.LDF + FSLAB - 1) / FSLAB));
+        if (la) SA_LAUNCH(favor_fseq_la_kernel, dim3(nst + nla), dim3(256), 0, st, s, laa, (int)nst);
+        else SA_LAUNCH(favor_fstate_seq_kernel, dim3(nst), dim3(256), 0, st, s);
+        SA_CHECK_LAUNCH();
+        SA_LAUNCH(favor_fout_a_kernel, dim3(nblk), dim3(256), 0, st, s);
+        SA_CHECK_LAUNCH();
+        return 0;
+    }
     SA_LAUNCH(favor_fstate_kernel, dim3(nblk), dim3(256), 0, st, s);
     SA_CHECK_LAUNCH();
     if (int rc = fused_prefix(state, B, G, s.S, s.LDF, st)) return rc;
@@ -1062,12 +1220,19 @@ extern "C" int sa_favor_fused_bwd(const float* q, const float* k, const float* v
     // Independent launches share a grid (favor_fpair_*): [scan B for dq | reversed chunk states] when the forward's states were kept, and [scan B for dk | scan A for dv].
     // SA_PP_DBG bit 9 keeps the five separate launches (A/B runs; results are bit-identical either way).
     const bool pair = !(g_tunables.pp_dbg & 512u);
+    const bool seq = fused_seq_states();
+    const unsigned nst = (unsigned)((int64_t)B * G * ((s.LDF + FSLAB - 1) / FSLAB));
     if (state_fwd) s.state = (float*)state_fwd;
     else {
         s.state = state_ws;
-        SA_LAUNCH(favor_fstate_kernel, dim3(nblk), dim3(256), 0, st, s);
-        SA_CHECK_LAUNCH();
-        if (int rc = fused_prefix(state_ws, B, G, s.S, s.LDF, st)) return rc;
+        if (seq) {
+            SA_LAUNCH(favor_fstate_seq_kernel, dim3(nst), dim3(256), 0, st, s);
+            SA_CHECK_LAUNCH();
+        } else {
+            SA_LAUNCH(favor_fstate_kernel, dim3(nblk), dim3(256), 0, st, s);
+            SA_CHECK_LAUNCH();
+            if (int rc = fused_prefix(state_ws, B, G, s.S, s.LDF, st)) return rc;
+        }
     }
     const FusedArgs sq = s;
     // ---- d loss / d k and d loss / d v: reversed scans over i >= j of phi_q(i) (x) (dattn_i inv_i), running sums weighted by d den_i
@@ -1078,17 +1243,25 @@ extern "C" int sa_favor_fused_bwd(const float* q, const float* k, const float* v
     s.zmode = 2; s.ex_const = 0.f; s.reverse = 1; s.is_query = 0; s.amx = nullptr; s.dx = dk; s.state = state_ws;
     s.dx_lp = (unsigned short*)dk_lp;
     const FusedArgs sk = s;
-    if (pair && state_fwd) {
-        if (la) SA_LAUNCH(favor_fpair_b_state_la_kernel, dim3(2 * nblk + nla), dim3(256), 0, st, sq, sk, laa, (int)nblk);
-        else SA_LAUNCH(favor_fpair_b_state_kernel, dim3(2 * nblk), dim3(256), 0, st, sq, sk, (int)nblk);
+    if (pair && state_fwd && seq) {   // [reversed chunk states, sequential | scan B for dq | local dq]: the states leave as exclusive prefixes, no prefix launch
+        if (la) SA_LAUNCH(favor_fpair_seq_b_la_kernel, dim3(nst + nblk + nla), dim3(256), 0, st, sk, sq, laa, (int)nst, (int)nblk);
+        else SA_LAUNCH(favor_fpair_seq_b_kernel, dim3(nst + nblk), dim3(256), 0, st, sk, sq, (int)nst, (int)nblk);
         SA_CHECK_LAUNCH();
     } else {
-        SA_LAUNCH(favor_fout_b_kernel, dim3(nblk), dim3(256), 0, st, sq);
-        SA_CHECK_LAUNCH();
-        SA_LAUNCH(favor_fstate_kernel, dim3(nblk), dim3(256), 0, st, sk);
-        SA_CHECK_LAUNCH();
+        if (pair && state_fwd) {
+            if (la) SA_LAUNCH(favor_fpair_b_state_la_kernel, dim3(2 * nblk + nla), dim3(256), 0, st, sq, sk, laa, (int)nblk);
+            else SA_LAUNCH(favor_fpair_b_state_kernel, dim3(2 * nblk), dim3(256), 0, st, sq, sk, (int)nblk);
+            SA_CHECK_LAUNCH();
+        } else {
+            SA_LAUNCH(favor_fout_b_kernel, dim3(nblk), dim3(256), 0, st, sq);
+            SA_CHECK_LAUNCH();
+            if (seq) SA_LAUNCH(favor_fstate_seq_kernel, dim3(nst), dim3(256), 0, st, sk);
+            else SA_LAUNCH(favor_fstate_kernel, dim3(nblk), dim3(256), 0, st, sk);
+            SA_CHECK_LAUNCH();
+        }
+        if (!(seq && !(pair && state_fwd)))
+            if (int rc = fused_prefix(state_ws, B, G, s.S, s.LDF, st)) return rc;
     }
-    if (int rc = fused_prefix(state_ws, B, G, s.S, s.LDF, st)) return rc;
     // dv_j[d] = sum_m phi_k(j)[m] R_j[m][d]: scan A on the same states (a = phi_q, b = dattn inv, reversed), per-position map phi_k, no normaliser
     s.zmode = 0; s.y = dv; s.y_stride = stride; s.inv_out = nullptr; s.accumulate = 0;
     s.y_lp = (unsigned short*)dv_lp;

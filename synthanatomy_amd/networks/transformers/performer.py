@@ -28,7 +28,7 @@ from ..._ffi import MASK_GELU
 from ... import engine as _engine
 from ...engine import ConvOp, PackSet
 from .img2seq_ordering import Ordering
-from .transformer import TransformerBase
+from .transformer import TransformerBase, sequence_to_grid
 
 
 class TransformerConditioningType(Enum):  # src/utils/transformer.py:21-24
@@ -1327,10 +1327,7 @@ class Performer(TransformerBase):
                 graph.replay()
             else:
                 one_step()
-        x = seq[:, P:]
-        x = x[:, self.ordering.get_revert_sequence_ordering()]
-        x = x.reshape(x.shape[0], *self.ordering.dimensions)
-        return torch.squeeze(x, 1)
+        return sequence_to_grid(seq, P, self.ordering)
 
     # ------------------------------------------------------------------------------------------------
     def _position_indices(self, n, dev):

@@ -161,7 +161,7 @@ def test_bf16_engine_follows_oracle_at_production_width(case):
     # FAVOR+ with the feature maps recomputed on chip (csrc/favor_fused.hip), flash-style local attention, bf16 dense layers
     # (backward: the independent chunk kernels share launches -- [scan B dq | reversed states], [scan B dk | scan A dv])
     #  and the local-window heads' split-bf16 blocks ride in the FAVOR+ launches: the *_la_kernel instances)
-    for need in ("favor_prepass_kernel", "favor_fstate_kernel", "favor_fout_a_la_kernel", "favor_fpair_b_state_la_kernel", "favor_fpair_b_a_la_kernel",
+    for need in ("favor_prepass_kernel", "favor_fseq_la_kernel", "favor_fout_a_kernel", "favor_fpair_seq_b_la_kernel", "favor_fpair_b_a_la_kernel",
                  "conv_fprop_dma_kernel<unsigned short"):
         assert need in joined, (need, names)
     for gone in ("favor_project_fwd_kernel", "favor_feat_fwd_kernel", "favor_feat_proj_bwd_kernel", "favor_chunk_out_b_split_kernel"):
