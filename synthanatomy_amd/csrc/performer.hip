@@ -1409,6 +1409,100 @@ __global__ void embed_step_kernel(const EmbedArgs a, const int* __restrict__ pos
     }
 }
 
+// ---- decode step, the decision for ALL rows in one launch (networks/transformers/transformer.choose_next without top-k + the sequence update of Performer._sample_stateful):
+// logits / temperature -> softmax -> categorical draw by inverse CDF with the caller's uniform u[b] (same rule as the torch expression it replaces:
+// index = #{v : cdf[v] < u * cdf[V - 1]}, clamped) or arg-max (lowest index on ties); position pos + 1 receives the token unless it belongs to the given prefix;
+// tok[b] = the token the NEXT step embeds; *pos += 1.  One block walks the rows (B is a handful): ~20 small torch launches per token -> 1.
+__global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restrict__ logits, int B, int V, float inv_temp, const float* __restrict__ u, int do_sample,
+                                                         int64_t* __restrict__ seq, int total, int P, int* __restrict__ pos, int64_t* __restrict__ tok) {
+    __shared__ float sred[16];
+    __shared__ int sidx[16];
+    __shared__ float sscan[16];
+    __shared__ int sfound;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int p = *pos;
+    const int ept = (V + 1023) / 1024;                 // elements per thread, contiguous: thread t owns [t * ept, (t + 1) * ept)
+    for (int b = 0; b < B; ++b) {
+        const float* lr = logits + (int64_t)b * V;
+        // row maximum (and its lowest index)
+        float mx = -INFINITY;
+        int am = 0x7fffffff;
+        for (int e = 0; e < ept; ++e) {
+            const int v = tid * ept + e;
+            if (v < V) {
+                const float x = lr[v] * inv_temp;
+                if (x > mx) { mx = x; am = v; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float om = __shfl_xor(mx, o, 64);
+            const int oa = __shfl_xor(am, o, 64);
+            const bool t0 = (om > mx) | ((om == mx) & (oa < am));
+            mx = t0 ? om : mx;
+            am = t0 ? oa : am;
+        }
+        if (lane == 0) { sred[wv] = mx; sidx[wv] = am; }
+        __syncthreads();
+        mx = sred[0];
+        am = sidx[0];
+        for (int w = 1; w < 16; ++w) {
+            const bool t0 = (sred[w] > mx) | ((sred[w] == mx) & (sidx[w] < am));
+            mx = t0 ? sred[w] : mx;
+            am = t0 ? sidx[w] : am;
+        }
+        int ix = am;
+        if (do_sample) {
+            // exclusive prefix of exp(x - max) in index order: per-thread sums -> wave scan -> scan of the 16 wave totals
+            float loc = 0.f;
+            for (int e = 0; e < ept; ++e) {
+                const int v = tid * ept + e;
+                if (v < V) loc += __expf(lr[v] * inv_temp - mx);
+            }
+            float inc = loc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float t = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += t;
+            }
+            __syncthreads();               // (sred / sidx of the maximum have been read by everyone)
+            if (lane == 63) sscan[wv] = inc;
+            if (tid == 0) sfound = V - 1;  // the clamp of the torch expression
+            __syncthreads();
+            float wbase = 0.f, tot = 0.f;
+            for (int w = 0; w < 16; ++w) {
+                if (w < wv) wbase += sscan[w];
+                tot += sscan[w];
+            }
+            const float target = u[b] * tot;
+            float run = wbase + inc - loc;  // cdf before this thread's first element
+            // the number of elements with cdf < target = the first index whose inclusive cdf reaches the target
+            if (run < target && run + loc >= target) {
+                int hit = V - 1;
+                for (int e = 0; e < ept; ++e) {
+                    const int v = tid * ept + e;
+                    if (v < V) {
+                        run += __expf(lr[v] * inv_temp - mx);
+                        if (run >= target) { hit = v; break; }
+                    }
+                }
+                atomicMin(&sfound, hit);
+            }
+            __syncthreads();
+            ix = sfound;
+        }
+        if (tid == 0) {
+            const int np = p + 1;
+            if (np < total) {
+                if (np >= P) seq[(int64_t)b * total + np] = ix;
+                tok[b] = seq[(int64_t)b * total + np];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *pos = p + 1;
+}
+
 // Phase A of a global-head step, one block per (batch, head): projections dd[m] = x . P[m] (P carries the data normaliser) of the new
 // query and key into scratch, and the maximum of the key projections into the step's slot of the double-buffered atomic maximum
 // (order-preserving integer encoding of the float).
@@ -2220,6 +2314,14 @@ extern "C" int sa_embed_step(int ntab, const float* const* tables, const int64_t
         a.per_position[t] = per_position[t];
     }
     SA_LAUNCH(embed_step_kernel, dim3(grid1d((int64_t)B * dim)), dim3(256), 0, ST(stream), a, pos, B, out);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_sample_step(const float* logits, int B, int V, float temperature, const float* u, int do_sample, int64_t* seq, int total, int P, int* pos,
+                              int64_t* tok, void* stream) {
+    if (!logits || !seq || !pos || !tok || (do_sample && !u) || B <= 0 || V <= 0 || total <= 0 || !(temperature > 0.f)) return SA_EINVAL;
+    SA_LAUNCH(sample_step_kernel, dim3(1), dim3(1024), 0, ST(stream), logits, B, V, 1.f / temperature, u, do_sample, seq, total, P, pos, tok);
     SA_CHECK_LAUNCH();
     return 0;
 }

@@ -22,6 +22,7 @@ _HOST_ENV = dict(no_fused_res="SA_NO_FUSED_RES", no_fused_1x1_bwd="SA_NO_FUSED_1
                  no_fused_sums="SA_NO_FUSED_SUMS", no_fused_qkv="SA_NO_FUSED_QKV", no_fused_favor="SA_NO_FUSED_FAVOR", no_convt1_fused_bwd="SA_NO_CONVT1_FUSED_BWD", no_fused_epilogues="SA_NO_FUSED_EPILOGUES", no_convt1_fused_fwd="SA_NO_CONVT1_FUSED_FWD", no_lp_mirrors="SA_NO_LP_MIRRORS", no_decode_bf16_weights="SA_NO_DECODE_BF16_WEIGHTS", no_attn_step_merge="SA_NO_ATTN_STEP_MERGE", no_attn_colaunch="SA_NO_ATTN_COLAUNCH", no_side_wgrad="SA_NO_SIDE_WGRAD", side_wgrad_vqvae="SA_SIDE_WGRAD_VQVAE",
                  ddp_single_rank="SA_DDP_SINGLE_RANK",   # collectives issued on a ONE-rank process group too (RCCL on a one-GPU box: tests/test_rccl_single_rank_gpu.py)
                  no_f16_forward="SA_NO_F16_FORWARD",     # VQ-VAE encoder forward on bf16 operands like the rest (default in throughput mode: float16, the reference's AMP dtype)
+                 no_sample_step="SA_NO_SAMPLE_STEP",     # stateful sampler: the decision + sequence update as torch ops instead of sa_sample_step (A/B, equality test)
                  opt_in_backward="SA_OPT_IN_BACKWARD",   # CLIs: FusedAdam(in_backward=reducer) -- per-bucket optimizer slices + re-packs behind the gradients (measured slower on one GPU)
                  share_device="SA_SHARE_DEVICE",         # test aid: every rank on cuda:0 over gloo (RCCL refuses two ranks per device) -- the N > 1 code path of the CLIs on a one-GPU box
                  keep_ipc_mode="SA_KEEP_IPC_MODE")       # do NOT default HSA_ENABLE_IPC_MODE_LEGACY=0 (runtime/ddp.ipc_mode_default; hosts whose driver wants legacy IPC)

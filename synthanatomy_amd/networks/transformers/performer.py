@@ -1267,10 +1267,14 @@ class Performer(TransformerBase):
         for l in layers:
             l.__dict__.pop("_dec_w", None)     # bf16 decode copies of the parameters: rebuilt from the current values by the warm-up step
         col = torch.arange(total, device=dev)[None, :]
+        tok.copy_(seq0[:, 0])
+
+        fused_tail = top_k is None and not debug.host("no_sample_step")     # one launch for the decision + sequence update (sa_sample_step)
 
         def one_step():
-            p64 = pos.to(torch.int64)
-            tok.copy_(seq.gather(1, p64.expand(B, 1)).squeeze(1))
+            if not fused_tail:
+                p64 = pos.to(torch.int64)
+                tok.copy_(seq.gather(1, p64.expand(B, 1)).squeeze(1))
             x = torch.empty(B, dim, dtype=torch.float32, device=dev)
             _ck(lib.sa_embed_step(n, tp, ip, pp, dim, _ffi.ptr(pos), B, _ffi.ptr(x), _ffi.stream()), "sa_embed_step")
             for l, stt in zip(layers, states):
@@ -1278,8 +1282,16 @@ class Performer(TransformerBase):
             h = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
             logits = torch.empty(B, self.to_out.weight.shape[0], dtype=torch.float32, device=dev)
             layers[0]._gemv(h, [self.to_out], logits)
+            if fused_tail:
+                # temperature, softmax, the draw (inverse CDF on a captured torch.rand -- torch.multinomial cannot be captured in a HIP graph) or arg-max,
+                # seq[:, pos + 1] (unless it belongs to the given prefix), the next step's token, pos += 1: one launch instead of ~20 small torch kernels
+                u = torch.rand(B, device=dev, dtype=torch.float32) if sample else None
+                _ck(lib.sa_sample_step(_ffi.ptr(logits), B, logits.shape[1], float(temperature), _ffi.ptr(u), int(bool(sample)), _ffi.ptr(seq), total, P,
+                                       _ffi.ptr(pos), _ffi.ptr(tok), _ffi.stream()), "sa_sample_step")
+                return
             logits = logits / temperature
-            if top_k is not None:   # transformer.py:11-17 (_top_k_logits) without the boolean-mask assignment, which cannot be captured
+            # transformer.py:11-17 (_top_k_logits) without the boolean-mask assignment, which cannot be captured
+            if top_k is not None:
                 kth = torch.topk(logits, top_k)[0][:, -1:]
                 logits = torch.where(logits < kth, torch.full_like(logits, float("-inf")), logits)
             probs = torch.softmax(logits, dim=-1)
@@ -1309,6 +1321,7 @@ class Performer(TransformerBase):
                     l.reset_state(stt)
                 pos.zero_()
                 seq.copy_(seq0)
+                tok.copy_(seq0[:, 0])
                 graph = torch.cuda.CUDAGraph()
                 # thread_local: other threads of the process (the RCCL watchdog of a distributed run) may call HIP during the capture
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
@@ -1322,6 +1335,7 @@ class Performer(TransformerBase):
                     l.reset_state(stt)
                 pos.zero_()
                 seq.copy_(seq0)
+                tok.copy_(seq0[:, 0])
         for _ in range(npos):
             if graph is not None:
                 graph.replay()

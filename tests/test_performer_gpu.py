@@ -585,8 +585,51 @@ def test_stateful_sampler_equals_the_quadratic_loop(rezero, shape, window, local
     ref = x[:, 1:][:, o.get_revert_sequence_ordering()].reshape(3, *shape)
     assert torch.equal(fast.cpu(), ref)
     # stochastic path runs and stays in range
-    smp = net.sample(prefix, sample=True, top_k=5, temperature=0.9)
+    smp = net.sample(prefix, sample=True, top_k=5, temperature=0.9)       # top-k: the torch expressions
     assert int(smp.min()) >= 0 and int(smp.max()) <= 18
+    smp = net.sample(prefix, sample=True, temperature=0.9)                # no top-k: sa_sample_step
+    assert int(smp.min()) >= 0 and int(smp.max()) <= 18
+    from synthanatomy_amd import debug
+    with debug.override(no_sample_step=True):                            # the same greedy chain with the decision made by torch ops
+        assert torch.equal(net.sample(prefix, sample=False, use_graph=use_graph), quad)
+
+
+@pytest.mark.parametrize("B,V,P_,temperature", [(6, 2049, 1, 1.0), (3, 19, 2, 0.7), (17, 1000, 1, 1.3)])
+def test_sample_step_kernel_matches_the_torch_decision(B, V, P_, temperature):
+    """sa_sample_step (one launch per token: temperature, softmax, inverse-CDF draw with the caller's uniforms or arg-max, sequence update, next token, pos += 1)
+    against the torch expressions of the stateful sampler it replaces, position by position."""
+    from synthanatomy_amd import _ffi
+    lib = _ffi.lib()
+    g = torch.Generator().manual_seed(B + V)
+    total = 9
+    mism = 0
+    for do_sample in (0, 1):
+        seq = torch.randint(0, V, (B, total), generator=g).cuda()
+        seq_t = seq.clone()
+        pos = torch.zeros(1, dtype=torch.int32, device="cuda")
+        tok = torch.zeros(B, dtype=torch.int64, device="cuda")
+        for step in range(total - 1):
+            logits = (torch.randn(B, V, generator=g) * 3).cuda()
+            u = torch.rand(B, generator=g).cuda()
+            _ffi.check(lib.sa_sample_step(_ffi.ptr(logits), B, V, float(temperature), _ffi.ptr(u), do_sample, _ffi.ptr(seq), total, P_, _ffi.ptr(pos), _ffi.ptr(tok),
+                                          _ffi.stream()), "sa_sample_step")
+            probs = torch.softmax(logits / temperature, dim=-1)
+            if do_sample:
+                cdf = probs.cumsum(-1)
+                ix = (cdf < u[:, None] * cdf[:, -1:]).sum(-1).clamp(max=V - 1)
+            else:
+                ix = probs.argmax(-1)
+            if step + 1 >= P_:
+                seq_t[:, step + 1] = ix
+            torch.cuda.synchronize()
+            assert int(pos) == step + 1
+            assert torch.equal(tok, seq[:, step + 1])
+            if do_sample:      # a cdf value within rounding of the target may fall on either side: count, then continue from the kernel's choice
+                mism += int((seq[:, step + 1] != seq_t[:, step + 1]).sum())
+                seq_t[:, step + 1] = seq[:, step + 1]
+            else:
+                assert torch.equal(seq, seq_t), step
+    assert mism <= 1, mism
 
 
 @pytest.mark.parametrize("N,W", [(23, 5), (100, 420), (150, 64), (200, 70), (321, 128), (1400, 420), (1000, 420)])
