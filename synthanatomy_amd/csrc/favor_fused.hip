@@ -1135,7 +1135,11 @@ static void fused_common(FusedArgs& s, const void* tiles, const float* ps, const
     s.ratio = 1.f / sqrtf((float)m); s.reps = s.ratio * 1e-4f; s.c2 = c * c;
 }
 // SA_PP_DBG bit 11 keeps the parallel chunk-state launch + prefix launch (A/B runs; the two forms differ in the association of the fp32 sums only)
-static inline bool fused_seq_states() { return !(g_tunables.pp_dbg & 2048u); }
+// The walk is a chain of S dependent chunk steps (~4 us each) per (batch, head, slab) block, whatever the batch: it pays when there are enough (batch, head) pairs
+// to fill the chip with such chains (README shape: 6 x 8 pairs x 5 slabs = 240 blocks, 22 steps), not for ONE long sequence (N = 14 000, batch 1: 40 blocks x 219
+// steps = 0.9 ms against 0.16 ms for the parallel states + prefix launches; measured 207 vs 287 k tokens/s).
+// SA_PP_DBG bit 11: never (A/B runs); SA_DBG_FAVOR_SEQ_ALWAYS: always (the tests run both forms against the reference at small shapes).
+static inline bool fused_seq_states(int B, int G) { return !(g_tunables.pp_dbg & 2048u) && (B * G >= 40 || dbg(SA_DBG_FAVOR_SEQ_ALWAYS)); }
 static int fused_prefix(float* state, int B, int G, int S, int LDF, hipStream_t st) {
     const int64_t bg = (int64_t)B * G, e4 = ((int64_t)LDF * 65) / 4;   // LDF % 16 == 0
     SA_LAUNCH(favor_fprefix_kernel, dim3((unsigned)((bg * e4 + 255) / 256)), dim3(256), 0, st, state, bg, S, e4);
@@ -1164,7 +1168,7 @@ extern "C" int sa_favor_fused_fwd(const float* q, const float* k, const float* v
     s.b = v; s.b_stride = stride; s.state = state; s.zmode = 1; s.den_eps = den_eps; s.inv_out = inv_out; s.y = attn; s.y_stride = attn_stride;
     s.y_lp = (unsigned short*)attn_lp;
     const unsigned nblk = (unsigned)((int64_t)B * G * s.S);
-    if (fused_seq_states()) {
+    if (fused_seq_states(B, G)) {
         // sequential chunk states (exclusive prefixes written directly: no prefix launch), the local-window heads' forward beside them; then scan A
         const unsigned nst = (unsigned)((int64_t)B * G * ((s.LDF + FSLAB - 1) / FSLAB));
         if (la) SA_LAUNCH(favor_fseq_la_kernel, dim3(nst + nla), dim3(256), 0, st, s, laa, (int)nst);
@@ -1220,7 +1224,7 @@ extern "C" int sa_favor_fused_bwd(const float* q, const float* k, const float* v
     // Independent launches share a grid (favor_fpair_*): [scan B for dq | reversed chunk states] when the forward's states were kept, and [scan B for dk | scan A for dv].
     // SA_PP_DBG bit 9 keeps the five separate launches (A/B runs; results are bit-identical either way).
     const bool pair = !(g_tunables.pp_dbg & 512u);
-    const bool seq = fused_seq_states();
+    const bool seq = fused_seq_states(B, G);
     const unsigned nst = (unsigned)((int64_t)B * G * ((s.LDF + FSLAB - 1) / FSLAB));
     if (state_fwd) s.state = (float*)state_fwd;
     else {

@@ -525,7 +525,7 @@ class _LayerEngine:
                 rc = lib.sa_favor_fused_fwd(_ffi.ptr(q), _ffi.ptr(k), _ffi.ptr(v), qs, _ffi.ptr(tiles), _ffi.ptr(ps), _ffi.ptr(offq), _ffi.ptr(offk), _ffi.ptr(gws),
                                             _ffi.ptr(attn), inner, _ffi.ptr(inv), 1e-6, B, N, G, m, _ffi.ptr(state), _ffi.ptr(attn_lp), None, st)
             _ck(rc, "sa_favor_fused_fwd")
-            _favor_bracket_end(t0, "favor_prepass+fstate+fprefix+fout_a" + ("_la" if la_args is not None else ""), B * N * G * FAVOR_FWD_FLOP_PER_HEAD_ROW(m, dh))
+            _favor_bracket_end(t0, "favor_prepass+fstates+fout_a" + ("_la" if la_args is not None else ""), B * N * G * FAVOR_FWD_FLOP_PER_HEAD_ROW(m, dh))
             sv.update(fused=True, offq=offq, offk=offk, amq=amq, gws=gws, inv=inv, scan_state=state if tape is not None else None)
         elif G > 0:
             pop = self._proj_op()
@@ -851,7 +851,7 @@ class _LayerEngine:
                 la_args = None
                 rc = favor_bwd(None)
             _ck(rc, "sa_favor_fused_bwd")
-            _favor_bracket_end(t0, "favor_fdden+fpair_b_state+fprefix+fpair_b_a+fkey_fix" + ("_la" if la_args is not None else ""),
+            _favor_bracket_end(t0, "favor_fdden+fpair_states_b+fpair_b_a+fkey_fix" + ("_la" if la_args is not None else ""),
                                2.0 * B * N * G * FAVOR_FWD_FLOP_PER_HEAD_ROW(m, dh))
             local_done = la_args is not None
             sv["scan_state"] = None

@@ -79,14 +79,18 @@ def _fused(q, k, v, proj, dattn, local_cols=64):
     return un(attn), un(dq), un(dk), un(dv), dict(offq=offq, offk=offk, amq=amq, gws=gws, ps=ps)
 
 
+@pytest.mark.parametrize("seq_states", [False, True])
 @pytest.mark.parametrize("B,G,N,m", [(2, 2, 150, 266), (1, 3, 64, 266), (2, 1, 333, 266), (1, 2, 77, 120), (1, 8, 1400, 266)])
-def test_fused_favor_matches_fp64_reference(B, G, N, m):
+def test_fused_favor_matches_fp64_reference(B, G, N, m, seq_states):
+    """Both forms of the chunk states: the parallel launch + prefix launch (what batches below 40 (batch, head) pairs take) and the sequential walk."""
+    from synthanatomy_amd import debug
     g = torch.Generator().manual_seed(N + m)
     q, k, v = (torch.randn(B, G, N, 64, generator=g) for _ in range(3))
     dattn = torch.randn(B, G, N, 64, generator=g)
     proj = P.gaussian_orthogonal_random_matrix(m, 64, g)
     ref = _reference(q, k, v, proj, dattn)
-    out, dq, dk, dv, aux = _fused(q, k, v, proj, dattn)
+    with debug.override(favor_seq_always=seq_states):
+        out, dq, dk, dv, aux = _fused(q, k, v, proj, dattn)
     # pre-pass: row offsets, argmax and the global key maximum
     c = 64 ** -0.25
     ddq = torch.einsum("bgnd,md->bgnm", q.double() * c, proj.double())

@@ -69,15 +69,30 @@ def _counters(path, by_grid=False):
     for eid, pid, val in db.execute(f'select event_id, pmc_id, value from "{T("pmc_event")}"'):
         if eid in disp:
             per[disp[eid][0]][cname.get(pid, str(pid))][eid] += val
-    return {k: {c: (sum(ev.values()) / len(ev), len(ev)) for c, ev in cs.items()} for k, cs in per.items()}
+    res = {k: {c: (sum(ev.values()) / len(ev), len(ev)) for c, ev in cs.items()} for k, cs in per.items()}
+    dur = defaultdict(list)
+    for k, d in disp.values():
+        dur[k].append(d)
+    for k in res:      # mean launch duration of the SAME pass (counter passes run slower than a plain trace)
+        res[k]["_duration_ns"] = (sum(dur[k]) / len(dur[k]), len(dur[k]))
+    return res
 
 
 def pmc(path, by_grid=False):
     for k, cs in _counters(path, by_grid).items():
         print(k[:110])
         wc = cs.get("SQ_WAVE_CYCLES", (0, 0))[0] or 1.0
+        dur = cs.pop("_duration_ns", (0.0, 0))[0]
         for c, (v, n) in sorted(cs.items()):
             print(f"    {c:28s} launches={n:4d} mean={v:18.1f}  /WAVE_CYCLES={v / wc:7.3f}")
+        gui = cs.get("GRBM_GUI_ACTIVE", (0, 0))[0]
+        if gui and dur:
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES over the 1 024 SIMDs
+            line = f"    launch {dur / 1e3:.1f} us in this pass -> shader clock ~ {gui / 8 / dur:.2f} GHz"
+            busy = cs.get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0))[0]
+            if busy:
+                line += f"; MFMA busy {busy / (gui / 8 * 1024):.3f} of the launch's cycles"
+            print(line)
 
 
 def traffic(fetch_db, write_db, out=None, provenance="", by_grid=False):
