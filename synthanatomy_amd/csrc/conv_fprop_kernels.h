@@ -630,6 +630,9 @@ __device__ unsigned long long g_timing[8];
 // 4-wave block runs at ~45 % of the MFMA rate (s_memtime: ~1 000 cycles of DMA issue, address arithmetic, LDS latency and barrier per
 // 1 024-cycle slab) and its partner block spends half its life in halo reloads / the epilogue; with four waves per SIMD the other three
 // cover those cycles.
+#ifndef SA_EPI_BUDGET8
+#define SA_EPI_BUDGET8 24   // VGPRs of packed addend / mask pieces per epilogue batch of the eight-wave kernels
+#endif
 template <typename T, bool FUSE = false, int NW = 4>
 __global__ __launch_bounds__(NW * 64, NW / 2) void conv_fprop_halo256_kernel(const FpropArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -866,7 +869,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_fprop_halo256_kernel(con
                 for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], w2[i][NW == 4 ? ks : 0], xf[j]);
         }
     }
-    fprop_epilogue_regs<MI, NI, (NW == 4 ? 64 : 24), std::is_same<T, f16_t>::value>(a, acc, wm, wn, frow, fq, n_base, row_vox);
+    fprop_epilogue_regs<MI, NI, (NW == 4 ? 64 : SA_EPI_BUDGET8), std::is_same<T, f16_t>::value>(a, acc, wm, wn, frow, fq, n_base, row_vox);
 #ifdef SA_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SA_T(t_end);
