@@ -86,7 +86,7 @@ def pmc(path, by_grid=False):
         for c, (v, n) in sorted(cs.items()):
             print(f"    {c:28s} launches={n:4d} mean={v:18.1f}  /WAVE_CYCLES={v / wc:7.3f}")
         gui = cs.get("GRBM_GUI_ACTIVE", (0, 0))[0]
-        if gui and dur:
+        if gui and dur >= 100e3:      # (short launches: the counter window is dominated by the dispatch itself)
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES over the 1 024 SIMDs
             line = f"    launch {dur / 1e3:.1f} us in this pass -> shader clock ~ {gui / 8 / dur:.2f} GHz"
             busy = cs.get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0))[0]
