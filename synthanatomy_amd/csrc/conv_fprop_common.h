@@ -31,6 +31,7 @@ struct FpropArgs {
     const float* bias1;
     void* h_out;
     uint32_t HP, WP;      // halo mainloop: patches per plane along H (8 voxels) and W (16 voxels)
+    uint32_t DP;          // cell mainloop: tiles along D (2 planes), HP / WP = tiles of 8 x 8
     uint32_t group_m;     // im2col-order DMA mainloop, dense (1x1x1) layers with several channel tiles: blocks are ordered in groups of `group_m` row tiles x
                           // all channel tiles (0: row tiles fastest, the order in which convolution tiles share their halos)
     uint32_t dbg;         // dev only (env SA_PP_DBG): 256 = LDS-staged epilogue instead of the register one; with -DSA_PP_DEBUG_VARIANTS also the
