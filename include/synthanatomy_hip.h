@@ -216,10 +216,12 @@ int sa_embed_scatter(const float *dy, float *dtable, const int64_t *idx, int per
 int sa_embed_step(int ntab, const float *const *tables, const int64_t *const *idx, const int32_t *per_position, int dim, const int *pos, int B,
                   float *out, void *stream);
 /* The decision of one decode step for all B rows (TransformerBase.sample_next_index, transformer.py:19-56, without top-k) + the sequence update:
- * logits [B, V] / temperature -> softmax -> categorical draw by inverse CDF with the caller's uniforms u[B] (do_sample) or arg-max; seq[b, *pos + 1] receives
- * the token unless that position belongs to the given prefix (< P); tok[b] = seq[b, *pos + 1] (what the next step embeds); *pos += 1. */
-int sa_sample_step(const float *logits, int B, int V, float temperature, const float *u, int do_sample, int64_t *seq, int total, int P, int *pos,
-                   int64_t *tok, void *stream);
+ * logits [B, V] / temperature -> softmax -> categorical draw by inverse CDF with the caller's uniforms u[*pos * u_stride + b] (do_sample; u_stride = B: a table
+ * drawn once per sample() call, 0: one vector per step) or arg-max; seq[b, *pos + 1] receives the token unless that position belongs to the given prefix (< P);
+ * tok[b] = seq[b, *pos + 1] (what the next step embeds); *pos += 1.  ticket: NULL (one block walks the rows) or a zeroed int the launch leaves zeroed (one
+ * block per row; the last one to finish advances *pos). */
+int sa_sample_step(const float *logits, int B, int V, float temperature, const float *u, int u_stride, int do_sample, int64_t *seq, int total, int P, int *pos,
+                   int *ticket, int64_t *tok, void *stream);
 int sa_favor_step(const float *q, int q_stride, int q_off, const float *k, int k_stride, int k_off, const float *v, int v_stride, int v_off,
                   const float *proj, int B, int G, int dh, int m, int LDF, float *smax, int *kmax, float *dd, float *E, float *Ez, float *V1,
                   const int *pos, float *out, int out_stride, int out_off, void *stream);

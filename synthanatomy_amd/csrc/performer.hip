@@ -1413,8 +1413,11 @@ __global__ void embed_step_kernel(const EmbedArgs a, const int* __restrict__ pos
 // logits / temperature -> softmax -> categorical draw by inverse CDF with the caller's uniform u[b] (same rule as the torch expression it replaces:
 // index = #{v : cdf[v] < u * cdf[V - 1]}, clamped) or arg-max (lowest index on ties); position pos + 1 receives the token unless it belongs to the given prefix;
 // tok[b] = the token the NEXT step embeds; *pos += 1.  One block walks the rows (B is a handful): ~20 small torch launches per token -> 1.
-__global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restrict__ logits, int B, int V, float inv_temp, const float* __restrict__ u, int do_sample,
-                                                         int64_t* __restrict__ seq, int total, int P, int* __restrict__ pos, int64_t* __restrict__ tok) {
+// Grid: one block per row when the caller gives a zeroed `ticket` word (the last block to finish advances *pos and re-zeroes the ticket), else one block
+// that walks the rows.  u[*pos * u_stride + b]: a table of uniforms drawn once per sample() call (u_stride = B) or one vector per step (u_stride = 0).
+__global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restrict__ logits, int B, int V, float inv_temp, const float* __restrict__ u, int u_stride,
+                                                         int do_sample, int64_t* __restrict__ seq, int total, int P, int* __restrict__ pos, int* __restrict__ ticket,
+                                                         int64_t* __restrict__ tok) {
     __shared__ float sred[16];
     __shared__ int sidx[16];
     __shared__ float sscan[16];
@@ -1422,7 +1425,9 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = *pos;
     const int ept = (V + 1023) / 1024;                 // elements per thread, contiguous: thread t owns [t * ept, (t + 1) * ept)
-    for (int b = 0; b < B; ++b) {
+    const bool per_row = gridDim.x > 1;
+    const float* const ur = u ? u + (int64_t)p * u_stride : nullptr;
+    for (int b = per_row ? (int)blockIdx.x : 0; b < (per_row ? (int)blockIdx.x + 1 : B); ++b) {
         const float* lr = logits + (int64_t)b * V;
         // row maximum (and its lowest index)
         float mx = -INFINITY;
@@ -1474,7 +1479,7 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
                 if (w < wv) wbase += sscan[w];
                 tot += sscan[w];
             }
-            const float target = u[b] * tot;
+            const float target = ur[b] * tot;
             float run = wbase + inc - loc;  // cdf before this thread's first element
             // the number of elements with cdf < target = the first index whose inclusive cdf reaches the target
             if (run < target && run + loc >= target) {
@@ -1500,7 +1505,16 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
         }
         __syncthreads();
     }
-    if (tid == 0) *pos = p + 1;
+    if (tid == 0) {
+        if (!per_row) *pos = p + 1;
+        else {
+            __threadfence();
+            if (atomicAdd(ticket, 1) == B - 1) {      // every block has read *pos (at its start) and finished its row
+                *ticket = 0;
+                *pos = p + 1;
+            }
+        }
+    }
 }
 
 // Phase A of a global-head step, one block per (batch, head): projections dd[m] = x . P[m] (P carries the data normaliser) of the new
@@ -2318,10 +2332,11 @@ extern "C" int sa_embed_step(int ntab, const float* const* tables, const int64_t
     return 0;
 }
 
-extern "C" int sa_sample_step(const float* logits, int B, int V, float temperature, const float* u, int do_sample, int64_t* seq, int total, int P, int* pos,
-                              int64_t* tok, void* stream) {
-    if (!logits || !seq || !pos || !tok || (do_sample && !u) || B <= 0 || V <= 0 || total <= 0 || !(temperature > 0.f)) return SA_EINVAL;
-    SA_LAUNCH(sample_step_kernel, dim3(1), dim3(1024), 0, ST(stream), logits, B, V, 1.f / temperature, u, do_sample, seq, total, P, pos, tok);
+extern "C" int sa_sample_step(const float* logits, int B, int V, float temperature, const float* u, int u_stride, int do_sample, int64_t* seq, int total, int P,
+                              int* pos, int* ticket, int64_t* tok, void* stream) {
+    if (!logits || !seq || !pos || !tok || (do_sample && !u) || u_stride < 0 || B <= 0 || V <= 0 || total <= 0 || !(temperature > 0.f)) return SA_EINVAL;
+    SA_LAUNCH(sample_step_kernel, dim3(ticket ? B : 1), dim3(1024), 0, ST(stream), logits, B, V, 1.f / temperature, u, u_stride, do_sample, seq, total, P, pos, ticket,
+              tok);
     SA_CHECK_LAUNCH();
     return 0;
 }

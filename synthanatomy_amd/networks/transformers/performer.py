@@ -1243,7 +1243,8 @@ class Performer(TransformerBase):
         seq = torch.zeros(B, total, dtype=torch.int64, device=dev)
         seq[:, :P] = prefix.to(dev).long()
         seq0 = seq.clone()
-        pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        posbuf = torch.zeros(2, dtype=torch.int32, device=dev)     # [position, ticket word of sa_sample_step]
+        pos, ticket = posbuf[:1], posbuf[1:]
         tok = torch.zeros(B, dtype=torch.int64, device=dev)
         pidx, sp = self._position_indices(npos, dev)
         tok_table = self.token_emb.weight
@@ -1270,6 +1271,8 @@ class Performer(TransformerBase):
         tok.copy_(seq0[:, 0])
 
         fused_tail = top_k is None and not debug.host("no_sample_step")     # one launch for the decision + sequence update (sa_sample_step)
+        # the uniforms of every step, drawn once (a torch.rand inside the captured step costs three launches per token: the generator's seed / offset fills + the draw)
+        u_all = torch.rand(npos + 1, B, device=dev, dtype=torch.float32) if (fused_tail and sample) else None
 
         def one_step():
             if not fused_tail:
@@ -1283,11 +1286,10 @@ class Performer(TransformerBase):
             logits = torch.empty(B, self.to_out.weight.shape[0], dtype=torch.float32, device=dev)
             layers[0]._gemv(h, [self.to_out], logits)
             if fused_tail:
-                # temperature, softmax, the draw (inverse CDF on a captured torch.rand -- torch.multinomial cannot be captured in a HIP graph) or arg-max,
+                # temperature, softmax, the draw (inverse CDF against the pre-drawn uniforms -- torch.multinomial cannot be captured in a HIP graph) or arg-max,
                 # seq[:, pos + 1] (unless it belongs to the given prefix), the next step's token, pos += 1: one launch instead of ~20 small torch kernels
-                u = torch.rand(B, device=dev, dtype=torch.float32) if sample else None
-                _ck(lib.sa_sample_step(_ffi.ptr(logits), B, logits.shape[1], float(temperature), _ffi.ptr(u), int(bool(sample)), _ffi.ptr(seq), total, P,
-                                       _ffi.ptr(pos), _ffi.ptr(tok), _ffi.stream()), "sa_sample_step")
+                _ck(lib.sa_sample_step(_ffi.ptr(logits), B, logits.shape[1], float(temperature), _ffi.ptr(u_all), B, int(bool(sample)), _ffi.ptr(seq), total, P,
+                                       _ffi.ptr(pos), _ffi.ptr(ticket), _ffi.ptr(tok), _ffi.stream()), "sa_sample_step")
                 return
             logits = logits / temperature
             # transformer.py:11-17 (_top_k_logits) without the boolean-mask assignment, which cannot be captured
@@ -1319,7 +1321,7 @@ class Performer(TransformerBase):
                 torch.cuda.synchronize()
                 for l, stt in zip(layers, states):
                     l.reset_state(stt)
-                pos.zero_()
+                posbuf.zero_()
                 seq.copy_(seq0)
                 tok.copy_(seq0[:, 0])
                 graph = torch.cuda.CUDAGraph()
@@ -1333,7 +1335,7 @@ class Performer(TransformerBase):
                 torch.cuda.synchronize()
                 for l, stt in zip(layers, states):
                     l.reset_state(stt)
-                pos.zero_()
+                posbuf.zero_()
                 seq.copy_(seq0)
                 tok.copy_(seq0[:, 0])
         for _ in range(npos):

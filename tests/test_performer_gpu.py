@@ -594,10 +594,12 @@ def test_stateful_sampler_equals_the_quadratic_loop(rezero, shape, window, local
         assert torch.equal(net.sample(prefix, sample=False, use_graph=use_graph), quad)
 
 
+@pytest.mark.parametrize("per_row", [False, True])
 @pytest.mark.parametrize("B,V,P_,temperature", [(6, 2049, 1, 1.0), (3, 19, 2, 0.7), (17, 1000, 1, 1.3)])
-def test_sample_step_kernel_matches_the_torch_decision(B, V, P_, temperature):
+def test_sample_step_kernel_matches_the_torch_decision(B, V, P_, temperature, per_row):
     """sa_sample_step (one launch per token: temperature, softmax, inverse-CDF draw with the caller's uniforms or arg-max, sequence update, next token, pos += 1)
-    against the torch expressions of the stateful sampler it replaces, position by position."""
+    against the torch expressions of the stateful sampler it replaces, position by position; one block walking the rows with a fresh vector of uniforms per step,
+    and one block per row (ticket word) reading a table of uniforms by position."""
     from synthanatomy_amd import _ffi
     lib = _ffi.lib()
     g = torch.Generator().manual_seed(B + V)
@@ -606,13 +608,15 @@ def test_sample_step_kernel_matches_the_torch_decision(B, V, P_, temperature):
     for do_sample in (0, 1):
         seq = torch.randint(0, V, (B, total), generator=g).cuda()
         seq_t = seq.clone()
-        pos = torch.zeros(1, dtype=torch.int32, device="cuda")
+        posbuf = torch.zeros(2, dtype=torch.int32, device="cuda")
+        pos, ticket = posbuf[:1], posbuf[1:]
         tok = torch.zeros(B, dtype=torch.int64, device="cuda")
+        table = torch.rand(total, B, generator=g).cuda()
         for step in range(total - 1):
             logits = (torch.randn(B, V, generator=g) * 3).cuda()
-            u = torch.rand(B, generator=g).cuda()
-            _ffi.check(lib.sa_sample_step(_ffi.ptr(logits), B, V, float(temperature), _ffi.ptr(u), do_sample, _ffi.ptr(seq), total, P_, _ffi.ptr(pos), _ffi.ptr(tok),
-                                          _ffi.stream()), "sa_sample_step")
+            u = table[step] if per_row else torch.rand(B, generator=g).cuda()
+            _ffi.check(lib.sa_sample_step(_ffi.ptr(logits), B, V, float(temperature), _ffi.ptr(table if per_row else u), B if per_row else 0, do_sample, _ffi.ptr(seq),
+                                          total, P_, _ffi.ptr(pos), _ffi.ptr(ticket) if per_row else None, _ffi.ptr(tok), _ffi.stream()), "sa_sample_step")
             probs = torch.softmax(logits / temperature, dim=-1)
             if do_sample:
                 cdf = probs.cumsum(-1)
@@ -622,7 +626,7 @@ def test_sample_step_kernel_matches_the_torch_decision(B, V, P_, temperature):
             if step + 1 >= P_:
                 seq_t[:, step + 1] = ix
             torch.cuda.synchronize()
-            assert int(pos) == step + 1
+            assert int(pos) == step + 1 and int(ticket) == 0
             assert torch.equal(tok, seq[:, step + 1])
             if do_sample:      # a cdf value within rounding of the target may fall on either side: count, then continue from the kernel's choice
                 mism += int((seq[:, step + 1] != seq_t[:, step + 1]).sum())
