@@ -1548,12 +1548,18 @@ __device__ __forceinline__ void favor_step_proj_body(const FavorProjArgs& a, con
     __syncthreads();
     float mx = -INFINITY;
     for (int e = tid; e < m; e += 256) {
-        const float* pr = proj + (int64_t)e * dh;
+        // the 16 pieces of the projection row are fetched BEFORE the dependent fma chain (dh = 64, checked by the launcher): one L2 round trip instead of 16 --
+        // this loop was most of the launch's 11 us
+        const float4* pr = (const float4*)(proj + (int64_t)e * 64);
+        float4 pv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pv[i] = pr[i];
         float aq = 0.f, ak = 0.f;
-        for (int d = 0; d < dh; d += 4) {
-            const float4 pv = *(const float4*)(pr + d);
-            aq = fmaf(sq[d], pv.x, fmaf(sq[d + 1], pv.y, fmaf(sq[d + 2], pv.z, fmaf(sq[d + 3], pv.w, aq))));
-            ak = fmaf(sk[d], pv.x, fmaf(sk[d + 1], pv.y, fmaf(sk[d + 2], pv.z, fmaf(sk[d + 3], pv.w, ak))));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int d = 4 * i;
+            aq = fmaf(sq[d], pv[i].x, fmaf(sq[d + 1], pv[i].y, fmaf(sq[d + 2], pv[i].z, fmaf(sq[d + 3], pv[i].w, aq))));
+            ak = fmaf(sk[d], pv[i].x, fmaf(sk[d + 1], pv[i].y, fmaf(sk[d + 2], pv[i].z, fmaf(sk[d + 3], pv[i].w, ak))));
         }
         dd[(int64_t)bg * LDF + e] = aq;
         dd[(rows + bg) * LDF + e] = ak;
@@ -1588,6 +1594,19 @@ __device__ __forceinline__ void favor_step_body(const FavorStepArgs& a, const in
     __shared__ float sq[64], sk[64], sv[64], sqf[320], sek[320], red[32], snum[16][64];
     const int b = bg / a.G, g = bg % a.G, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int dh = a.dh, m = a.m;
+    // everything the step reads from global memory that does not depend on another load is requested here (the 68 KB of state rows first), so that the
+    // reductions below run under ONE round trip instead of five dependent ones
+    float* const E = a.E + (int64_t)bg * a.LDF * dh;
+    float ev[17];
+#pragma unroll
+    for (int it = 0; it < 17; ++it) {
+        const int e = wv + 16 * it;
+        ev[it] = e < m ? E[e * dh + lane] : 0.f;
+    }
+    const int p = *a.pos;
+    const float ddq_t = tid < m ? a.ddq[(int64_t)bg * a.LDF + tid] : -INFINITY;
+    const float ddk_t = tid < m ? a.ddk[(int64_t)bg * a.LDF + tid] : 0.f;
+    const float ez_t = tid < m ? a.Ez[(int64_t)bg * a.LDF + tid] : 0.f;
     if (tid < dh) {
         sq[tid] = a.q[(int64_t)b * a.q_stride + a.q_off + g * dh + tid];
         sk[tid] = a.k[(int64_t)b * a.k_stride + a.k_off + g * dh + tid];
@@ -1603,7 +1622,7 @@ __device__ __forceinline__ void favor_step_body(const FavorStepArgs& a, const in
     dq *= nrm;
     dk *= nrm;
     // query stabiliser: row maximum of its own projections
-    float qm = tid < m ? a.ddq[(int64_t)bg * a.LDF + tid] : -INFINITY;
+    float qm = ddq_t;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) qm = fmaxf(qm, __shfl_xor(qm, o, 64));
     if (lane == 0) red[wv] = qm;
@@ -1611,7 +1630,6 @@ __device__ __forceinline__ void favor_step_body(const FavorStepArgs& a, const in
     qm = red[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) qm = fmaxf(qm, red[w]);
-    const int p = *a.pos;
     const float s_old = a.smax[p & 1], s_new = fmaxf(s_old, ord2f(a.kmax[p & 1]));
     const float scale = s_old == -INFINITY ? 0.f : __expf(s_old - s_new);
     const int cnt = p + 1;   // keys seen including this one
@@ -1623,11 +1641,11 @@ __device__ __forceinline__ void favor_step_body(const FavorStepArgs& a, const in
     // features: q' and the exp part of k'; denominator sum_m q'[m] * (ratio * (Ez[m] + eps * cnt) + eps_den)
     float den = 0.f, qsum = 0.f;
     if (tid < m) {
-        const float qf = ratio * (__expf(a.ddq[(int64_t)bg * a.LDF + tid] - dq - qm) + a.eps_feat);
-        const float ek = __expf(a.ddk[(int64_t)bg * a.LDF + tid] - dk - s_new);
+        const float qf = ratio * (__expf(ddq_t - dq - qm) + a.eps_feat);
+        const float ek = __expf(ddk_t - dk - s_new);
         sqf[tid] = qf;
         sek[tid] = ek;
-        const float z = fmaf(a.Ez[(int64_t)bg * a.LDF + tid], scale, ek);
+        const float z = fmaf(ez_t, scale, ek);
         a.Ez[(int64_t)bg * a.LDF + tid] = z;
         den = qf * (ratio * (z + a.eps_feat * (float)cnt) + a.eps_den);
         qsum = qf;
@@ -1643,13 +1661,6 @@ __device__ __forceinline__ void favor_step_body(const FavorStepArgs& a, const in
     }
     __syncthreads();
     // state update + numerator: thread = (feature slice wv, value dim lane)
-    float* E = a.E + (int64_t)bg * a.LDF * dh;
-    float ev[17];
-#pragma unroll
-    for (int it = 0; it < 17; ++it) {
-        const int e = wv + 16 * it;
-        ev[it] = e < m ? E[e * dh + lane] : 0.f;
-    }
     float num = 0.f;
 #pragma unroll
     for (int it = 0; it < 17; ++it) {
@@ -1903,32 +1914,48 @@ __device__ __forceinline__ void local_step_partial_body(const LocalStepArgs& a, 
     const int dh = a.dh, half = dh / 2, t = *a.pos;
     float* kc = a.kc + ((int64_t)bl * a.N) * dh;
     float* vc = a.vc + ((int64_t)bl * a.N) * dh;
+    const int w = t / a.W, lo = (w > 0 ? w - 1 : 0) * a.W, nk = t - lo + 1;
+    const int per = (nk + LSPLIT - 1) / LSPLIT, j0 = sp * per, j1 = min(nk, j0 + per);      // per <= 2 W / 4 <= 256 (checked by the launcher)
+    const int cnt = max(0, j1 - j0);
+    // Every cache row this block needs is requested NOW -- the key row of this thread (16 pieces) and the value elements of its (key slice wv, dim lane)
+    // walk (up to 64) -- so that the whole step waits for ONE memory round trip beside the q / k / v rows; the value walk used to issue eight rows at a time
+    // behind the softmax (seven dependent round trips at 210 keys).  Position t itself comes from LDS (this step's k / v rows).
+    // (16 lanes per key row with a cross-lane reduction -- coalesced 256-byte requests -- measured SLOWER: 13.8 vs 10.5 us for the launch)
+    float4 kv[16];
+    if (tid < cnt) {
+        const int j = lo + j0 + tid;
+        const float4* kj = (const float4*)(kc + (int64_t)(j == t ? lo : j) * dh);     // (j == t: replaced below; any valid row)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) kv[e] = kj[e];
+    }
+    float vv[64];
+#pragma unroll
+    for (int u = 0; u < 64; ++u) {
+        const int j = wv + 4 * u, jj = lo + j0 + j;
+        vv[u] = (j < cnt && jj != t) ? vc[(int64_t)jj * dh + lane] : 0.f;
+    }
     if (tid < dh) {
         const float* qr = a.q + (int64_t)b * a.q_stride + a.q_off + l * dh;
         const float* kr = a.k + (int64_t)b * a.k_stride + a.k_off + l * dh;
         const float cs = a.cosb[t * dh + tid], sn = a.sinb[t * dh + tid];
         const float qrot = tid < half ? -qr[tid + half] : qr[tid - half];
         const float krot = tid < half ? -kr[tid + half] : kr[tid - half];
-        const float kv = kr[tid] * cs + krot * sn, vv = a.v[(int64_t)b * a.v_stride + a.v_off + l * dh + tid];
+        const float kvv = kr[tid] * cs + krot * sn, vvv = a.v[(int64_t)b * a.v_stride + a.v_off + l * dh + tid];
         sq[tid] = (qr[tid] * cs + qrot * sn) * rsqrtf((float)dh);
-        skt[tid] = kv;
-        svt[tid] = vv;
+        skt[tid] = kvv;
+        svt[tid] = vvv;
         if (sp == 0) {
-            kc[(int64_t)t * dh + tid] = kv;
-            vc[(int64_t)t * dh + tid] = vv;
+            kc[(int64_t)t * dh + tid] = kvv;
+            vc[(int64_t)t * dh + tid] = vvv;
         }
     }
     __syncthreads();
-    const int w = t / a.W, lo = (w > 0 ? w - 1 : 0) * a.W, nk = t - lo + 1;
-    const int per = (nk + LSPLIT - 1) / LSPLIT, j0 = sp * per, j1 = min(nk, j0 + per);      // per <= 2 W / 4 <= 256 (checked by the launcher)
-    const int cnt = max(0, j1 - j0);
     float d = -INFINITY;
     if (tid < cnt) {
-        const int j = lo + j0 + tid;
-        const float4* kj = j == t ? (const float4*)skt : (const float4*)(kc + (int64_t)j * dh);
-        float4 kv[16];
+        if (lo + j0 + tid == t) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) kv[e] = kj[e];
+            for (int e = 0; e < 16; ++e) kv[e] = *(const float4*)(skt + 4 * e);
+        }
         d = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -1951,21 +1978,11 @@ __device__ __forceinline__ void local_step_partial_body(const LocalStepArgs& a, 
     if (lane == 0) red[wv] = sum;
     __syncthreads();
     sum = (red[0] + red[1]) + (red[2] + red[3]);
-    float acc = 0.f;          // thread = (key slice wv, value dim lane)
-    int j = wv;
-    for (; j + 28 < cnt; j += 32) {
-        float vv[8];
+    float acc = 0.f;          // thread = (key slice wv, value dim lane); keys in ascending order, as before
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int jj = lo + j0 + j + 4 * u;
-            vv[u] = jj == t ? svt[lane] : vc[(int64_t)jj * dh + lane];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc = fmaf(sc[j + 4 * u], vv[u], acc);
-    }
-    for (; j < cnt; j += 4) {
-        const int jj = lo + j0 + j;
-        acc = fmaf(sc[j], jj == t ? svt[lane] : vc[(int64_t)jj * dh + lane], acc);
+    for (int u = 0; u < 64; ++u) {
+        const int j = wv + 4 * u;
+        if (j < cnt) acc = fmaf(sc[j], lo + j0 + j == t ? svt[lane] : vv[u], acc);
     }
     sacc[wv][lane] = acc;
     __syncthreads();
