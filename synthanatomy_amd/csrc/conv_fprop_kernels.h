@@ -633,14 +633,19 @@ __device__ unsigned long long g_timing[8];
 #ifndef SA_EPI_BUDGET8
 #define SA_EPI_BUDGET8 24   // VGPRs of packed addend / mask pieces per epilogue batch of the eight-wave kernels
 #endif
-template <typename T, bool FUSE = false, int NW = 4>
+// P2 (round 4): the 256-voxel tile as TWO planes of 8 x 16 voxels.  The halo image is two plane slots (10 x 18 rows each); a plane sits in the slot of its
+// parity, so that consecutive kd groups -- visited innermost, (chunk, kd) order -- share one plane and a kd switch re-loads ONE plane (23 pieces) instead of the
+// whole image (41): 8 plane loads per tile instead of 6 images (180 vs 246 KB), half-size reload bubbles, and 8-row patches waste less at 40 x 56 x 40
+// (3 360 instead of 3 840 tiles).
+template <typename T, bool FUSE = false, int NW = 4, bool P2 = false>
 __global__ __launch_bounds__(NW * 64, NW / 2) void conv_fprop_halo256_kernel(const FpropArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     constexpr int MI = 32 / NW, NI = 4;
     constexpr int WPIECES = 16 / NW;          // weight pieces (1 KiB) per wave per slab
     constexpr int BN = 128;
-    constexpr int HW_ = 18, HROWS = 324, HPIECES = 41;
+    static_assert(!P2 || NW == 8, "two-plane tiles: eight waves");
+    constexpr int HW_ = 18, HROWS = P2 ? 180 : 324, PLPIECES = 23, HPIECES = P2 ? 2 * PLPIECES : 41;   // (P2: rows / pieces per plane slot)
     constexpr int SZ = sizeof(T);
     constexpr int HALO_BYTES = HPIECES * 1024;
 
@@ -655,14 +660,16 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_fprop_halo256_kernel(con
     const uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
     const uint32_t n_base = bn * BN;
     const sa_conv_geom& g = a.g;
-    // tile order = (n, band of 2 patch rows, d, row in band, wp)
-    const uint32_t per_vol = a.HP * a.WP * (uint32_t)g.Dm, band = 2u * a.WP * (uint32_t)g.Dm;
+    // tile order = (n, band of 2 patch rows, d (P2: plane pair), row in band, wp)
+    const uint32_t ND = P2 ? a.DP : (uint32_t)g.Dm;
+    const uint32_t per_vol = a.HP * a.WP * ND, band = 2u * a.WP * ND;
     const uint32_t pn = bm / per_vol, rv = bm - pn * per_vol;
     const uint32_t bc = rv / band, r2 = rv - bc * band;
     const uint32_t rows_c = a.HP - 2u * bc < 2u ? a.HP - 2u * bc : 2u;
     const uint32_t pd = r2 / (rows_c * a.WP), r3 = r2 - pd * rows_c * a.WP;
     const uint32_t hpi = r3 / a.WP, wp = r3 - hpi * a.WP, hp = 2u * bc + hpi;
-    const int32_t h0 = (int32_t)hp * 16, w0 = (int32_t)wp * 16;
+    const int32_t h0 = (int32_t)hp * (P2 ? 8 : 16), w0 = (int32_t)wp * 16;
+    const int32_t d0 = P2 ? (int32_t)pd * 2 : (int32_t)pd;     // first output plane of the tile
     const int32_t oh = g.in_off[1] + (g.tap_step[1] < 0 ? 2 * g.tap_step[1] : 0), ow = g.in_off[2] + (g.tap_step[2] < 0 ? 2 * g.tap_step[2] : 0);
 
     __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
@@ -680,25 +687,43 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_fprop_halo256_kernel(con
     const uint32_t vox_bytes = (uint32_t)(g.Cin * SZ);
     const uint32_t base_vox = (uint32_t)((int32_t)pn * g.Di * g.Hi * g.Wi);
 
-    // the whole halo image of group gi: pieces wave, wave + 4, ... (11 for wave 0, 10 for the others); offsets are recomputed here
+    // group -> (kd tap, channel chunk): kd-major for the one-plane tile, (chunk, kd) for the two-plane one (kd switches keep a plane)
+    auto group_td = [&](uint32_t gi) __attribute__((always_inline)) { return P2 ? gi % 3u : gi / nchunk; };
+    auto group_ch = [&](uint32_t gi) __attribute__((always_inline)) { return P2 ? gi / 3u : gi - (gi / nchunk) * nchunk; };
+    // one plane (absolute input plane id, channel chunk ch) -> LDS at `dst`: pieces wave, wave + NW, ...; offsets are recomputed here
     // (no registers held across the loop: the 128 accumulators need them)
-    auto issue_halo = [&](uint32_t gi) __attribute__((always_inline)) {
-        const uint32_t td = gi / nchunk, ch = gi - td * nchunk;
-        const int32_t id = (int32_t)pd + g.in_off[0] + (int32_t)td * g.tap_step[0];
+    auto issue_plane = [&](int32_t id, uint32_t ch, unsigned char* dst, uint32_t npieces) __attribute__((always_inline)) {
         const bool dok = (uint32_t)id < (uint32_t)g.Di;
         const uint32_t goff = (uint32_t)id * plane_bytes + ch * 128u + lv * 16u;
 #pragma unroll 1
-        for (uint32_t p = wave; p < (uint32_t)HPIECES; p += NW) {
+        for (uint32_t p = wave; p < npieces; p += NW) {
             const uint32_t r = p * 8 + prow;
             const uint32_t hh = r / HW_, ww = r - hh * HW_;
             const int32_t ih = h0 + oh + (int32_t)hh, iw = w0 + ow + (int32_t)ww;
             const bool ok = dok && r < (uint32_t)HROWS && (uint32_t)ih < (uint32_t)g.Hi && (uint32_t)iw < (uint32_t)g.Wi;
             const uint32_t voff = ok ? (base_vox + (uint32_t)(ih * g.Wi + iw)) * vox_bytes + goff : OOB_OFF;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(sA + p * 1024), 16, voff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, voff, 0, 0, 0);
+        }
+    };
+    // first input plane of group gi's tile planes
+    auto group_plane = [&](uint32_t gi) __attribute__((always_inline)) { return d0 + g.in_off[0] + (int32_t)group_td(gi) * g.tap_step[0]; };
+    // the halo image of group gi; `only_new` (P2, kd switch inside a chunk): just the plane the previous group did not hold
+    auto issue_halo = [&](uint32_t gi, bool only_new) __attribute__((always_inline)) {
+        const uint32_t ch = group_ch(gi);
+        const int32_t pb = group_plane(gi);
+        if constexpr (P2) {
+            const int32_t pnew = g.tap_step[0] > 0 ? pb + 1 : pb;
+            if (only_new) issue_plane(pnew, ch, sA + ((uint32_t)pnew & 1u) * (PLPIECES * 1024), PLPIECES);
+            else {
+                issue_plane(pb, ch, sA + ((uint32_t)pb & 1u) * (PLPIECES * 1024), PLPIECES);
+                issue_plane(pb + 1, ch, sA + ((uint32_t)(pb + 1) & 1u) * (PLPIECES * 1024), PLPIECES);
+            }
+        } else {
+            issue_plane(pb, ch, sA, HPIECES);
         }
     };
     auto issue_w = [&](uint32_t gi, uint32_t t9, uint32_t buf) __attribute__((always_inline)) {
-        const uint32_t td = gi / nchunk, ch = gi - td * nchunk;
+        const uint32_t td = group_td(gi), ch = group_ch(gi);
         const uint32_t col = ((td * 9u + t9) * (uint32_t)g.Cin) * SZ + ch * 128u;
 #pragma unroll
         for (int j = 0; j < WPIECES; ++j)
@@ -722,12 +747,13 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_fprop_halo256_kernel(con
             for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
 #endif
     const uint32_t frow = lane & 15u, fq = lane >> 4;
-    const uint32_t a_base = ((wm * (uint32_t)MI) * HW_ + frow) * 128u + fq * 16u;   // unswizzled; patch row j adds 18 * 128 j
+    // unswizzled; patch row j adds 18 * 128 j.  P2: the wave's rows are rows (wm & 1) * 4 .. of tile plane wm >> 1, whose slot depends on the group
+    const uint32_t a_base = P2 ? (((wm & 1u) * (uint32_t)MI) * HW_ + frow) * 128u + fq * 16u : ((wm * (uint32_t)MI) * HW_ + frow) * 128u + fq * 16u;
     const uint32_t b_off = tile_off(wn * (NI * 16) + frow, fq);
     const bool fh = g.tap_step[1] < 0, fw = g.tap_step[2] < 0;
 
     SA_T(t_k0);
-    issue_halo(0);
+    issue_halo(0, false);
     issue_w(0, 0, 0);
     __syncthreads();
     SA_T(t_k1);
@@ -738,6 +764,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_fprop_halo256_kernel(con
     uint32_t buf = 0;
     for (uint32_t gi = 0; gi < ngroups; ++gi) {
         const bool next_group = gi + 1 < ngroups;
+        const uint32_t a_grp = P2 ? a_base + (((uint32_t)(group_plane(gi) + (int32_t)(wm >> 1))) & 1u) * (PLPIECES * 1024) : a_base;   // (slot of this wave's plane)
 #pragma unroll 1
         for (uint32_t t9 = 0; t9 < 9; ++t9) {
             const uint32_t th = t9 / 3u, tw = t9 - th * 3u;
@@ -754,7 +781,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_fprop_halo256_kernel(con
                 for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + ((b_off + i * 2048u) ^ (ks * 64u)));
 #pragma unroll
                 for (int j = 0; j < MI; ++j) {
-                    const uint32_t ad = a_base + tapoff + (uint32_t)j * (HW_ * 128u);
+                    const uint32_t ad = a_grp + tapoff + (uint32_t)j * (HW_ * 128u);
                     xf[j] = *(const u32x4*)(sA + ((ad ^ (((ad >> 7) & 7u) << 4)) ^ (ks * 64u)));
                 }
 #ifdef SA_MFMA32_PROBE
@@ -791,7 +818,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_fprop_halo256_kernel(con
             buf ^= 1u;
         }
         if (next_group) {      // every wave is past its last read of the halo image: reload it (the first weight slab of the group is in flight)
-            issue_halo(gi + 1);
+            issue_halo(gi + 1, P2 && group_td(gi + 1) != 0u);
             __syncthreads();
 #ifdef SA_TIMING
             SA_T(t_h);
@@ -803,8 +830,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_fprop_halo256_kernel(con
     SA_TACC(0, s_comp); SA_TACC(1, s_dma); SA_TACC(2, s_bar); SA_TACC(3, s_halo);
 #endif
     auto row_vox = [&](uint32_t row) __attribute__((always_inline)) {
-        const uint32_t h = (uint32_t)h0 + (row >> 4), w = (uint32_t)w0 + (row & 15u);
-        return h < (uint32_t)g.Ho && w < (uint32_t)g.Wo ? (((long long)pn * g.Do + pd) * g.Ho + h) * g.Wo + w : -1ll;
+        const uint32_t pr = row >> 4, w = (uint32_t)w0 + (row & 15u);
+        const uint32_t h = (uint32_t)h0 + (P2 ? (pr & 7u) : pr), d = (uint32_t)d0 + (P2 ? (pr >> 3) : 0u);
+        return d < (uint32_t)g.Do && h < (uint32_t)g.Ho && w < (uint32_t)g.Wo ? (((long long)pn * g.Do + d) * g.Ho + h) * g.Wo + w : -1ll;
     };
 #ifdef SA_MFMA32_PROBE
     if constexpr (sizeof(T) == 2 && NW == 8) {
@@ -1161,31 +1189,47 @@ static bool halo256_eligible(const FpropArgs& a, int sz) {
     return eff >= 0.7 && (int64_t)g.N * g.Dm * hp * wp >= 256;
 }
 
-template <typename T, bool FUSE, int NW>
+template <typename T, bool FUSE, int NW, bool P2 = false>
 static int launch_fprop_halo256_impl(const FpropArgs& a, uint32_t nbn, size_t lds, hipStream_t st) {
     static std::atomic<uint64_t> attr_done{0};   // one bit per device (one static per template instance)
-    configure_once_per_device(attr_done, [] { (void)hipFuncSetAttribute((const void*)conv_fprop_halo256_kernel<T, FUSE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); });
-    hipLaunchKernelGGL((conv_fprop_halo256_kernel<T, FUSE, NW>), dim3(a.nblk_m * nbn), dim3(NW * 64), lds, st, a);
+    configure_once_per_device(attr_done, [] { (void)hipFuncSetAttribute((const void*)conv_fprop_halo256_kernel<T, FUSE, NW, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); });
+    hipLaunchKernelGGL((conv_fprop_halo256_kernel<T, FUSE, NW, P2>), dim3(a.nblk_m * nbn), dim3(NW * 64), lds, st, a);
     SA_CHECK_LAUNCH();
     return 0;
 }
 
 template <typename T, bool FUSE = false>
 static int launch_fprop_halo256(FpropArgs a, hipStream_t st) {
+    const uint32_t nbn = (uint32_t)a.g.cout_valid / 128;
+    if constexpr (sizeof(T) == 2) {
+        // two-plane tiles (2 x 8 x 16 voxels, plane slots shared between consecutive kd groups) when they tile the grid at least as well as 16 x 16 patches
+        // (SA_PP_DBG bit 10: never, bit 12: wherever they fit)
+        const int hp8 = (a.g.Ho + 7) / 8, hp16 = (a.g.Ho + 15) / 16, wp = (a.g.Wo + 15) / 16, dp = (a.g.Dm + 1) / 2;
+        const int64_t tiles1 = (int64_t)a.g.Dm * hp16 * wp, tiles2 = (int64_t)dp * hp8 * wp;
+        const bool p2 = !(g_tunables.pp_dbg & 1024u) && ((g_tunables.pp_dbg & 4096u) ? true : tiles2 <= tiles1);
+        if (p2) {
+            a.HP = (uint32_t)hp8;
+            a.WP = (uint32_t)wp;
+            a.DP = (uint32_t)dp;
+            a.nblk_m = (uint32_t)a.g.N * a.DP * a.HP * a.WP;
+            const size_t lds = 46 * 1024 + 2 * 128 * 128;   // 78 KiB: two plane slots + two weight slabs (>= the 64 KiB hidden tile of the fused variant)
+            (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo256_kernel<%s, %s, 8, true>", tname<T>(), FUSE ? "true" : "false"), note_kernel(g_last_conv_kernel));
+            return launch_fprop_halo256_impl<T, FUSE, 8, true>(a, nbn, lds, st);
+        }
+    }
     a.HP = (uint32_t)(a.g.Ho + 15) / 16;
     a.WP = (uint32_t)(a.g.Wo + 15) / 16;
     a.nblk_m = (uint32_t)a.g.N * (uint32_t)a.g.Dm * a.HP * a.WP;
-    const uint32_t nbn = (uint32_t)a.g.cout_valid / 128;
     const size_t lds = 41 * 1024 + 2 * 128 * 128;   // 73 KiB (>= the 64 KiB hidden tile of the fused variant)
     // bf16: eight waves per block (two blocks = four waves per SIMD): fused block 4.76 -> 4.51 ms, data gradient 4.73 -> 4.29 ms on the C = 128 /
     // 80 x 112 x 80 layer.  fp32 keeps four (its 128 accumulators + wider fragments do not fit 128 VGPRs).  SA_DBG_HALO256_4W selects four for A/B runs.
     // (the four-wave bf16 instances of THIS kernel -- 1 MB of device code each -- left the build after the measurement; SA_DBG_HALO256_4W still selects the
     //  four-wave forms of the im2col-order and weight-gradient kernels)
     if constexpr (sizeof(T) == 2) {
-        (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo256_kernel<%s, %s, 8>", tname<T>(), FUSE ? "true" : "false"), note_kernel(g_last_conv_kernel));
+        (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo256_kernel<%s, %s, 8, false>", tname<T>(), FUSE ? "true" : "false"), note_kernel(g_last_conv_kernel));
         return launch_fprop_halo256_impl<T, FUSE, 8>(a, nbn, lds, st);
     } else {
-        (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo256_kernel<%s, %s, 4>", tname<T>(), FUSE ? "true" : "false"), note_kernel(g_last_conv_kernel));
+        (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_halo256_kernel<%s, %s, 4, false>", tname<T>(), FUSE ? "true" : "false"), note_kernel(g_last_conv_kernel));
         return launch_fprop_halo256_impl<T, FUSE, 4>(a, nbn, lds, st);
     }
 }

@@ -138,7 +138,7 @@ def test_encoder_chain_f16_forward_tracks_fp32_and_trains_like_bf16():
         _ffi.lib().sa_kernel_log_read(buf, len(buf), 1)
         log = buf.value.decode()
         zbf = nbf.eval().encode(x)[0].float()
-    assert "conv1_fwd_f16_kernel" in log and "conv_fprop_halo256_kernel<f16_t, true, 8>" in log and "unsigned short" not in log, log
+    assert "conv1_fwd_f16_kernel" in log and "conv_fprop_halo256_kernel<f16_t, true, 8, " in log and "unsigned short" not in log, log
     e16, ebf = _rel(z16, z32), _rel(zbf, z32)
     print(f"[f16 forward] z vs fp32 encoder: f16 {e16:.2e}, bf16 {ebf:.2e}")
     assert e16 < 1.5e-3 and e16 < 0.35 * ebf, (e16, ebf)
