@@ -163,6 +163,7 @@ def test_conv_large_m_tail():
 
 @pytest.mark.parametrize("dtype,kind,cin,cout,k,st,dims", [
     (torch.bfloat16, "conv", 128, 128, 3, 1, (33, 45, 47)),
+    (torch.bfloat16, "conv", 128, 256, 3, 1, (35, 40, 47)),      # two-plane tiles with an odd number of planes, ragged in W, two channel tiles
     (torch.bfloat16, "conv", 64, 136, 3, 1, (29, 48, 50)),
     (torch.float32, "conv", 32, 128, 3, 1, (33, 45, 47)),
     (torch.bfloat16, "conv", 128, 128, 4, 2, (82, 84, 86)),

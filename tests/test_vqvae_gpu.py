@@ -212,10 +212,11 @@ def test_discriminator_matches_reference_fixture(dtype):
         assert _relerr(ye.cpu().numpy(), g["eval/logits"]) < 5e-3
 
 
-@pytest.mark.parametrize("shape", [(2, 9, 10, 11), (2, 33, 32, 44)])
+@pytest.mark.parametrize("shape", [(2, 9, 10, 11), (2, 33, 32, 44), (2, 35, 40, 44)])
 def test_fused_residual_block_matches_two_launch_path(shape):
     """sa_resblock_fprop (one launch) against the two-launch path of the same stage: y and the stored hidden activation.  The larger
-    shape runs on the halo mainloop (8 x 16 patches, ragged in W); its reference path is forced onto the im2col-order kernels."""
+    shapes run on the halo mainloops (16 x 16 patches; two-plane 2 x 8 x 16 tiles with an odd number of planes, ragged in W); their reference path is forced
+    onto the im2col-order kernels."""
     from synthanatomy_amd.networks.vqvae.baseline import ResidualLayer, _ResStage
     torch.manual_seed(3)
     mod = ResidualLayer(128, 128, 0.0).cuda()
@@ -224,7 +225,11 @@ def test_fused_residual_block_matches_two_launch_path(shape):
     tape = []
     y_f = st.fwd(x, tape)
     h_f = tape[0][1]
-    from synthanatomy_amd import debug
+    from synthanatomy_amd import _ffi, debug
+    if shape[1] == 35:
+        assert _ffi.lib().sa_last_conv_kernel().decode() == "conv_fprop_halo256_kernel<unsigned short, true, 8, true>"
+    elif shape[1] == 33:
+        assert _ffi.lib().sa_last_conv_kernel().decode() == "conv_fprop_halo256_kernel<unsigned short, true, 8, false>"
     with debug.override(no_fused_res=True, no_halo=True):
         tape2 = []
         y_r = st.fwd(x, tape2)
