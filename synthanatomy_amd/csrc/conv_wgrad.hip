@@ -51,6 +51,17 @@ __device__ __forceinline__ v4s_t lds_tr16(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(p));
 }
 
+// LDS-DMA load the COMPILER DOES NOT SEE (round 4).  The transposing LDS reads of these kernels are intrinsics without alias information, so after a
+// __builtin_amdgcn_raw_ptr_buffer_load_lds the waitcnt pass puts s_waitcnt vmcnt(0) in front of the next ds_read_b64_tr_b16 -- i.e. the prefetch of step s + 1,
+// issued at the top of step s, was WAITED FOR before step s multiplied anything (the "40 % of wave time parked on the per-step wait" of round 2 was this, not DMA
+// throughput).  Issued from inline assembly the load stays in flight over the step; the kernel waits for it itself (dma_wait) before the barrier that hands the
+// stage over.  Extra loads in flight only make the compiler's own vmcnt waits longer, never shorter.  lds_addr: wave-uniform LDS byte address (M0).
+__device__ __forceinline__ void dma16_hidden(__amdgpu_buffer_rsrc_t rsrc, uint32_t lds_addr, uint32_t voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
+
 // Column sums of a bf16 gradient tile [ROWS m][128 c] already in LDS (layout `roff`): thread = (channel pair tid & 63, row group tid >> 6).
 template <int ROWS, int NGROUPS>
 __device__ __forceinline__ void tile_colsum(const unsigned char* pg, uint32_t tid, float& s0, float& s1) {
@@ -375,9 +386,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_wgrad_dma_kernel(const W
         gcol[v] = ct * 128u + vec * VE;
         gok[v] = gcol[v] + VE <= (uint32_t)g.Cout;
     }
+    const uint32_t sx_addr = __builtin_amdgcn_readfirstlane(lds_address(sX)), sg_addr = __builtin_amdgcn_readfirstlane(lds_address(sG));
     auto issue = [&](uint32_t chunk, uint32_t buf) __attribute__((always_inline)) {
-        unsigned char* px = sX + buf * TILE_BYTES;
-        unsigned char* pg = sG + buf * TILE_BYTES;
         const uint32_t mb = chunk * MK;
 #pragma unroll
         for (int j = 0; j < NPIECE; ++j) {
@@ -387,8 +397,13 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_wgrad_dma_kernel(const W
             const bool okx = in_range(r, tp[v], g);
             const uint32_t xoff = okx ? (uint32_t)(r.ibase + tp[v].off) * (uint32_t)(g.Cin * SZ) + tp[v].c0 * SZ : 0xfffffff0u;
             const uint32_t goff = (r.ok && gok[v]) ? (uint32_t)r.ovox * (uint32_t)(g.Cout * SZ) + gcol[v] * SZ : 0xfffffff0u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)(px + piece * 1024), 16, xoff, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, (__attribute__((address_space(3))) void*)(pg + piece * 1024), 16, goff, 0, 0, 0);
+            if constexpr (IS_BF16) {   // (invisible to the compiler: see dma16_hidden; the fp32 kernel reads LDS with plain loads, which carry alias information)
+                dma16_hidden(rX, sx_addr + buf * TILE_BYTES + piece * 1024, xoff);
+                dma16_hidden(rG, sg_addr + buf * TILE_BYTES + piece * 1024, goff);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)(sX + buf * TILE_BYTES + piece * 1024), 16, xoff, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, (__attribute__((address_space(3))) void*)(sG + buf * TILE_BYTES + piece * 1024), 16, goff, 0, 0, 0);
+            }
         }
     };
 
@@ -407,6 +422,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_wgrad_dma_kernel(const W
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dgw[ic][ks] = *(const u32x4*)(wp + (wn * 64 + ic * 16 + frow) * 128 + ks * 32 + fq * 8);
     }
+    dma_wait();
     __syncthreads();
     const bool do_db = IS_BF16 && a.db != nullptr && kt == 0;   // the gradient rows of this split pass through exactly one kt = 0 block per co tile
     float bs0 = 0.f, bs1 = 0.f;
@@ -507,7 +523,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv_wgrad_dma_kernel(const W
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[i], gf[j], acc[i][j], 0, 0, 0);
             }
         }
-        __syncthreads();  // drains the DMA (vmcnt(0)) and frees this buffer
+        dma_wait();       // the next chunk's tiles have landed (dma16_hidden: the compiler does not wait for them)
+        __syncthreads();  // ... in every wave, and this buffer is free
     }
 
     if (do_db) colsum_finish<NW>((float*)smem, tid, bs0, bs1, a.db, ct * 128u, (uint32_t)g.cout_valid);   // (the loop's last barrier freed the tiles)
@@ -733,6 +750,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_halo9_kernel(const WgradAr
 
     __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)a.gout, 0, (int)a.g_bytes, 0x00020000);
+    const uint32_t smem_addr = __builtin_amdgcn_readfirstlane(lds_address(smem));
     // piece q = wave + 8 i: q < 23 activation halo (8 rows x 128 B: lane -> row l>>3, 16-byte slot l&7), else gradient (4 rows x 256 B:
     // row l>>4, slot l&15).  The DMA writes lane-linearly, so each lane fetches the SOURCE vector its slot holds after the swizzle.
     int32_t p_h[PPW], p_w[PPW];
@@ -757,7 +775,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_halo9_kernel(const WgradAr
         }
     }
     auto issue = [&](uint32_t step, uint32_t buf) __attribute__((always_inline)) {
-        unsigned char* ps = smem + buf * STAGE;
+        const uint32_t ps = smem_addr + buf * STAGE;
         uint32_t q1 = fdiv(step, a.dWP);
         const uint32_t wp = step - q1 * a.WP;
         uint32_t q2 = fdiv(q1, a.dHQ);
@@ -776,16 +794,16 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_halo9_kernel(const WgradAr
             const int32_t hh = h0 + p_h[i], ww = w0 + p_w[i];
             if (q < (uint32_t)XP) {
                 const bool ok = dok && (uint32_t)hh < (uint32_t)g.Hi && (uint32_t)ww < (uint32_t)g.Wi;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (__attribute__((address_space(3))) void*)(ps + q * 1024), 16, ok ? xbase + p_off[i] : 0xfffffff0u, 0, 0, 0);
+                dma16_hidden(rX, ps + q * 1024, ok ? xbase + p_off[i] : 0xfffffff0u);
             } else {
                 const bool ok = (uint32_t)hh < (uint32_t)g.Ho && (uint32_t)ww < (uint32_t)g.Wo;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, (__attribute__((address_space(3))) void*)(ps + XT + (q - (uint32_t)XP) * 1024), 16, ok ? gbase + p_off[i] : 0xfffffff0u, 0, 0,
-                                                         0);
+                dma16_hidden(rG, ps + XT + (q - (uint32_t)XP) * 1024, ok ? gbase + p_off[i] : 0xfffffff0u);
             }
         }
     };
 
     issue(step0, 0);
+    dma_wait();
     __syncthreads();
     const uint32_t frow = lane & 15u, fq = lane >> 4;
     const uint32_t trow = fq * 4u + (frow >> 2), tcol = (frow & 3u) * 4u;
@@ -831,7 +849,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_halo9_kernel(const WgradAr
                 for (int j = 0; j < NJ; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, gf[j], acc[t][j], 0, 0, 0);
             }
         }
-        __syncthreads();  // drains the DMA (vmcnt(0)) and frees this buffer
+        dma_wait();       // the next step's tiles have landed (the compiler does not know about them: dma16_hidden)
+        __syncthreads();  // ... in every wave, and this buffer is free
     }
     if (do_db) colsum_finish<NW>((float*)smem, tid, bs0, bs1, a.db, ct * 128u, (uint32_t)g.cout_valid);
     // partial tiles of the nine taps of this kd -> workspace [split][tile = tap + 27*ct][co 128][ci 128]
