@@ -1754,34 +1754,67 @@ __global__ __launch_bounds__(512) void gemv_rows_kernel(const GemvArgs a, int b0
             if (a.res) e_res[r] = a.res[(int64_t)b * a.res_stride + oc];
         }
     }
+    // The wave's K range in blocks of eight MFMA steps whose operand loads are ALL issued before the first product (steps beyond the range multiply a zero
+    // input fragment): the compiler does not unroll the run-time loop ("loop not unrolled" with #pragma unroll 8), and one step per iteration was one dependent
+    // memory round trip per step -- eight per wave for K = 2 048.
     if constexpr (BF16) {
         const bf16_t* wrb = (const bf16_t*)a.w[sgi] + (int64_t)oo * a.in;
-#pragma unroll 8
-        for (int k0 = kbeg; k0 < kend; k0 += 32) {
-            short8_t wa, xb;
-            if constexpr (WB) {
-                wa = *(const short8_t*)(wrb + k0 + kg * 8);
-            } else {
-                const float4 w0 = *(const float4*)(wr + k0 + kg * 8), w1 = *(const float4*)(wr + k0 + kg * 8 + 4);
-                wa[0] = (short)f32_to_bf16(w0.x); wa[1] = (short)f32_to_bf16(w0.y); wa[2] = (short)f32_to_bf16(w0.z); wa[3] = (short)f32_to_bf16(w0.w);
-                wa[4] = (short)f32_to_bf16(w1.x); wa[5] = (short)f32_to_bf16(w1.y); wa[6] = (short)f32_to_bf16(w1.z); wa[7] = (short)f32_to_bf16(w1.w);
+        // NS steps from kb: loads first, then the products (steps beyond the range multiply a zero input fragment)
+        auto block = [&](auto ns_tag, int kb) __attribute__((always_inline)) {
+            constexpr int NS = decltype(ns_tag)::value;
+            short8_t wa[NS];
+            float4 x0[NS], x1[NS];
+            float4 w0[WB ? 1 : NS], w1[WB ? 1 : NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int k0 = kb + 32 * i < kend ? kb + 32 * i : kbeg;      // (a valid address; its product is zeroed below)
+                if constexpr (WB) {
+                    wa[i] = *(const short8_t*)(wrb + k0 + kg * 8);
+                } else {
+                    w0[i] = *(const float4*)(wr + k0 + kg * 8);
+                    w1[i] = *(const float4*)(wr + k0 + kg * 8 + 4);
+                }
+                x0[i] = *(const float4*)(xr + k0 + kg * 8);
+                x1[i] = *(const float4*)(xr + k0 + kg * 8 + 4);
             }
-            const float4 x0 = *(const float4*)(xr + k0 + kg * 8), x1 = *(const float4*)(xr + k0 + kg * 8 + 4);
-            xb[0] = (short)f32_to_bf16(x0.x); xb[1] = (short)f32_to_bf16(x0.y); xb[2] = (short)f32_to_bf16(x0.z); xb[3] = (short)f32_to_bf16(x0.w);
-            xb[4] = (short)f32_to_bf16(x1.x); xb[5] = (short)f32_to_bf16(x1.y); xb[6] = (short)f32_to_bf16(x1.z); xb[7] = (short)f32_to_bf16(x1.w);
-            if (!brow) xb = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                if constexpr (!WB) {
+                    wa[i][0] = (short)f32_to_bf16(w0[i].x); wa[i][1] = (short)f32_to_bf16(w0[i].y); wa[i][2] = (short)f32_to_bf16(w0[i].z); wa[i][3] = (short)f32_to_bf16(w0[i].w);
+                    wa[i][4] = (short)f32_to_bf16(w1[i].x); wa[i][5] = (short)f32_to_bf16(w1[i].y); wa[i][6] = (short)f32_to_bf16(w1[i].z); wa[i][7] = (short)f32_to_bf16(w1[i].w);
+                }
+                short8_t xb;
+                xb[0] = (short)f32_to_bf16(x0[i].x); xb[1] = (short)f32_to_bf16(x0[i].y); xb[2] = (short)f32_to_bf16(x0[i].z); xb[3] = (short)f32_to_bf16(x0[i].w);
+                xb[4] = (short)f32_to_bf16(x1[i].x); xb[5] = (short)f32_to_bf16(x1[i].y); xb[6] = (short)f32_to_bf16(x1[i].z); xb[7] = (short)f32_to_bf16(x1[i].w);
+                if (!brow || kb + 32 * i >= kend) xb = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[i], xb, acc, 0, 0, 0);
+            }
+        };
+        const int nsteps = (kend - kbeg + 31) / 32;      // (block-uniform up to the last wave: waves take the branch of their own count)
+        if (nsteps > 0) {
+            if (nsteps <= 2) block(std::integral_constant<int, 2>{}, kbeg);
+            else if (nsteps <= 4) block(std::integral_constant<int, 4>{}, kbeg);
+            else
+                for (int kb = kbeg; kb < kend; kb += 8 * 32) block(std::integral_constant<int, 8>{}, kb);
         }
     } else {
-#pragma unroll 4
-        for (int k0 = kbeg; k0 < kend; k0 += 16) {   // MFMA e of a group uses k = k0 + kg*4 + e on both operands
-            const float4 w0 = *(const float4*)(wr + k0 + kg * 4);
-            float4 x0 = *(const float4*)(xr + k0 + kg * 4);
-            if (!brow) x0 = make_float4(0.f, 0.f, 0.f, 0.f);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, x0.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, x0.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, x0.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, x0.w, acc, 0, 0, 0);
+        for (int kb = kbeg; kb < kend; kb += 8 * 16) {   // MFMA e of a group uses k = k0 + kg*4 + e on both operands
+            float4 w0[8], x0[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k0 = kb + 16 * i < kend ? kb + 16 * i : kbeg;
+                w0[i] = *(const float4*)(wr + k0 + kg * 4);
+                x0[i] = *(const float4*)(xr + k0 + kg * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float4 xv = x0[i];
+                if (!brow || kb + 16 * i >= kend) xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[i].x, xv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[i].y, xv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[i].z, xv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[i].w, xv.w, acc, 0, 0, 0);
+            }
         }
     }
     // D: lane holds output columns o0 + 4*kg + r (r = 0..3) of batch row b0 + fr
