@@ -1961,11 +1961,13 @@ __device__ __forceinline__ void local_step_partial_body(const LocalStepArgs& a, 
 #pragma unroll
         for (int e = 0; e < 16; ++e) kv[e] = kj[e];
     }
+    // (unconditional loads from a clamped row + a bit mask: a select would put every load under its own branch -- 64 branches, ~1.5 us of issue)
     float vv[64];
 #pragma unroll
     for (int u = 0; u < 64; ++u) {
         const int j = wv + 4 * u, jj = lo + j0 + j;
-        vv[u] = (j < cnt && jj != t) ? vc[(int64_t)jj * dh + lane] : 0.f;
+        const float x = vc[(int64_t)min(jj, a.N - 1) * dh + lane];
+        vv[u] = __uint_as_float(__float_as_uint(x) & ((j < cnt && jj != t) ? 0xffffffffu : 0u));
     }
     if (tid < dh) {
         const float* qr = a.q + (int64_t)b * a.q_stride + a.q_off + l * dh;
@@ -2012,10 +2014,11 @@ __device__ __forceinline__ void local_step_partial_body(const LocalStepArgs& a, 
     __syncthreads();
     sum = (red[0] + red[1]) + (red[2] + red[3]);
     float acc = 0.f;          // thread = (key slice wv, value dim lane); keys in ascending order, as before
+    const float svl = svt[lane];
 #pragma unroll
     for (int u = 0; u < 64; ++u) {
-        const int j = wv + 4 * u;
-        if (j < cnt) acc = fmaf(sc[j], lo + j0 + j == t ? svt[lane] : vv[u], acc);
+        const int j = wv + 4 * u;      // (j >= cnt: sc[j] = 0 and vv[u] = 0)
+        acc = fmaf(sc[j], lo + j0 + j == t ? svl : vv[u], acc);
     }
     sacc[wv][lane] = acc;
     __syncthreads();
