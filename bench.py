@@ -77,12 +77,12 @@ def _physical_cores():
 
 def cpu_baseline():
     """Reference-equivalent CPU path (the oracle restatement, fp32 torch-CPU) on this host: ONE full 160x224x160 volume, forward + MSE + backward
-    of the config-2 network, after a warm-up step on a small crop that also bounds the run: if the crop's rate says the full volume
-    would take more than ~45 s, the crop (scaled by voxel count) is reported instead and the sample says so."""
+    of the config-2 network -- always the full volume, no extrapolation -- timed once with every physical core and once with half of
+    them (on the pool's 2 x 64-core hosts the 64-thread run has been the faster one: cross-socket traffic); `value` is the better of the two and
+    both are listed.  A small crop step per thread count warms the thread pool and the allocator first.  About 50-60 s of CPU work."""
     from oracle import vqvae_ref
 
-    threads = _physical_cores()               # SURVEY 8(d): all physical cores of the host (SMT siblings add nothing to MKL / oneDNN kernels)
-    torch.set_num_threads(threads)
+    phys = _physical_cores()               # SURVEY 8(d): all physical cores of the host (SMT siblings add nothing to MKL / oneDNN kernels)
     cfg = vqvae_ref.VQVAEConfig(**NET)
     st = vqvae_ref.init_state(cfg, seed=4)
     leaf = {k: v.requires_grad_(True) for k, v in st.items() if "quantizer" not in k}
@@ -97,19 +97,17 @@ def cpu_baseline():
         vqvae_ref.mse_loss(out, x).backward()
         return time.perf_counter() - t0
 
-    crop = (64, 96, 64)
-    one(crop)                       # thread pool / allocator warm-up
-    t_crop = one(crop)
-    frac = (crop[0] * crop[1] * crop[2]) / float(VOL[0] * VOL[1] * VOL[2])
-    host = _host_description()
-    if t_crop / frac <= 45.0:
+    runs = []
+    for threads in sorted({phys, max(1, phys // 2)}):
+        torch.set_num_threads(threads)
+        one((32, 48, 32))               # thread pool / allocator warm-up
         dt = one(VOL)
-        return {"value": 1.0 / dt, "unit": "volumes/s", "cores": threads, "kind": "port",
-                "sample": f"1 training step (fwd + MSE + bwd, fp32 torch-CPU oracle) of the config-2 network on ONE full {VOL[0]}x{VOL[1]}x{VOL[2]} volume: {dt:.2f} s "
-                          f"with {threads} threads (warm-up crop {crop}: {t_crop:.2f} s); host: {host}"}
-    return {"value": frac / t_crop, "unit": "volumes/s", "cores": threads, "kind": "port",
-            "sample": f"1 training step on a {crop[0]}x{crop[1]}x{crop[2]} crop = {frac:.4f} of a volume, {t_crop:.2f} s with {threads} threads, scaled by voxel count "
-                      f"(the full volume was projected at {t_crop / frac:.0f} s > 45 s); host: {host}"}
+        runs.append({"threads": threads, "seconds": round(dt, 2), "volumes_per_sec": round(1.0 / dt, 5)})
+    best = max(runs, key=lambda r: r["volumes_per_sec"])
+    torch.set_num_threads(best["threads"])
+    return {"value": best["volumes_per_sec"], "unit": "volumes/s", "cores": best["threads"], "kind": "port", "runs": runs,
+            "sample": f"1 training step (fwd + MSE + bwd, fp32 torch-CPU oracle) of the config-2 network on ONE full {VOL[0]}x{VOL[1]}x{VOL[2]} volume per thread "
+                      f"count ({', '.join(str(r['threads']) + ' threads: ' + str(r['seconds']) + ' s' for r in runs)}); value = the faster; host: {_host_description()}"}
 
 
 def cpu_baseline_performer():
@@ -242,14 +240,18 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     dtm = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if dist.is_initialized():
         t = torch.tensor([dtm], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -298,7 +300,9 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
                     "workload": f"sample() of {B} sequences x {N} tokens per GPU, stateful O(N) decoding (HIP graph per token), graph capture included"}
         assert tuple(out.shape) == (B, *spatial)
     res = {"metric": "performer_train_tokens_per_sec", "value": round(toks, 1), "unit": "tokens/s", "ms_per_step": round(dtm / args.steps * 1e3, 3),
-           "dtype": args.dtype, "scaling": "weak", "final_loss": round(float(loss.item()), 5),
+           "dtype": args.dtype, "scaling": "weak", "final_loss": round(float(loss.item()), 5), "steps": args.steps, "warmup": args.warmup,
+           "step_ms": {"median": round(step_ms[len(step_ms) // 2], 3), "min": round(step_ms[0], 3), "max": round(step_ms[-1], 3),
+                       "tokens_per_sec_at_median": round(B * N * world / (step_ms[len(step_ms) // 2] * 1e-3), 1)},
            "tflops_per_gpu": round(toks / world * PERFORMER_STEP_MFLOP_PER_TOKEN / 1e6, 2),
            "config": {"workload": f"performer n_embd=512 n_layers=24 n_head=16 local_attn_heads=8 local_window=420 vocab=2048, N={N} raster-ordered "
                                   f"{'x'.join(map(str, spatial))} latents, training step = fwd + CE + bwd + Adam, projections redrawn every other step", "batch_per_gpu": B,
@@ -614,8 +618,9 @@ def bench_adversarial(dev, dtype, batch, steps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50, help="timed steps (SURVEY 8(d): >= 50)")
+    ap.add_argument("--warmup", type=int, default=20, help="untimed steps before them (SURVEY 8(d): 20)")
+    ap.add_argument("--roofline-steps", type=int, default=3, help="steps of the separate per-kernel pass behind the timed region")
     ap.add_argument("--batch", type=int, default=8, help="volumes per GPU per step (README.md:72: batch 8/GPU)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -695,32 +700,47 @@ def main():
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
-    timer = None
-    if not args.no_kernel_timer:
-        timer = engine.KernelTimer()
-        engine.TIMER = timer
+    # the timed region: EXACTLY args.steps steps, nothing else on the streams (no per-launch events: the roofline pass below is separate), a HIP event on the
+    # launch stream at every step boundary (hipEventElapsedTime per step, median reported next to the wall-clock mean that `value` uses)
     reducer.timing = dist.is_initialized()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    engine.TIMER = None
     reducer.timing = False
     comm = reducer.comm_stats()
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
 
+    # roofline pass, AFTER the timed region: a few more steps with HIP events around every launch on the launch stream (engine.KernelTimer)
+    timer = None
+    if not args.no_kernel_timer:          # (every rank runs the steps -- they contain collectives --, rank 0 carries the events)
+        if rank == 0:
+            timer = engine.KernelTimer()
+            engine.TIMER = timer
+        for _ in range(args.roofline_steps):
+            step()
+        torch.cuda.synchronize()
+        if timer is not None:
+            stats = timer.collect()
+        engine.TIMER = None
+    if dist.is_initialized():
+        dist.barrier()
+
     roof = None
     if timer is not None:
-        stats = timer.collect()
         # brackets that cover two kernels (wgrad + its partial-tile reduce) stay in `kernels` but are not the roofline kernel:
         # its avg_launch_us has to be comparable with rocprofv3's per-kernel average
         single = {k: v for k, v in stats.items() if "+" not in k} or stats
@@ -731,6 +751,7 @@ def main():
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": _pmc_traffic(name, args), "traffic_source": _pmc_source(),
                 "kernel": name, "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
+                "how": f"separate pass of {args.roofline_steps} steps after the timed region, HIP events around every launch on the launch stream",
                 "kernels": {k: {"launches": v[0], "ms": round(v[2], 3), "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2) if v[2] > 0 else None}
                             for k, v in sorted(stats.items(), key=lambda kv: -kv[1][2])}}
 
@@ -754,6 +775,11 @@ def main():
             "metric": "vqvae_train_volumes_per_sec", "value": round(value, 4), "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
+            "step_ms": {"median": round(step_ms[len(step_ms) // 2], 3), "min": round(step_ms[0], 3), "max": round(step_ms[-1], 3),
+                        "p10": round(step_ms[len(step_ms) // 10], 3), "p90": round(step_ms[(len(step_ms) * 9) // 10 if len(step_ms) > 1 else 0], 3),
+                        "volumes_per_sec_at_median": round(args.batch * world / (step_ms[len(step_ms) // 2] * 1e-3), 3),
+                        "how": "hipEventElapsedTime between events recorded on the launch stream at every step boundary of the timed region (rank 0); "
+                               "`value` = volumes / wall time of the whole region (barrier + synchronize on both sides, MAX over ranks)"},
             "config": {"workload": "baseline_vqvae no_levels=4 no_channels=256 embedding_dim=32 num_embeddings=2048, 160x224x160 fp32 volumes, "
                                    "training step = fwd + MSE + bwd + EMA codebook update + Adam", "batch_per_gpu": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
@@ -775,7 +801,7 @@ def main():
     # "report also inference (index_quantize + decode_samples) volumes/s"
     net.eval()
     with torch.no_grad():
-        for _ in range(max(1, args.warmup)):
+        for _ in range(max(1, min(3, args.warmup))):
             rec = net.decode_samples(net.index_quantize(x))
         torch.cuda.synchronize()
         if dist.is_initialized():

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 2   /* 2 (round 4): sa_local_attn_fwd/bwd + sa_epilogue grew trailing pointers in round 3, SA_F16 operand type, sa_mse partials; a caller built against 1 must not load this library */
+#define SA_ABI_VERSION 3   /* 3 (round 5): sa_sample_step takes top_k.  2 (round 4): sa_local_attn_fwd/bwd + sa_epilogue grew trailing pointers in round 3, SA_F16 operand type, sa_mse partials; a caller built against 1 must not load this library */
 enum { SA_F32 = 0, SA_BF16 = 1, SA_F16 = 2 /* IEEE half: FORWARD operand / activation type only (the reference's AMP dtype, src/engines/trainer.py:161-163); see sa_conv_fprop */ };
 enum { SA_ACT_NONE = 0, SA_ACT_RELU = 1, SA_ACT_LRELU = 2, SA_ACT_GELU = 3 };
 enum { SA_MASK_NONE = 0, SA_MASK_POS = 1 /* out *= (mask > 0) */, SA_MASK_LRELU = 2 /* out *= mask>0 ? 1 : slope */,
@@ -215,13 +215,13 @@ int sa_embed_scatter(const float *dy, float *dtable, const int64_t *idx, int per
  *                 [B, L, N, dh] and attends over the previous and the current window up to *pos (look_backward = 1, causal). */
 int sa_embed_step(int ntab, const float *const *tables, const int64_t *const *idx, const int32_t *per_position, int dim, const int *pos, int B,
                   float *out, void *stream);
-/* The decision of one decode step for all B rows (TransformerBase.sample_next_index, transformer.py:19-56, without top-k) + the sequence update:
- * logits [B, V] / temperature -> softmax -> categorical draw by inverse CDF with the caller's uniforms u[*pos * u_stride + b] (do_sample; u_stride = B: a table
+/* The decision of one decode step for all B rows (TransformerBase.sample_next_index, transformer.py:11-17,19-56) + the sequence update:
+ * logits [B, V] / temperature -> top-k cut (top_k in (0, V): everything below the k-th largest value of a row is masked, ties with it stay; <= 0 or >= V: none) -> softmax -> categorical draw by inverse CDF with the caller's uniforms u[*pos * u_stride + b] (do_sample; u_stride = B: a table
  * drawn once per sample() call, 0: one vector per step) or arg-max; seq[b, *pos + 1] receives the token unless that position belongs to the given prefix (< P);
  * tok[b] = seq[b, *pos + 1] (what the next step embeds); *pos += 1.  ticket: NULL (one block walks the rows) or a zeroed int the launch leaves zeroed (one
  * block per row; the last one to finish advances *pos). */
-int sa_sample_step(const float *logits, int B, int V, float temperature, const float *u, int u_stride, int do_sample, int64_t *seq, int total, int P, int *pos,
-                   int *ticket, int64_t *tok, void *stream);
+int sa_sample_step(const float *logits, int B, int V, float temperature, const float *u, int u_stride, int do_sample, int top_k, int64_t *seq, int total, int P,
+                   int *pos, int *ticket, int64_t *tok, void *stream);
 int sa_favor_step(const float *q, int q_stride, int q_off, const float *k, int k_stride, int k_off, const float *v, int v_stride, int v_off,
                   const float *proj, int B, int G, int dh, int m, int LDF, float *smax, int *kmax, float *dd, float *E, float *Ez, float *V1,
                   const int *pos, float *out, int out_stride, int out_off, void *stream);

@@ -99,7 +99,7 @@ _SIGS = {
     "sa_bn_sums_ws_floats": (c_int64, [c_int]),
     "sa_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
     "sa_embed_sum": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), c_int, c_int, c_int64, c_void_p, c_void_p]),
-    "sa_sample_step": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sa_sample_step": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sa_embed_step": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "sa_favor_step": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -199,7 +199,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 2   # include/synthanatomy_hip.h: SA_ABI_VERSION
+ABI_VERSION = 3   # include/synthanatomy_hip.h: SA_ABI_VERSION
 SA_EINVAL, SA_EUNSUPPORTED, SA_ENOGPU = -1, -2, -3   # include/synthanatomy_hip.h
 
 

@@ -529,6 +529,7 @@ __device__ __forceinline__ void favor_fstate_seq_body(const FusedArgs& s, const 
         pslab_load(pre, s.ptiles, sl, tid);
         pslab_store(sPh, pre, tid);     // (hi tile | lo tile, contiguous)
     }
+    __syncthreads();    // every thread's pieces of the projection slab are in LDS before chunk 0 builds features from the whole tile
     float4_t acc[4], accz = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int f = 0; f < 4; ++f) acc[f] = (float4_t){0.f, 0.f, 0.f, 0.f};

@@ -1409,19 +1409,28 @@ __global__ void embed_step_kernel(const EmbedArgs a, const int* __restrict__ pos
     }
 }
 
-// ---- decode step, the decision for ALL rows in one launch (networks/transformers/transformer.choose_next without top-k + the sequence update of Performer._sample_stateful):
-// logits / temperature -> softmax -> categorical draw by inverse CDF with the caller's uniform u[b] (same rule as the torch expression it replaces:
-// index = #{v : cdf[v] < u * cdf[V - 1]}, clamped) or arg-max (lowest index on ties); position pos + 1 receives the token unless it belongs to the given prefix;
-// tok[b] = the token the NEXT step embeds; *pos += 1.  One block walks the rows (B is a handful): ~20 small torch launches per token -> 1.
+// ---- decode step, the decision for ALL rows in one launch (networks/transformers/transformer.choose_next + the sequence update of Performer._sample_stateful;
+// reference transformer.py:11-17,42-54): logits / temperature -> optional top-k cut (everything below the k-th largest value of the row becomes -inf; ties with
+// it stay, as `out[out < v[:, [-1]]] = -inf` keeps them) -> softmax -> categorical draw by inverse CDF with the caller's uniform u[b]
+// (the first token of non-zero probability whose inclusive cdf reaches u * total -- with exact sums this is the torch rule index = #{v : cdf[v] < u * total};
+// a target that falls between two threads' differently associated partial sums yields the neighbouring token, never a spurious V - 1 or a masked one) or arg-max (lowest index on ties, clamped into range when the row is all
+// NaN); position pos + 1 receives the token unless it belongs to the given prefix; tok[b] = the token the NEXT step embeds; *pos += 1.
 // Grid: one block per row when the caller gives a zeroed `ticket` word (the last block to finish advances *pos and re-zeroes the ticket), else one block
 // that walks the rows.  u[*pos * u_stride + b]: a table of uniforms drawn once per sample() call (u_stride = B) or one vector per step (u_stride = 0).
+__device__ __forceinline__ unsigned f2ukey(float f) { const unsigned i = __float_as_uint(f); return (i & 0x80000000u) ? ~i : (i | 0x80000000u); }   // unsigned order = float order
+__device__ __forceinline__ float ukey2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
 __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restrict__ logits, int B, int V, float inv_temp, const float* __restrict__ u, int u_stride,
-                                                         int do_sample, int64_t* __restrict__ seq, int total, int P, int* __restrict__ pos, int* __restrict__ ticket,
-                                                         int64_t* __restrict__ tok) {
+                                                         int do_sample, int top_k, int64_t* __restrict__ seq, int total, int P, int* __restrict__ pos,
+                                                         int* __restrict__ ticket, int64_t* __restrict__ tok) {
     __shared__ float sred[16];
     __shared__ int sidx[16];
     __shared__ float sscan[16];
-    __shared__ int sfound;
+    __shared__ int sfound, slast;
+    __shared__ int shist[256];
+    __shared__ int swtot[4];
+    __shared__ unsigned sprefix;
+    __shared__ int skrem;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = *pos;
     const int ept = (V + 1023) / 1024;                 // elements per thread, contiguous: thread t owns [t * ept, (t + 1) * ept)
@@ -1456,13 +1465,58 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
             mx = t0 ? sred[w] : mx;
             am = t0 ? sidx[w] : am;
         }
-        int ix = am;
+        int ix = min(am, V - 1);                       // (all-NaN row: no element ever compared greater)
         if (do_sample) {
-            // exclusive prefix of exp(x - max) in index order: per-thread sums -> wave scan -> scan of the 16 wave totals
+            // top-k cut: the k-th largest scaled logit by a four-pass radix select over order-preserving keys (256-bin histogram of the keys that share the
+            // digits chosen so far; the digit whose suffix count reaches the remaining k is the next one)
+            float kth = -INFINITY;
+            if (top_k > 0 && top_k < V) {
+                if (tid == 0) { sprefix = 0u; skrem = top_k; }
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int shift = 24 - 8 * pass;
+                    if (tid < 256) shist[tid] = 0;
+                    __syncthreads();
+                    const unsigned pref = sprefix, pmask = pass ? (0xffffffffu << (shift + 8)) : 0u;
+                    const int krem = skrem;
+                    for (int e = 0; e < ept; ++e) {
+                        const int v = tid * ept + e;
+                        if (v < V) {
+                            const unsigned key = f2ukey(lr[v] * inv_temp);
+                            if ((key & pmask) == pref) atomicAdd(&shist[(key >> shift) & 0xffu], 1);
+                        }
+                    }
+                    __syncthreads();
+                    int c = 0, inc = 0;
+                    if (tid < 256) {
+                        c = shist[tid];
+                        inc = c;               // inclusive suffix count inside the wave: keys of this pass with digit >= tid
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const int t = __shfl_down(inc, o, 64);
+                            if (lane + o < 64) inc += t;
+                        }
+                        if (lane == 0) swtot[wv] = inc;
+                    }
+                    __syncthreads();
+                    if (tid < 256) {
+                        for (int w = wv + 1; w < 4; ++w) inc += swtot[w];
+                        if (inc >= krem && inc - c < krem) {        // exactly one digit: the suffix counts are monotone
+                            sprefix = pref | ((unsigned)tid << shift);
+                            skrem = krem - (inc - c);
+                        }
+                    }
+                    __syncthreads();
+                }
+                kth = ukey2f(sprefix);
+            }
+            // prefix of exp(x - max) over the kept elements in index order: per-thread sums -> wave scan -> scan of the 16 wave totals
             float loc = 0.f;
             for (int e = 0; e < ept; ++e) {
                 const int v = tid * ept + e;
-                if (v < V) loc += __expf(lr[v] * inv_temp - mx);
+                if (v < V) {
+                    const float x = lr[v] * inv_temp;
+                    loc += x < kth ? 0.f : __expf(x - mx);
+                }
             }
             float inc = loc;
 #pragma unroll
@@ -1472,7 +1526,7 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
             }
             __syncthreads();               // (sred / sidx of the maximum have been read by everyone)
             if (lane == 63) sscan[wv] = inc;
-            if (tid == 0) sfound = V - 1;  // the clamp of the torch expression
+            if (tid == 0) { sfound = 0x7fffffff; slast = -1; }
             __syncthreads();
             float wbase = 0.f, tot = 0.f;
             for (int w = 0; w < 16; ++w) {
@@ -1481,20 +1535,32 @@ __global__ __launch_bounds__(1024) void sample_step_kernel(const float* __restri
             }
             const float target = ur[b] * tot;
             float run = wbase + inc - loc;  // cdf before this thread's first element
-            // the number of elements with cdf < target = the first index whose inclusive cdf reaches the target
-            if (run < target && run + loc >= target) {
-                int hit = V - 1;
+            // the first token of non-zero probability whose inclusive cdf reaches the target: every thread that owns probability mass walks its elements and
+            // offers its first hit; the lowest index wins.  No "is the target inside my interval" test -- neighbouring threads' differently associated sums
+            // can leave one-ulp gaps between intervals -- and a token the top-k cut removed (or with exp() = 0) can never be returned.
+            int hit = 0x7fffffff, lastnz = -1;
+            if (loc > 0.f) {
                 for (int e = 0; e < ept; ++e) {
                     const int v = tid * ept + e;
                     if (v < V) {
-                        run += __expf(lr[v] * inv_temp - mx);
-                        if (run >= target) { hit = v; break; }
+                        const float x = lr[v] * inv_temp;
+                        const float pe = x < kth ? 0.f : __expf(x - mx);
+                        run += pe;
+                        if (pe > 0.f) {
+                            lastnz = v;
+                            if (run >= target && hit == 0x7fffffff) hit = v;
+                        }
                     }
                 }
-                atomicMin(&sfound, hit);
             }
+            if (hit != 0x7fffffff) atomicMin(&sfound, hit);
             __syncthreads();
-            ix = sfound;
+            if (sfound == 0x7fffffff) {     // rounding left every recomputed cdf value below the target (u close to 1): the last token that carries mass
+                if (lastnz >= 0) atomicMax(&slast, lastnz);
+                __syncthreads();
+                ix = max(slast, 0);
+            } else
+                ix = sfound;
         }
         if (tid == 0) {
             const int np = p + 1;
@@ -2385,11 +2451,11 @@ extern "C" int sa_embed_step(int ntab, const float* const* tables, const int64_t
     return 0;
 }
 
-extern "C" int sa_sample_step(const float* logits, int B, int V, float temperature, const float* u, int u_stride, int do_sample, int64_t* seq, int total, int P,
-                              int* pos, int* ticket, int64_t* tok, void* stream) {
+extern "C" int sa_sample_step(const float* logits, int B, int V, float temperature, const float* u, int u_stride, int do_sample, int top_k, int64_t* seq, int total,
+                              int P, int* pos, int* ticket, int64_t* tok, void* stream) {
     if (!logits || !seq || !pos || !tok || (do_sample && !u) || u_stride < 0 || B <= 0 || V <= 0 || total <= 0 || !(temperature > 0.f)) return SA_EINVAL;
-    SA_LAUNCH(sample_step_kernel, dim3(ticket ? B : 1), dim3(1024), 0, ST(stream), logits, B, V, 1.f / temperature, u, u_stride, do_sample, seq, total, P, pos, ticket,
-              tok);
+    SA_LAUNCH(sample_step_kernel, dim3(ticket ? B : 1), dim3(1024), 0, ST(stream), logits, B, V, 1.f / temperature, u, u_stride, do_sample, top_k, seq, total, P, pos,
+              ticket, tok);
     SA_CHECK_LAUNCH();
     return 0;
 }

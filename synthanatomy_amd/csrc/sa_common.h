@@ -68,9 +68,12 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(
 // bit-twiddling form it replaces in round 4 cost ~6 per value and was a visible share of the convolution epilogues: 64.6 -> 66.2 volumes/s)
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
-// round-to-nearest-even; finite values beyond the half range saturate to +-65504 instead of becoming infinities (the un-normalised residual stream)
+// round-to-nearest-even; FINITE values beyond the half range saturate to +-65504 instead of becoming infinities (the un-normalised residual stream);
+// NaN and +-inf inputs come out as NaN, so a diverged run shows in z and the loss: v_med3_f32 alone returns min3 = -65504 when an input is NaN (a NaN
+// activation would turn into zero behind the next ReLU while the bf16 copy of the same value still carried it); f * 0 is 0 for finite f and NaN otherwise,
+// which costs one fused multiply-add per value instead of a compare + select.
 __device__ __forceinline__ unsigned short f32_to_f16(float f) {
-    const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f);
+    const _Float16 h = (_Float16)__builtin_fmaf(f, 0.f, __builtin_amdgcn_fmed3f(f, -65504.f, 65504.f));
     return __builtin_bit_cast(unsigned short, h);
 }
 __device__ __forceinline__ float f16_to_f32(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }

@@ -338,16 +338,18 @@ class _GradCtx:
             # were queued on the main stream (bias / gate gradients) and on the weight-gradient stream, so report them from the latter after it has caught up
             self.side.side.wait_stream(self.side.main)
             with torch.cuda.stream(self.side.side):
-                if hasattr(self.sink, "flush"):
-                    self.sink.flush()     # optimizer slices deferred by EARLIER reports: everything that reads their parameters is queued (runtime/ddp.GradReducer.flush)
-                for p in params:
-                    if p is not None:
-                        self.sink.ready(p)
+                self._report(params)
             return
+        self._report(params)
+
+    def _report(self, params):
+        params = [p for p in params if p is not None]
         if hasattr(self.sink, "flush"):
-            self.sink.flush()
-        for p in params:
-            if p is not None:
+            tok = self.sink.flush()       # optimizer slices deferred by EARLIER reports: everything that reads their parameters is queued (runtime/ddp.GradReducer.flush)
+            for p in params:
+                self.sink.ready(p, tok)
+        else:
+            for p in params:
                 self.sink.ready(p)
 
 
@@ -1270,7 +1272,10 @@ class Performer(TransformerBase):
         col = torch.arange(total, device=dev)[None, :]
         tok.copy_(seq0[:, 0])
 
-        fused_tail = top_k is None and not debug.host("no_sample_step")     # one launch for the decision + sequence update (sa_sample_step)
+        fused_tail = not debug.host("no_sample_step")     # one launch for the decision (incl. the top-k cut) + sequence update (sa_sample_step)
+        n_vocab = self.to_out.weight.shape[0]
+        if top_k is not None and not 0 < int(top_k) <= n_vocab:   # what torch.topk of the reference (transformer.py:14) raises on
+            raise RuntimeError(f"selected index k out of range (top_k = {top_k}, vocabulary {n_vocab})")
         # the uniforms of every step, drawn once (a torch.rand inside the captured step costs three launches per token: the generator's seed / offset fills + the draw)
         u_all = torch.rand(npos + 1, B, device=dev, dtype=torch.float32) if (fused_tail and sample) else None
 
@@ -1288,8 +1293,8 @@ class Performer(TransformerBase):
             if fused_tail:
                 # temperature, softmax, the draw (inverse CDF against the pre-drawn uniforms -- torch.multinomial cannot be captured in a HIP graph) or arg-max,
                 # seq[:, pos + 1] (unless it belongs to the given prefix), the next step's token, pos += 1: one launch instead of ~20 small torch kernels
-                _ck(lib.sa_sample_step(_ffi.ptr(logits), B, logits.shape[1], float(temperature), _ffi.ptr(u_all), B, int(bool(sample)), _ffi.ptr(seq), total, P,
-                                       _ffi.ptr(pos), _ffi.ptr(ticket), _ffi.ptr(tok), _ffi.stream()), "sa_sample_step")
+                _ck(lib.sa_sample_step(_ffi.ptr(logits), B, logits.shape[1], float(temperature), _ffi.ptr(u_all), B, int(bool(sample)), int(top_k or 0), _ffi.ptr(seq),
+                                       total, P, _ffi.ptr(pos), _ffi.ptr(ticket), _ffi.ptr(tok), _ffi.stream()), "sa_sample_step")
                 return
             logits = logits / temperature
             # transformer.py:11-17 (_top_k_logits) without the boolean-mask assignment, which cannot be captured

@@ -544,15 +544,18 @@ class _GradCtx:
             # DDP: the bucket's all-reduce waits for an event of the CURRENT stream; these gradients were queued on the main and on the weight-gradient stream
             self.side.side.wait_stream(self.side.main)
             with torch.cuda.stream(self.side.side):
-                if hasattr(self.sink, "flush"):
-                    self.sink.flush()     # optimizer slices deferred by EARLIER reports: everything that reads their parameters is queued (runtime/ddp.GradReducer.flush)
-                for p in params:
-                    self.sink.ready(p)
+                self._report(params)
             return
+        self._report(params)
+
+    def _report(self, params):
         if hasattr(self.sink, "flush"):
-            self.sink.flush()
-        for p in params:
-            self.sink.ready(p)
+            tok = self.sink.flush()       # optimizer slices deferred by EARLIER reports: everything that reads their parameters is queued (runtime/ddp.GradReducer.flush)
+            for p in params:
+                self.sink.ready(p, tok)
+        else:
+            for p in params:
+                self.sink.ready(p)
 
 
 class _Chain:
@@ -736,8 +739,8 @@ class BaselineVQVAE(VQVAEBase, nn.Module):
         return nn.ModuleList([nn.Sequential(*seq)])
 
     # ---------------------------------------------------------------- launch chains over those parameters
-    def _build_encoder_chain(self) -> _Chain:
-        dt, fdt = self.compute_dtype, self.encoder_forward_dtype
+    def _build_encoder_chain(self, fdt: Optional[torch.dtype] = None) -> _Chain:
+        dt, fdt = self.compute_dtype, fdt or self.encoder_forward_dtype
         mods = list(self.encoder[0])
         stages = []
         for lvl in range(self.n_levels):
@@ -767,23 +770,44 @@ class BaselineVQVAE(VQVAEBase, nn.Module):
             i += 2 if last else 3
         return _Chain(stages, dt, in_channels=self.embed_dim)
 
+    def _chains(self) -> List[_Chain]:
+        return [c for c in (self._enc_chain, getattr(self, "_enc_chain_lp", None), self._dec_chain) if c is not None]
+
+    def _encoder_chain_for(self, images: torch.Tensor) -> _Chain:
+        """The f16 forward instances exist in LDS-DMA form only (32-bit buffer offsets): when the largest encoder activation reaches 4 GiB (first-level
+        output, 80x112x80x128 at batch ~24) or SA_NO_DMA is set, the encoder runs the all-bf16 chain (the round-3 mode, which has register-staged
+        kernels for such operands) over the same parameters instead of failing with SA_EUNSUPPORTED."""
+        if self.encoder_forward_dtype == self.compute_dtype:
+            return self._enc_chain
+        k, s_, p_, _ = self.downsample_parameters[0]
+        vox = images.shape[0]
+        for d in images.shape[2:]:
+            vox *= (d + 2 * p_ - k) // s_ + 1
+        too_big = vox * self._level_width(0, decoder=False) * 2 >= 0xfffffff0 - 4096
+        if not (too_big or (_ffi.lib().sa_get_debug_flags() & debug.LIB_FLAGS["no_dma"])):
+            return self._enc_chain
+        if getattr(self, "_enc_chain_lp", None) is None:
+            self._enc_chain_lp = self._build_encoder_chain(self.compute_dtype)
+            self._enc_chain_lp.grad_sink = self._enc_chain.grad_sink
+        return self._enc_chain_lp
+
     def set_grad_sink(self, sink):
         """Route weight gradients into a ``runtime.ddp.GradReducer`` (flat buffer + overlapped RCCL all-reduce)."""
-        self._enc_chain.grad_sink = sink
-        self._dec_chain.grad_sink = sink
+        for c in self._chains():
+            c.grad_sink = sink
 
     def invalidate_packed_weights(self):
         """Tell the launch chains that parameters were modified through raw pointers (fused Adam kernel)."""
-        self._enc_chain.invalidate()
-        self._dec_chain.invalidate()
+        for c in self._chains():
+            c.invalidate()
         if getattr(self, "_packset", None) is None:
             self._packset = PackSet()
-        self._packset.repack(self._enc_chain.ops() + self._dec_chain.ops())   # all packed operands again, in one launch
+        self._packset.repack([op for c in self._chains() for op in c.ops()])   # all packed operands again, in one launch
 
     def range_repacker(self, flat):
         """For ``FusedAdam(in_backward=reducer)`` (see networks/transformers/performer.Performer.range_repacker)."""
         from ...engine import RangeRepacker
-        return RangeRepacker(flat, lambda: self._enc_chain.ops() + self._dec_chain.ops())
+        return RangeRepacker(flat, lambda: [op for c in self._chains() for op in c.ops()])
 
     # ---------------------------------------------------------------- accessors (baseline.py:301-327)
     def get_ema_decay(self) -> Sequence[float]:
@@ -820,7 +844,7 @@ class BaselineVQVAE(VQVAEBase, nn.Module):
         return _ChainFn.apply(chain, record, x, *params)
 
     def encode(self, images: torch.Tensor) -> List[torch.Tensor]:
-        return [self._run(self._enc_chain, images)]
+        return [self._run(self._encoder_chain_for(images), images)]
 
     def quantize(self, encodings: List[torch.Tensor]) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
         x, x_loss = self.quantizer[0](encodings[0])

@@ -35,11 +35,24 @@ def ipc_mode_default(env=None, verbose: bool = True) -> bool:
     return True
 
 
-def init_distributed(backend: Optional[str] = None):
+DEFAULT_TIMEOUT_S = 300.0
+
+
+def init_distributed(backend: Optional[str] = None, timeout_s: Optional[float] = None):
     """torchrun-style bootstrap (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); replaces deepspeed.init_distributed
     (run_vqvae.py:831-842).  Returns (rank, local_rank, world_size).  ``SA_SHARE_DEVICE=1`` (test aid) puts every rank on cuda:0 over gloo:
-    the N > 1 code path of the CLIs on a one-GPU box (RCCL refuses two ranks per device)."""
+    the N > 1 code path of the CLIs on a one-GPU box (RCCL refuses two ranks per device).
+
+    Failure detection (the one knob the reference leaves at its default): every collective carries ``timeout_s`` (argument, else
+    ``SA_DIST_TIMEOUT_S``, else 300 s instead of torch's 10 / 30 minutes), and the RCCL watchdog is told to tear the process down on an asynchronous
+    error or a timed-out collective (``TORCH_NCCL_ASYNC_ERROR_HANDLING=1`` unless the caller exported another policy) -- so when a rank dies the others
+    FAIL within the timeout (gloo raises in the waiting call; RCCL aborts the communicator and the process) and the launcher (torchrun) ends the job,
+    instead of seven ranks spinning in an all-reduce kernel.  ``tests/test_ddp_gloo.py::test_dead_rank_fails_the_others_within_the_timeout``."""
+    import datetime
     ipc_mode_default()
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("SA_DIST_TIMEOUT_S", DEFAULT_TIMEOUT_S))
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -54,7 +67,7 @@ def init_distributed(backend: Optional[str] = None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, local, world
@@ -162,6 +175,9 @@ class GradReducer:
                                  # reports a layer's parameters before it queues that layer's data gradient -- so the call is deferred to the next ready() /
                                  # finish(): by then everything that reads the bucket's parameters has been queued, and the side stream waits for it
         self._deferred = []
+        self._final = []         # optimizer slices of buckets completed by a report that did NOT follow the flush-then-ready discipline: released in finish() only
+        self._report = 0         # token handed out by flush(); ready(p, report) proves the caller flushed before this layer's report
+        self._tainted = set()    # buckets that received a ready() without the current token
         self.timing = False      # bench.py: record HIP events around every bucket's collective and around the wait in finish()
         self._ev = []            # per finished step: (bucket (start, end) events on the side stream, main-stream arrival, side-stream end)
         self._bucket_ev = []
@@ -176,6 +192,7 @@ class GradReducer:
     def reset(self):
         self._pending = [hi - lo + 1 for (_, _, lo, hi) in self.buckets]
         self._works = []
+        self._tainted = set()
 
     # ---- gradient sink protocol used by the backward chains --------------------------------------------------
     def buffer(self, p: torch.nn.Parameter) -> Optional[torch.Tensor]:
@@ -204,17 +221,29 @@ class GradReducer:
     def flush(self):
         """Called by a backward chain at the START of a layer's report (before its ready() calls): everything queued so far belongs to layers whose launches
         are complete, so the optimizer slices deferred by earlier reports may go.  (A bucket boundary can fall between the weight and the bias of ONE layer:
-        flushing inside ready() would step that layer's weight before its data-gradient launch, which reads the packed weight, has been queued.)"""
+        flushing inside ready() would step that layer's weight before its data-gradient launch, which reads the packed weight, has been queued.)
+        Returns the report token to pass to this layer's ready() calls."""
         self._flush_deferred()
+        self._report += 1
+        return self._report
 
-    def ready(self, p: torch.nn.Parameter):
+    def ready(self, p: torch.nn.Parameter, report: Optional[int] = None):
+        """``report``: the token of the flush() that opened this layer's report.  The optimizer-in-backward path (``on_bucket``) overwrites parameters and
+        packed operands behind a bucket's gradients; that is only safe early for buckets whose EVERY parameter was reported flush-then-ready by a chain
+        that queues nothing reading them afterwards.  A bucket that receives a ready() without the current token (autograd hooks of the embeddings, the
+        adversarial trainer, any third-party sink user) keeps its optimizer slice until finish()."""
         i = self.flat.index.get(id(p))
         if i is None:
             return
         b = self.bucket_of[i]
+        if report is None or report != self._report:
+            self._tainted.add(b)
         self._pending[b] -= 1
         if self._pending[b] == 0:
             self._launch(b)
+
+    def _defer(self, b: int, lo: int, hi: int, scale: float):
+        (self._final if b in self._tainted else self._deferred).append((lo, hi, scale))
 
     def _collective(self, view: torch.Tensor):
         """The bucket's reduction on the CURRENT stream (device) or synchronously (host tensors of the gloo tests)."""
@@ -249,7 +278,7 @@ class GradReducer:
         lo, hi = self.buckets[b][0], self.buckets[b][1]
         view = self.flat.grad[lo:hi]
         if not self._collects():          # one rank, optimizer in backward: no collective, only the bucket's (deferred) optimizer slice
-            self._deferred.append((lo, hi, 1.0))
+            self._defer(b, lo, hi, 1.0)
             return
         if view.is_cuda:
             if self._side is None:
@@ -267,13 +296,13 @@ class GradReducer:
                     e1.record()
                     self._bucket_ev.append((e0, e1))
             if self.on_bucket is not None:
-                self._deferred.append((lo, hi, 1.0 / self.world))
+                self._defer(b, lo, hi, 1.0 / self.world)
         elif self.mode == "all_reduce" and self.transport == "fp32" and self.on_bucket is None:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self._collective(view)
             if self.on_bucket is not None:
-                self._deferred.append((lo, hi, 1.0 / self.world))
+                self._defer(b, lo, hi, 1.0 / self.world)
 
     def finish(self) -> float:
         """Wait for every bucket (launching any bucket whose parameters never reported, e.g. unused ones) and return the
@@ -281,7 +310,10 @@ class GradReducer:
         for b, left in enumerate(self._pending):
             if left > 0:
                 self._pending[b] = 0
+                self._tainted.add(b)
                 self._launch(b)
+        self._deferred += self._final
+        self._final = []
         self._flush_deferred()
         if self._side is not None:
             if self.timing and self._bucket_ev:

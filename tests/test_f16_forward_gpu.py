@@ -172,3 +172,56 @@ def test_encoder_chain_f16_forward_tracks_fp32_and_trains_like_bf16():
     loss.backward()
     torch.cuda.synchronize()
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in n16.parameters() if p.requires_grad)
+
+
+def test_f16_forward_network_falls_back_to_bf16_chain_when_dma_is_unavailable():
+    """The f16 forward instances are LDS-DMA kernels (32-bit buffer offsets).  With operands the DMA cannot address (>= 4 GiB: first-level activations at
+    batch ~24; here forced with the no_dma switch) the default throughput-mode network must keep training on the all-bf16 encoder chain over the SAME
+    parameters -- identical to a network built with encoder_forward_dtype=bfloat16 under the same switch -- instead of raising SA_EUNSUPPORTED."""
+    from synthanatomy_amd import debug
+    from synthanatomy_amd.networks.vqvae.baseline import BaselineVQVAE
+    small = dict(n_levels=2, downsample_parameters=((4, 2, 1, 1),) * 2, upsample_parameters=((4, 2, 1, 0, 1),) * 2, n_embed=64, embed_dim=16, n_channels=32,
+                 n_res_channels=32, n_res_layers=1)
+    torch.manual_seed(2)
+    n16 = BaselineVQVAE(**small, compute_dtype=BF).cuda().train()
+    nbf = BaselineVQVAE(**small, compute_dtype=BF, encoder_forward_dtype=BF).cuda().train()
+    nbf.load_state_dict(n16.state_dict())
+    x = torch.rand(2, 1, 16, 24, 16, generator=torch.Generator().manual_seed(1)).cuda()
+    res = {}
+    with debug.override(no_dma=True):
+        for name, net in (("f16", n16), ("bf16", nbf)):
+            out = net(x)
+            loss = F.mse_loss(out["reconstruction"][0].float(), x) + out["quantization_losses"][0]
+            loss.backward()
+            torch.cuda.synchronize()
+            res[name] = (loss.item(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert getattr(n16, "_enc_chain_lp", None) is not None
+    assert res["f16"][0] == res["bf16"][0]
+    for k, g in res["bf16"][1].items():
+        assert torch.equal(res["f16"][1][k], g), k
+    # without the switch the f16 chain is back (and differs from the bf16 one)
+    with torch.no_grad():
+        z16 = n16.eval().encode(x)[0].float()
+        zbf = nbf.eval().encode(x)[0].float()
+    assert not torch.equal(z16, zbf)
+    # the re-pack after an optimizer step covers both chains' operands
+    n16.invalidate_packed_weights()
+
+
+def test_f16_conversion_saturates_finite_values_and_keeps_nan_visible():
+    """f32 -> f16 in every epilogue / cast: finite overflow saturates to +-65504 (no loss scaling needed), NaN and +-inf come out as NaN -- a diverged run must
+    show in z and the loss (v_med3_f32 alone turned a NaN into -65504, i.e. zero behind the next ReLU)."""
+    from synthanatomy_amd import engine
+    vals = torch.tensor([[1.0, -2.5, 7e4, -7e4, 65504.0, 3e38, float("nan"), float("inf"), float("-inf"), 0.0, -0.0, 1e-8, 65519.9, 6.1e-5, -1e6, 0.333251953125]])
+    out = engine.cast_pad(vals.cuda(), H16, 16).cpu()[0]
+    exp = vals[0].clamp(-65504, 65504).to(H16)
+    fin = torch.isfinite(vals[0])
+    assert torch.equal(out[fin], exp[fin]), (out, exp)
+    assert bool(torch.isnan(out[~fin]).all()), out
+    # through a launch's epilogue: one NaN input voxel poisons its 3x3x3 neighbourhood in the f16 output AND in the bf16 copy
+    op = engine.ConvOp("conv", 16, 16, 3, 1, 1, (torch.randn(16, 16, 3, 3, 3) * 0.05).cuda(), torch.zeros(16).cuda(), BF, fwd_dtype=H16)
+    x = torch.randn(1, 6, 8, 8, 16)
+    x[0, 3, 4, 4, 5] = float("nan")
+    y, _, lp = op.fprop(x.cuda().to(H16), want_lp=True)      # (no activation: the kernels' ReLU is fmaxf(x, 0), which maps NaN to 0 in every dtype)
+    assert bool(torch.isnan(y[0, 3, 4, 4].float()).all()) and bool(torch.isnan(lp[0, 3, 4, 4].float()).all())
+    assert bool(torch.isfinite(y[0, 0, 0, 0].float()).all())

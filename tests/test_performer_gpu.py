@@ -571,6 +571,7 @@ def test_stateful_sampler_equals_the_quadratic_loop(rezero, shape, window, local
                     use_rezero=rezero, spatial_position_emb="absolute", spatial_shape=shape, feature_redraw_interval=None)
     net.load_state_dict({k: v.clone() for k, v in st.items()}, strict=False)
     net = net.cuda()
+    from synthanatomy_amd import debug
     prefix = torch.full((3, 1), 18, dtype=torch.long, device="cuda")
     quad = net.sample(prefix, sample=False, stateful=False)
     fast = net.sample(prefix, sample=False, stateful=True, use_graph=use_graph)
@@ -585,21 +586,25 @@ def test_stateful_sampler_equals_the_quadratic_loop(rezero, shape, window, local
     ref = x[:, 1:][:, o.get_revert_sequence_ordering()].reshape(3, *shape)
     assert torch.equal(fast.cpu(), ref)
     # stochastic path runs and stays in range
-    smp = net.sample(prefix, sample=True, top_k=5, temperature=0.9)       # top-k: the torch expressions
+    smp = net.sample(prefix, sample=True, top_k=5, temperature=0.9)       # top-k inside sa_sample_step
+    assert int(smp.min()) >= 0 and int(smp.max()) <= 18
+    with debug.override(no_sample_step=True):
+        smp = net.sample(prefix, sample=True, top_k=5, temperature=0.9)   # top-k: the torch expressions
     assert int(smp.min()) >= 0 and int(smp.max()) <= 18
     smp = net.sample(prefix, sample=True, temperature=0.9)                # no top-k: sa_sample_step
     assert int(smp.min()) >= 0 and int(smp.max()) <= 18
-    from synthanatomy_amd import debug
     with debug.override(no_sample_step=True):                            # the same greedy chain with the decision made by torch ops
         assert torch.equal(net.sample(prefix, sample=False, use_graph=use_graph), quad)
 
 
 @pytest.mark.parametrize("per_row", [False, True])
-@pytest.mark.parametrize("B,V,P_,temperature", [(6, 2049, 1, 1.0), (3, 19, 2, 0.7), (17, 1000, 1, 1.3)])
-def test_sample_step_kernel_matches_the_torch_decision(B, V, P_, temperature, per_row):
-    """sa_sample_step (one launch per token: temperature, softmax, inverse-CDF draw with the caller's uniforms or arg-max, sequence update, next token, pos += 1)
-    against the torch expressions of the stateful sampler it replaces, position by position; one block walking the rows with a fresh vector of uniforms per step,
-    and one block per row (ticket word) reading a table of uniforms by position."""
+@pytest.mark.parametrize("B,V,P_,temperature,top_k", [(6, 2049, 1, 1.0, 0), (3, 19, 2, 0.7, 0), (17, 1000, 1, 1.3, 0), (6, 2049, 1, 0.9, 40), (3, 19, 1, 1.0, 5),
+                                                     (5, 16384, 1, 1.0, 1), (4, 300, 1, 1.1, 299)])
+def test_sample_step_kernel_matches_the_torch_decision(B, V, P_, temperature, top_k, per_row):
+    """sa_sample_step (one launch per token: temperature, top-k cut, softmax, inverse-CDF draw with the caller's uniforms or arg-max, sequence update, next token,
+    pos += 1) against the torch expressions of the stateful sampler it replaces (transformer.py:11-17,42-54), position by position; one block walking the rows with
+    a fresh vector of uniforms per step, and one block per row (ticket word) reading a table of uniforms by position.  Logits are rounded to a coarse grid when
+    top-k is on, so that rows hold TIES with the k-th value (the reference keeps them)."""
     from synthanatomy_amd import _ffi
     lib = _ffi.lib()
     g = torch.Generator().manual_seed(B + V)
@@ -613,11 +618,20 @@ def test_sample_step_kernel_matches_the_torch_decision(B, V, P_, temperature, pe
         tok = torch.zeros(B, dtype=torch.int64, device="cuda")
         table = torch.rand(total, B, generator=g).cuda()
         for step in range(total - 1):
-            logits = (torch.randn(B, V, generator=g) * 3).cuda()
+            logits = torch.randn(B, V, generator=g) * 3
+            if top_k:
+                logits = (logits * 8).round() / 8
+                logits[0, :3] = 0.0
+                logits[0, 1] = -0.0
+            logits = logits.cuda()
             u = table[step] if per_row else torch.rand(B, generator=g).cuda()
-            _ffi.check(lib.sa_sample_step(_ffi.ptr(logits), B, V, float(temperature), _ffi.ptr(table if per_row else u), B if per_row else 0, do_sample, _ffi.ptr(seq),
-                                          total, P_, _ffi.ptr(pos), _ffi.ptr(ticket) if per_row else None, _ffi.ptr(tok), _ffi.stream()), "sa_sample_step")
-            probs = torch.softmax(logits / temperature, dim=-1)
+            _ffi.check(lib.sa_sample_step(_ffi.ptr(logits), B, V, float(temperature), _ffi.ptr(table if per_row else u), B if per_row else 0, do_sample, top_k,
+                                          _ffi.ptr(seq), total, P_, _ffi.ptr(pos), _ffi.ptr(ticket) if per_row else None, _ffi.ptr(tok), _ffi.stream()), "sa_sample_step")
+            scaled = logits / temperature
+            if top_k:
+                kth = torch.topk(scaled, top_k, dim=-1).values[:, -1:]
+                scaled = scaled.masked_fill(scaled < kth, float("-inf"))
+            probs = torch.softmax(scaled, dim=-1)
             if do_sample:
                 cdf = probs.cumsum(-1)
                 ix = (cdf < u[:, None] * cdf[:, -1:]).sum(-1).clamp(max=V - 1)
@@ -629,11 +643,56 @@ def test_sample_step_kernel_matches_the_torch_decision(B, V, P_, temperature, pe
             assert int(pos) == step + 1 and int(ticket) == 0
             assert torch.equal(tok, seq[:, step + 1])
             if do_sample:      # a cdf value within rounding of the target may fall on either side: count, then continue from the kernel's choice
+                if step + 1 >= P_:   # ... but never on a token the cut removed
+                    assert bool((probs.gather(1, seq[:, step + 1:step + 2]) > 0).all())
                 mism += int((seq[:, step + 1] != seq_t[:, step + 1]).sum())
                 seq_t[:, step + 1] = seq[:, step + 1]
             else:
                 assert torch.equal(seq, seq_t), step
     assert mism <= 1, mism
+
+
+@pytest.mark.parametrize("V", [256, 2048, 16384])
+def test_sample_step_kernel_never_emits_an_unclaimed_token(V):
+    """The draw is the first token with mass whose cdf reaches the target (lowest index over all threads), not 'the thread whose interval contains the target':
+    with per-thread partial sums associated differently, neighbouring intervals can leave one-ulp gaps, and a target in a gap used to fall through to token V - 1
+    (2e-6 to 6e-6 per draw).  Here
+    token V - 1 carries zero probability (logit -inf) and every other token a comparable one: across 2^18 draws -- incl. u = 0 and u = 1 - 2^-24 -- the kernel
+    must never return it, and an all-NaN row must stay in range on both the arg-max and the sampling path."""
+    from synthanatomy_amd import _ffi
+    lib = _ffi.lib()
+    g = torch.Generator().manual_seed(V)
+    B = 64
+    logits = torch.randn(B, V, generator=g)
+    logits[:, V - 1] = float("-inf")
+    logits = logits.cuda()
+    steps = 4096
+    u = torch.rand(steps, B, generator=g)
+    u[0] = 0.0
+    u[1] = 1.0 - 2.0 ** -24
+    u = u.cuda()
+    seq = torch.zeros(B, steps + 1, dtype=torch.int64, device="cuda")
+    posbuf = torch.zeros(2, dtype=torch.int32, device="cuda")
+    tok = torch.zeros(B, dtype=torch.int64, device="cuda")
+    for _ in range(steps):
+        _ffi.check(lib.sa_sample_step(_ffi.ptr(logits), B, V, 1.0, _ffi.ptr(u), B, 1, 0, _ffi.ptr(seq), steps + 1, 1, _ffi.ptr(posbuf[:1]), _ffi.ptr(posbuf[1:]),
+                                      _ffi.ptr(tok), _ffi.stream()), "sa_sample_step")
+    torch.cuda.synchronize()
+    assert int(posbuf[0]) == steps
+    drawn = seq[:, 1:]
+    assert int(drawn.max()) < V - 1 and int(drawn.min()) >= 0
+    assert int((drawn[:, 0] != 0).sum()) <= 0        # u = 0: nothing lies below the target
+    # the empirical distribution follows the softmax (a coarse check that the count rule is the inverse CDF)
+    p = torch.softmax(logits[0].double(), -1).cpu()
+    f = torch.bincount(drawn[0].cpu(), minlength=V).double() / steps
+    assert float((f - p).abs().sum()) < 2.5 * (V / steps) ** 0.5 + 0.05
+    nan_logits = torch.full((2, V), float("nan"), device="cuda")
+    for do_sample in (0, 1):
+        posbuf.zero_()
+        _ffi.check(lib.sa_sample_step(_ffi.ptr(nan_logits), 2, V, 1.0, _ffi.ptr(u), B, do_sample, 0, _ffi.ptr(seq), steps + 1, 1, _ffi.ptr(posbuf[:1]),
+                                      _ffi.ptr(posbuf[1:]), _ffi.ptr(tok), _ffi.stream()), "sa_sample_step")
+        torch.cuda.synchronize()
+        assert 0 <= int(seq[0, 1]) < V and 0 <= int(seq[1, 1]) < V
 
 
 @pytest.mark.parametrize("N,W", [(23, 5), (100, 420), (150, 64), (200, 70), (321, 128), (1400, 420), (1000, 420)])
