@@ -14,8 +14,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libsynthanatomy_hip.so")
-OBJ = os.path.join(HERE, "_obj")
+# SA_BUILD_VARIANT=name (dev): a second library next to the product one -- libsynthanatomy_hip_<name>.so from _obj_<name>/ with SA_EXTRA_HIPCC_FLAGS --,
+# loaded with SA_HIP_LIB=<path> for A/B runs (e.g. -DSA_PP_DEBUG_VARIANTS, -DSA_TIMING); the product build is untouched
+_VARIANT = os.environ.get("SA_BUILD_VARIANT", "")
+LIB = os.path.join(HERE, f"libsynthanatomy_hip{'_' + _VARIANT if _VARIANT else ''}.so")
+OBJ = os.path.join(HERE, f"_obj{'_' + _VARIANT if _VARIANT else ''}")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off", "-Wno-unused-value"]
 FLAGS += os.environ.get("SA_EXTRA_HIPCC_FLAGS", "").split()  # dev: e.g. -DSA_PP_DEBUG_VARIANTS
@@ -28,15 +31,22 @@ def _sources():
 def _digest(path):
     h = hashlib.sha1()
     hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
-    if not path.endswith(("conv_fprop.hip", "conv_fprop_f16.hip")):
-        hdrs = [h for h in hdrs if not h.endswith(("conv_fprop_common.h", "conv_fprop_kernels.h"))]     # only the two forward translation units depend on them
+    if not path.endswith(("conv_fprop.hip", "conv_fprop_f16.hip", "dense.hip")):
+        hdrs = [h for h in hdrs if not h.endswith(("conv_fprop_common.h", "conv_fprop_kernels.h"))]     # only the forward translation units depend on them
+    elif path.endswith("dense.hip"):
+        hdrs = [h for h in hdrs if not h.endswith("conv_fprop_kernels.h")]
     if not path.endswith(("local_attn.hip", "favor_fused.hip")):
         hdrs = [h for h in hdrs if not h.endswith("local_attn_split.h")]
     for dep in [path, *hdrs, os.path.join(HERE, "..", "include", "synthanatomy_hip.h")]:
         with open(dep, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + EXTRA.get(os.path.basename(path), [])).encode())
     return h.hexdigest()
+
+
+# per-file flags: dense.hip keeps its MFMA accumulators in VGPRs (at one wave per SIMD the allocator would otherwise move them to AGPRs and shuffle
+# ~120 v_accvgpr copies per K-slab between the two halves of the rotated main loop)
+EXTRA = {"dense.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wno-inline-asm"]}
 
 
 def _compile(src):
@@ -46,7 +56,7 @@ def _compile(src):
     dg = _digest(path)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dg:
         return obj, False
-    cmd = [HIPCC, *FLAGS, "-c", path, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *EXTRA.get(src, []), "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

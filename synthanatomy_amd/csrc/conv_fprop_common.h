@@ -112,6 +112,141 @@ __device__ __forceinline__ void fprop_epilogue_ov(const FpropArgs& a, float4_t (
     constexpr int RPP = NT / NG;         // rows per pass
     const uint32_t grp = tid % NG, r0 = tid / NG;
     const uint32_t co0 = n_base + grp * 4;
+    // Whole tiles of valid channels with 16-byte aligned rows (every dense layer, every 128-channel convolution): phase B in BATCHES of U rows per thread --
+    // the U LDS reads, then the U addend / mask loads, then the arithmetic as passes over the batch with each run-time switch (activation, mask mode, operand
+    // types) taken ONCE per batch, then the stores.  Same operations per element, in the same order, as the row-at-a-time loop below (bit-identical results);
+    // that loop executed ~100 instructions and a dozen scalar branches per 16-byte store, and a store-pattern probe (tools/probes/store_pattern.hip) writes the
+    // same tiles 2x faster than the epilogue it models: 35 of the 65 us of the q|k|v projection (103 MB of fp32 output) were this loop.
+    if (vec_ok && n_base + BN <= (uint32_t)g.cout_valid) {
+        constexpr int ITERS = BM / RPP, U = ITERS % 4 == 0 ? 4 : (ITERS % 3 == 0 ? 3 : (ITERS % 2 == 0 ? 2 : 1));
+        const int add_kind = !ep.addend ? 0 : (ep.add_dtype == SA_F32 ? 1 : 2);
+        const int mask_kind = ep.mask_mode == SA_MASK_NONE ? 0 : (ep.mask_dtype == SA_F32 ? 1 : 2);
+        for (int it0 = 0; it0 < ITERS; it0 += U) {
+            long long ov[U];
+            float v[U][4], ad[U][4], mk[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t row = r0 + (it0 + u) * RPP;
+                ov[u] = sOv[row];
+                const float4_t tv = *(const float4_t*)(sT + row * LDT + grp * 4);
+                v[u][0] = tv[0]; v[u][1] = tv[1]; v[u][2] = tv[2]; v[u][3] = tv[3];
+            }
+            int64_t o[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) o[u] = (ov[u] < 0 ? 0 : ov[u]) * g.Cout + co0;      // (rows beyond M: a valid address that is never stored to)
+            if (add_kind == 1) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float4_t t4 = ov[u] >= 0 ? *(const float4_t*)((const float*)ep.addend + o[u]) : (float4_t){0.f, 0.f, 0.f, 0.f};
+                    ad[u][0] = t4[0]; ad[u][1] = t4[1]; ad[u][2] = t4[2]; ad[u][3] = t4[3];
+                }
+            } else if (add_kind == 2) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint2 t2 = ov[u] >= 0 ? *(const uint2*)((const bf16_t*)ep.addend + o[u]) : make_uint2(0u, 0u);
+                    unpack2_dt(ep.add_dtype, t2.x, ad[u][0], ad[u][1]);
+                    unpack2_dt(ep.add_dtype, t2.y, ad[u][2], ad[u][3]);
+                }
+            }
+            if (mask_kind == 1) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float4_t t4 = ov[u] >= 0 ? *(const float4_t*)((const float*)ep.mask + o[u]) : (float4_t){0.f, 0.f, 0.f, 0.f};
+                    mk[u][0] = t4[0]; mk[u][1] = t4[1]; mk[u][2] = t4[2]; mk[u][3] = t4[3];
+                }
+            } else if (mask_kind == 2) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint2 t2 = ov[u] >= 0 ? *(const uint2*)((const bf16_t*)ep.mask + o[u]) : make_uint2(0u, 0u);
+                    mk[u][0] = __uint_as_float(t2.x << 16); mk[u][1] = __uint_as_float(t2.x & 0xffff0000u);
+                    mk[u][2] = __uint_as_float(t2.y << 16); mk[u][3] = __uint_as_float(t2.y & 0xffff0000u);
+                }
+            }
+            if (ep.out_pre) {   // pre-activation copy (bf16): acc + bias
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (ov[u] >= 0) {
+                        uint2 pk;
+                        pk.x = (uint32_t)f32_to_bf16(v[u][0]) | ((uint32_t)f32_to_bf16(v[u][1]) << 16);
+                        pk.y = (uint32_t)f32_to_bf16(v[u][2]) | ((uint32_t)f32_to_bf16(v[u][3]) << 16);
+                        *(uint2*)((bf16_t*)ep.out_pre + o[u]) = pk;
+                    }
+            }
+            if (add_kind && ep.add_before_act) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[u][r] += ad[u][r];
+            }
+            if (ep.act == SA_ACT_RELU) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[u][r] = fmaxf(v[u][r], 0.f);
+            } else if (ep.act == SA_ACT_LRELU) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[u][r] = v[u][r] > 0.f ? v[u][r] : v[u][r] * ep.slope;
+            } else if (ep.act == SA_ACT_GELU) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[u][r] = gelu_f(v[u][r]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[u][r] *= alpha;
+            if (add_kind && !ep.add_before_act) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[u][r] += ad[u][r];
+            }
+            if (ep.mask_mode == SA_MASK_POS) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[u][r] = mk[u][r] > 0.f ? v[u][r] : 0.f;
+            } else if (ep.mask_mode == SA_MASK_LRELU) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[u][r] = mk[u][r] > 0.f ? v[u][r] : v[u][r] * ep.slope;
+            } else if (ep.mask_mode == SA_MASK_GELU) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[u][r] *= gelu_grad_f(mk[u][r]);
+            }
+            if (ep.out_dtype == SA_F32) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (ov[u] >= 0) *(float4_t*)((float*)a.out + o[u]) = (float4_t){v[u][0], v[u][1], v[u][2], v[u][3]};
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (ov[u] >= 0) {
+                        uint2 pk;
+                        pk.x = pack2_dt(ep.out_dtype, v[u][0], v[u][1]);
+                        pk.y = pack2_dt(ep.out_dtype, v[u][2], v[u][3]);
+                        *(uint2*)((bf16_t*)a.out + o[u]) = pk;
+                    }
+            }
+            if (ep.out_lp) {        // bf16 copy of the final value
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (ov[u] >= 0) {
+                        uint2 pk;
+                        pk.x = (uint32_t)f32_to_bf16(v[u][0]) | ((uint32_t)f32_to_bf16(v[u][1]) << 16);
+                        pk.y = (uint32_t)f32_to_bf16(v[u][2]) | ((uint32_t)f32_to_bf16(v[u][3]) << 16);
+                        *(uint2*)((bf16_t*)ep.out_lp + o[u]) = pk;
+                    }
+            }
+        }
+        return;
+    }
     if (co0 < (uint32_t)g.cout_valid) {
 #pragma unroll 4
         for (int it = 0; it < BM / RPP; ++it) {
@@ -410,6 +545,10 @@ __device__ __forceinline__ void fprop_epilogue(const FpropArgs& a, float4_t (&ac
                                                   [&](uint32_t row) __attribute__((always_inline)) { return linear_row_voxel(a, m_base + row); });
 }
 
+
+// dense.hip: one-tap layers (nn.Linear) on the four-wave ring mainloop
+bool dense_gemm_eligible(const FpropArgs& a, int sz);
+int launch_dense_gemm(const FpropArgs& a, int dtype, hipStream_t st);
 
 // 32-bit buffer offset that is out of bounds for every operand: LDS-DMA loads from it deliver zeros (padding taps, rows beyond M)
 constexpr uint32_t OOB_OFF = 0xfffffff0u;

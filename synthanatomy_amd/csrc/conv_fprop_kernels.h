@@ -377,7 +377,11 @@ __global__ __launch_bounds__(WM * WN * 64 * KG) void conv_fprop_dma_kernel(const
         if (s + 1 < s1) issue(s + 1, buf ^ 1u);
         const unsigned char* pa = smem + buf * (BM * 128);
         const unsigned char* pb = smem + 2 * BM * 128 + buf * (BN * 128);
-        if (KG == 1 || s < s1) {
+        if ((KG == 1 || s < s1)
+#ifdef SA_PP_DEBUG_VARIANTS
+            && !(a.dbg & 32u)
+#endif
+        ) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 u32x4 xf[MI], wf[NI];
@@ -1282,6 +1286,8 @@ static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
     if (halo_eligible(a, (int)sizeof(T))) return launch_fprop_halo<T, false>(a, st);
     if constexpr (sizeof(T) == 2) {
         if (cells_eligible(a, 2)) return launch_fprop_cells<T>(a, st);
+        // dense layers (one tap, identity row map): opt-in (SA_DBG_DENSE_RING) four-wave ring mainloop of dense.hip
+        if (dense_gemm_eligible(a, 2)) return launch_dense_gemm(a, std::is_same<T, f16_t>::value ? SA_F16 : SA_BF16, st);
     }
     // (measured and removed: a 3-stage ring with 8 waves and counted vmcnt = the 2-stage loop; an 8-wave ping-pong with staggered
     // barriers and s_setprio = -7 %: the L2 -> LDS operand stream bounds this loop, not the barrier structure.  DESIGN.md section 4.1)
@@ -1303,7 +1309,9 @@ static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
         // q|k|v data gradient 76.3 -> 51.6 us) and q|k|v forward (N = 3 072) by 15 %.  SA_DENSE_NARROW=1 restores the round-2 rule for A/B runs.
         // (a three-stage 128 x 256 DMA ring for the few-wide-tile dense shapes -- csrc/dense_ring.hip, SA_DENSE_RING -- was measured 15 % SLOWER in round 3 and
         //  left the tree in round 4; history: commit 3edf44f)
-        const bool narrow_shape = (a.nk <= 8 && cv <= 2048) || dbg(SA_DBG_DENSE_NARROW);
+        // Round 5: with the batched phase B of the LDS-staged epilogue (conv_fprop_common.h) the wide tile wins these shapes too at M = 8 400 (w1 forward 46.3 vs
+        // 37.9 us, w2 data gradient 44.5 vs 36.1, to_out data gradient 27.3 vs 24.7): the narrow tile stays for grids that would not fill the CUs with wide ones.
+        const bool narrow_shape = (a.nk <= 8 && cv <= 2048 && blocks128 < 2u * (uint64_t)device_cu_count()) || dbg(SA_DBG_DENSE_NARROW);
         if (small_ok && narrow_shape && blocks128 < 2048 && a.in_bytes != 0) return w8 ? launch_fprop<T, 4, 2, 2, 2>(a, st) : launch_fprop<T, 4, 1, 2, 4>(a, st);
         return w8 ? launch_fprop<T, 4, 2, 2, 4>(a, st) : launch_fprop<T, 2, 2, 4, 4>(a, st);
     }

@@ -197,8 +197,8 @@ def test_f16_forward_network_falls_back_to_bf16_chain_when_dma_is_unavailable():
             res[name] = (loss.item(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
     assert getattr(n16, "_enc_chain_lp", None) is not None
     assert res["f16"][0] == res["bf16"][0]
-    for k, g in res["bf16"][1].items():
-        assert torch.equal(res["f16"][1][k], g), k
+    for k, g in res["bf16"][1].items():      # (same kernels on the same operands; the weight gradients accumulate with fp32 atomics, so not bit for bit)
+        assert torch.allclose(res["f16"][1][k], g, rtol=1e-4, atol=1e-6), k
     # without the switch the f16 chain is back (and differs from the bf16 one)
     with torch.no_grad():
         z16 = n16.eval().encode(x)[0].float()
