@@ -45,33 +45,44 @@ __device__ __forceinline__ void c1_gather(unsigned char* tile, const C1Args& a, 
     const int h = (int)(q - hq * (uint32_t)a.H);
     const uint32_t n = fdiv(hq, a.dD_);
     const int d = (int)(hq - n * (uint32_t)a.D);
-    const bool inner = w > 0 && w < a.W - 1;             // all four kw taps inside the row
+    // The four kw taps 2w - 1 .. 2w + 2 of a row: ONE 16-byte load per (kd, kh) for every lane, at a position clamped into the row (w = 0 reads from column 0,
+    // w = W - 1 from column 2W - 4) and shifted into place afterwards -- no divergent border branch inside the loop, so the loads of a batch are issued back to
+    // back and waited for once.  (Round 4 form: `if (inner) 16-byte load else four clamped scalar loads` per (kd, kh): the branch kept every load behind the
+    // previous iteration's use -- sixteen dependent L2 round trips per thread, 0.64 of the waves' cycles waiting, 30 us per 256-cell block.)
     const int iw0 = 2 * w - 1;
+    const int sh = w == 0 ? 1 : (w == a.W - 1 ? -1 : 0);   // the load window starts `sh` columns right of the first tap (+1: left border, -1: right border)
+    const int iwl = iw0 + sh;                              // in [0, 2W - 4] for W >= 2
+    constexpr int BATCH = PER < 8 ? PER : 8;
 #pragma unroll
-    for (int it = 0; it < PER; ++it) {
-        const uint32_t kk = part * PER + it, kd = kk >> 2, kh = kk & 3u;
-        const int id = 2 * d - 1 + (int)kd, ih = 2 * h - 1 + (int)kh;
-        const bool ok = cell < a.cells && (unsigned)id < (unsigned)(2 * a.D) && (unsigned)ih < (unsigned)(2 * a.H);
-        const int cd = min(max(id, 0), 2 * a.D - 1), chh = min(max(ih, 0), 2 * a.H - 1);
-        const float* row = a.x + (((int64_t)n * 2 * a.D + cd) * 2 * a.H + chh) * 2 * a.W;
-        float v[4];
-        if (inner) {
-            const float4u_t t = *(const float4u_t*)(row + iw0);
-            v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-        } else {
+    for (int it0 = 0; it0 < PER; it0 += BATCH) {
+        float4u_t t[BATCH];
+        bool okv[BATCH];
 #pragma unroll
-            for (int kw = 0; kw < 4; ++kw) {
-                const int iw = iw0 + kw;
-                const float xv = row[min(max(iw, 0), 2 * a.W - 1)];
-                v[kw] = (unsigned)iw < (unsigned)(2 * a.W) ? xv : 0.f;
-            }
+        for (int u = 0; u < BATCH; ++u) {
+            const uint32_t kk = part * PER + it0 + u, kd = kk >> 2, kh = kk & 3u;
+            const int id = 2 * d - 1 + (int)kd, ih = 2 * h - 1 + (int)kh;
+            okv[u] = cell < a.cells && (unsigned)id < (unsigned)(2 * a.D) && (unsigned)ih < (unsigned)(2 * a.H);
+            const int cd = min(max(id, 0), 2 * a.D - 1), chh = min(max(ih, 0), 2 * a.H - 1);
+            const float* row = a.x + (((int64_t)n * 2 * a.D + cd) * 2 * a.H + chh) * 2 * a.W;
+            t[u] = *(const float4u_t*)(row + iwl);
         }
-        // every input voxel is covered exactly once by the taps {1,2}^3 of its cell
-        if (centre_sum && ok && (kd == 1u || kd == 2u) && (kh == 1u || kh == 2u)) *centre_sum += v[1] + v[2];
-        uint2 pk;
-        pk.x = ok ? (F16 ? pack2<f16_t>(v[0], v[1]) : pack_bf16x2(v[0], v[1])) : 0u;
-        pk.y = ok ? (F16 ? pack2<f16_t>(v[2], v[3]) : pack_bf16x2(v[2], v[3])) : 0u;
-        *(uint2*)(tile + lroff(cl, kk * 4u)) = pk;
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const uint32_t kk = part * PER + it0 + u, kd = kk >> 2, kh = kk & 3u;
+            float v[4];
+            // sh = +1: taps (-, t0, t1, t2);  sh = 0: (t0, t1, t2, t3);  sh = -1: (t1, t2, t3, -)
+            v[0] = sh > 0 ? 0.f : (sh < 0 ? t[u][1] : t[u][0]);
+            v[1] = sh > 0 ? t[u][0] : (sh < 0 ? t[u][2] : t[u][1]);
+            v[2] = sh > 0 ? t[u][1] : (sh < 0 ? t[u][3] : t[u][2]);
+            v[3] = sh > 0 ? t[u][2] : (sh < 0 ? 0.f : t[u][3]);
+            const bool ok = okv[u];
+            // every input voxel is covered exactly once by the taps {1,2}^3 of its cell
+            if (centre_sum && ok && (kd == 1u || kd == 2u) && (kh == 1u || kh == 2u)) *centre_sum += v[1] + v[2];
+            uint2 pk;
+            pk.x = ok ? (F16 ? pack2<f16_t>(v[0], v[1]) : pack_bf16x2(v[0], v[1])) : 0u;
+            pk.y = ok ? (F16 ? pack2<f16_t>(v[2], v[3]) : pack_bf16x2(v[2], v[3])) : 0u;
+            *(uint2*)(tile + lroff(cl, kk * 4u)) = pk;
+        }
     }
 }
 
@@ -288,7 +299,7 @@ int conv1_im2col_bf16(const float* g, void* gc, float* db, int N, int D, int H, 
 
 static int c1_fill(C1Args& a, int N, int D, int H, int W, int cout) {
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return SA_EINVAL;
-    if (cout != 128 || (int64_t)N * D * H * W >= ((int64_t)1 << 31) - 256) return SA_EUNSUPPORTED;
+    if (cout != 128 || W < 2 || (int64_t)N * D * H * W >= ((int64_t)1 << 31) - 256) return SA_EUNSUPPORTED;   // (W >= 2: the gather's clamped 16-byte row window)
     a.N = N; a.D = D; a.H = H; a.W = W;
     a.cells = (uint32_t)((int64_t)N * D * H * W);
     a.dW_ = make_fastdiv((uint32_t)W);

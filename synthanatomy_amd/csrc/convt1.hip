@@ -10,6 +10,8 @@
 // out[o] = b + sum_{i,k : 2i-1+k = o} x[i] . w[:,k]   per dimension (k = 0..3).
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "sa_common.h"
 
 namespace sa {
@@ -354,6 +356,7 @@ struct CFArgs {
     const float* bias;
     float* out;          // [N, 2D, 2H, 2W]
     int32_t N, D, H, W, nhp, nwp;
+    int32_t dsplit, dchunk;   // the depth walk is cut into `dsplit` ranges of `dchunk` steps (a step d emits output planes 2d - 1 and 2d), one block each
 };
 
 __global__ __launch_bounds__(256, 3) void convt1_fused_fwd_kernel(const CFArgs a) {
@@ -361,9 +364,12 @@ __global__ __launch_bounds__(256, 3) void convt1_fused_fwd_kernel(const CFArgs a
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g = lane >> 4;
     int t = blockIdx.x;
     const int wp = t % a.nwp; t /= a.nwp;
-    const int hp = t % a.nhp;
-    const int n = t / a.nhp;
+    const int hp = t % a.nhp; t /= a.nhp;
+    const int ds = t % a.dsplit;
+    const int n = t / a.dsplit;
     const int h0 = hp * CF_TH, w0 = wp * CF_TW;
+    // steps [d_lo, d_hi) of the depth walk 0 .. D; a range that starts inside the volume first rebuilds the plane below it (d_lo - 1) without emitting anything
+    const int d_lo = ds * a.dchunk, d_hi = min(a.D + 1, d_lo + a.dchunk), d_first = max(d_lo - 1, 0);
     // weights: A operand, tap tile tt (16 taps) x k-step ks (32 channels)
     short8_t wf[4][4];
 #pragma unroll
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(256, 3) void convt1_fused_fwd_kernel(const CFArgs a
                 xb[q][ks] = v;
             }
     };
-    load_plane(0);
+    load_plane(d_first);
     // gather role: thread = output (oh_l, ow_l) of the 16 x 16 output tile; per dimension two (cell, tap) pairs
     const int oh_l = tid >> 4, ow_l = tid & 15;
     const int oh = 2 * h0 + oh_l, ow = 2 * w0 + ow_l;
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(256, 3) void convt1_fused_fwd_kernel(const CFArgs a
         pcol[1] = pw_ ? qw + 1 : qw;     ptap_w[1] = pw_ ? 2 : 3;
     }
     const float bias = a.bias ? a.bias[0] : 0.f;
-    for (int d = 0; d <= a.D; ++d) {
+    for (int d = d_first; d < d_hi; ++d) {
         float* cur = sP[d & 1];
         const float* prev = sP[(d & 1) ^ 1];
         if (d < a.D) {
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(256, 3) void convt1_fused_fwd_kernel(const CFArgs a
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int od = 2 * d - 1 + e;
-            if (od < 0 || od >= 2 * a.D || !o_ok) continue;
+            if (od < 0 || od >= 2 * a.D || !o_ok || d < d_lo) continue;
             float sum = bias;
 #pragma unroll
             for (int uh = 0; uh < 2; ++uh)
@@ -528,7 +534,30 @@ extern "C" int sa_convt1_fused_fwd(const void* x, const void* wpk, const float* 
     CFArgs a = {};
     a.x = (const bf16_t*)x; a.wpk = (const bf16_t*)wpk; a.bias = bias; a.out = out; a.N = N; a.D = D; a.H = H; a.W = W;
     a.nhp = (H + CF_TH - 1) / CF_TH; a.nwp = (W + CF_TW - 1) / CF_TW;
-    const int64_t blocks = (int64_t)N * a.nhp * a.nwp;
+    int64_t blocks = (int64_t)N * a.nhp * a.nwp;
+    // Depth ranges: a block walks its patch through D + 1 steps, three blocks per CU.  Config 2 at batch 8 is 1 120 patches = 1.46 rounds of the 768 slots, i.e.
+    // two full-length rounds with the second half empty; cut into two ranges (one rebuilt plane each) it is 2.92 rounds of half the length (631 -> 485 us).
+    static std::atomic<int> cu_cache{0};
+    int cus = cu_cache.load(std::memory_order_relaxed);
+    if (cus <= 0) {
+        int dev = 0;
+        cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        cu_cache.store(cus, std::memory_order_relaxed);
+    }
+    const int64_t slots = 3ll * cus;
+    int best = 1;
+    int64_t best_cost = -1;
+    for (int sp = 1; sp <= 8; ++sp) {
+        const int chunk = (D + 1 + sp - 1) / sp;
+        if (sp > 1 && chunk < 8) break;
+        const int64_t cost = ((blocks * sp + slots - 1) / slots) * (chunk + (sp > 1 ? 1 : 0));
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = sp; }
+    }
+    a.dsplit = best;
+    a.dchunk = (D + 1 + best - 1) / best;
+    blocks *= best;
     if (blocks >= ((int64_t)1 << 31)) return SA_EUNSUPPORTED;
     SA_LAUNCH(convt1_fused_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     SA_CHECK_LAUNCH();

@@ -300,7 +300,7 @@ class _Conv1Stage:
         N, D, H, W = x.shape
         Do, Ho, Wo, cout = D // 2, H // 2, W // 2, self.op.cout
         fused = (self.dtype == torch.bfloat16 and cout == 128 and not debug.host("no_conv1_fused") and not debug.deterministic())   # (its weight gradient ends in fp32 atomics)
-        if (D % 2 or H % 2 or W % 2 or N * Do * Ho * Wo < self.GEMM_MIN_CELLS or debug.host("no_conv1_gemm")   # generic stage
+        if (D % 2 or H % 2 or W % 2 or Wo < 2 or N * Do * Ho * Wo < self.GEMM_MIN_CELLS or debug.host("no_conv1_gemm")   # generic stage
                 or (self.mixed and not fused)):      # (an f16 forward chain has the fused kernel and the generic stage, not the im2col route)
             vec = vec_of(self.dtype)
             xc = cast_pad(x.unsqueeze(-1), self.op.fwd_dtype, vec)
@@ -405,7 +405,7 @@ class _ConvT1Stage:
         G = G.float().contiguous()
         dw, db = grads.buf(self.mod.weight), grads.buf(self.mod.bias)
         lib, st = _ffi.lib(), _ffi.stream()
-        if self._gemm(x) and x.dtype == torch.bfloat16 and not debug.host("no_convt1_fused_bwd") and not debug.deterministic():
+        if self._gemm(x) and W >= 2 and x.dtype == torch.bfloat16 and not debug.host("no_convt1_fused_bwd") and not debug.deterministic():
             # csrc/conv1.hip: the data gradient is the FIRST layer's forward on the volume G, the weight gradient its weight gradient with x in the
             # role of the output gradient; no [cells][64] matrix in HBM
             self._sync()
