@@ -275,7 +275,9 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
         name, (n, flops, ms, _nb) = max(single.items(), key=lambda kv: kv[1][2])
         ach = flops / (ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if dt == torch.bfloat16 else PEAK_F32_TFLOPS
-        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "kernel": name,
+        traffic = _pmc_lookup(name, PMC_FILE_PERFORMER, PERFORMER_KERNEL_SOURCES) if (B == 6 and dt == torch.bfloat16) else None
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                "traffic_source": _pmc_source(PMC_FILE_PERFORMER), "kernel": name,
                 "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                 "note": "one-stream pass (weight gradients not overlapped) of 2 steps; dense layers (nn.Linear) on the im2col-order MFMA kernel; brackets with '+' "
                         "cover several launches (FAVOR+ groups: algorithmic FLOPs, the kernels execute ~3x on split-bf16 products)",
@@ -316,21 +318,23 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
     return res
 
 
-PMC_FILE = "r04_pmc_traffic.json"   # profiles/: HBM bytes per launch from the committed PMC passes (its `_provenance` names the command and commit)
+PMC_FILE = "r05_pmc_traffic.json"   # profiles/: HBM bytes per launch from the committed PMC passes (its `_provenance` names the command and commit)
+PMC_FILE_PERFORMER = "r05_pmc_traffic_performer.json"
 
 
 VQVAE_KERNEL_SOURCES = ("conv1.hip", "conv_fprop.hip", "conv_fprop_f16.hip", "conv_fprop_kernels.h", "conv_fprop_common.h", "conv_wgrad.hip", "convt1.hip",
                         "elementwise.hip", "norm.hip", "vq.hip", "sa_common.h", "split_bf16.h")
+PERFORMER_KERNEL_SOURCES = ("performer.hip", "favor_fused.hip", "favor_proj.hip", "local_attn.hip", "local_attn_split.h", "conv_fprop.hip", "conv_fprop_kernels.h",
+                            "conv_fprop_common.h", "conv_wgrad.hip", "dense.hip", "elementwise.hip", "norm.hip", "sa_common.h", "split_bf16.h")
 
 
-def csrc_digest():
-    """SHA-1 over the sources of the kernels the VQ-VAE step launches (synthanatomy_amd/csrc/: VQVAE_KERNEL_SOURCES, in that order):
-    `tools/rocpd_tools.py traffic` stores it next to the counters it summarises, and `roofline.traffic` is only reported while the sources are the ones that
-    were profiled."""
+def csrc_digest(sources=VQVAE_KERNEL_SOURCES):
+    """SHA-1 over the sources of the kernels a workload launches (synthanatomy_amd/csrc/, in the given order): `tools/rocpd_tools.py traffic` stores it next to
+    the counters it summarises, and `roofline.traffic` is only reported while the sources are the ones that were profiled."""
     import hashlib
     d = os.path.join(ROOT, "synthanatomy_amd", "csrc")
     h = hashlib.sha1()
-    for f in VQVAE_KERNEL_SOURCES:
+    for f in sources:
         with open(os.path.join(d, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()
@@ -339,32 +343,37 @@ def csrc_digest():
 _PMC_STATE = {}
 
 
-def _pmc_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the PMC passes of this same command (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3
-    --pmc runs; counters cannot be read from inside the process).  Recorded in profiles/<PMC_FILE> with its provenance and the digest of the
-    kernel sources it was collected on; reported only for the configuration it was collected on (default batch, bf16) and only while that
-    digest matches the sources of this tree -- a stale file gives null (and `traffic_source` says so), never an old number."""
-    if args.batch != 8 or args.dtype != "bf16":
-        return None
+def _pmc_lookup(kernel, fname, sources):
+    """HBM bytes per launch of `kernel` from the PMC passes of the same command (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc runs; counters
+    cannot be read from inside the process), recorded in profiles/<fname> with its provenance and the digest of the kernel sources it was collected on;
+    reported only while that digest matches the sources of this tree -- a stale file gives null, never an old number."""
     try:
-        if "rec" not in _PMC_STATE:
-            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
-                rec = json.load(f)
-            _PMC_STATE["rec"] = rec
-            _PMC_STATE["fresh"] = rec.get("csrc_sha1") == csrc_digest()
-        if not _PMC_STATE["fresh"]:
+        st = _PMC_STATE.setdefault(fname, {})
+        if "rec" not in st:
+            with open(os.path.join(ROOT, "profiles", fname)) as f:
+                st["rec"] = json.load(f)
+            st["fresh"] = st["rec"].get("csrc_sha1") == csrc_digest(sources)
+        if not st["fresh"]:
             return None
-        rec = _PMC_STATE["rec"]["kernels"].get(kernel)
+        rec = st["rec"]["kernels"].get(kernel)
         return int(rec["hbm_bytes_per_launch"]) if rec else None
     except (OSError, ValueError, KeyError):
-        _PMC_STATE.setdefault("fresh", False)
+        _PMC_STATE.setdefault(fname, {}).setdefault("fresh", False)
         return None
 
 
-def _pmc_source():
-    if _PMC_STATE.get("fresh"):
-        return f"profiles/{PMC_FILE} (separate rocprofv3 --pmc passes of this command on these kernel sources; not sampled in this run)"
-    return f"null: profiles/{PMC_FILE} is missing or was collected on other kernel sources (csrc digest mismatch) -- re-run the PMC passes (tools/rocpd_tools.py traffic)"
+def _pmc_traffic(kernel, args):
+    """(VQ-VAE step: only for the configuration the counters were collected on -- default batch, bf16)"""
+    if args.batch != 8 or args.dtype != "bf16":
+        return None
+    return _pmc_lookup(kernel, PMC_FILE, VQVAE_KERNEL_SOURCES)
+
+
+def _pmc_source(fname=None):
+    fname = fname or PMC_FILE
+    if _PMC_STATE.get(fname, {}).get("fresh"):
+        return f"profiles/{fname} (separate rocprofv3 --pmc passes of this command on these kernel sources; not sampled in this run)"
+    return f"null: profiles/{fname} is missing or was collected on other kernel sources (csrc digest mismatch) -- re-run the PMC passes (tools/profile_round.sh)"
 
 
 def _respawn(args):
@@ -500,13 +509,19 @@ def bench_fp32_mode(dev, batch=2, steps=2):
             "ms_per_step": round(dt * 1e3, 2), "tflops_per_gpu": round(batch / dt * STEP_TFLOP_PER_VOLUME, 2), "peak_f32_tflops": PEAK_F32_TFLOPS}
 
 
-def bench_bf16_vs_fp32(dev, batch=2):
+def bench_bf16_vs_fp32(dev, batch=2, state=None, what="random-init weights"):
     """The benchmarked mode against the fp32 product path (the mode pinned to the reference at 1e-3) on the real config: same weights, `batch`
-    160x224x160 volumes, eval.  Index agreement of the bf16 encoder + quantizer with the fp32 one, and the bf16 decoder against the fp32 decoder
-    on the SAME (fp32) indices."""
+    160x224x160 volumes, eval.  Index agreement of the bf16 encoder + quantizer with the fp32 one, the evidence for every index that differs
+    (utils/general.index_flip_report: how far from the fp32 optimum the 16-bit path landed, against the distance change ONE half-precision ulp of z
+    would cause), and the bf16 decoder against the fp32 decoder on the SAME (fp32) indices.  `state`: a state_dict to compare on (the weights and the
+    EMA codebook the timed training steps left) instead of a fresh initialisation."""
     from synthanatomy_amd.networks.vqvae.baseline import BaselineVQVAE
+    from synthanatomy_amd.utils.general import index_flip_report
     torch.manual_seed(4)
-    ref = BaselineVQVAE(**NET, compute_dtype=torch.float32).to(dev).eval()
+    ref = BaselineVQVAE(**NET, compute_dtype=torch.float32)
+    if state is not None:
+        ref.load_state_dict(state)
+    ref = ref.to(dev).eval()
     low = BaselineVQVAE(**NET, compute_dtype=torch.bfloat16)
     low.load_state_dict(ref.state_dict())
     low = low.to(dev).eval()
@@ -516,15 +531,23 @@ def bench_bf16_vs_fp32(dev, batch=2):
     x = torch.rand(batch, 1, *VOL, generator=torch.Generator(device=dev).manual_seed(4), device=dev)
     with torch.no_grad():
         i32, i16, ibf = ref.index_quantize(x)[0], low.index_quantize(x)[0], old.index_quantize(x)[0]
-        z32, z16, zbf = ref.encode(x)[0].double(), low.encode(x)[0].double(), old.encode(x)[0].double()
+        z32f, z16f = ref.encode(x)[0].float(), low.encode(x)[0].float()
+        z32, z16, zbf = z32f.double(), z16f.double(), old.encode(x)[0].double()
         r32, r16 = ref.decode_samples([i32]).double(), low.decode_samples([i32]).double()
+    rep = index_flip_report(z32f, z16f, ref.quantizer[0].impl.weight.detach(), i32, i16, max_list=32)
     res = {"index_agreement_vs_fp32": round(float((i32 == i16).float().mean()), 5), "positions": int(i32.numel()),
            "z_max_rel": float(f"{float((z16 - z32).abs().max() / z32.abs().max()):.3e}"),
            "recon_max_rel_same_indices": float(f"{float((r16 - r32).abs().max() / r32.abs().max()):.3e}"),
            "encoder_forward_dtype": str(low.encoder_forward_dtype).replace("torch.", ""),
+           "flips": {"count": rep["flipped"], "max_ratio_gap_over_one_f16_ulp_of_z": float(f"{rep['max_flip_ratio']:.3g}"),
+                     "median_ratio_unflipped": float(f"{rep['median_ratio_of_unflipped']:.3g}"), "p01_ratio_unflipped": float(f"{rep['p01_ratio_of_unflipped']:.3g}"),
+                     "codebook_norm_max": float(f"{rep['codebook_norm_max']:.3g}"), "codebook_norm_median": float(f"{rep['codebook_norm_median']:.3g}"),
+                     "each": [{k: (float(f"{v:.3g}") if isinstance(v, float) else v) for k, v in f.items()} for f in rep["flips"]],
+                     "how": "fp32 path's distance from its optimum to the code the 16-bit path chose, divided by the distance change one IEEE-half ulp of every "
+                            "channel of z would cause between the two codes (utils/general.index_flip_report); unflipped: the same ratio with the runner-up code"},
            "bf16_forward_operands": {"index_agreement_vs_fp32": round(float((i32 == ibf).float().mean()), 5),
                                      "z_max_rel": float(f"{float((zbf - z32).abs().max() / z32.abs().max()):.3e}")},
-           "what": f"benchmarked mode (bf16 MFMA, encoder forward on float16 operands) vs fp32 product path, same random-init weights, {batch} volumes "
+           "what": f"benchmarked mode (bf16 MFMA, encoder forward on float16 operands) vs fp32 product path, {what}, {batch} volumes "
                    f"{VOL[0]}x{VOL[1]}x{VOL[2]}, eval"}
     del ref, low, old, x
     torch.cuda.empty_cache()
@@ -829,8 +852,13 @@ def main():
             if "roofline_hbm" in line:
                 line["roofline_hbm"]["peak_measured_gbs"] = pk["copy_gbs"]
         if dtype == torch.bfloat16:
+            trained = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}      # weights + EMA codebook after the warm-up, timed and roofline steps
+            n_trained = args.warmup + args.steps + (0 if args.no_kernel_timer else args.roofline_steps)
             line["fp32_mode"] = bench_fp32_mode(dev)
             line["fp32_mode"]["bf16_vs_fp32"] = bench_bf16_vs_fp32(dev)
+            line["fp32_mode"]["bf16_vs_fp32_trained"] = bench_bf16_vs_fp32(
+                dev, state=trained, what=f"the weights and EMA codebook after the {n_trained} training steps of this run (synthetic volumes)")
+            del trained
     secondary = secondary_14k = None
     del net, flat, opt, reducer, x
     torch.cuda.empty_cache()

@@ -262,3 +262,41 @@ def list_inputs(spec, postfix: str = None):
 def log(rank, msg):
     if rank == 0:
         print(msg, flush=True)
+
+
+def index_flip_report(z_ref: "torch.Tensor", z_low: "torch.Tensor", codebook: "torch.Tensor", idx_ref: "torch.Tensor", idx_low: "torch.Tensor",
+                      ulp: float = 2.0 ** -11, max_list: int = 64) -> dict:
+    """Evidence for code indices that differ between a reference path (fp32) and a 16-bit path (`north_star`: bit-exact argmin indices).
+
+    z_* [B, D, ...] encoder outputs (channel dim 1), codebook [K, D] (the reference path's), idx_* [B, ...] the two paths' code indices.  For every position
+    the reference distances d_k = |z|^2 - 2 z.e_k + |e_k|^2 (baseline.py:49-53) give the reference's top-2 gap d_(2) - d_(1); for a FLIPPED position, `gap_to_chosen`
+    = d_ref(code of the 16-bit path) - d_ref(code of the reference) is how far from the optimum the other path landed.  Both are put next to the distance
+    change that rounding the FINAL z alone to the 16-bit type would cause between those two codes, noise_1ulp = 2 * sum_i |z_i| * ulp * |e_a,i - e_b,i| (one
+    half-precision ulp per channel, ulp = 2^-11 for IEEE half; the real z carries the rounding of ~30 layers).  A flip whose ratio gap / noise_1ulp is a small
+    number is a tie below the 16-bit path's resolution; the report lists every flip (up to `max_list`) and, for context, the median ratio of the positions
+    that did NOT flip."""
+    import torch
+    C = z_ref.shape[1]
+    zr = z_ref.detach().double().movedim(1, -1).reshape(-1, C)
+    zl = z_low.detach().double().movedim(1, -1).reshape(-1, C)
+    E = codebook.detach().double()
+    ir, il = idx_ref.reshape(-1).long(), idx_low.reshape(-1).long()
+    d = (zr * zr).sum(1, keepdim=True) - 2.0 * zr @ E.t() + (E * E).sum(1)[None, :]
+    top2 = torch.topk(d, 2, dim=1, largest=False)
+    gap_top2 = top2.values[:, 1] - top2.values[:, 0]
+    runner = torch.where(top2.indices[:, 0] == ir, top2.indices[:, 1], top2.indices[:, 0])
+    other = torch.where(il != ir, il, runner)                     # the code the decision is compared against: the 16-bit path's, else the runner-up
+    noise = 2.0 * (zr.abs() * (E[ir] - E[other]).abs()).sum(1) * ulp
+    gap_other = d.gather(1, other[:, None])[:, 0] - d.gather(1, ir[:, None])[:, 0]
+    ratio = gap_other / noise.clamp_min(1e-300)
+    flipped = (il != ir).nonzero()[:, 0]
+    kept = (il == ir)
+    flips = [{"position": int(p), "code_ref": int(ir[p]), "code_low": int(il[p]), "gap_to_chosen": float(gap_other[p]), "ref_top2_gap": float(gap_top2[p]),
+              "noise_1ulp": float(noise[p]), "ratio": float(ratio[p]), "z_rel_err_here": float((zl[p] - zr[p]).norm() / zr[p].norm().clamp_min(1e-300))}
+             for p in flipped[:max_list].tolist()]
+    return {"positions": int(ir.numel()), "flipped": int(flipped.numel()), "agreement": float(kept.double().mean()),
+            "max_flip_ratio": max((f["ratio"] for f in flips), default=0.0),
+            "median_ratio_of_unflipped": float(ratio[kept].median()) if bool(kept.any()) else None,
+            "p01_ratio_of_unflipped": float(ratio[kept].quantile(0.01)) if bool(kept.any()) else None,
+            "codebook_norm_max": float(E.norm(dim=1).max()), "codebook_norm_median": float(E.norm(dim=1).median()),
+            "ulp": ulp, "flips": flips}

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+FLIP_NOISE_RATIO = 4.0    # a flipped index must be a tie within 4 half-precision ulps of z (measured: 0.11 at random init -- 4 flips of 2 800 --; unflipped positions: median 44)
 GATE_INDEX_AGREEMENT = 0.9975   # measured 0.9986 (4 of 2 800 differ) minus ~0.1 %; round 3 (bf16 forward operands): 0.9918
 
 NET = dict(n_levels=4, downsample_parameters=((4, 2, 1, 1),) * 4, upsample_parameters=((4, 2, 1, 0, 1),) * 4, n_embed=2048, embed_dim=32, n_channels=256,
@@ -133,7 +134,58 @@ def test_bf16_mode_against_the_fp32_product_path_at_full_size():
     assert agree >= GATE_INDEX_AGREEMENT, agree
     assert ez < 2e-3 and er < 2e-2, (ez, er)
     assert ez < 0.35 * ezbf
+    # every index that differs is a tie below the 16-bit path's resolution: the fp32 path's distance from its optimum to the code the f16 path chose, against the
+    # distance change ONE half-precision ulp of every channel of z would cause between the two codes (the real z carries the rounding of ~30 layers)
+    from synthanatomy_amd.utils.general import index_flip_report
+    rep = index_flip_report(z32, z16, ref.quantizer[0].impl.weight.detach(), i32, i16)
+    print(f"[flips, random init] {rep['flipped']} of {rep['positions']}; gap / one-ulp noise: flipped max {rep['max_flip_ratio']:.2f}, "
+          f"unflipped median {rep['median_ratio_of_unflipped']:.0f}, 1st percentile {rep['p01_ratio_of_unflipped']:.1f}")
+    assert rep["flipped"] == int((i32 != i16).sum())
+    assert rep["max_flip_ratio"] <= FLIP_NOISE_RATIO, rep["flips"]
     del ref, low, old
+    torch.cuda.empty_cache()
+
+
+def test_index_flips_stay_sub_noise_on_a_trained_codebook():
+    """The same evidence after TRAINING: 24 steps of the throughput-mode network (EMA codebook updates, Adam) on synthetic volumes move the codebook away from
+    its initialisation -- used codes drift to the data, unused ones decay (dead codes: SURVEY section 7 'hard parts') --, then both paths are compared on the
+    trained state.  Gate: index agreement as at initialisation, and every flipped index within the same multiple of one half-precision ulp of z."""
+    from synthanatomy_amd.losses.vqvae import MSELoss
+    from synthanatomy_amd.networks.vqvae.baseline import BaselineVQVAE
+    from synthanatomy_amd.runtime.optim import FlatParams, FusedAdam
+    from synthanatomy_amd.utils.general import index_flip_report
+    torch.manual_seed(5)
+    low = BaselineVQVAE(**NET, compute_dtype=torch.bfloat16).cuda().train()
+    flat = FlatParams(low.parameters())
+    opt = FusedAdam(flat, lr=1.65e-4)
+    opt.on_step.append(low.invalidate_packed_weights)
+    loss_fn = MSELoss()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    w0 = low.quantizer[0].impl.weight.detach().clone()
+    for _ in range(24):
+        x = torch.rand(2, 1, *VOL, generator=g, device="cuda")
+        flat.zero_grad()
+        loss_fn(low(x), x).backward()
+        opt.step()
+    state = {k: v.detach().cpu().clone() for k, v in low.state_dict().items()}
+    moved = float((low.quantizer[0].impl.weight.detach() - w0).norm() / w0.norm())
+    assert moved > 1e-2, moved                       # the EMA really changed the codebook
+    ref = BaselineVQVAE(**NET, compute_dtype=torch.float32)
+    ref.load_state_dict(state)
+    ref = ref.cuda().eval()
+    low.eval()
+    x = torch.rand(2, 1, *VOL, generator=g, device="cuda")
+    with torch.no_grad():
+        i32, i16 = ref.index_quantize(x)[0], low.index_quantize(x)[0]
+        z32, z16 = ref.encode(x)[0].float(), low.encode(x)[0].float()
+    rep = index_flip_report(z32, z16, ref.quantizer[0].impl.weight.detach(), i32, i16)
+    used = int(torch.unique(i32).numel())
+    print(f"[flips, after 24 training steps] codebook moved {moved:.3f} (relative), {used} codes in use, norms max {rep['codebook_norm_max']:.3g} / median "
+          f"{rep['codebook_norm_median']:.3g}; {rep['flipped']} of {rep['positions']} indices differ (agreement {rep['agreement']:.4f}); gap / one-ulp noise: "
+          f"flipped max {rep['max_flip_ratio']:.2f}, unflipped median {rep['median_ratio_of_unflipped']:.0f}")
+    assert rep["agreement"] >= GATE_INDEX_AGREEMENT, rep["agreement"]
+    assert rep["max_flip_ratio"] <= FLIP_NOISE_RATIO, rep["flips"]
+    del ref, low, flat, opt
     torch.cuda.empty_cache()
 
 

@@ -95,7 +95,7 @@ def pmc(path, by_grid=False):
             print(line)
 
 
-def traffic(fetch_db, write_db, out=None, provenance="", by_grid=False):
+def traffic(fetch_db, write_db, out=None, provenance="", by_grid=False, sources="vqvae"):
     """by_grid: rows per (kernel, launch size); the JSON then ALSO keeps the per-kernel means under the plain names (what bench.py looks up)."""
     f, w = _counters(fetch_db, by_grid), _counters(write_db, by_grid)
     if by_grid:
@@ -115,9 +115,10 @@ def traffic(fetch_db, write_db, out=None, provenance="", by_grid=False):
     if out:
         import os
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        from bench import csrc_digest      # the digest of the kernel sources the counters were collected on: bench.py reports the traffic only while it matches
+        import bench                       # the digest of the kernel sources the counters were collected on: bench.py reports the traffic only while it matches
+        srcs = bench.PERFORMER_KERNEL_SOURCES if sources == "performer" else bench.VQVAE_KERNEL_SOURCES
         with open(out, "w") as fh:
-            json.dump({"_provenance": provenance, "csrc_sha1": csrc_digest(), "kernels": rec}, fh, indent=1)
+            json.dump({"_provenance": provenance, "csrc_sha1": bench.csrc_digest(srcs), "sources": sources, "kernels": rec}, fh, indent=1)
 
 
 if __name__ == "__main__":
@@ -127,5 +128,7 @@ if __name__ == "__main__":
     elif cmd == "pmc":
         pmc(sys.argv[2], by_grid="--by-grid" in sys.argv[3:])
     elif cmd == "traffic":
-        args = [x for x in sys.argv[2:] if x != "--by-grid"]
-        traffic(args[0], args[1], args[2] if len(args) > 2 else None, args[3] if len(args) > 3 else "", by_grid="--by-grid" in sys.argv[2:])
+        args = [x for x in sys.argv[2:] if x != "--by-grid" and not x.startswith("--sources=")]
+        src = [x.split("=", 1)[1] for x in sys.argv[2:] if x.startswith("--sources=")]
+        traffic(args[0], args[1], args[2] if len(args) > 2 else None, args[3] if len(args) > 3 else "", by_grid="--by-grid" in sys.argv[2:],
+                sources=src[0] if src else "vqvae")
