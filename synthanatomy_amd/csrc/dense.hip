@@ -158,6 +158,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) woff[i] = (n_base + wave * 32u + (uint32_t)i * 16u + frow) * (uint32_t)(g.Kpad * SZ) + fq * 16u;
+#ifdef SA_PP_DEBUG_VARIANTS
+    if (a.dbg & 512u)     // TIMING PROBE ONLY (wrong results): the weight fragments read as if the operand were K-blocked ([K / 8][N][8]): 256 contiguous bytes per 16 lanes
+#pragma unroll
+        for (int i = 0; i < NI; ++i) woff[i] = (n_base + wave * 32u + (uint32_t)i * 16u) * 16u + frow * 16u + fq * (uint32_t)(g.CoutPad * 16);
+#endif
     const uint32_t kbytes = (uint32_t)(g.Cin * SZ);               // bytes of an activation row (slabs beyond it multiply zero columns of the packed weights)
     uint32_t nk = a.nk;
 #ifdef SA_PP_DEBUG_VARIANTS
@@ -178,6 +183,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             dense_dma16(rA, alds[j] == dump ? dump : alds[j] + (uint32_t)(slot * STAGE), a_ok ? aoff[j] : OOB_OFF, a_ok ? s * 128u : 0u);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
+#ifdef SA_PP_DEBUG_VARIANTS
+            if (a.dbg & 512u) {       // (timing probe, see above: slab s = 8 K-groups of CoutPad x 16 bytes, K step 1 four groups further)
+                W[slot][0][i] = dense_load16<0>(rB, live ? woff[i] : OOB_OFF, live ? s * (uint32_t)(g.CoutPad * 128) : 0u);
+                W[slot][1][i] = dense_load16<0>(rB, live ? woff[i] + (uint32_t)(g.CoutPad * 64) : OOB_OFF, live ? s * (uint32_t)(g.CoutPad * 128) : 0u);
+                continue;
+            }
+#endif
             W[slot][0][i] = dense_load16<0>(rB, live ? woff[i] : OOB_OFF, live ? s * 128u : 0u);
             W[slot][1][i] = dense_load16<64>(rB, live ? woff[i] : OOB_OFF, live ? s * 128u : 0u);
         }

@@ -9,7 +9,7 @@ for shape in ${SHAPES:-"w2 fwd"}; do
   for dbg in ${DBGS:-0 16 224 240 232 248}; do
     echo "== $shape SA_PP_DBG=$dbg"
     rm -rf $OUT/t
-    DENSE_ONLY="${shape/_/ }" SA_PP_DBG=$dbg timeout 300 rocprofv3 --kernel-trace -d $OUT/t -o t -- python tools/bench_dense_tiles.py > $OUT/log.txt 2>&1
+    DENSE_ONLY="${shape/_/ }" SA_DENSE_RING=1 SA_PP_DBG=$dbg timeout 300 rocprofv3 --kernel-trace -d $OUT/t -o t -- python tools/bench_dense_tiles.py > $OUT/log.txt 2>&1
     python tools/rocpd_tools.py stats "$(find $OUT/t -name '*_results.db' | head -1)" --by-grid | grep -E "dense_gemm|conv_fprop_dma" | cut -c1-150
   done
 done
