@@ -753,9 +753,11 @@ def main():
         if rank == 0:
             timer = engine.KernelTimer()
             engine.TIMER = timer
-        for _ in range(args.roofline_steps):
-            step()
-        torch.cuda.synchronize()
+        from synthanatomy_amd import debug as _dbg
+        with _dbg.override(no_side_wgrad=True):      # one stream: overlapped weight gradients would inflate every per-kernel duration
+            for _ in range(args.roofline_steps):
+                step()
+            torch.cuda.synchronize()
         if timer is not None:
             stats = timer.collect()
         engine.TIMER = None

@@ -19,7 +19,7 @@ SCAN_EXACT_SHIFT = 10   # scan_exact=0..7
 
 _HOST_ENV = dict(no_fused_res="SA_NO_FUSED_RES", no_fused_1x1_bwd="SA_NO_FUSED_1X1_BWD", no_conv1_gemm="SA_NO_CONV1_GEMM",
                  no_conv1_fused="SA_NO_CONV1_FUSED", convt1_direct="SA_CONVT1_DIRECT", no_batched_pack="SA_NO_BATCHED_PACK",
-                 no_fused_sums="SA_NO_FUSED_SUMS", no_fused_qkv="SA_NO_FUSED_QKV", no_fused_favor="SA_NO_FUSED_FAVOR", no_convt1_fused_bwd="SA_NO_CONVT1_FUSED_BWD", no_fused_epilogues="SA_NO_FUSED_EPILOGUES", no_convt1_fused_fwd="SA_NO_CONVT1_FUSED_FWD", no_lp_mirrors="SA_NO_LP_MIRRORS", no_decode_bf16_weights="SA_NO_DECODE_BF16_WEIGHTS", no_attn_step_merge="SA_NO_ATTN_STEP_MERGE", no_attn_colaunch="SA_NO_ATTN_COLAUNCH", no_side_wgrad="SA_NO_SIDE_WGRAD", side_wgrad_vqvae="SA_SIDE_WGRAD_VQVAE",
+                 no_fused_sums="SA_NO_FUSED_SUMS", no_fused_qkv="SA_NO_FUSED_QKV", no_fused_favor="SA_NO_FUSED_FAVOR", no_convt1_fused_bwd="SA_NO_CONVT1_FUSED_BWD", no_fused_epilogues="SA_NO_FUSED_EPILOGUES", no_convt1_fused_fwd="SA_NO_CONVT1_FUSED_FWD", no_lp_mirrors="SA_NO_LP_MIRRORS", no_decode_bf16_weights="SA_NO_DECODE_BF16_WEIGHTS", no_attn_step_merge="SA_NO_ATTN_STEP_MERGE", no_attn_colaunch="SA_NO_ATTN_COLAUNCH", no_side_wgrad="SA_NO_SIDE_WGRAD", no_side_wgrad_vqvae="SA_NO_SIDE_WGRAD_VQVAE",
                  ddp_single_rank="SA_DDP_SINGLE_RANK",   # collectives issued on a ONE-rank process group too (RCCL on a one-GPU box: tests/test_rccl_single_rank_gpu.py)
                  no_f16_forward="SA_NO_F16_FORWARD",     # VQ-VAE encoder forward on bf16 operands like the rest (default in throughput mode: float16, the reference's AMP dtype)
                  no_sample_step="SA_NO_SAMPLE_STEP",     # stateful sampler: the decision + sequence update as torch ops instead of sa_sample_step (A/B, equality test)

@@ -614,9 +614,10 @@ class _Chain:
 
     def backward(self, G: torch.Tensor, tape):
         side = None
-        # (opt-in here, SA_SIDE_WGRAD_VQVAE=1: +0.9 % on the step -- the big kernels fill the CUs by themselves -- but overlapping launches inflate every per-kernel
-        #  duration, and bench.py's roofline record is per kernel; the Performer, whose dense data-gradient launches leave the CUs half empty, runs it by default)
-        if (self.dtype != torch.float32 and debug.host("side_wgrad_vqvae") and not debug.host("no_side_wgrad")
+        # Weight gradients are leaves of the backward pass: they run on a second HIP stream beside the data-gradient chain (round 5: default, +0.9 % on the
+        # step -- 113.5 -> 112.5 ms in alternating same-box runs; overlapping launches inflate every per-kernel duration, which is why bench.py's roofline record
+        # comes from a separate pass with SA_NO_SIDE_WGRAD semantics).  SA_NO_SIDE_WGRAD=1 / --deterministic: one stream.
+        if (self.dtype != torch.float32 and not debug.host("no_side_wgrad") and not debug.host("no_side_wgrad_vqvae")
                 and not debug.deterministic() and G.is_cuda):
             from ..transformers.performer import _SideWgrad
             side = _SideWgrad(G.device)

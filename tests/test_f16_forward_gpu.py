@@ -225,3 +225,33 @@ def test_f16_conversion_saturates_finite_values_and_keeps_nan_visible():
     y, _, lp = op.fprop(x.cuda().to(H16), want_lp=True)      # (no activation: the kernels' ReLU is fmaxf(x, 0), which maps NaN to 0 in every dtype)
     assert bool(torch.isnan(y[0, 3, 4, 4].float()).all()) and bool(torch.isnan(lp[0, 3, 4, 4].float()).all())
     assert bool(torch.isfinite(y[0, 0, 0, 0].float()).all())
+
+
+def test_side_stream_weight_gradients_equal_the_one_stream_backward():
+    """VQ-VAE backward with the weight gradients on a second HIP stream (round-5 default in throughput mode) against the same pass on one stream
+    (SA_NO_SIDE_WGRAD): same kernels on the same operands, so the gradients agree to the fp32 atomics' ordering noise; twice in a row (the second pass must
+    not see stale workspaces or un-joined streams)."""
+    from synthanatomy_amd import debug
+    from synthanatomy_amd.networks.vqvae.baseline import BaselineVQVAE
+    small = dict(n_levels=2, downsample_parameters=((4, 2, 1, 1),) * 2, upsample_parameters=((4, 2, 1, 0, 1),) * 2, n_embed=64, embed_dim=16, n_channels=64,
+                 n_res_channels=64, n_res_layers=2)
+    torch.manual_seed(3)
+    net = BaselineVQVAE(**small, compute_dtype=BF).cuda().train()
+    x = torch.rand(2, 1, 32, 48, 32, generator=torch.Generator().manual_seed(2)).cuda()
+
+    def grads():
+        net.zero_grad(set_to_none=True)
+        out = net(x)
+        (F.mse_loss(out["reconstruction"][0].float(), x) + out["quantization_losses"][0]).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    net.eval()      # (no EMA update between the passes: identical forward)
+    for p in net.parameters():
+        p.requires_grad_(True)
+    with debug.override(no_side_wgrad=True):
+        ref = grads()
+    for _ in range(2):
+        got = grads()
+        assert got.keys() == ref.keys()
+        for k in ref:
+            assert torch.allclose(got[k], ref[k], rtol=2e-4, atol=1e-6), (k, float((got[k] - ref[k]).abs().max()))
