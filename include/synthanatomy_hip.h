@@ -99,6 +99,7 @@ int sa_kernel_log_read(char *buf, int cap, int stop);
 #define SA_DBG_NO_KGROUPS        (1u << 17)  /* dense layers with about one tile per CU on the one-group kernel instead of two K groups of eight waves (conv_fprop_dma_kernel<..., 2>) */
 #define SA_DBG_CELLS             (1u << 19)  /* stride-2 convolutions / transposed-convolution classes on the cell mainloop (conv_fprop_cells_kernel): opt-in, measured equal */
 #define SA_DBG_DENSE_RING        (1u << 20)  /* opt-in (SA_DENSE_RING=1): dense layers (nn.Linear) on the four-wave ring mainloop of dense.hip (dense_gemm_kernel) -- parity-exact, measured slower than the im2col-order loops on 5 of the 8 shapes of a Performer layer */
+#define SA_DBG_NO_CELLS256       (1u << 21)  /* stride-2 family on the im2col-order kernel instead of the 256-voxel cell mainloop (conv_fprop_cells256_kernel): A/B + cross-family tests */
 #define SA_DBG_FAVOR_SEQ_ALWAYS  (1u << 18)  /* FAVOR+ chunk states in the sequential form for every batch (default: from 40 (batch, head) pairs; tests) */
 #define SA_DBG_DETERMINISTIC     (1u << 16)  /* fixed-order reductions where the library itself chooses (BatchNorm sums); see the deterministic-mode section */
 #define SA_DBG_SCAN_EXACT_SHIFT  10          /* 3 bits: chunk states | scan A outputs | scan B outputs on the exact-fp32 MFMA kernels */

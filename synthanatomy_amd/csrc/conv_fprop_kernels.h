@@ -1078,6 +1078,167 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fprop_cells_kernel(const Fpro
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Mainloop v10 "cells256" (round 5): the cell mainloop above with 256-voxel tiles.  Ablation of the im2col-order loop on the config-2 down-sampling layer at
+// batch 8 (tools/conv_ablate.sh: 1.90 ms in full, 1.17 ms without the activation DMA, 1.43 ms without the weight DMA, 0.98 ms with neither) says the stride-2
+// family is bound by what it pulls through L2 -> L1 -> LDS: 2 MB of activation rows AND 2 MB of weight slabs per 128 x 128 tile (23 GB per launch, ~15 TB/s).
+// The 128-voxel cell tile cuts the activation half (each staged halo row serves eight taps) and ties; the weight half only shrinks with more voxels per block.
+// Here a tile is 4 (D) x 8 (H) x 8 (W) cells = 256 voxels (no padded rows at 40 x 56 x 40), eight waves of 64 voxels x 64 channels (wave = (depth plane, channel
+// half), register epilogue) like the 3x3x3 kernels, and the halo is kept as FOUR plane slots of 9 x 9 cells (11 pieces each): tap depth shift 0 reads planes
+// 0..3, shift 1 reads planes 1..4 -- plane 4 takes plane 0's slot, so a depth switch re-loads ONE plane.  44 + 2 x 16 KiB = 76 KiB: two blocks per CU.
+// Per 256 voxels and (class, chunk): 55 KiB of halo + 128 KiB of weight slabs, against 2 x (31 + 128) KiB for two 128-voxel cell tiles and 2 x 256 KiB in
+// im2col order.
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_fprop_cells256_kernel(const FpropArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = 8, MI = 4, NI = 4, WPIECES = 16 / NW, BN = 128;
+    constexpr int PROWS = 81, PPIECES = 11, PLB = PPIECES * 1024, NSLOT = 4;    // plane: 9 x 9 cells in 11 pieces of 8 rows; slot stride
+    constexpr int SZ = sizeof(T);
+    constexpr int HALO_BYTES = NSLOT * PLB;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const sA = smem;                   // 4 plane slots
+    unsigned char* const sB = smem + HALO_BYTES;      // 2 weight slabs
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wm = wave >> 1, wn = wave & 1u;    // wm = depth plane of the tile
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
+    const uint32_t n_base = bn * BN;
+    const sa_conv_geom& g = a.g;
+    // tile -> (n, d quad, hp, wp)
+    uint32_t q = bm / a.WP;
+    const uint32_t wp = bm - q * a.WP;
+    uint32_t q2 = q / a.HP;
+    const uint32_t hp = q - q2 * a.HP;
+    const uint32_t pn = q2 / a.DP, dp = q2 - pn * a.DP;
+    const int32_t d0 = (int32_t)dp * 4, h0 = (int32_t)hp * 8, w0 = (int32_t)wp * 8;
+
+    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (int)a.w_bytes, 0x00020000);
+
+    const uint32_t prow = lane >> 3;
+    const uint32_t lv = (lane & 7u) ^ prow;
+    uint32_t boff[WPIECES];
+#pragma unroll
+    for (int j = 0; j < WPIECES; ++j) boff[j] = (n_base + (wave * WPIECES + j) * 8 + prow) * (uint32_t)(g.Kpad * SZ) + lv * 16u;
+
+    const uint32_t npar = (uint32_t)g.in_mult[1];                 // 2: strided convolution (eight tap classes); 1: one class
+    const uint32_t nchunk = (uint32_t)(g.Cin * SZ) / 128u;
+    const uint32_t ngroups = npar * npar * npar * nchunk * 2u;    // group = (class, channel chunk, depth shift): four (kh, kw) slabs
+    const uint32_t vox_bytes = (uint32_t)(g.Cin * SZ);
+
+    auto axis_base = [&](int ax, uint32_t pcls) __attribute__((always_inline)) {
+        return g.in_off[ax] + (npar == 2u ? (int32_t)pcls * g.tap_step[ax] : (g.tap_step[ax] < 0 ? g.tap_step[ax] : 0));
+    };
+    auto axis_tap = [&](int ax, uint32_t pcls, uint32_t c) __attribute__((always_inline)) {
+        return npar == 2u ? pcls + 2u * c : (g.tap_step[ax] < 0 ? 1u - c : c);
+    };
+    // halo plane `pl` (0..4, relative to the tile's first depth plane) of (class, chunk) -> slot pl & 3: pieces wave, wave + 8
+    auto issue_plane = [&](uint32_t cls, uint32_t ch, uint32_t pl) __attribute__((always_inline)) {
+        const int32_t bd = axis_base(0, cls >> 2), bh = axis_base(1, (cls >> 1) & 1u), bw = axis_base(2, cls & 1u);
+        const int32_t id = g.in_mult[0] * (d0 + (int32_t)pl) + bd;
+        const bool dok = (uint32_t)id < (uint32_t)g.Di;
+        unsigned char* const dst = sA + (pl & 3u) * PLB;
+#pragma unroll 1
+        for (uint32_t p = wave; p < (uint32_t)PPIECES; p += (uint32_t)NW) {
+            const uint32_t r = p * 8 + prow;
+            const uint32_t hh = r / 9u, ww = r - hh * 9u;
+            const int32_t ih = g.in_mult[1] * (h0 + (int32_t)hh) + bh, iw = g.in_mult[2] * (w0 + (int32_t)ww) + bw;
+            const bool ok = dok && r < (uint32_t)PROWS && (uint32_t)ih < (uint32_t)g.Hi && (uint32_t)iw < (uint32_t)g.Wi;
+            const uint32_t voff = ok ? (uint32_t)((((int32_t)pn * g.Di + id) * g.Hi + ih) * g.Wi + iw) * vox_bytes + ch * 128u + lv * 16u : OOB_OFF;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, voff, 0, 0, 0);
+        }
+    };
+    // group -> (class, chunk, depth shift)
+    auto g_cls = [&](uint32_t gi) __attribute__((always_inline)) { return (gi >> 1) / nchunk; };
+    auto g_ch = [&](uint32_t gi) __attribute__((always_inline)) { return (gi >> 1) - ((gi >> 1) / nchunk) * nchunk; };
+    // the planes group gi needs that its predecessor did not leave in the slots: shift 0 = planes 0..3 (a new class / chunk), shift 1 = plane 4 only
+    auto issue_halo = [&](uint32_t gi) __attribute__((always_inline)) {
+        const uint32_t cls = g_cls(gi), ch = g_ch(gi);
+        if (gi & 1u) issue_plane(cls, ch, 4u);
+        else {
+            issue_plane(cls, ch, 0u);
+            issue_plane(cls, ch, 1u);
+            issue_plane(cls, ch, 2u);
+            issue_plane(cls, ch, 3u);
+        }
+    };
+    // weight slab of (group gi, tap t4 = (kh shift, kw shift)) -> buffer `buf`
+    auto issue_w = [&](uint32_t gi, uint32_t t4, uint32_t buf) __attribute__((always_inline)) {
+        const uint32_t cls = g_cls(gi), ch = g_ch(gi);
+        const uint32_t kd = axis_tap(0, cls >> 2, gi & 1u), kh = axis_tap(1, (cls >> 1) & 1u, (t4 >> 1) & 1u), kw = axis_tap(2, cls & 1u, t4 & 1u);
+        const uint32_t col = (((kd * (uint32_t)g.KT[1] + kh) * (uint32_t)g.KT[2] + kw) * (uint32_t)g.Cin) * SZ + ch * 128u;
+#pragma unroll
+        for (int j = 0; j < WPIECES; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(sB + buf * (BN * 128) + (wave * WPIECES + j) * 1024), 16, boff[j], col, 0, 0);
+    };
+
+    float4_t acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t frow = lane & 15u, fq = lane >> 4;
+    // unswizzled byte address inside a plane slot of tile voxel 16 j + frow of this wave's plane = (h, w) = (v >> 3, v & 7), vector fq
+    uint32_t a0[MI];
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+        const uint32_t v = (uint32_t)j * 16u + frow;
+        a0[j] = ((v >> 3) * 9u + (v & 7u)) * 128u + fq * 16u;
+    }
+    const uint32_t b_off = tile_off(wn * (NI * 16) + frow, fq);
+
+    issue_halo(0);
+    issue_w(0, 0, 0);
+    __syncthreads();
+    uint32_t buf = 0;
+    for (uint32_t gi = 0; gi < ngroups; ++gi) {
+        const bool next_group = gi + 1 < ngroups;
+        const uint32_t slot = ((wm + (gi & 1u)) & 3u) * PLB;     // this wave's depth plane, shifted by the group's depth tap
+#pragma unroll 1
+        for (uint32_t t4 = 0; t4 < 4; ++t4) {
+            const bool same = t4 < 3;
+            if (same || next_group) issue_w(same ? gi : gi + 1, same ? t4 + 1 : 0, buf ^ 1u);
+            const uint32_t tapoff = (((t4 >> 1) & 1u) * 9u + (t4 & 1u)) * 128u;
+            const unsigned char* pb = sB + buf * (BN * 128);
+            uint32_t ax[MI];
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                const uint32_t ad = a0[j] + tapoff;
+                ax[j] = slot + (ad ^ (((ad >> 7) & 7u) << 4));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 xf[MI], wf[NI];
+#pragma unroll
+                for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(sA + (ax[j] ^ (ks * 64u)));
+#pragma unroll
+                for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + ((b_off + i * 2048u) ^ (ks * 64u)));
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
+            }
+            __syncthreads();   // next weight slab landed (vmcnt(0)), this one free
+            buf ^= 1u;
+        }
+        if (next_group) {      // every wave is past its last read of the planes the next group replaces
+            issue_halo(gi + 1);
+            __syncthreads();
+        }
+    }
+    auto row_vox = [&](uint32_t row) __attribute__((always_inline)) {
+        const uint32_t d = (uint32_t)d0 + (row >> 6), h = (uint32_t)h0 + ((row >> 3) & 7u), w = (uint32_t)w0 + (row & 7u);
+        if (d >= (uint32_t)g.Dm || h >= (uint32_t)g.Hm || w >= (uint32_t)g.Wm) return -1ll;
+        return (((long long)pn * g.Do + (d * g.out_mult[0] + g.out_off[0])) * g.Ho + (h * g.out_mult[1] + g.out_off[1])) * g.Wo + (w * g.out_mult[2] + g.out_off[2]);
+    };
+    fprop_epilogue_regs<MI, NI, SA_EPI_BUDGET8, std::is_same<T, f16_t>::value>(a, acc, wm, wn, frow, fq, n_base, row_vox);
+#endif
+}
+
 // compute units of the current device (queried once per device ordinal)
 static inline int device_cu_count() {
     static std::atomic<int> cu_count[64];
@@ -1255,6 +1416,38 @@ static bool cells_eligible(const FpropArgs& a, int sz) {
     return eff >= 0.85 && (int64_t)g.N * dp * hp * wp >= 512;
 }
 
+// cells256: default for the stride-2 family when the register epilogue applies (whole 128-channel tiles, 16-byte rows, no pre-activation copy, a bf16 copy of
+// the output only from f16 launches) and 4 x 8 x 8-cell tiles waste little; SA_DBG_NO_CELLS256 (SA_NO_CELLS256=1) restores the im2col-order kernel.
+static bool cells256_eligible(const FpropArgs& a, int sz, bool f16) {
+    const sa_conv_geom& g = a.g;
+    if (dbg(SA_DBG_NO_CELLS256) || dbg(SA_DBG_CELLS) || dbg(SA_DBG_NO_HALO) || sz != 2 || a.in_bytes == 0 || ((size_t)g.Cin * sz) % 128 != 0) return false;
+    if (g.cout_valid % 128 != 0 || (g.Cout & 7) != 0 || a.ep.out_pre || (a.ep.out_lp && !f16)) return false;
+    const bool strided = g.KT[0] == 4;
+    for (int d = 0; d < 3; ++d) {
+        if (strided ? (g.KT[d] != 4 || g.in_mult[d] != 2 || g.tap_step[d] != 1) : (g.KT[d] != 2 || g.in_mult[d] != 1 || (g.tap_step[d] != 1 && g.tap_step[d] != -1))) return false;
+    }
+    if ((size_t)g.Kpad != (size_t)g.KT[0] * g.KT[1] * g.KT[2] * g.Cin) return false;
+    const int dp = (g.Dm + 3) / 4, hp = (g.Hm + 7) / 8, wp = (g.Wm + 7) / 8;
+    const double eff = (double)g.Dm * g.Hm * g.Wm / ((double)dp * 4 * hp * 8 * wp * 8);
+    return eff >= 0.85 && (int64_t)g.N * dp * hp * wp >= 256;
+}
+
+template <typename T>
+static int launch_fprop_cells256(FpropArgs a, hipStream_t st) {
+    a.DP = (uint32_t)(a.g.Dm + 3) / 4;
+    a.HP = (uint32_t)(a.g.Hm + 7) / 8;
+    a.WP = (uint32_t)(a.g.Wm + 7) / 8;
+    a.nblk_m = (uint32_t)a.g.N * a.DP * a.HP * a.WP;
+    const uint32_t nbn = (uint32_t)a.g.cout_valid / 128u;
+    const size_t lds = 4 * 11 * 1024 + 2 * 128 * 128;     // 76 KiB: four plane slots + two weight slabs
+    static std::atomic<uint64_t> attr_done{0};
+    configure_once_per_device(attr_done, [] { (void)hipFuncSetAttribute((const void*)conv_fprop_cells256_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); });
+    (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_cells256_kernel<%s>", tname<T>()), note_kernel(g_last_conv_kernel));
+    hipLaunchKernelGGL((conv_fprop_cells256_kernel<T>), dim3(a.nblk_m * nbn), dim3(512), lds, st, a);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T>
 static int launch_fprop_cells(FpropArgs a, hipStream_t st) {
     a.DP = (uint32_t)(a.g.Dm + 1) / 2;
@@ -1285,6 +1478,7 @@ static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
     if (halo256_eligible(a, (int)sizeof(T))) return launch_fprop_halo256<T>(a, st);
     if (halo_eligible(a, (int)sizeof(T))) return launch_fprop_halo<T, false>(a, st);
     if constexpr (sizeof(T) == 2) {
+        if (cells256_eligible(a, 2, std::is_same<T, f16_t>::value)) return launch_fprop_cells256<T>(a, st);
         if (cells_eligible(a, 2)) return launch_fprop_cells<T>(a, st);
         // dense layers (one tap, identity row map): opt-in (SA_DBG_DENSE_RING) four-wave ring mainloop of dense.hip
         if (dense_gemm_eligible(a, 2)) return launch_dense_gemm(a, std::is_same<T, f16_t>::value ? SA_F16 : SA_BF16, st);

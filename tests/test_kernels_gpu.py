@@ -129,7 +129,7 @@ def test_stride2_layers_on_the_cell_mainloop(kind, cin, cout, dims, fwd_dtype):
     odims = op.out_dims(dims)
     g = (torch.randn(N, *odims, cout, device=dev) * 0.1).to(dtype)
     res = {}
-    for name, flags in (("cells", dict(cells=True)), ("im2col", {})):
+    for name, flags in (("cells", dict(cells=True)), ("im2col", dict(no_cells256=True)), ("cells256", {})):
         with debug.override(**flags):
             y = op.fprop(x, act=_ffi.ACT_RELU, out_dtype=torch.float32)
             kf = _ffi.lib().sa_last_conv_kernel().decode()
@@ -139,9 +139,12 @@ def test_stride2_layers_on_the_cell_mainloop(kind, cin, cout, dims, fwd_dtype):
             res[name] = (y, dx, kf, kd)
     assert res["cells"][2].startswith("conv_fprop_cells_kernel") and res["cells"][3].startswith("conv_fprop_cells_kernel"), res["cells"][2:]
     assert res["im2col"][2].startswith("conv_fprop_dma_kernel") and res["im2col"][3].startswith("conv_fprop_dma_kernel"), res["im2col"][2:]
+    # round 5: the 256-voxel cell mainloop (4 x 8 x 8-cell tiles, four plane slots) is what the dispatcher picks for these layers
+    assert res["cells256"][2].startswith("conv_fprop_cells256_kernel") and res["cells256"][3].startswith("conv_fprop_cells256_kernel"), res["cells256"][2:]
     for i, what in ((0, "forward"), (1, "data gradient")):
         scale = float(res["im2col"][i].abs().max())
         assert float((res["cells"][i] - res["im2col"][i]).abs().max()) <= 2e-5 * scale + 1e-6, what
+        assert float((res["cells256"][i] - res["im2col"][i]).abs().max()) <= 2e-5 * scale + 1e-6, what + " (256-voxel tiles)"
     xr = x.float().permute(0, 4, 1, 2, 3).requires_grad_(True)
     yr = F.conv3d(xr, w, b, stride=2, padding=1) if kind == "conv" else F.conv_transpose3d(xr, w, b, stride=2, padding=1)
     yr.backward(g.float().permute(0, 4, 1, 2, 3))
