@@ -5,6 +5,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof; mkdir -p $OUT
+export SA_NO_SIDE_WGRAD_VQVAE=1   # one stream: overlapped weight gradients inflate (and reorder) every per-kernel duration; the timed bench runs with both streams
 VQ="python bench.py --no-performer --no-cpu-baseline --no-extras --no-kernel-timer --steps 2 --warmup 1"
 db() { find "$1" -name "*_results.db" | head -1; }
 case "${1:-vqvae}" in
