@@ -1148,6 +1148,9 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_cells256_kernel(const Fprop
             const int32_t ih = g.in_mult[1] * (h0 + (int32_t)hh) + bh, iw = g.in_mult[2] * (w0 + (int32_t)ww) + bw;
             const bool ok = dok && r < (uint32_t)PROWS && (uint32_t)ih < (uint32_t)g.Hi && (uint32_t)iw < (uint32_t)g.Wi;
             const uint32_t voff = ok ? (uint32_t)((((int32_t)pn * g.Di + id) * g.Hi + ih) * g.Wi + iw) * vox_bytes + ch * 128u + lv * 16u : OOB_OFF;
+#ifdef SA_PP_DEBUG_VARIANTS
+            if (a.dbg & 64u) continue;
+#endif
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, voff, 0, 0, 0);
         }
     };
@@ -1170,6 +1173,9 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_cells256_kernel(const Fprop
         const uint32_t cls = g_cls(gi), ch = g_ch(gi);
         const uint32_t kd = axis_tap(0, cls >> 2, gi & 1u), kh = axis_tap(1, (cls >> 1) & 1u, (t4 >> 1) & 1u), kw = axis_tap(2, cls & 1u, t4 & 1u);
         const uint32_t col = (((kd * (uint32_t)g.KT[1] + kh) * (uint32_t)g.KT[2] + kw) * (uint32_t)g.Cin) * SZ + ch * 128u;
+#ifdef SA_PP_DEBUG_VARIANTS
+        if (a.dbg & 128u) return;
+#endif
 #pragma unroll
         for (int j = 0; j < WPIECES; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(sB + buf * (BN * 128) + (wave * WPIECES + j) * 1024), 16, boff[j], col, 0, 0);
@@ -1210,6 +1216,9 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_cells256_kernel(const Fprop
                 const uint32_t ad = a0[j] + tapoff;
                 ax[j] = slot + (ad ^ (((ad >> 7) & 7u) << 4));
             }
+#ifdef SA_PP_DEBUG_VARIANTS
+            if (!(a.dbg & 32u))
+#endif
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 u32x4 xf[MI], wf[NI];
