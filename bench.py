@@ -467,9 +467,11 @@ def bench_end_to_end():
     import tempfile
 
     from tools import end_to_end
+    import contextlib
     tmp = tempfile.mkdtemp(prefix="sa_e2e_")
     try:
-        res = end_to_end.run_chain(tmp, volumes=4, extract=4, samples=2)
+        with contextlib.redirect_stdout(sys.stderr):      # the CLIs log to stdout; bench.py's stdout carries the ONE JSON line
+            res = end_to_end.run_chain(tmp, volumes=4, extract=4, samples=2)
         return {"workload": res["workload"], "seconds": res["seconds"], "total_s": res["total_s"], "codes": len(res["codes"]),
                 "samples": len(res["samples"]), "decoded_volumes": len(res["decoded"]), "bos_tokens_clamped": res["bos_tokens_clamped"]}
     finally:

@@ -1,21 +1,25 @@
 // Dense layers (nn.Linear of the Performer: reference src/networks/transformers/performer.py:194-221, the q|k|v / to_out / feed-forward projections of
 // performer-pytorch's SelfAttention and FeedForward) and their data gradients as ONE-TAP implicit GEMMs on MFMA (gfx950), round 5.
 //
+// OPT-IN (SA_DENSE_RING=1 / SA_DBG_DENSE_RING): parity-exact, but slower than the im2col-order kernel on 7 of the 8 shapes of a Performer layer as long as the
+// packed weights are row-major; kept with its ablation tooling (tools/dense_ablate.sh) because the measurements behind it re-shaped
+// the product path (batched epilogue, 256-voxel cell tiles).
+//
 // Why a dedicated mainloop.  The im2col-order kernel (conv_fprop_kernels.h: conv_fprop_dma_kernel) serves these layers with eight waves of 32 x 64 outputs, two
-// stage buffers and `s_waitcnt vmcnt(0)` + barrier per 64-element K-slab.  Ablated on the 512-column shapes at M = 8 400 (tools/dense_ablate.sh, K = 2 048):
-// 39.3 us in full, 36.3 us without the MFMAs / LDS reads, 33.8 us WITHOUT ANY DMA -- the compute phase alone runs at ~0.6 us per slab for 256 cycles of MFMA
-// issue per wave: each wave reads 12 fragments for 16 MFMAs and waits for them behind every barrier, and a deeper ring on the same wave layout was slower still
-// (50 us).  hipBLASLt takes 22 us on the same shape.  This kernel changes the wave layout, not just the depth:
-//   * FOUR waves per block, one per SIMD, each owning ALL rows of the tile x 32 output channels (MI x 2 accumulator fragments): (MI + 2) fragment reads for
-//     2 MI MFMAs per 32-element K step -- 0.61 reads per MFMA at MI = 9 against 0.75 -- and no second wave on the SIMD to share the matrix pipe with;
-//   * the fragments of the NEXT K step are requested before the MFMAs of the current one (register double buffer, also across the slab boundary: the first
-//     step of slab s + 1 is requested during the last step of slab s), so the LDS latency sits under 2 MI MFMAs instead of in front of them;
-//   * a ring of S stage buffers filled by LDS-DMA issued from inline assembly (invisible to the compiler's waitcnt pass, which would drain vmcnt(0) before every
-//     LDS read that follows a builtin LDS-DMA) with counted waits: at the top of slab s the wave waits until slab s + 1 has landed, ONE barrier, issues slab
-//     s + S - 1 into the buffer slab s - 1 left, multiplies slab s;
-//   * the tile height is a template parameter (16 MI rows), chosen per launch so that the grid fills whole rounds of the 256 CUs: M = 8 400 rows x 512 columns
-//     is 264 tiles of 128 rows (a second round of 8 blocks) but 236 tiles of 144.
-// Epilogue: the LDS-staged one of the convolution kernels (bias, activation, ReZero gate, residual, bf16 copies: conv_fprop_common.h).
+// stage buffers and `s_waitcnt vmcnt(0)` + barrier per 64-element K-slab.  Ablated on the 512-column shapes at M = 8 400 (K = 2 048, rocprofv3 durations):
+// 38.6 us in full, 35.1 us without the MFMAs / LDS reads, 32.8 us WITHOUT ANY DMA, 17.8 us with neither -- the compute phase alone runs at ~0.5 us per slab for
+// 0.21 us of MFMA issue (each wave reads 12 fragments for 16 MFMAs; the LDS port also takes the DMA's writes), and a deeper ring on the same wave layout was
+// slower still (50 us).  This kernel changes the wave layout, not just the depth:
+//   * FOUR waves per block, one per SIMD, each owning ALL rows of the tile x 32 output channels (MI x 2 accumulator fragments);
+//   * the weight fragments of a wave are private to it, so they come global -> VGPR in MFMA operand layout, S slabs ahead, and never touch LDS; only the
+//     activation rows (shared by the four waves) go through a ring of S LDS stage buffers filled by LDS-DMA;
+//   * both load streams are issued from inline assembly (invisible to the compiler's waitcnt pass, which would drain vmcnt(0) before every LDS read that
+//     follows a builtin LDS-DMA) and counted by the kernel: at the top of slab s the wave waits until slab s + 1 has landed, ONE barrier, issues slab
+//     s + S - 1 into the slot slab s - 1 left, multiplies slab s; the loop is unrolled by S so that ring slots and weight registers are compile-time indices;
+//   * the fragments of the NEXT K step are requested before the MFMAs of the current one (register double buffer, also across the slab boundary);
+//   * the tile height is a template parameter (16 MI rows), chosen per launch so that the grid fills whole rounds of two blocks per CU.
+// Epilogue: the LDS-staged one of the convolution kernels (bias, activation, ReZero gate, residual, bf16 copies: conv_fprop_common.h); the register form below
+// (a.dbg & 256) measured slower.
 #include <type_traits>
 
 #include "conv_fprop_common.h"
