@@ -100,6 +100,7 @@ int sa_kernel_log_read(char *buf, int cap, int stop);
 #define SA_DBG_CELLS             (1u << 19)  /* stride-2 convolutions / transposed-convolution classes on the cell mainloop (conv_fprop_cells_kernel): opt-in, measured equal */
 #define SA_DBG_DENSE_RING        (1u << 20)  /* opt-in (SA_DENSE_RING=1): dense layers (nn.Linear) on the four-wave ring mainloop of dense.hip (dense_gemm_kernel) -- parity-exact, measured slower than the im2col-order loops on 5 of the 8 shapes of a Performer layer */
 #define SA_DBG_NO_CELLS256       (1u << 21)  /* stride-2 family on the im2col-order kernel instead of the 256-voxel cell mainloop (conv_fprop_cells256_kernel): A/B + cross-family tests */
+#define SA_DBG_NO_CLASS_LAUNCH    (1u << 22)  /* sa_conv_fprop_classes answers SA_EUNSUPPORTED: the parity classes of a transposed convolution as separate launches (A/B, equality test) */
 #define SA_DBG_FAVOR_SEQ_ALWAYS  (1u << 18)  /* FAVOR+ chunk states in the sequential form for every batch (default: from 40 (batch, head) pairs; tests) */
 #define SA_DBG_DETERMINISTIC     (1u << 16)  /* fixed-order reductions where the library itself chooses (BatchNorm sums); see the deterministic-mode section */
 #define SA_DBG_SCAN_EXACT_SHIFT  10          /* 3 bits: chunk states | scan A outputs | scan B outputs on the exact-fp32 MFMA kernels */
@@ -140,6 +141,12 @@ int sa_pack_weights_batch(const sa_pack_desc *table, const int32_t *block_first,
  * output from either epilogue (what the bf16 backward pass of the next layer reads).  Mixing 16-bit types otherwise -> SA_EUNSUPPORTED. */
 int sa_conv_fprop(const sa_conv_geom *g, int dtype, const void *in, const void *wpk, void *out, const sa_epilogue *ep,
                   void *stream);
+/* n launch geometries of ONE layer that differ only in in_off / out_off, with their packed operands, in one launch: the eight output-parity classes of
+ * nn.ConvTranspose3d k4 s2 p1 (baseline.py:283-293) and of the data gradient of the strided nn.Conv3d (baseline.py:218-227).  SA_EUNSUPPORTED (nothing
+ * launched) when they differ in anything else, n > 8, or the kernel the dispatcher picks does not take classes (fp32, operands >= 4 GiB): the caller then
+ * issues sa_conv_fprop per geometry. */
+int sa_conv_fprop_classes(const sa_conv_geom *geoms, int n, int dtype, const void *in, const void *const *wpks, void *out, const sa_epilogue *ep,
+                          void *stream);
 
 /* ---- ResidualLayer forward in ONE launch (baseline.py:150-160), bf16 or f16 (dtype = type of x, the packed weights and y; addend / out dtypes of
  * ep must equal it; h_out is ALWAYS bf16 -- it is an operand of the bf16 backward pass -- and ep->out_lp takes a bf16 copy of an f16 y), 128 channels, k3 s1 p1 geometry `g`:

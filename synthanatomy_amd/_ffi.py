@@ -82,6 +82,7 @@ _SIGS = {
     "sa_pack_weights_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "sa_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int32), c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "sa_conv_fprop": (c_int, [POINTER(ConvGeom), c_int, c_void_p, c_void_p, c_void_p, POINTER(Epilogue), c_void_p]),
+    "sa_conv_fprop_classes": (c_int, [POINTER(ConvGeom), c_int, c_int, c_void_p, POINTER(c_void_p), c_void_p, POINTER(Epilogue), c_void_p]),
     "sa_resblock_fprop": (c_int, [POINTER(ConvGeom), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(Epilogue), c_void_p]),
     "sa_conv_wgrad": (c_int, [POINTER(ConvGeom), c_int, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int32), c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "sa_conv_wgrad_workspace_bytes": (c_int64, [POINTER(ConvGeom), c_int]),

@@ -1,13 +1,15 @@
 // Implicit-GEMM convolution forward / data-gradient on MFMA (gfx950): the C-ABI entry points and the fp32 / bf16 kernel instances.
 // Kernels, launchers and the dispatch rules are templates in conv_fprop_kernels.h; the f16 forward-operand instances are compiled by
 // conv_fprop_f16.hip.
+#include <string.h>
+
 #define SA_FPROP_MAIN_TU
 #include "conv_fprop_kernels.h"
 
-extern "C" int sa_conv_fprop(const sa_conv_geom* g, int dtype, const void* in, const void* wpk, void* out, const sa_epilogue* ep,
-                             void* stream) {
+// ncls = 0: one geometry (sa_conv_fprop); ncls >= 2: geoms[0 .. ncls) differ only in in_off / out_off (checked), wpks[c] = class c's packed operand
+static int conv_fprop_impl(const sa_conv_geom* g, int ncls, int dtype, const void* in, const void* const* wpks, void* out, const sa_epilogue* ep, void* stream) {
     using namespace sa;
-    if (!g || !in || !wpk || !out || !ep) return SA_EINVAL;
+    const void* wpk = wpks[0];
     const int vec = dtype == SA_F32 ? 4 : 8;
     const int bke = dtype == SA_F32 ? 32 : 64;
     if (dtype != SA_F32 && dtype != SA_BF16 && dtype != SA_F16) return SA_EUNSUPPORTED;
@@ -43,6 +45,26 @@ extern "C" int sa_conv_fprop(const sa_conv_geom* g, int dtype, const void* in, c
     a.h_out = nullptr;
     a.dbg = g_tunables.pp_dbg;
     a.group_m = 0;
+    a.ncls = 0;
+    for (int c = 0; c < 8; ++c) {
+        a.cls_wpk[c] = nullptr;
+        for (int d = 0; d < 3; ++d) a.cls_in_off[c][d] = a.cls_out_off[c][d] = 0;
+    }
+    if (ncls >= 2) {
+        if (ncls > 8) return SA_EUNSUPPORTED;
+        for (int c = 0; c < ncls; ++c) {
+            sa_conv_geom t = g[c];
+            for (int d = 0; d < 3; ++d) {
+                a.cls_in_off[c][d] = t.in_off[d];
+                a.cls_out_off[c][d] = t.out_off[d];
+                t.in_off[d] = g->in_off[d];
+                t.out_off[d] = g->out_off[d];
+            }
+            if (memcmp(&t, g, sizeof t) != 0 || !wpks[c]) return SA_EUNSUPPORTED;      // (anything else differs: the caller launches them one by one)
+            a.cls_wpk[c] = wpks[c];
+        }
+        a.ncls = (uint32_t)ncls;
+    }
     {
         const int sz = dtype == SA_F32 ? 4 : 2;
         const uint64_t ib = (uint64_t)g->N * g->Di * g->Hi * g->Wi * g->Cin * sz, wb = (uint64_t)g->CoutPad * g->Kpad * sz;
@@ -53,6 +75,24 @@ extern "C" int sa_conv_fprop(const sa_conv_geom* g, int dtype, const void* in, c
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SA_F16) return a.in_bytes ? dispatch_fprop_f16(a, st) : SA_EUNSUPPORTED;
     return dtype == SA_F32 ? dispatch_fprop<float>(a, st) : dispatch_fprop<bf16_t>(a, st);
+}
+
+extern "C" int sa_conv_fprop(const sa_conv_geom* g, int dtype, const void* in, const void* wpk, void* out, const sa_epilogue* ep,
+                             void* stream) {
+    if (!g || !in || !wpk || !out || !ep) return SA_EINVAL;
+    return conv_fprop_impl(g, 0, dtype, in, &wpk, out, ep, stream);
+}
+
+// The launch geometries of ONE layer that differ only in in_off / out_off and their packed operands -- the eight output-parity classes of
+// nn.ConvTranspose3d k4 s2 p1 (baseline.py:283-293) and of the strided convolution's data gradient -- in one launch (grid = n x the blocks of a class).
+// SA_EUNSUPPORTED (nothing launched) when the geometries differ in anything else or the kernel the dispatcher would pick does not take classes: the caller then
+// issues sa_conv_fprop per geometry.  Seven launch tails fewer per layer; at the small levels a class is a fraction of a round of the 256 CUs.
+extern "C" int sa_conv_fprop_classes(const sa_conv_geom* geoms, int n, int dtype, const void* in, const void* const* wpks, void* out, const sa_epilogue* ep,
+                                     void* stream) {
+    if (!geoms || n < 1 || !in || !wpks || !wpks[0] || !out || !ep) return SA_EINVAL;
+    if (n == 1) return conv_fprop_impl(geoms, 0, dtype, in, wpks, out, ep, stream);
+    if (sa::dbg(SA_DBG_NO_CLASS_LAUNCH)) return SA_EUNSUPPORTED;
+    return conv_fprop_impl(geoms, n, dtype, in, wpks, out, ep, stream);
 }
 
 // Residual block forward in ONE launch (reference src/networks/vqvae/baseline.py:150-160):
@@ -97,5 +137,6 @@ extern "C" int sa_resblock_fprop(const sa_conv_geom* g, int dtype, const void* x
     a.h_out = h_out;
     a.dbg = 0;
     a.group_m = 0;
+    a.ncls = 0;
     return dtype == SA_F16 ? launch_resblock_f16(a, (hipStream_t)stream) : launch_resblock<bf16_t>(a, (hipStream_t)stream);
 }

@@ -34,6 +34,12 @@ struct FpropArgs {
     uint32_t DP;          // cell mainloop: tiles along D (2 planes), HP / WP = tiles of 8 x 8
     uint32_t group_m;     // im2col-order DMA mainloop, dense (1x1x1) layers with several channel tiles: blocks are ordered in groups of `group_m` row tiles x
                           // all channel tiles (0: row tiles fastest, the order in which convolution tiles share their halos)
+    // Several launch geometries that differ ONLY in in_off / out_off and their packed weights -- the eight output-parity classes of ConvTranspose3d k4 s2 (and
+    // of the strided convolution's data gradient) -- in ONE launch: the grid is ncls x the blocks of one class, class-major; a block takes its class's
+    // offsets and operand.  (sa_conv_fprop_classes; ncls <= 1: a.g / a.wpk as they are.)
+    uint32_t ncls;
+    int32_t cls_in_off[8][3], cls_out_off[8][3];
+    const void* cls_wpk[8];
     uint32_t dbg;         // dev only (env SA_PP_DBG): 256 = LDS-staged epilogue instead of the register one; with -DSA_PP_DEBUG_VARIANTS also the
                           // ablation bits (halo: 1 skip halo DMA, 2 skip weight DMA, 64 skip epilogue; im2col-order: 64 / 128 skip activation / weight DMA)
 };
@@ -59,6 +65,21 @@ __device__ __forceinline__ void mma_slab<float>(float4_t& acc, const u32x4& wa, 
 
 // byte offset of 16-byte vector `vec` (0..7) of row `row` inside a [rows][128 B] swizzled tile
 __device__ __forceinline__ uint32_t tile_off(uint32_t row, uint32_t vec) { return row * 128u + ((vec ^ (row & 7u)) << 4); }
+
+// block -> (class, block id inside the class, after the XCD-aware remap); patches the class's offsets / operand into the block's copy of the arguments
+// (scalar values: forced into SGPRs -- the kernels that take classes sit at their VGPR line)
+__device__ __forceinline__ uint32_t select_class(FpropArgs& a, const FpropArgs& karg) {
+    // (the class tables are indexed in the KERNEL ARGUMENT -- scalar loads --, never in the block's copy: a dynamically indexed local copy lives in scratch)
+    if (karg.ncls <= 1u) return xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t per = gridDim.x / karg.ncls, cls = blockIdx.x / per;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        a.g.in_off[d] = karg.cls_in_off[cls][d];
+        a.g.out_off[d] = karg.cls_out_off[cls][d];
+    }
+    a.wpk = karg.cls_wpk[cls];
+    return xcd_remap(blockIdx.x - cls * per, per);
+}
 
 // ---- epilogue shared by both mainloops, staged through LDS so that HBM sees full channel rows
 // output voxel (linear index into [N, Do, Ho, Wo]) of GEMM row m of the launch grid, or -1 beyond M

@@ -235,8 +235,10 @@ __device__ __forceinline__ void resblock_second_gemm(const FpropArgs& a, float4_
 // For launches with about ONE tile per CU and a long reduction (the 512-column dense layers of the Performer at M = 8 400: 264 tiles, K = 1 024 .. 3 072), where a
 // lone eight-wave block waits out every DMA round trip: sixteen waves per CU without needing more tiles (128 KiB of LDS: one block per CU).
 template <typename T, int WM, int WN, int MI, int NI, bool UNIFORM, bool FUSE = false, int KG = 1>
-__global__ __launch_bounds__(WM * WN * 64 * KG) void conv_fprop_dma_kernel(const FpropArgs a) {
+__global__ __launch_bounds__(WM * WN * 64 * KG) void conv_fprop_dma_kernel(const FpropArgs a_) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins only exist in the device pass; the host pass needs just the stub
+    FpropArgs a = a_;
+    const uint32_t bid = select_class(a, a_);       // (one class: the launch's own geometry)
     constexpr int BM = WM * MI * 16;
     constexpr int BN = WN * NI * 16;
     constexpr int NW = WM * WN;                           // 4 waves, or 8 (half-size wave tiles: twice the waves per SIMD to cover DMA / LDS latency)
@@ -257,7 +259,6 @@ __global__ __launch_bounds__(WM * WN * 64 * KG) void conv_fprop_dma_kernel(const
     const uint32_t wave = KG == 1 ? wave_all : wave_all - kg * NW;
     unsigned char* const smem = smem_all + kg * STAGE;
     const uint32_t wm = wave / WN, wn = wave % WN;
-    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
     uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
     if (a.group_m) {
         // dense layer: the blocks one XCD runs at a time cover group_m row tiles x (up to) all channel tiles, so its L2 fetches group_m activation
@@ -1089,8 +1090,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_fprop_cells_kernel(const Fpro
 // Per 256 voxels and (class, chunk): 55 KiB of halo + 128 KiB of weight slabs, against 2 x (31 + 128) KiB for two 128-voxel cell tiles and 2 x 256 KiB in
 // im2col order.
 template <typename T>
-__global__ __launch_bounds__(512, 2) void conv_fprop_cells256_kernel(const FpropArgs a) {
+__global__ __launch_bounds__(512, 2) void conv_fprop_cells256_kernel(const FpropArgs a_) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    FpropArgs a = a_;
+    const uint32_t bid = select_class(a, a_);
     constexpr int NW = 8, MI = 4, NI = 4, WPIECES = 16 / NW, BN = 128;
     constexpr int PROWS = 81, PPIECES = 11, PLB = PPIECES * 1024, NSLOT = 4;    // plane: 9 x 9 cells in 11 pieces of 8 rows; slot stride
     constexpr int SZ = sizeof(T);
@@ -1103,7 +1106,6 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_cells256_kernel(const Fprop
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wm = wave >> 1, wn = wave & 1u;    // wm = depth plane of the tile
-    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
     const uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
     const uint32_t n_base = bn * BN;
     const sa_conv_geom& g = a.g;
@@ -1271,7 +1273,9 @@ static int launch_fprop(const FpropArgs& a, hipStream_t st) {
     (void)nbn;
     const size_t pipe = 2 * (BM + BN) * 128, epi = (size_t)BM * (BN + 4) * 4 + BM * 8;
     const size_t lds = pipe > epi ? pipe : epi;
-    dim3 grid(a.nblk_m * nbn_valid);
+    const uint32_t ncls = a.ncls > 1u ? a.ncls : 1u;
+    dim3 grid(a.nblk_m * nbn_valid * ncls);
+    if (ncls > 1u && a.in_bytes == 0) return SA_EUNSUPPORTED;      // (several classes per launch: the LDS-DMA kernels only)
     if (a.in_bytes != 0) {  // every operand addressable with 32-bit buffer offsets -> LDS-DMA mainloop
         const bool uniform = ((size_t)a.g.Cin * sizeof(T)) % 128 == 0;
         if constexpr (BM == 256) {
@@ -1293,7 +1297,7 @@ static int launch_fprop(const FpropArgs& a, hipStream_t st) {
             // Measured (tools/bench_dense_tiles.py, K = 1 024 / 2 048 / 3 072 -> 512 columns): M = 8 192 (256 tiles) 25.1 / 37.3 / 48.3 -> 21.7 / 31.6 / 40.9 us;
             // M = 8 400 (264 tiles: a second round of 8) 26.9 / 39.6 / 52.0 -> 34.2 / 50.2 / 70.4 us, which is why the README batch stays on the one-group kernel.
             // SA_NO_KGROUPS / SA_DBG_NO_KGROUPS keeps the one-group kernel everywhere (A/B runs and the equality test).
-            if (uniform && b.ntaps == 1 && b.nk >= 8 && (int)grid.x <= device_cu_count() && !dbg(SA_DBG_NO_KGROUPS)) {
+            if (uniform && b.ntaps == 1 && b.nk >= 8 && ncls == 1u && (int)grid.x <= device_cu_count() && !dbg(SA_DBG_NO_KGROUPS)) {
                 static std::atomic<uint64_t> attr2_done{0};
                 configure_once_per_device(attr2_done, [] {
                     (void)hipFuncSetAttribute((const void*)conv_fprop_dma_kernel<T, WM, WN, MI, NI, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1452,7 +1456,7 @@ static int launch_fprop_cells256(FpropArgs a, hipStream_t st) {
     static std::atomic<uint64_t> attr_done{0};
     configure_once_per_device(attr_done, [] { (void)hipFuncSetAttribute((const void*)conv_fprop_cells256_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); });
     (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_cells256_kernel<%s>", tname<T>()), note_kernel(g_last_conv_kernel));
-    hipLaunchKernelGGL((conv_fprop_cells256_kernel<T>), dim3(a.nblk_m * nbn), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((conv_fprop_cells256_kernel<T>), dim3(a.nblk_m * nbn * (a.ncls > 1u ? a.ncls : 1u)), dim3(512), lds, st, a);
     SA_CHECK_LAUNCH();
     return 0;
 }
@@ -1484,11 +1488,14 @@ static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
         const bool halo = halo256_eligible(a, (int)sizeof(T)) || halo_eligible(a, (int)sizeof(T));
         if ((halo && (a.ep.out_pre || !std::is_same<T, f16_t>::value)) || (cv & 3) || (a.g.Cout & 3)) return SA_EUNSUPPORTED;
     }
-    if (halo256_eligible(a, (int)sizeof(T))) return launch_fprop_halo256<T>(a, st);
-    if (halo_eligible(a, (int)sizeof(T))) return launch_fprop_halo<T, false>(a, st);
+    const bool multi = a.ncls > 1u;      // several classes in one launch: the cell-256 and im2col-order LDS-DMA kernels take them
+    if (multi && (sizeof(T) != 2 || a.in_bytes == 0)) return SA_EUNSUPPORTED;
+    if (!multi && halo256_eligible(a, (int)sizeof(T))) return launch_fprop_halo256<T>(a, st);
+    if (!multi && halo_eligible(a, (int)sizeof(T))) return launch_fprop_halo<T, false>(a, st);
     if constexpr (sizeof(T) == 2) {
         if (cells256_eligible(a, 2, std::is_same<T, f16_t>::value)) return launch_fprop_cells256<T>(a, st);
-        if (cells_eligible(a, 2)) return launch_fprop_cells<T>(a, st);
+        if (cells_eligible(a, 2)) return multi ? SA_EUNSUPPORTED : launch_fprop_cells<T>(a, st);      // (the opt-in 128-voxel cell kernel: one class per launch)
+        if (multi && dense_gemm_eligible(a, 2)) return SA_EUNSUPPORTED;
         // dense layers (one tap, identity row map): opt-in (SA_DBG_DENSE_RING) four-wave ring mainloop of dense.hip
         if (dense_gemm_eligible(a, 2)) return launch_dense_gemm(a, std::is_same<T, f16_t>::value ? SA_F16 : SA_BF16, st);
     }

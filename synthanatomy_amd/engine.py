@@ -284,13 +284,28 @@ class ConvOp:
         lp = torch.empty((N, *od, cout_s), dtype=torch.bfloat16, device=x.device) if want_lp else None
         ep = self._epilogue(self._bias_padded() if use_bias else None, addend, mask, alpha, act, mask_mode, add_before_act, out_dtype, slope, pre, lp)
         lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.fwd_dtype)
-        for pl in plans["fwd"]:
-            _launch(None, _geom_flops(pl.geom),
-                    lambda pl=pl: _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(x), _ffi.ptr(pl.wpk), _ffi.ptr(out), ctypes.byref(ep), st),
-                                             "sa_conv_fprop"))
+        self._run_plans(plans["fwd"], did, x, out, ep, "sa_conv_fprop")
         if want_pre or want_lp:
             return out, pre, lp
         return out
+
+    def _run_plans(self, plans, did, src, dst, ep, what):
+        """One launch per geometry -- or ONE launch for the eight output-parity classes of a stride-2 layer (sa_conv_fprop_classes: geometries that differ
+        only in their offsets, each with its packed operand); the library answers SA_EUNSUPPORTED when the kernel it would pick does not take classes."""
+        lib, st = _ffi.lib(), _ffi.stream()
+        if len(plans) > 1:
+            n = len(plans)
+            geoms = (ConvGeom * n)(*[pl.geom for pl in plans])
+            wpks = (ctypes.c_void_p * n)(*[pl.wpk.data_ptr() for pl in plans])
+            rc = []
+            _launch(None, sum(_geom_flops(pl.geom) for pl in plans),
+                    lambda: rc.append(lib.sa_conv_fprop_classes(geoms, n, did, _ffi.ptr(src), wpks, _ffi.ptr(dst), ctypes.byref(ep), st)))
+            if rc[0] != _ffi.SA_EUNSUPPORTED:
+                _ffi.check(rc[0], what + " (classes)")
+                return
+        for pl in plans:
+            _launch(None, _geom_flops(pl.geom),
+                    lambda pl=pl: _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(src), _ffi.ptr(pl.wpk), _ffi.ptr(dst), ctypes.byref(ep), st), what))
 
     def dgrad(self, g: torch.Tensor, idims: Tuple[int, int, int], *, addend=None, mask=None, mask_mode=MASK_NONE, out_dtype=None, slope=0.2,
               fwd_out_stride=None) -> torch.Tensor:
@@ -309,10 +324,7 @@ class ConvOp:
             dx.zero_()
         ep = self._epilogue(None, addend, mask, None, ACT_NONE, mask_mode, False, out_dtype, slope)
         lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
-        for pl in plans["dgrad"]:
-            _launch(None, _geom_flops(pl.geom),
-                    lambda pl=pl: _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(g), _ffi.ptr(pl.wpk), _ffi.ptr(dx), ctypes.byref(ep), st),
-                                             "sa_conv_fprop(dgrad)"))
+        self._run_plans(plans["dgrad"], did, g, dx, ep, "sa_conv_fprop(dgrad)")
         return dx
 
     def wgrad(self, x: torch.Tensor, g: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor] = None, fwd_out_stride=None):

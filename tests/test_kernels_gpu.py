@@ -129,7 +129,8 @@ def test_stride2_layers_on_the_cell_mainloop(kind, cin, cout, dims, fwd_dtype):
     odims = op.out_dims(dims)
     g = (torch.randn(N, *odims, cout, device=dev) * 0.1).to(dtype)
     res = {}
-    for name, flags in (("cells", dict(cells=True)), ("im2col", dict(no_cells256=True)), ("cells256", {})):
+    for name, flags in (("cells", dict(cells=True)), ("im2col", dict(no_cells256=True)), ("cells256", {}), ("cells256_separate", dict(no_class_launch=True)),
+                        ("im2col_separate", dict(no_cells256=True, no_class_launch=True))):
         with debug.override(**flags):
             y = op.fprop(x, act=_ffi.ACT_RELU, out_dtype=torch.float32)
             kf = _ffi.lib().sa_last_conv_kernel().decode()
@@ -141,6 +142,9 @@ def test_stride2_layers_on_the_cell_mainloop(kind, cin, cout, dims, fwd_dtype):
     assert res["im2col"][2].startswith("conv_fprop_dma_kernel") and res["im2col"][3].startswith("conv_fprop_dma_kernel"), res["im2col"][2:]
     # round 5: the 256-voxel cell mainloop (4 x 8 x 8-cell tiles, four plane slots) is what the dispatcher picks for these layers
     assert res["cells256"][2].startswith("conv_fprop_cells256_kernel") and res["cells256"][3].startswith("conv_fprop_cells256_kernel"), res["cells256"][2:]
+    # the eight output-parity classes of a layer in ONE launch (sa_conv_fprop_classes) against eight launches: the same blocks, bit for bit
+    for fam in ("cells256", "im2col"):
+        assert torch.equal(res[fam][0], res[fam + "_separate"][0]) and torch.equal(res[fam][1], res[fam + "_separate"][1]), fam
     for i, what in ((0, "forward"), (1, "data gradient")):
         scale = float(res["im2col"][i].abs().max())
         assert float((res["cells"][i] - res["im2col"][i]).abs().max()) <= 2e-5 * scale + 1e-6, what
