@@ -38,18 +38,52 @@ class _CEFn(torch.autograd.Function):
         return (d.mul_(g).transpose(1, 2) if d is not None else None), None, None
 
 
+class _WeightedCEFn(torch.autograd.Function):
+    """``F.cross_entropy(..., weight=w)`` (reference transformer.py:28-30 with a class-weight vector): per-row log-sum-exp / NLL / gradient from the same fused
+    kernel in its per-row form (sa_cross_entropy_rows), then loss = sum_r w[y_r] nll_r (/ sum_r w[y_r] for "mean"; targets equal to -100 carry weight 0, as
+    torch's ignore_index does) and d logits_r scaled by w[y_r] (/ the same denominator).  The per-row scaling is a broadcast multiply on the device."""
+
+    @staticmethod
+    def forward(ctx, logits_bvn, target, weight, mean):
+        _ffi.require_gpu()
+        rows = logits_bvn.float().transpose(1, 2).contiguous()
+        B, N, V = rows.shape
+        R = B * N
+        tgt = target.to(rows.device).long().contiguous().view(-1)
+        row_loss = torch.empty(R, dtype=torch.float32, device=rows.device)
+        d = torch.empty_like(rows) if logits_bvn.requires_grad else None
+        _ffi.check(_ffi.lib().sa_cross_entropy_rows(_ffi.ptr(rows), _ffi.ptr(tgt), R, V, _ffi.ptr(row_loss), _ffi.ptr(d), _ffi.SA_F32, 1.0, _ffi.stream()),
+                   "sa_cross_entropy_rows")
+        w = weight.to(device=rows.device, dtype=torch.float32)
+        wr = torch.where(tgt >= 0, w[tgt.clamp(min=0, max=V - 1)], torch.zeros((), device=rows.device))     # (-100: ignored rows weigh nothing)
+        if mean:
+            wr = wr / wr.sum()
+        if d is not None:
+            d.mul_(wr.view(B, N, 1))
+        ctx.d = d
+        return (row_loss * wr).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        d = ctx.d
+        ctx.d = None
+        return (d.mul_(g).transpose(1, 2) if d is not None else None), None, None, None
+
+
 class CELoss(torch.nn.Module):
     def __init__(self, weight=None, size_average: bool = None, reduce: bool = None, reduction: str = "mean"):
         super().__init__()
         if reduction not in ["sum", "mean"]:
             raise ValueError("Reduction must be either 'sum' or 'mean'")
-        if weight is not None:
-            raise NotImplementedError("class weights")
+        self._weight = weight
         self.reduction = reduction
         self.summaries: Dict = {"scalar": {}}
 
     def forward(self, y_pred: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-        loss = _CEFn.apply(y_pred, y, self.reduction == "mean")
+        if self._weight is not None:
+            loss = _WeightedCEFn.apply(y_pred, y, self._weight, self.reduction == "mean")
+        else:
+            loss = _CEFn.apply(y_pred, y, self.reduction == "mean")
         self.summaries["scalar"]["Loss-CE-Prediction"] = loss.detach()
         return loss
 

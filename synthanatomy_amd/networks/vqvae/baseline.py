@@ -199,13 +199,15 @@ class Quantizer(nn.Module):
 # ------------------------------------------------------------------------------------------------ parameter holders
 class ResidualLayer(nn.Sequential):
     """relu(x + conv1x1(dropout(relu(conv3x3(x)))))  (baseline.py:150-160).  Holder of the two convs' parameters; the
-    arithmetic runs in ``_ResStage``.  Dropout3d is kept for key numbering; only p == 0 is implemented."""
+    arithmetic runs in ``_ResStage``.  p_dropout > 0 (not the README configuration): training steps take the two-launch form of the block with the
+    Dropout3d channel mask applied between the launches (``_ResStage._dropout_mask``); p == 0 and eval: the fused one-launch block."""
 
     def __init__(self, n_channels, n_res_channels, p_dropout):
         super().__init__(nn.Conv3d(n_channels, n_res_channels, kernel_size=3, padding=1), nn.ReLU(True), nn.Dropout3d(p_dropout),
                          nn.Conv3d(n_res_channels, n_channels, kernel_size=1))
-        if p_dropout != 0.0:
-            raise NotImplementedError("baseline_vqvae on MI355X implements dropout=0.0 (the reference's configuration, README.md:93)")
+        if not 0.0 <= p_dropout < 1.0:
+            raise ValueError(f"dropout probability has to be in [0, 1), but got {p_dropout}")
+        self.p_dropout = float(p_dropout)
 
 
 # ------------------------------------------------------------------------------------------------ chain stages
@@ -439,6 +441,7 @@ class _ConvT1Stage:
 class _ResStage:
     def __init__(self, mod: ResidualLayer, in_act, dtype, fwd_dtype=None):
         c3, c1 = mod[0], mod[3]
+        self.mod = mod
         self.c3m, self.c1m, self.in_act, self.dtype = c3, c1, in_act, dtype
         self.c3 = ConvOp("conv", c3.in_channels, c3.out_channels, 3, 1, 1, c3.weight, c3.bias, dtype, fwd_dtype=fwd_dtype)
         self.c1 = ConvOp("conv", c1.in_channels, c1.out_channels, 1, 1, 0, c1.weight, c1.bias, dtype, fwd_dtype=fwd_dtype)
@@ -477,10 +480,37 @@ class _ResStage:
                                                                        ctypes.byref(ep), st), "sa_resblock_fprop"))
         return (_Act(y, ys) if self.mixed else y), h
 
+    def _dropout_mask(self, N, C, dev):
+        """nn.Dropout3d (baseline.py:155): whole channels of a sample are zeroed with probability p, the others scaled by 1 / (1 - p); [N, 1, 1, 1, C] fp32."""
+        p = self.mod.p_dropout
+        keep = torch.bernoulli(torch.full((N, 1, 1, 1, C), 1.0 - p, device=dev))
+        return keep / (1.0 - p)
+
+    def _fwd_dropout(self, xf, xs, tape):
+        """Training step with p_dropout > 0: relu(conv3(x)) -> channel mask -> conv1 + x -> relu as two launches with the mask (a broadcast multiply on the device)
+        between them.  Saved for the backward pass: x, the MASKED hidden activation (the operand of the 1x1x1 weight gradient; its sign pattern is the ReLU mask
+        of the surviving channels) and the mask."""
+        N, C = xf.shape[0], self.c3.cout
+        m = self._dropout_mask(N, C, xf.device)
+        if self.mixed:
+            hf, _, h = self.c3.fprop(xf, act=ACT_RELU, want_lp=True)
+            hf = (hf * m).to(hf.dtype)
+            h = (h * m).to(h.dtype)
+            yf, _, ys = self.c1.fprop(hf, act=ACT_RELU, addend=xf, add_before_act=True, want_lp=True)
+            y = _Act(yf, ys)
+        else:
+            h = self.c3.fprop(xf, act=ACT_RELU)
+            h = (h * m).to(h.dtype)
+            y = self.c1.fprop(h, act=ACT_RELU, addend=xf, add_before_act=True)
+        tape.append((xs, h, m))
+        return y
+
     def fwd(self, x, tape):
         self._sync()
         xf, xs = _fs(x)
         rec = tape is not None
+        if rec and self.mod.p_dropout > 0.0 and self.mod.training:
+            return self._fwd_dropout(xf, xs, tape)
         if self._fused_ok(xf):
             y, h = self._fwd_fused(xf, rec)
         elif self.mixed:     # two launches; each writes its f16 output and, when recording, the bf16 copy the backward pass reads
@@ -499,7 +529,8 @@ class _ResStage:
         return y
 
     def bwd(self, G, saved, grads):
-        x, h = saved
+        x, h = saved[0], saved[1]
+        drop = saved[2] if len(saved) > 2 else None      # Dropout3d mask of this step: the gradient wrt the hidden activation is scaled by it
         self._sync()
         dims = tuple(x.shape[1:4])
         from ...engine import conv1x1_backward
@@ -508,6 +539,8 @@ class _ResStage:
             self.c1.wgrad(h, G, grads.buf(self.c1m.weight), grads.buf(self.c1m.bias))
             dp = self.c1.dgrad(G, dims, mask=h, mask_mode=MASK_POS)
         grads.done(self.c1m.weight, self.c1m.bias)
+        if drop is not None:
+            dp = (dp * drop).to(dp.dtype)
         grads.wgrad(self.c3, x, dp, grads.buf(self.c3m.weight), grads.buf(self.c3m.bias))
         grads.done(self.c3m.weight, self.c3m.bias)
         return self.c3.dgrad(dp, dims, addend=G, mask=x if self.in_act else None, mask_mode=MASK_POS)

@@ -192,6 +192,28 @@ def test_cross_entropy_class_ids_outside_the_vocabulary():
     assert float(logits.grad[1, :, 2].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("reduction", ["mean", "sum"])
+def test_cross_entropy_with_class_weights_matches_torch(reduction):
+    """CELoss(weight=w) (reference src/losses/transformer/transformer.py:10-33: the weight vector goes to F.cross_entropy): value and gradient against torch on
+    the CPU, incl. an ignored (-100) target."""
+    from synthanatomy_amd.losses.transformer import CELoss
+    g = torch.Generator().manual_seed(3)
+    V = 11
+    logits = torch.randn(3, V, 6, generator=g)
+    tgt = torch.randint(0, V, (3, 6), generator=g)
+    tgt[2, 1] = -100
+    w = torch.rand(V, generator=g) + 0.1
+    lr = logits.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lr, tgt, weight=w, reduction=reduction)
+    ref.backward()
+    ld = logits.cuda().requires_grad_(True)
+    got = CELoss(weight=w, reduction=reduction)(ld, tgt.cuda())
+    got.backward()
+    assert abs(float(got) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert torch.allclose(ld.grad.cpu(), lr.grad, rtol=1e-5, atol=1e-6)
+    assert float(ld.grad[2, :, 1].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("which", ["vqvae", "performer"])
 def test_optimizer_in_backward_equals_the_serial_step(which):
     """FusedAdam(in_backward=reducer): every bucket's Adam slice and operand re-pack run on the reducer's side stream as soon as the bucket's gradients are

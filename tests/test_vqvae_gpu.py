@@ -3,6 +3,7 @@
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -240,3 +241,90 @@ def test_fused_residual_block_matches_two_launch_path(shape):
     assert _relerr(y_f.float().cpu().numpy(), y_r.float().cpu().numpy()) < 1e-2  # h enters the 1x1 GEMM as the same bf16 values
     y_e = st.fwd(x, None)                                # eval: h is not written
     assert torch.equal(y_e, y_f)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_residual_layer_with_dropout_matches_torch(dtype):
+    """ResidualLayer with p_dropout > 0 (baseline.py:150-160: Conv3d -> ReLU -> Dropout3d -> Conv3d 1x1x1, + x, ReLU) in TRAINING mode: forward, data gradient and
+    all four parameter gradients against torch on the CPU with the SAME channel mask; eval mode ignores the dropout (the fused block)."""
+    from synthanatomy_amd.networks.vqvae.baseline import ResidualLayer, _GradCtx, _ResStage
+    torch.manual_seed(11)
+    C, p = 128, 0.3
+    mod = ResidualLayer(C, C, p).cuda().train()
+    st = _ResStage(mod, in_act=True, dtype=dtype)
+    masks = []
+
+    def fixed_mask(N, Cc, dev):
+        g = torch.Generator().manual_seed(100 + len(masks))
+        m = (torch.bernoulli(torch.full((N, 1, 1, 1, Cc), 1.0 - p), generator=g) / (1.0 - p)).to(dev)
+        masks.append(m)
+        return m
+    st._dropout_mask = fixed_mask
+    x = torch.relu(torch.randn(2, 6, 7, 9, C)).to(dtype)
+    G = (torch.randn(2, 6, 7, 9, C) * 0.1).to(dtype)
+    tape = []
+    y = st.fwd(x.cuda(), tape)
+    gc = _GradCtx(None)
+    Gm = (G.cuda().float() * (y.float() > 0)).to(dtype)      # (the ReLU mask of a stage's OUTPUT is applied by the stage behind it: hand bwd the masked gradient)
+    dx = st.bwd(Gm, tape[0], gc)
+    torch.cuda.synchronize()
+    assert len(masks) == 1 and 0 < int((masks[0] == 0).sum()) < 2 * C
+    # torch reference on the same (rounded) operands
+    xr = x.float().permute(0, 4, 1, 2, 3).clone().requires_grad_(True)
+    w3, b3 = mod[0].weight.detach().cpu().float().requires_grad_(True), mod[0].bias.detach().cpu().float().requires_grad_(True)
+    w1, b1 = mod[3].weight.detach().cpu().float().requires_grad_(True), mod[3].bias.detach().cpu().float().requires_grad_(True)
+    if dtype == torch.bfloat16:
+        w3e, w1e = w3.to(dtype).float(), w1.to(dtype).float()
+    else:
+        w3e, w1e = w3, w1
+    mref = masks[0].cpu().permute(0, 4, 1, 2, 3)
+    h = F.relu(F.conv3d(xr, w3e, b3, padding=1)) * mref
+    if dtype == torch.bfloat16:
+        h = h + (h.to(dtype).float() - h).detach()          # the hidden activation is stored in bf16
+    yr = F.relu(xr + F.conv3d(h, w1e, b1))
+    yr.backward(G.float().permute(0, 4, 1, 2, 3))
+    tol = 2e-5 if dtype == torch.float32 else 5e-2      # (bf16: the gate of the throughput-mode gradients in tests/test_width_parity_gpu.py is 4e-2)
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    assert rel(y.float().cpu().permute(0, 4, 1, 2, 3), yr.detach()) < tol
+    assert rel(dx.float().cpu().permute(0, 4, 1, 2, 3), xr.grad * (x.float().permute(0, 4, 1, 2, 3) > 0)) < tol      # (in_act: the stage applies the ReLU mask of its input)
+    errs = [rel(gc.grads[prm].cpu(), ref) for prm, ref in ((mod[0].weight, w3.grad), (mod[0].bias, b3.grad), (mod[3].weight, w1.grad), (mod[3].bias, b1.grad))]
+    assert max(errs) < tol, errs
+    # eval: no dropout, no mask drawn
+    mod.eval()
+    y_eval = st.fwd(x.cuda(), None)
+    h0 = F.relu(F.conv3d(x.float().permute(0, 4, 1, 2, 3), w3e.detach(), b3.detach(), padding=1))
+    if dtype == torch.bfloat16:
+        h0 = h0.to(dtype).float()
+    y0 = F.relu(x.float().permute(0, 4, 1, 2, 3) + F.conv3d(h0, w1e.detach(), b1.detach()))
+    assert len(masks) == 1 and rel(y_eval.float().cpu().permute(0, 4, 1, 2, 3), y0) < tol
+
+
+def test_network_with_dropout_trains_and_evaluates_deterministically():
+    """baseline_vqvae with dropout > 0 through the plugin surface (configure.py:27-37 passes `dropout` as p_dropout): a training step runs on the dropout form of
+    every residual block (two steps draw different masks), eval is deterministic and equals the p = 0 network on the same weights."""
+    from synthanatomy_amd.networks.vqvae.baseline import BaselineVQVAE
+    cfg = dict(n_levels=2, downsample_parameters=((4, 2, 1, 1),) * 2, upsample_parameters=((4, 2, 1, 0, 1),) * 2, n_embed=64, embed_dim=16, n_channels=64,
+               n_res_channels=64, n_res_layers=2)
+    torch.manual_seed(8)
+    net = BaselineVQVAE(**cfg, p_dropout=0.25, compute_dtype=torch.bfloat16).cuda()
+    ref = BaselineVQVAE(**cfg, p_dropout=0.0, compute_dtype=torch.bfloat16).cuda()
+    ref.load_state_dict(net.state_dict())
+    x = torch.rand(2, 1, 16, 24, 16, generator=torch.Generator().manual_seed(1)).cuda()
+    net.eval()
+    ref.eval()
+    with torch.no_grad():
+        a, b = net(x)["reconstruction"][0], net(x)["reconstruction"][0]
+        c = ref(x)["reconstruction"][0]
+    assert torch.equal(a, b) and torch.equal(a, c)
+    net.train()
+    losses = []
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        out = net(x)
+        loss = F.mse_loss(out["reconstruction"][0].float(), x) + out["quantization_losses"][0]
+        loss.backward()
+        losses.append(float(loss))
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.requires_grad)
+    assert all(np.isfinite(losses)) and losses[0] != losses[1]
