@@ -963,17 +963,17 @@ __global__ __launch_bounds__(256, FUSED_WPS) void favor_fpair_b_state_la_kernel(
 // short blocks of the other bodies fill the slots beside them
 __global__ __launch_bounds__(256, FUSED_WPS) void favor_fseq_la_kernel(const FusedArgs ss, const LAArgs la, const int nst) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
-    if ((int)blockIdx.x < nst) favor_fstate_seq_body(ss, (int)blockIdx.x, lds);
+    if ((int)blockIdx.x < nst) favor_fstate_seq_body(ss, (int)xcd_remap(blockIdx.x, (uint32_t)nst), lds);   // (the feature-slab blocks of a (batch, head) walk the SAME k / v rows: one XCD, one L2)
     else local_attn_q_split_body<0>(la, (int)blockIdx.x - nst, lds);
 }
 __global__ __launch_bounds__(256, FUSED_WPS) void favor_fpair_seq_b_kernel(const FusedArgs ss, const FusedArgs sb, const int nst, const int nb) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
-    if ((int)blockIdx.x < nst) favor_fstate_seq_body(ss, (int)blockIdx.x, lds);
+    if ((int)blockIdx.x < nst) favor_fstate_seq_body(ss, (int)xcd_remap(blockIdx.x, (uint32_t)nst), lds);   // (the feature-slab blocks of a (batch, head) walk the SAME k / v rows: one XCD, one L2)
     else favor_fout_b_body(sb, (int)blockIdx.x - nst, lds);
 }
 __global__ __launch_bounds__(256, FUSED_WPS) void favor_fpair_seq_b_la_kernel(const FusedArgs ss, const FusedArgs sb, const LAArgs la, const int nst, const int nb) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];
-    if ((int)blockIdx.x < nst) favor_fstate_seq_body(ss, (int)blockIdx.x, lds);
+    if ((int)blockIdx.x < nst) favor_fstate_seq_body(ss, (int)xcd_remap(blockIdx.x, (uint32_t)nst), lds);   // (the feature-slab blocks of a (batch, head) walk the SAME k / v rows: one XCD, one L2)
     else if ((int)blockIdx.x < nst + nb) favor_fout_b_body(sb, (int)blockIdx.x - nst, lds);
     else local_attn_q_split_body<1>(la, (int)blockIdx.x - nst - nb, lds);
 }
