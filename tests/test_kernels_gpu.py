@@ -425,6 +425,23 @@ def test_elementwise_kernels():
         _ffi.check(lib.sa_adam(_ffi.ptr(pd), _ffi.ptr(g_d), _ffi.ptr(m), _ffi.ptr(v), 5000, 1.65e-4, 0.9, 0.999, 1e-8, 0.0, step, 1.0, st))
         torch.cuda.synchronize()
     np.testing.assert_allclose(pd.cpu().numpy(), pr.detach().numpy(), rtol=1e-5, atol=1e-7)
+    # the 16-byte-vector form: slices at every misalignment (optimizer-in-backward ranges of the flat buffers) and odd lengths give the bits of one whole call
+    n = 40013
+    p0, g0 = torch.randn(n, device="cuda"), torch.randn(n, device="cuda")
+    whole = [p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")]
+    _ffi.check(lib.sa_adam(_ffi.ptr(whole[0]), _ffi.ptr(g0), _ffi.ptr(whole[1]), _ffi.ptr(whole[2]), n, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, 0.5, st))
+    parts = [p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")]
+    cuts = [0, 1, 3, 6, 10, 4099, 4100, 20001, 20002, 20003, n]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        _ffi.check(lib.sa_adam(_ffi.ptr(parts[0][lo:]), _ffi.ptr(g0[lo:]), _ffi.ptr(parts[1][lo:]), _ffi.ptr(parts[2][lo:]), hi - lo, 1e-3, 0.9, 0.999, 1e-8, 0.01,
+                               1, 0.5, st))
+    torch.cuda.synchronize()
+    for a_, b_ in zip(whole, parts):
+        assert torch.equal(a_, b_)
+    ref = torch.optim.Adam([torch.nn.Parameter(p0.clone())], lr=1e-3, weight_decay=0.01)
+    ref.param_groups[0]["params"][0].grad = g0 * 0.5
+    ref.step()
+    np.testing.assert_allclose(whole[0].cpu().numpy(), ref.param_groups[0]["params"][0].detach().cpu().numpy(), rtol=1e-5, atol=1e-7)
     # cast + channel pad
     x = torch.randn(37, 3)
     y = engine.cast_pad(x.cuda(), torch.bfloat16, 8)
