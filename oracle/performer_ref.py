@@ -262,6 +262,14 @@ def fixed_spatial_table(dim, seq):
     return torch.cat((sin_inp.sin(), sin_inp.cos()), dim=-1)[:-1]
 
 
+def fixed_position_table(dim, max_seq_len):
+    """performer_pytorch 1.0.11 FixedPositionalEmbedding (the wrapper's `fixed_position_emb=True`, performer.py:138-140): sin | cos of position x inverse frequency."""
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim))
+    position = torch.arange(0, max_seq_len, dtype=torch.float)
+    sin_inp = torch.einsum("i,j->ij", position, inv_freq)
+    return torch.cat((sin_inp.sin(), sin_inp.cos()), dim=-1)
+
+
 def embed(st, cfg: PerformerConfig, tokens, spatial_index_sequences, conditionings=None, conditioning_type="none", spatial_position_emb="absolute"):
     """performer.py:241-266: token emb + zero-front-padded spatial embeddings (learned `absolute` tables indexed by coordinate, or `fixed`
     sinusoids) [+ conditioning: BOS replacement or prepending] + absolute positional embedding."""
@@ -279,7 +287,8 @@ def embed(st, cfg: PerformerConfig, tokens, spatial_index_sequences, conditionin
     elif conditionings and conditioning_type == "prepending":          # performer.py:262-264 (the last conditioning ends up first)
         for i, cond in enumerate(conditionings):
             x = torch.cat((F.embedding(cond, st[f"conditioning_emb.{i}.weight"]), x), dim=1)
-    x = x + st["pos_emb.emb.weight"][: x.shape[1]][None]
+    pos = st["pos_emb.emb"] if "pos_emb.emb" in st else st["pos_emb.emb.weight"]      # the fixed sinusoidal buffer, or the learned table
+    x = x + pos[: x.shape[1]][None]
     return x
 
 

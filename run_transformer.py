@@ -44,8 +44,8 @@ def build(cfg, dims, dev):
     from synthanatomy_amd.networks.transformers.performer import Performer
     if cfg["network"] != "performer":
         raise ValueError(f"Transformer unknown. Was given {cfg['network']} but choices are ['performer'].")
-    if cfg["position_emb"] != "absolute":
-        raise NotImplementedError("position_emb other than 'absolute'")
+    if cfg["position_emb"] not in ("absolute", "fixed"):      # run_transformer.py:86-88 maps "fixed" to fixed_position_emb, everything else to the learned table
+        raise NotImplementedError("position_emb other than 'absolute' / 'fixed'")
     ordering = Ordering(ordering_type=cfg["ordering_type"], spatial_dims=len(dims), dimensions=(1,) + tuple(dims),
                         reflected_spatial_dims=cfg["reflected_spatial_dims"], transpositions_axes=cfg["transpositions_axes"],
                         rot90_axes=cfg["rot90_axes"], transformation_order=cfg["transformation_order"])
@@ -53,7 +53,7 @@ def build(cfg, dims, dev):
                     ordering=ordering, local_attn_heads=cfg["local_attn_heads"], local_window_size=cfg["local_window_size"],
                     feature_redraw_interval=cfg["feature_redraw_interval"], generalized_attention=cfg["generalized_attention"],
                     emb_dropout=cfg["emb_dropout"], ff_dropout=cfg["ff_dropout"], attn_dropout=cfg["attn_dropout"], use_rezero=cfg["use_rezero"],
-                    spatial_position_emb=cfg["spatial_position_emb"], spatial_shape=tuple(dims),
+                    fixed_position_emb=cfg["position_emb"] == "fixed", spatial_position_emb=cfg["spatial_position_emb"], spatial_shape=tuple(dims),
                     compute_dtype=torch.bfloat16 if cfg["compute_dtype"] == "bf16" else torch.float32)
     return net.to(dev), ordering
 

@@ -52,6 +52,18 @@ class AbsolutePositionalEmbedding(nn.Module):  # performer_pytorch.AbsolutePosit
         self.emb = nn.Embedding(max_seq_len, dim)
 
 
+class FixedPositionalEmbedding(nn.Module):
+    """performer_pytorch.FixedPositionalEmbedding (1.0.11): rows sin | cos of position x inverse frequency, a buffer named ``emb`` (no parameters);
+    `fixed_position_emb=True` of the wrapper (performer.py:138-140)."""
+
+    def __init__(self, dim, max_seq_len):
+        super().__init__()
+        inv_freq = 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim))
+        position = torch.arange(0, max_seq_len, dtype=torch.float)
+        sinusoid_inp = torch.einsum("i,j->ij", position, inv_freq)
+        self.register_buffer("emb", torch.cat((sinusoid_inp.sin(), sinusoid_inp.cos()), dim=-1).contiguous())
+
+
 class AbsoluteSpatialPositionalEmbedding(nn.Module):  # performer.py:23-40
     def __init__(self, dim: int, spatial_indices_sequence: torch.Tensor):
         super().__init__()
@@ -1148,13 +1160,15 @@ class Performer(TransformerBase):
             f"rotary_position_emb, fixed_position_emb and axial_position_emb are exclusive, but received "
             f"{rotary_position_emb} {fixed_position_emb} and {axial_position_emb}."
         )
-        if rotary_position_emb or fixed_position_emb or axial_position_emb or tie_embed or emb_dropout:
-            raise NotImplementedError("performer on MI355X implements the absolute positional embedding path (README configuration)")
+        if rotary_position_emb or axial_position_emb or tie_embed or emb_dropout:
+            raise NotImplementedError("performer on MI355X implements the absolute (README configuration) and the fixed sinusoidal positional embedding; "
+                                      "rotary / axial position embeddings, tied embeddings and embedding dropout are not built")
         # accounting for the number of prepended conditionings (performer.py:119-125)
         self.max_seq_len = max_seq_len + (len(conditioning_num_tokens)
                                           if conditioning_num_tokens and conditioning_type == TransformerConditioningType.PREPENDING.value else 0)
         self.token_emb = nn.Embedding(num_tokens, dim)
-        self.pos_emb = AbsolutePositionalEmbedding(dim, self.max_seq_len)
+        # performer.py:138-147: the sinusoidal table (a buffer) or the learned one
+        self.pos_emb = FixedPositionalEmbedding(dim, self.max_seq_len) if fixed_position_emb else AbsolutePositionalEmbedding(dim, self.max_seq_len)
         self.ordering = ordering
         self.spatial_position_emb = nn.ModuleList()
         if spatial_position_emb:
@@ -1257,7 +1271,7 @@ class Performer(TransformerBase):
             tok_table = torch.cat((self.token_emb.weight.detach(), c.to(self.token_emb.weight.dtype)), dim=0).contiguous()
             seq[:, 0] = tok_table.shape[0] - B + torch.arange(B, device=dev)
             seq0 = seq.clone()
-        tables = [tok_table] + [(m.emb if isinstance(m, FixedSpatialPositionalEmbedding) else m.emb.weight) for m in self.spatial_position_emb] + [self.pos_emb.emb.weight]
+        tables = [tok_table] + [(m.emb if isinstance(m, FixedSpatialPositionalEmbedding) else m.emb.weight) for m in self.spatial_position_emb] + [self._pos_table()]
         idx = [tok] + sp + [pidx]
         per_pos = [0] + [1] * len(sp) + [1]
         n = len(tables)
@@ -1351,6 +1365,9 @@ class Performer(TransformerBase):
         return sequence_to_grid(seq, P, self.ordering)
 
     # ------------------------------------------------------------------------------------------------
+    def _pos_table(self):
+        return self.pos_emb.emb if isinstance(self.pos_emb, FixedPositionalEmbedding) else self.pos_emb.emb.weight
+
     def _position_indices(self, n, dev):
         key = (n, str(dev))
         if key not in self._idx_cache:
@@ -1388,10 +1405,10 @@ class Performer(TransformerBase):
                 h = torch.cat((emb(conditionings[i].to(dev)), h), dim=1)
             nt = h.shape[1]
             assert nt <= self.max_seq_len, f"sequence length {nt} must be less than the max sequence length {self.max_seq_len}"
-            ptab = [self.pos_emb.emb.weight]
+            ptab = [self._pos_table()]
             h = h + _EmbedFn.apply(ptab, [torch.arange(nt, device=dev, dtype=torch.int64)], [1], b, nt, *ptab)
         else:
-            tables = [self.token_emb.weight] + sp_tables + [self.pos_emb.emb.weight]
+            tables = [self.token_emb.weight] + sp_tables + [self._pos_table()]
             idx = [tok] + sp + [pos]
             per_pos = [0] + [1] * len(sp) + [1]
             h = _EmbedFn.apply(tables, idx, per_pos, b, n, *tables)
@@ -1399,7 +1416,7 @@ class Performer(TransformerBase):
             # performer.py:252-261: the BOS embedding (incl. its spatial terms) is REPLACED by the summed conditioning embeddings,
             # the absolute positional embedding is added afterwards
             c = sum(emb(conditionings[i].to(dev))[:, 0, :] for i, emb in enumerate(self.conditioning_emb))
-            first = c + self.pos_emb.emb.weight[0]
+            first = c + self._pos_table()[0]
             h = torch.cat((first[:, None, :], h[:, 1:, :]), dim=1)
         if self.performer.auto_check_redraw:
             self.performer.proj_updater.redraw_projections()

@@ -768,9 +768,10 @@ def test_small_batch_dense_kernel(B, cin, segs, act, resid, rnd):
         assert torch.equal(y2, y)
 
 
-@pytest.mark.parametrize("variant", ["fixed", "prepending", "bos_replacement"])
+@pytest.mark.parametrize("variant", ["fixed", "prepending", "bos_replacement", "fixed_pos"])
 def test_embedding_variants_match_oracle(variant):
-    """`spatial_position_emb="fixed"` (sinusoids of the coordinate value, reference performer.py:43-66) and the two conditioning types
+    """`spatial_position_emb="fixed"` (sinusoids of the coordinate value, reference performer.py:43-66), `fixed_position_emb=True` (the sinusoidal
+    positional buffer instead of the learned table, performer.py:138-140; with BOS replacement so that row 0 of the buffer is used too) and the two conditioning types
     (BOS replacement :252-261, prepending :262-264 with the conditioning positions cut off after the norm :279-281): logits and gradients."""
     from synthanatomy_amd.losses.transformer import CELoss
     from synthanatomy_amd.networks.transformers.img2seq_ordering import Ordering
@@ -787,17 +788,23 @@ def test_embedding_variants_match_oracle(variant):
         if k.endswith(".g"):
             st[k] = torch.tensor(0.4)
     sp = "fixed" if variant == "fixed" else "absolute"
-    ctype = {"fixed": "none", "prepending": "prepending", "bos_replacement": "bos_replacement"}[variant]
+    ctype = {"fixed": "none", "prepending": "prepending", "bos_replacement": "bos_replacement", "fixed_pos": "bos_replacement"}[variant]
+    if variant == "fixed_pos":
+        del st["pos_emb.emb.weight"]
+        st["pos_emb.emb"] = P.fixed_position_table(32, n)
     o = Ordering("raster_scan", 3, (1,) + shape, (False,) * 3, (), ())
     net = Performer(num_tokens=33, max_seq_len=n, dim=32, depth=2, heads=4, ordering=o, dim_head=64, local_attn_heads=2, local_window_size=6, use_rezero=True,
                     spatial_position_emb=sp, spatial_shape=shape, feature_redraw_interval=None, compute_dtype=torch.float32,
-                    conditioning_num_tokens=ncond if variant != "fixed" else None, conditioning_type=ctype)
+                    conditioning_num_tokens=ncond if variant != "fixed" else None, conditioning_type=ctype, fixed_position_emb=variant == "fixed_pos")
     assert net.max_seq_len == n + (2 if prep else 0)
     load = {k: v.clone() for k, v in st.items() if not (variant == "fixed" and "spatial_position_emb" in k) and not (variant == "fixed" and "conditioning_emb" in k)}
     missing, unexpected = net.load_state_dict(load, strict=False)
     assert not unexpected, unexpected
     net = net.cuda().train()
     seqs = P.spatial_index_sequences(shape, o.get_sequence_ordering())
+    if variant == "fixed_pos":
+        assert "pos_emb.emb" in net.state_dict() and "pos_emb.emb.weight" not in net.state_dict()
+        assert torch.allclose(net.pos_emb.emb.cpu(), st["pos_emb.emb"], atol=1e-6)
     if variant == "fixed":     # the product's buffers are the oracle's tables
         for a in range(3):
             assert torch.allclose(net.spatial_position_emb[a].emb.cpu(), P.fixed_spatial_table(32, seqs[a]), atol=1e-6)
@@ -824,8 +831,9 @@ def test_embedding_variants_match_oracle(variant):
         assert float(params["conditioning_emb.0.weight"].grad.abs().max()) > 0
 
 
-def test_stateful_sampler_with_bos_replacement_conditioning():
-    """O(N) decoding with `conditioning_type="bos_replacement"` (reference performer.py:252-261 through transformer.py:58-101): position 0 carries the
+@pytest.mark.parametrize("fixed_pos", [False, True])
+def test_stateful_sampler_with_bos_replacement_conditioning(fixed_pos):
+    """(`fixed_pos`: the sinusoidal positional buffer of `fixed_position_emb=True` instead of the learned table.)  O(N) decoding with `conditioning_type="bos_replacement"` (reference performer.py:252-261 through transformer.py:58-101): position 0 carries the
     summed conditioning embeddings; token for token equal to the reference-faithful loop and to the CPU oracle's greedy chain."""
     from synthanatomy_amd.networks.transformers.img2seq_ordering import Ordering
     from synthanatomy_amd.networks.transformers.performer import Performer
@@ -838,10 +846,13 @@ def test_stateful_sampler_with_bos_replacement_conditioning():
     for k in st:
         if k.endswith(".g"):
             st[k] = torch.full_like(st[k], 0.7)
+    if fixed_pos:
+        del st["pos_emb.emb.weight"]
+        st["pos_emb.emb"] = P.fixed_position_table(32, n)
     o = Ordering("raster_scan", 3, (1,) + shape, (False,) * 3, (), ())
     net = Performer(num_tokens=19, max_seq_len=n, dim=32, depth=2, heads=4, ordering=o, dim_head=64, local_attn_heads=2, local_window_size=6, use_rezero=True,
                     spatial_position_emb="absolute", spatial_shape=shape, feature_redraw_interval=None, conditioning_num_tokens=ncond,
-                    conditioning_type="bos_replacement")
+                    conditioning_type="bos_replacement", fixed_position_emb=fixed_pos)
     net.load_state_dict({k: v.clone() for k, v in st.items()}, strict=False)
     net = net.cuda()
     B = 3
