@@ -26,10 +26,17 @@ namespace sa {
 // scan A body: [10] prologue, [11] slab loop, [12] epilogue, [13] blocks;   state body: [15] prologue, [16] slab loop, [17] blocks
 __device__ unsigned long long g_ftime[24];
 #define FT_T(var) const unsigned long long var = __builtin_readcyclecounter()
-#define FT_ACC(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_ftime[i], (unsigned long long)(v)); } while (0)
+// (phase sums are kept in registers and added to g_ftime ONCE per block.  Until round 5 every phase boundary issued its own atomic: it sat in the vector-memory
+//  queue in front of the next s_waitcnt vmcnt and was billed to whatever phase waited next -- the "tile writes + wait" and "VALU + split" figures of
+//  profiles/r04_favor_phase_timing.txt were mostly that, and the probe ran at 182 k tokens/s instead of 269 k.)
+#define FT_DECL unsigned long long ft_sum[24] = {}
+#define FT_ACC(i, v) (ft_sum[i] += (unsigned long long)(v))
+#define FT_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 24; ++i_) if (ft_sum[i_]) atomicAdd(&g_ftime[i_], ft_sum[i_]); } while (0)
 #else
 #define FT_T(var)
+#define FT_DECL
 #define FT_ACC(i, v)
+#define FT_FLUSH()
 #endif
 constexpr int FT_BYTES = 64 * 128;   // one [64 rows][64 bf16] tile
 constexpr int FSLAB = 64;
@@ -750,6 +757,7 @@ __device__ __forceinline__ void favor_fout_b_body(const FusedArgs& s, const int 
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, g4 = lane >> 4;
     const int chunk = bid % s.S, g = (bid / s.S) % s.G, b = bid / (s.S * s.G);
     FT_T(ft_start);
+    FT_DECL;
     const float kmax = unpack_max(*s.gmax);
     const __amdgpu_buffer_rsrc_t rc = f_rsrc(s.c + (int64_t)b * s.N * s.c_stride, (int64_t)s.N * s.c_stride * 4);
     const __amdgpu_buffer_rsrc_t rcs = f_rsrc((s.c_scale ? s.c_scale : s.c) + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G * 4);
@@ -911,6 +919,7 @@ __device__ __forceinline__ void favor_fout_b_body(const FusedArgs& s, const int 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     FT_T(ft_end);
     FT_ACC(7, ft_end - ft_ep); FT_ACC(8, 1); FT_ACC(9, ft_end - ft_start);
+    FT_FLUSH();
 #endif
 }
 

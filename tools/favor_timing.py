@@ -1,6 +1,6 @@
 """dev: s_memtime phase sums of the FAVOR+ scan-B body (library built with SA_EXTRA_HIPCC_FLAGS=-DSA_TIMING_FAVOR into a separate .so)"""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from synthanatomy_amd import _ffi
 import bench, argparse
