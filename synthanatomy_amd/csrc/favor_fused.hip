@@ -216,6 +216,21 @@ __device__ __forceinline__ void pslab_store(unsigned char* sP, const PSlabRegs& 
     for (int t = 0; t < 4; ++t) ((u32x4*)sP)[tid + 256 * t] = r.v[t];
 }
 
+// the same 16 KiB straight into LDS (LDS-DMA, sixteen 1 KiB pieces: wave w takes pieces w, w + 4, ...), issued from inline assembly: invisible to the
+// compiler's waitcnt pass (which answers a builtin LDS-DMA with s_waitcnt vmcnt(0) in front of the next LDS read) -- the caller waits (pslab_dma_wait) and
+// synchronises before the slab is read.  No staging registers.
+__device__ __forceinline__ void pslab_dma(unsigned char* sP, const unsigned char* ptiles, int slab, int wave, int lane) {
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(ptiles + (size_t)slab * (2 * FT_BYTES)), 0, 2 * FT_BYTES, 0x00020000);
+    const uint32_t l0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)sP;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t piece = (uint32_t)(wave + 4 * t);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                     : : "s"(l0 + piece * 1024u), "v"(piece * 1024u + (uint32_t)lane * 16u), "s"(rp) : "memory", "m0");
+    }
+}
+__device__ __forceinline__ void pslab_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
+
 // rows [slab0, slab0 + 64) of the chunk's exclusive-prefix state (64 value columns); zeros outside the matrix
 __device__ __forceinline__ void tslab_load(u32x4 (&t)[4], __amdgpu_buffer_rsrc_t rt, int slab0, int tid) {
 #pragma unroll
@@ -415,8 +430,7 @@ __device__ __forceinline__ void favor_fstate_body(const FusedArgs& s, const int 
     const int ri = f_row(s, p);
     XOperand xa;
     load_x_operand(xa, s.fa, s, b, g, ri, g4, kmax);
-    PSlabRegs pre;
-    pslab_load(pre, s.ptiles, 0, tid);
+    pslab_dma(sP[0], s.ptiles, 0, w, lane);      // projection slabs: global -> LDS without staging registers (see pslab_dma)
     f_stage_values(sBh, sBl, s.b, s.b_stride, s.b_scale, s, b, g, chunk, tid);
     if (tid < 64) {
         const int pj = chunk * 64 + tid;
@@ -427,7 +441,7 @@ __device__ __forceinline__ void favor_fstate_body(const FusedArgs& s, const int 
         }
         sW[tid] = wv;
     }
-    pslab_store(sP[0], pre, tid);
+    pslab_dma_wait();
     __syncthreads();
     const uint32_t trow = (uint32_t)g4 * 4u + ((uint32_t)fr >> 2), tcol = (uint32_t)(fr & 3) * 4u;
     short8_t bh[2], bl[2], wh[2], wl[2];   // this wave's 16 value columns d = w*16 + (lane & 15); the weights of the running sums in column 0
@@ -448,12 +462,11 @@ __device__ __forceinline__ void favor_fstate_body(const FusedArgs& s, const int 
     for (int sl = 0; sl < nslab; ++sl) {
         const int slab0 = sl * FSLAB;
         const unsigned char* sPc = sP[sl & 1];
-        if (sl + 1 < nslab) pslab_load(pre, s.ptiles, sl + 1, tid);
         float4_t F[4];
         feat_slab(F, sPc, sPc + FT_BYTES, xa, valid, slab0, s, fr, g4);
-        if (sl) __syncthreads();            // the previous slab's feature tile has been consumed
+        // (the barrier at the end of the previous trip: its feature tile has been consumed, the other projection buffer has no readers left)
         feat_to_tile(sAh, sAl, F, w, fr, g4);
-        if (sl + 1 < nslab) pslab_store(sP[(sl + 1) & 1], pre, tid);   // (its last readers finished before the barrier above)
+        if (sl + 1 < nslab) pslab_dma(sP[(sl + 1) & 1], s.ptiles, sl + 1, w, lane);
         __syncthreads();
         float4_t acc[4];
 #pragma unroll
@@ -466,6 +479,10 @@ __device__ __forceinline__ void favor_fstate_body(const FusedArgs& s, const int 
                 const uint32_t o0 = lroff(ks * 32 + trow, w * 16 + tcol), o1 = lroff(ks * 32 + 16 + trow, w * 16 + tcol);
                 accz = mfma3(f_tr_operand(sAh, o0, o1), f_tr_operand(sAl, o0, o1), wh[ks], wl[ks], accz);
             }
+        }
+        if (sl + 1 < nslab) {      // the next projection slab has landed, for every wave; every wave is done with this trip's tiles (before the stores below:
+            pslab_dma_wait();      // the wait counts them too)
+            __syncthreads();
         }
 #pragma unroll
         for (int f = 0; f < 4; ++f)
@@ -651,9 +668,8 @@ __device__ __forceinline__ void favor_fout_a_body(const FusedArgs& s, const int 
     XOperand xa, xc;
     load_x_operand(xa, s.fa, s, b, g, ri, g4, kmax);
     load_x_operand(xc, s.fx, s, b, g, ri, g4, kmax);
-    PSlabRegs pre;
     u32x4 pt[4], pz[4];
-    pslab_load(pre, s.ptiles, 0, tid);
+    pslab_dma(sP[0], s.ptiles, 0, w, lane);      // projection slabs: global -> LDS without staging registers (see pslab_dma)
     tslab_load(pt, rt, 0, tid);
 #pragma unroll
     for (int q = 0; q < 4; ++q) pz[q] = f_ld4(rz, (uint32_t)(q * 16 + g4 * 4) * 4u);
@@ -667,7 +683,7 @@ __device__ __forceinline__ void favor_fout_a_body(const FusedArgs& s, const int 
     float den = 0.f;
     const int nslab = (s.LDF + FSLAB - 1) / FSLAB;
     tile_stage(sT[0], sT[0] + FT_BYTES, pt, tid);
-    pslab_store(sP[0], pre, tid);
+    pslab_dma_wait();
     __syncthreads();
     for (int sl = 0; sl < nslab; ++sl) {
         const int slab0 = sl * FSLAB;
@@ -678,14 +694,13 @@ __device__ __forceinline__ void favor_fout_a_body(const FusedArgs& s, const int 
 #pragma unroll
         for (int q = 0; q < 4; ++q) zc[q] = pz[q];
         if (sl + 1 < nslab) {
-            pslab_load(pre, s.ptiles, sl + 1, tid);
             tslab_load(pt, rt, slab0 + FSLAB, tid);
 #pragma unroll
             for (int q = 0; q < 4; ++q) pz[q] = f_ld4(rz, (uint32_t)(slab0 + FSLAB + q * 16 + g4 * 4) * 4u);
         }
         float4_t Fa[4], F[4];
         feat_slab2(Fa, F, sPc, sPc + FT_BYTES, xa, xc, vi, slab0, s, fr, g4);
-        if (sl) __syncthreads();   // the previous slab's GEMMs are done with the feature tile (and with the other slab buffers)
+        // (the barrier at the end of the previous trip: its GEMMs are done with the feature tile and with the other slab buffers)
         feat_to_tile(sAh, sAl, Fa, w, fr, g4);
 #pragma unroll
         for (int f = 0; f < 4; ++f)
@@ -695,12 +710,16 @@ __device__ __forceinline__ void favor_fout_a_body(const FusedArgs& s, const int 
         acc_to_operand(Ch, Cl, F);
         if (sl + 1 < nslab) {      // next slab's operands into the other buffers while this slab's GEMMs run
             tile_stage(sT[(sl + 1) & 1], sT[(sl + 1) & 1] + FT_BYTES, pt, tid);
-            pslab_store(sP[(sl + 1) & 1], pre, tid);
+            pslab_dma(sP[(sl + 1) & 1], s.ptiles, sl + 1, w, lane);
         }
         __syncthreads();
         const int nks = (min(64, s.LDF - slab0) + 31) >> 5;
         tile_rows_gemm_perm(P, sAh, sAl, Ch, Cl, fr, g4, nks);   // pair products phi_a(j) . phi_x(i)
         tile_cols_gemm(acc, sTh, sTl, Ch, Cl, lane, nks);        // inter-chunk: T_prev^T phi_x(i)
+        if (sl + 1 < nslab) {      // the next projection slab has landed, for every wave; every wave is done with this trip's tiles
+            pslab_dma_wait();
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int jf = 0; jf < 4; ++jf)
@@ -773,9 +792,8 @@ __device__ __forceinline__ void favor_fout_b_body(const FusedArgs& s, const int 
     XOperand xa, xx;
     load_x_operand(xa, s.fa, s, b, g, ri, g4, kmax);
     load_x_operand(xx, s.fx, s, b, g, ri, g4, kmax);
-    PSlabRegs pre;
     u32x4 pt[4];
-    pslab_load(pre, s.ptiles, 0, tid);
+    pslab_dma(sP[0], s.ptiles, 0, w, lane);      // projection slabs go global -> LDS without staging registers (sP is not aliased by the prologue's tiles)
     tslab_load(pt, rt, 0, tid);
     f_stage_values(sBh, sBl, s.b, s.b_stride, s.b_scale, s, b, g, chunk, tid);
     short8_t Ch[2], Cl[2];   // c_i (times c_scale) as B operand, natural order d = ks*32 + g4*8 + e
@@ -820,7 +838,7 @@ __device__ __forceinline__ void favor_fout_b_body(const FusedArgs& s, const int 
     const int nslab = (s.LDF + FSLAB - 1) / FSLAB;
     __syncthreads();   // the pair products have read the value tile
     tile_stage(sT[0], sT[0] + FT_BYTES, pt, tid);
-    pslab_store(sP[0], pre, tid);
+    pslab_dma_wait();
     __syncthreads();
     FT_T(ft_loop);
     FT_ACC(0, ft_loop - ft_start);
@@ -830,21 +848,18 @@ __device__ __forceinline__ void favor_fout_b_body(const FusedArgs& s, const int 
         const unsigned char* sTh = sT[sl & 1];
         const unsigned char* sTl = sTh + FT_BYTES;
         FT_T(ft0);
-        if (sl + 1 < nslab) {
-            pslab_load(pre, s.ptiles, sl + 1, tid);
-            tslab_load(pt, rt, slab0 + FSLAB, tid);
-        }
+        if (sl + 1 < nslab) tslab_load(pt, rt, slab0 + FSLAB, tid);
         u32x4 zc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) zc[q] = f_ld4(rz, (uint32_t)(slab0 + q * 16 + g4 * 4) * 4u);
         float4_t F[4], Fx[4];
         feat_slab2(F, Fx, sPc, sPc + FT_BYTES, xa, xx, vi, slab0, s, fr, g4);
         FT_T(ft1);
-        if (sl) __syncthreads();   // the previous slab's GEMMs are done with the feature tile (and with the other slab buffers)
+        // (no barrier here: the one at the end of the previous trip already says that its GEMMs are done with the feature tile and with the other slab buffers)
         feat_to_tile(sAh, sAl, F, w, fr, g4);
         if (sl + 1 < nslab) {      // next slab's operands into the other buffers while this slab's GEMMs run
             tile_stage(sT[(sl + 1) & 1], sT[(sl + 1) & 1] + FT_BYTES, pt, tid);
-            pslab_store(sP[(sl + 1) & 1], pre, tid);
+            pslab_dma(sP[(sl + 1) & 1], s.ptiles, sl + 1, w, lane);
         }
         FT_T(ft2);
         __syncthreads();
@@ -880,6 +895,10 @@ __device__ __forceinline__ void favor_fout_b_body(const FusedArgs& s, const int 
 #endif
         FT_T(ft6);
         FT_ACC(5, ft5 - ft4); FT_ACC(6, ft6 - ft5);
+        if (sl + 1 < nslab) {      // the next projection slab has landed (requested a slab's GEMMs ago) -- for every wave; every wave is done with this trip's tiles
+            pslab_dma_wait();
+            __syncthreads();
+        }
     }
     FT_T(ft_ep);
     float t = tp;
