@@ -209,19 +209,30 @@ __device__ __forceinline__ void adam_one(float& pe, float gr, float& me, float& 
 }
 
 // HBM-bound (28 bytes per element): 16-byte accesses, `n4` = n / 4 whole vectors (the four arrays 16-byte aligned: the flat parameter buffers are), the
-// remainder and unaligned slices by the scalar loop below.  Round 5: the 4-byte loop ran the Performer's 28 M parameters at 1.25 TB/s (628 us per step).
+// remainder and unaligned slices by the scalar loop below.  A block trip takes ONE contiguous 16 KiB piece of each array (4 x 256 vectors, all sixteen loads
+// requested before the first use) instead of a grid-wide stride: 382 vs 448 us for the Performer's 79 M parameters in tools/probes/adam_bw.hip (5.8 vs 4.9 TB/s).
 __global__ __launch_bounds__(256) void adam_vec4_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m, float4* __restrict__ v, int64_t n4,
                                                         float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
-        float4 pe = p[e], me = m[e], ve = v[e];
-        const float4 ge = g[e];
-        adam_one(pe.x, ge.x, me.x, ve.x, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
-        adam_one(pe.y, ge.y, me.y, ve.y, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
-        adam_one(pe.z, ge.z, me.z, ve.z, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
-        adam_one(pe.w, ge.w, me.w, ve.w, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
-        m[e] = me;
-        v[e] = ve;
-        p[e] = pe;
+    constexpr int U = 4;
+    for (int64_t base = (int64_t)blockIdx.x * (256 * U); base < n4; base += (int64_t)gridDim.x * (256 * U)) {
+        float4 pe[U], ge[U], me[U], ve[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t e = base + u * 256 + threadIdx.x;
+            if (e < n4) { pe[u] = p[e]; ge[u] = g[e]; me[u] = m[e]; ve[u] = v[e]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t e = base + u * 256 + threadIdx.x;
+            if (e >= n4) continue;
+            adam_one(pe[u].x, ge[u].x, me[u].x, ve[u].x, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+            adam_one(pe[u].y, ge[u].y, me[u].y, ve[u].y, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+            adam_one(pe[u].z, ge[u].z, me[u].z, ve[u].z, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+            adam_one(pe[u].w, ge[u].w, me[u].w, ve[u].w, lr, b1, b2, eps, wd, bc1, bc2_sqrt, gscale);
+            m[e] = me[u];
+            v[e] = ve[u];
+            p[e] = pe[u];
+        }
     }
 }
 
@@ -426,7 +437,7 @@ extern "C" int sa_adam(float* p, const float* g, float* m, float* v, int64_t n, 
     const int64_t n4 = (n - head) / 4;
     if (head > 0) scalar(0, head);
     if (n4 > 0)
-        SA_LAUNCH(adam_vec4_kernel, dim3(grid_for(n4, 256, 8192)), dim3(256), 0, st, (float4*)(p + head), (const float4*)(g + head), (float4*)(m + head),
+        SA_LAUNCH(adam_vec4_kernel, dim3(grid_for((n4 + 3) / 4, 256, 16384)), dim3(256), 0, st, (float4*)(p + head), (const float4*)(g + head), (float4*)(m + head),
                   (float4*)(v + head), n4, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
     if (head + n4 * 4 < n) scalar(head + n4 * 4, n - head - n4 * 4);
     SA_CHECK_LAUNCH();
