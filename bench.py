@@ -326,7 +326,7 @@ PMC_FILE_PERFORMER = "r05_pmc_traffic_performer.json"
 VQVAE_KERNEL_SOURCES = ("conv1.hip", "conv_fprop.hip", "conv_fprop_f16.hip", "conv_fprop_kernels.h", "conv_fprop_common.h", "conv_wgrad.hip", "convt1.hip",
                         "elementwise.hip", "norm.hip", "vq.hip", "sa_common.h", "split_bf16.h")
 PERFORMER_KERNEL_SOURCES = ("performer.hip", "favor_fused.hip", "favor_proj.hip", "local_attn.hip", "local_attn_split.h", "conv_fprop.hip", "conv_fprop_kernels.h",
-                            "conv_fprop_common.h", "conv_wgrad.hip", "dense.hip", "elementwise.hip", "norm.hip", "sa_common.h", "split_bf16.h")
+                            "conv_fprop_common.h", "conv_wgrad.hip", "elementwise.hip", "norm.hip", "sa_common.h", "split_bf16.h")
 
 
 def _spin_until(event):
@@ -611,11 +611,13 @@ def bench_latency_b1(dev, dtype, steps=5):
 DISC_FWD_TFLOP_PER_VOLUME = 0.3108   # 155.4 GMAC forward per 160x224x160 volume
 
 
-def bench_adversarial(dev, dtype, batch, steps=3):
+def bench_adversarial(dev, dtype, batch, steps=5, warmup=3):
     """The README's training command (reference README.md:62-67): --adversarial_component=True with baseline_discriminator (ndf 64), least-square
     criteria weight 0.005, adaptive weight off -- one G + D iteration (src/engines/trainer.py:157-256) per step.  Added work per volume: the
     discriminator runs forward on the fakes and back to the reconstruction in the G step (2 x fwd), forward + full backward on fakes and reals in
-    the D step (2 x 3 x fwd): 8 x 0.311 = 2.49 TFLOP on top of the generator's 14.97."""
+    the D step (2 x 3 x fwd): 8 x 0.311 = 2.49 TFLOP on top of the generator's 14.97.  Per-iteration HIP events and the caching allocator's
+    counters ride along: a regression of this leg (round 5: 168 -> 1 431 ms, unnoticed) shows as iterations of unequal length or as
+    device allocations / retries inside the timed iterations."""
     from synthanatomy_amd.engines.trainer import AdversarialTrainer
     from synthanatomy_amd.losses.adversarial import get_discriminator_loss, get_generator_loss
     from synthanatomy_amd.losses.vqvae import MSELoss
@@ -632,21 +634,78 @@ def bench_adversarial(dev, dtype, batch, steps=3):
     tr = AdversarialTrainer(net, opt, get_generator_loss({"generator_loss": "least_square"}), MSELoss(), disc, d_opt,
                             get_discriminator_loss({"discriminator_loss": "least_square"}))
     x = torch.rand(batch, 1, *VOL, generator=torch.Generator(device=dev).manual_seed(4), device=dev)
-    res = tr.iteration(x, x, 1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(warmup):
         res = tr.iteration(x, x, 1)
     torch.cuda.synchronize()
+    ms0 = torch.cuda.memory_stats(dev)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(steps):
+        res = tr.iteration(x, x, 1)
+        marks[i + 1].record()
+    torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    ms1 = torch.cuda.memory_stats(dev)
+    it_ms = [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(steps)]
     tf = STEP_TFLOP_PER_VOLUME + 8 * DISC_FWD_TFLOP_PER_VOLUME
     out = {"metric": "vqvae_adversarial_train_volumes_per_sec", "value": round(batch / dt, 3), "unit": "volumes/s", "ms_per_step": round(dt * 1e3, 2),
-           "batch_per_gpu": batch, "steps": steps, "tflop_per_volume": round(tf, 2), "tflops_per_gpu": round(batch / dt * tf, 1),
+           "batch_per_gpu": batch, "steps": steps, "warmup": warmup, "iteration_ms": it_ms,
+           "allocator": {"device_allocs_in_timed_region": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
+                         "device_frees_in_timed_region": int(ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0)),
+                         "alloc_retries_in_timed_region": int(ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0)),
+                         "reserved_gb": round(ms1.get("reserved_bytes.all.current", 0) / 2 ** 30, 2),
+                         "peak_allocated_gb": round(ms1.get("allocated_bytes.all.peak", 0) / 2 ** 30, 2)},
+           "tflop_per_volume": round(tf, 2), "tflops_per_gpu": round(batch / dt * tf, 1),
            "losses": {k: round(float(res[k]), 6) for k in ("loss", "g_loss", "d_loss")},
            "workload": "G + D iteration: baseline_vqvae config 2 + baseline_discriminator(1, 64, 3), MSE + 0.005 x least-square GAN terms, two Adam steps"}
     del net, disc, tr, flat, d_flat, opt, d_opt, x
     torch.cuda.empty_cache()
     return out
+
+
+# ---- regression guard (round 6): every headline number of the line against the newest committed final line of an EARLIER tree.  The round-5 line carried an
+# "adversarial" record 8.5 x below round 4's through four committed lines because nothing compared the sub-records.
+GUARDED = (("value", True), ("inference.value", True), ("adversarial.value", True), ("latency_b1.train_volumes_per_sec", True),
+           ("latency_b1.extract_decode_volumes_per_sec", True), ("fp32_mode.value", True), ("secondary.value", True), ("secondary.sampling.value", True),
+           ("secondary_14k.value", True), ("end_to_end.total_s", False), ("roofline.frac", True), ("roofline_hbm.frac", True), ("secondary.roofline.frac", True))
+
+
+def _dig(d, path):
+    for k in path.split("."):
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d if isinstance(d, (int, float)) and not isinstance(d, bool) else None
+
+
+def regression_report(line, threshold=0.10, ref_path=None):
+    """{"against": file, "regressions": [...], "compared": {...}}: sub-records more than ``threshold`` worse than the reference line (the newest
+    profiles/rNN_final_bench_line.json, or SA_BENCH_REFERENCE_LINE)."""
+    import glob
+    import re
+    ref_path = ref_path or os.environ.get("SA_BENCH_REFERENCE_LINE")
+    if ref_path is None:
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_bench_line.json")),
+                       key=lambda f: int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)))
+        if not cands:
+            return None
+        ref_path = cands[-1]
+    try:
+        with open(ref_path) as f:
+            ref = json.loads(f.readline())
+    except (OSError, ValueError) as e:
+        return {"against": os.path.relpath(ref_path, ROOT), "error": str(e)}
+    compared, regs = {}, []
+    for path, higher in GUARDED:
+        new, old = _dig(line, path), _dig(ref, path)
+        if new is None or old is None or old == 0:
+            continue
+        ratio = new / old
+        compared[path] = round(ratio, 3)
+        if (ratio < 1 - threshold) if higher else (ratio > 1 + threshold):
+            regs.append({"record": path, "now": new, "reference": old, "ratio": round(ratio, 3)})
+    return {"against": os.path.relpath(ref_path, ROOT), "threshold": threshold, "regressions": regs, "compared": compared}
 
 
 def main():
@@ -665,6 +724,7 @@ def main():
     ap.add_argument("--no-performer", action="store_true", help="skip the secondary Performer tokens/s measurement")
     ap.add_argument("--no-sampling", dest="sampling", action="store_false", help="skip the autoregressive sampling tokens/s measurement")
     ap.add_argument("--only-performer", action="store_true", help="dev/profiling: measure only the Performer workload")
+    ap.add_argument("--only-adversarial", action="store_true", help="dev/profiling: measure only the adversarial G + D iteration sub-record")
     ap.add_argument("--performer-shape", default="10,14,10", help="latent grid of the Performer workload (20,28,25 = the 14 000-token variant)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo: exercise the launch + reduction plumbing only (no GPU, no kernels)")
     ap.add_argument("--ddp-mode", default=None, choices=["all_reduce", "reduce_scatter"],
@@ -692,6 +752,9 @@ def main():
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
+    if args.only_adversarial:
+        print(json.dumps(bench_adversarial(dev, dtype, args.batch)), flush=True)
+        return
     if args.only_performer:
         res = bench_performer(args, rank, world, dev)
         if rank == 0:
@@ -824,6 +887,7 @@ def main():
             **({"share_device": True} if args.share_device else {}),
             "tflops_per_gpu": round(value / world * STEP_TFLOP_PER_VOLUME, 2), "final_loss": round(final_loss, 6),
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            "reserved_mem_gb": round(torch.cuda.memory_reserved() / 2 ** 30, 2),     # the caching allocator's pool (round 5: 4 x the live bytes under record_stream)
         }
         if comm is not None:
             comm["backend"] = dist.get_backend()
@@ -892,6 +956,12 @@ def main():
             line["secondary"] = secondary
         if secondary_14k is not None:
             line["secondary_14k"] = secondary_14k
+        if world == 1:
+            rep = regression_report(line)
+            if rep is not None:
+                line["regression_guard"] = rep
+                for r in rep.get("regressions", []):
+                    print(f"[bench] REGRESSION {r['record']}: {r['now']} vs {r['reference']} in {rep['against']} (x{r['ratio']})", file=sys.stderr, flush=True)
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()

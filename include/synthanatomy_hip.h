@@ -97,8 +97,8 @@ int sa_kernel_log_read(char *buf, int cap, int stop);
 #define SA_DBG_RESERVED_14       (1u << 14)  /* (was SA_DBG_TILE256: 256 x 128 tiles for the im2col-order kernel -- measured slower, instance removed) */
 #define SA_DBG_DENSE_NARROW      (1u << 15)  /* A/B: 128 x 64 tiles for every small dense grid (the round-2 rule) */
 #define SA_DBG_NO_KGROUPS        (1u << 17)  /* dense layers with about one tile per CU on the one-group kernel instead of two K groups of eight waves (conv_fprop_dma_kernel<..., 2>) */
-#define SA_DBG_CELLS             (1u << 19)  /* stride-2 convolutions / transposed-convolution classes on the cell mainloop (conv_fprop_cells_kernel): opt-in, measured equal */
-#define SA_DBG_DENSE_RING        (1u << 20)  /* opt-in (SA_DENSE_RING=1): dense layers (nn.Linear) on the four-wave ring mainloop of dense.hip (dense_gemm_kernel) -- parity-exact, measured slower than the im2col-order loops on 5 of the 8 shapes of a Performer layer */
+#define SA_DBG_RESERVED_19      (1u << 19)  /* (was SA_DBG_CELLS: the 128-voxel cell mainloop conv_fprop_cells_kernel -- a tie with im2col order in round 4, superseded by cells256, removed in round 6) */
+#define SA_DBG_RESERVED_20      (1u << 20)  /* (was SA_DBG_DENSE_RING: the four-wave ring GEMM of dense.hip -- slower on 7 of the 8 Performer shapes in round 5, removed in round 6) */
 #define SA_DBG_NO_CELLS256       (1u << 21)  /* stride-2 family on the im2col-order kernel instead of the 256-voxel cell mainloop (conv_fprop_cells256_kernel): A/B + cross-family tests */
 #define SA_DBG_NO_CLASS_LAUNCH    (1u << 22)  /* sa_conv_fprop_classes answers SA_EUNSUPPORTED: the parity classes of a transposed convolution as separate launches (A/B, equality test) */
 #define SA_DBG_FAVOR_SEQ_ALWAYS  (1u << 18)  /* FAVOR+ chunk states in the sequential form for every batch (default: from 40 (batch, head) pairs; tests) */

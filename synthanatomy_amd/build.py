@@ -31,10 +31,8 @@ def _sources():
 def _digest(path):
     h = hashlib.sha1()
     hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
-    if not path.endswith(("conv_fprop.hip", "conv_fprop_f16.hip", "dense.hip")):
+    if not path.endswith(("conv_fprop.hip", "conv_fprop_f16.hip")):
         hdrs = [h for h in hdrs if not h.endswith(("conv_fprop_common.h", "conv_fprop_kernels.h"))]     # only the forward translation units depend on them
-    elif path.endswith("dense.hip"):
-        hdrs = [h for h in hdrs if not h.endswith("conv_fprop_kernels.h")]
     if not path.endswith(("local_attn.hip", "favor_fused.hip")):
         hdrs = [h for h in hdrs if not h.endswith("local_attn_split.h")]
     for dep in [path, *hdrs, os.path.join(HERE, "..", "include", "synthanatomy_hip.h")]:
@@ -44,9 +42,8 @@ def _digest(path):
     return h.hexdigest()
 
 
-# per-file flags: dense.hip keeps its MFMA accumulators in VGPRs (at one wave per SIMD the allocator would otherwise move them to AGPRs and shuffle
-# ~120 v_accvgpr copies per K-slab between the two halves of the rotated main loop)
-EXTRA = {"dense.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wno-inline-asm"]}
+# per-file flags (none since dense.hip and its compiler-internal -mllvm flag left the tree in round 6)
+EXTRA = {}
 
 
 def _compile(src):
@@ -73,6 +70,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         res = list(ex.map(_compile, _sources()))
     objs = [o for o, _ in res]
+    for f in os.listdir(OBJ):                     # objects of sources that left the tree
+        if f.endswith(".o") and os.path.join(OBJ, f) not in objs:
+            os.remove(os.path.join(OBJ, f))
+            res.append((None, True))
     if any(c for _, c in res) or not os.path.exists(LIB):
         r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
         if r.returncode != 0:

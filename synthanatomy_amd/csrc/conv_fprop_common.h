@@ -567,10 +567,6 @@ __device__ __forceinline__ void fprop_epilogue(const FpropArgs& a, float4_t (&ac
 }
 
 
-// dense.hip: one-tap layers (nn.Linear) on the four-wave ring mainloop
-bool dense_gemm_eligible(const FpropArgs& a, int sz);
-int launch_dense_gemm(const FpropArgs& a, int dtype, hipStream_t st);
-
 // 32-bit buffer offset that is out of bounds for every operand: LDS-DMA loads from it deliver zeros (padding taps, rows beyond M)
 constexpr uint32_t OOB_OFF = 0xfffffff0u;
 

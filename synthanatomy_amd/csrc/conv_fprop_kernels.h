@@ -922,165 +922,10 @@ namespace sa {
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Mainloop v9 "cells" (round 4): the stride-2 family -- Conv3d k4 s2 p1 (forward; as the data gradient of ConvTranspose3d k4 s2 p1) and the eight
-// output-parity classes of ConvTranspose3d k4 s2 p1 (forward; data gradient of the strided convolution): 2 x 2 x 2 taps per class.  The im2col-order loop
-// stages an activation tile per tap (32 KB per K-slab with the weights; 0.24-0.35 of the matrix peak at the power cap).  In cell coordinates every one of
-// these layers is a 2 x 2 x 2 tap group over a (2 + 1) x (8 + 1) x (8 + 1) neighbourhood of cells: a tile is a 2 (D) x 8 (H) x 8 (W) block of the LOGICAL grid
-// (no padded rows at 40 x 56 x 40), its halo image (3 x 9 x 9 cells x 128 B = 31 pieces, zero-filled outside the volume by the DMA's out-of-bounds rule) sits
-// in LDS once per (tap class, 64-channel chunk) and the EIGHT taps of the class read it at shifted rows: 16 + 3.9 KB per K-slab.  For the strided convolution
-// the classes are the parities (t0) of the taps per axis: taps k = t0 + 2 c (c = 0, 1) read input 2 (m + c) + t0 - 1 = cell m + c of the class's sub-grid.
-// Four waves of 64 voxels x 64 channels (wave = (depth plane, channel half)); halo single-buffered and re-loaded behind a barrier at every group switch
-// (31 + 2 x 16 KiB = 63 KiB: two blocks per CU, the other one covers the bubble), weight slabs double-buffered by DMA.
-template <typename T, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void conv_fprop_cells_kernel(const FpropArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-    constexpr int WM = NW / 2, WN = 2, MI = 8 / WM, NI = 4;     // wave = (32- or 64-voxel slice, channel half)
-    constexpr int WPIECES = 16 / NW;
-    constexpr int BM = 128, BN = 128;
-    constexpr int HROWS = 243, HPIECES = 31;
-    constexpr int SZ = sizeof(T);
-    constexpr int HALO_BYTES = HPIECES * 1024;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const sA = smem;                   // 1 halo image
-    unsigned char* const sB = smem + HALO_BYTES;      // 2 weight slabs
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t wm = wave / WN, wn = wave % WN;
-    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-    const uint32_t bm = bid % a.nblk_m, bn = bid / a.nblk_m;
-    const uint32_t n_base = bn * BN;
-    const sa_conv_geom& g = a.g;
-    // tile -> (n, d pair, hp, wp)
-    uint32_t q = bm / a.WP;
-    const uint32_t wp = bm - q * a.WP;
-    uint32_t q2 = q / a.HP;
-    const uint32_t hp = q - q2 * a.HP;
-    const uint32_t pn = q2 / a.DP, dp = q2 - pn * a.DP;
-    const int32_t d0 = (int32_t)dp * 2, h0 = (int32_t)hp * 8, w0 = (int32_t)wp * 8;
-
-    __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (int)a.w_bytes, 0x00020000);
-
-    const uint32_t prow = lane >> 3;
-    const uint32_t lv = (lane & 7u) ^ prow;
-    uint32_t boff[WPIECES];
-#pragma unroll
-    for (int j = 0; j < WPIECES; ++j) boff[j] = (n_base + (wave * WPIECES + j) * 8 + prow) * (uint32_t)(g.Kpad * SZ) + lv * 16u;
-
-    const uint32_t npar = (uint32_t)g.in_mult[1];                 // 2: strided convolution (eight tap classes); 1: one class
-    const uint32_t nchunk = (uint32_t)(g.Cin * SZ) / 128u;
-    const uint32_t ngroups = npar * npar * npar * nchunk;
-    const uint32_t vox_bytes = (uint32_t)(g.Cin * SZ);
-
-    // per-axis base of group gi's halo: input = mult * (m + c) + base;  and the tap index of shift c
-    auto axis_base = [&](int ax, uint32_t pcls) __attribute__((always_inline)) {
-        return g.in_off[ax] + (npar == 2u ? (int32_t)pcls * g.tap_step[ax] : (g.tap_step[ax] < 0 ? g.tap_step[ax] : 0));
-    };
-    auto axis_tap = [&](int ax, uint32_t pcls, uint32_t c) __attribute__((always_inline)) {
-        return npar == 2u ? pcls + 2u * c : (g.tap_step[ax] < 0 ? 1u - c : c);
-    };
-    // the whole halo image of group gi: pieces wave, wave + 4, ...; offsets are recomputed here (no registers held across the loop)
-    auto issue_halo = [&](uint32_t gi) __attribute__((always_inline)) {
-        const uint32_t cls = gi / nchunk, ch = gi - cls * nchunk;
-        const int32_t bd = axis_base(0, cls >> 2), bh = axis_base(1, (cls >> 1) & 1u), bw = axis_base(2, cls & 1u);
-#pragma unroll 1
-        for (uint32_t p = wave; p < (uint32_t)HPIECES; p += (uint32_t)NW) {
-            const uint32_t r = p * 8 + prow;
-            const uint32_t dd = r / 81u, r2 = r - dd * 81u;
-            const uint32_t hh = r2 / 9u, ww = r2 - hh * 9u;
-            const int32_t id = g.in_mult[0] * (d0 + (int32_t)dd) + bd, ih = g.in_mult[1] * (h0 + (int32_t)hh) + bh, iw = g.in_mult[2] * (w0 + (int32_t)ww) + bw;
-            const bool ok = r < (uint32_t)HROWS && (uint32_t)id < (uint32_t)g.Di && (uint32_t)ih < (uint32_t)g.Hi && (uint32_t)iw < (uint32_t)g.Wi;
-            const uint32_t voff = ok ? (uint32_t)((((int32_t)pn * g.Di + id) * g.Hi + ih) * g.Wi + iw) * vox_bytes + ch * 128u + lv * 16u : OOB_OFF;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(sA + p * 1024), 16, voff, 0, 0, 0);
-        }
-    };
-    // weight slab of (group gi, tap t8) -> buffer `buf`
-    auto issue_w = [&](uint32_t gi, uint32_t t8, uint32_t buf) __attribute__((always_inline)) {
-        const uint32_t cls = gi / nchunk, ch = gi - cls * nchunk;
-        const uint32_t kd = axis_tap(0, cls >> 2, t8 >> 2), kh = axis_tap(1, (cls >> 1) & 1u, (t8 >> 1) & 1u), kw = axis_tap(2, cls & 1u, t8 & 1u);
-        const uint32_t col = (((kd * (uint32_t)g.KT[1] + kh) * (uint32_t)g.KT[2] + kw) * (uint32_t)g.Cin) * SZ + ch * 128u;
-#pragma unroll
-        for (int j = 0; j < WPIECES; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(sB + buf * (BN * 128) + (wave * WPIECES + j) * 1024), 16, boff[j], col, 0, 0);
-    };
-
-    float4_t acc[NI][MI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < MI; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-
-    const uint32_t frow = lane & 15u, fq = lane >> 4;
-    // unswizzled byte address of tile voxel wm * (16 MI) + 16 j + frow = (d, h, w) = (v >> 6, (v >> 3) & 7, v & 7) in the halo image, vector fq
-    uint32_t a0[MI];
-#pragma unroll
-    for (int j = 0; j < MI; ++j) {
-        const uint32_t v = wm * (uint32_t)(MI * 16) + (uint32_t)j * 16u + frow;
-        a0[j] = ((v >> 6) * 81u + ((v >> 3) & 7u) * 9u + (v & 7u)) * 128u + fq * 16u;
-    }
-    const uint32_t b_off = tile_off(wn * (NI * 16) + frow, fq);
-
-    issue_halo(0);
-    issue_w(0, 0, 0);
-    __syncthreads();
-    uint32_t buf = 0;
-    for (uint32_t gi = 0; gi < ngroups; ++gi) {
-        const bool next_group = gi + 1 < ngroups;
-#pragma unroll 1
-        for (uint32_t t8 = 0; t8 < 8; ++t8) {
-            const bool same = t8 < 7;
-            if (same || next_group) issue_w(same ? gi : gi + 1, same ? t8 + 1 : 0, buf ^ 1u);
-            const uint32_t tapoff = ((t8 >> 2) * 81u + ((t8 >> 1) & 1u) * 9u + (t8 & 1u)) * 128u;
-            const unsigned char* pb = sB + buf * (BN * 128);
-            uint32_t ax[MI];
-#pragma unroll
-            for (int j = 0; j < MI; ++j) {
-                const uint32_t ad = a0[j] + tapoff;
-                ax[j] = ad ^ (((ad >> 7) & 7u) << 4);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                u32x4 xf[MI], wf[NI];
-#pragma unroll
-                for (int j = 0; j < MI; ++j) xf[j] = *(const u32x4*)(sA + (ax[j] ^ (ks * 64u)));
-#pragma unroll
-                for (int i = 0; i < NI; ++i) wf[i] = *(const u32x4*)(pb + ((b_off + i * 2048u) ^ (ks * 64u)));
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int j = 0; j < MI; ++j) mma_slab<T>(acc[i][j], wf[i], xf[j]);
-            }
-            __syncthreads();   // next weight slab landed (vmcnt(0)), this one free
-            buf ^= 1u;
-        }
-        if (next_group) {      // every wave is past its last read of the halo image: reload it (the first weight slab of the group is in flight)
-            issue_halo(gi + 1);
-            __syncthreads();
-        }
-    }
-    auto row_vox = [&](uint32_t row) __attribute__((always_inline)) {
-        const uint32_t d = (uint32_t)d0 + (row >> 6), h = (uint32_t)h0 + ((row >> 3) & 7u), w = (uint32_t)w0 + (row & 7u);
-        if (d >= (uint32_t)g.Dm || h >= (uint32_t)g.Hm || w >= (uint32_t)g.Wm) return -1ll;
-        return (((long long)pn * g.Do + (d * g.out_mult[0] + g.out_off[0])) * g.Ho + (h * g.out_mult[1] + g.out_off[1])) * g.Wo + (w * g.out_mult[2] + g.out_off[2]);
-    };
-    // full tile of valid channels and 16-byte aligned channel rows -> register epilogue; otherwise the LDS-staged one (block-uniform choice)
-    const bool regs_ok = n_base + BN <= (uint32_t)g.cout_valid && (g.Cout & 7) == 0 && !(a.dbg & 256u) && !a.ep.out_pre && (!a.ep.out_lp || std::is_same<T, f16_t>::value);
-    if constexpr (MI == 4) {
-        if (regs_ok) {
-            fprop_epilogue_regs<MI, NI, 32, std::is_same<T, f16_t>::value>(a, acc, wm, wn, frow, fq, n_base, row_vox);
-            return;
-        }
-    }
-    (void)regs_ok;
-    fprop_epilogue_ov<BM, BN, WM, WN, MI, NI, NW * 64>(a, acc, smem, tid, wm, wn, frow, fq, n_base, row_vox);
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-// Mainloop v10 "cells256" (round 5): the cell mainloop above with 256-voxel tiles.  Ablation of the im2col-order loop on the config-2 down-sampling layer at
+// Mainloop v10 "cells256" (round 5): the stride-2 family in CELL coordinates with 256-voxel tiles.  Conv3d k4 s2 p1 (eight tap-parity classes) and the eight
+// output-parity classes of ConvTranspose3d k4 s2 p1 are 2 x 2 x 2 tap groups over a neighbourhood of cells: for the strided convolution the classes are the
+// parities (t0) of the taps per axis, taps k = t0 + 2 c (c = 0, 1) read input 2 (m + c) + t0 - 1 = cell m + c of the class's sub-grid.  (Round 4's 128-voxel
+// form of this loop, conv_fprop_cells_kernel, tied with the im2col-order kernel and left the tree in round 6: DESIGN Appendix A.)  Ablation of the im2col-order loop on the config-2 down-sampling layer at
 // batch 8 (tools/conv_ablate.sh: 1.90 ms in full, 1.17 ms without the activation DMA, 1.43 ms without the weight DMA, 0.98 ms with neither) says the stride-2
 // family is bound by what it pulls through L2 -> L1 -> LDS: 2 MB of activation rows AND 2 MB of weight slabs per 128 x 128 tile (23 GB per launch, ~15 TB/s).
 // The 128-voxel cell tile cuts the activation half (each staged halo row serves eight taps) and ties; the weight half only shrinks with more voxels per block.
@@ -1412,28 +1257,11 @@ static int launch_fprop_halo256(FpropArgs a, hipStream_t st) {
     }
 }
 
-// the cell mainloop applies to the stride-2 family (taps 4 / input multiplier 2, or taps 2 / multiplier 1 with any output multiplier), 16-bit operands.
-// OPT-IN (SA_CELLS=1 / SA_DBG_CELLS): measured on the config-2 step it ties with the im2col-order kernel on the same launches (bf16: 65.6-67.2 vs 66.3-66.7 ms
-// per ten steps, f16 forward 17.9 vs 17.3 ms; step 122.7 / 124.3 vs 123.9 / 124.7 ms in alternating runs) although it stages a third fewer bytes per K-slab:
-// the single-buffered halo reload (31 pieces behind a barrier every eight slabs) costs what the smaller stream saves.
-static bool cells_eligible(const FpropArgs& a, int sz) {
-    const sa_conv_geom& g = a.g;
-    if (!dbg(SA_DBG_CELLS) || dbg(SA_DBG_NO_HALO) || sz != 2 || a.in_bytes == 0 || g.cout_valid <= 64 || ((size_t)g.Cin * sz) % 128 != 0) return false;
-    const bool strided = g.KT[0] == 4;
-    for (int d = 0; d < 3; ++d) {
-        if (strided ? (g.KT[d] != 4 || g.in_mult[d] != 2 || g.tap_step[d] != 1) : (g.KT[d] != 2 || g.in_mult[d] != 1 || (g.tap_step[d] != 1 && g.tap_step[d] != -1))) return false;
-    }
-    if ((size_t)g.Kpad != (size_t)g.KT[0] * g.KT[1] * g.KT[2] * g.Cin) return false;
-    const int dp = (g.Dm + 1) / 2, hp = (g.Hm + 7) / 8, wp = (g.Wm + 7) / 8;
-    const double eff = (double)g.Dm * g.Hm * g.Wm / ((double)dp * 2 * hp * 8 * wp * 8);
-    return eff >= 0.85 && (int64_t)g.N * dp * hp * wp >= 512;
-}
-
 // cells256: default for the stride-2 family when the register epilogue applies (whole 128-channel tiles, 16-byte rows, no pre-activation copy, a bf16 copy of
 // the output only from f16 launches) and 4 x 8 x 8-cell tiles waste little; SA_DBG_NO_CELLS256 (SA_NO_CELLS256=1) restores the im2col-order kernel.
 static bool cells256_eligible(const FpropArgs& a, int sz, bool f16) {
     const sa_conv_geom& g = a.g;
-    if (dbg(SA_DBG_NO_CELLS256) || dbg(SA_DBG_CELLS) || dbg(SA_DBG_NO_HALO) || sz != 2 || a.in_bytes == 0 || ((size_t)g.Cin * sz) % 128 != 0) return false;
+    if (dbg(SA_DBG_NO_CELLS256) || dbg(SA_DBG_NO_HALO) || sz != 2 || a.in_bytes == 0 || ((size_t)g.Cin * sz) % 128 != 0) return false;
     if (g.cout_valid % 128 != 0 || (g.Cout & 7) != 0 || a.ep.out_pre || (a.ep.out_lp && !f16)) return false;
     const bool strided = g.KT[0] == 4;
     for (int d = 0; d < 3; ++d) {
@@ -1462,24 +1290,6 @@ static int launch_fprop_cells256(FpropArgs a, hipStream_t st) {
 }
 
 template <typename T>
-static int launch_fprop_cells(FpropArgs a, hipStream_t st) {
-    a.DP = (uint32_t)(a.g.Dm + 1) / 2;
-    a.HP = (uint32_t)(a.g.Hm + 7) / 8;
-    a.WP = (uint32_t)(a.g.Wm + 7) / 8;
-    a.nblk_m = (uint32_t)a.g.N * a.DP * a.HP * a.WP;
-    const uint32_t nbn_valid = ((uint32_t)a.g.cout_valid + 127) / 128;
-    const size_t pipe = 31 * 1024 + 2 * 128 * 128, epi = (size_t)128 * (128 + 4) * 4 + 128 * 8;
-    static std::atomic<uint64_t> attr_done{0};   // one bit per device (one static per template instance)
-    configure_once_per_device(attr_done, [] { (void)hipFuncSetAttribute((const void*)conv_fprop_cells_kernel<T, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); });
-    // eight waves of 32 x 64 outputs (four waves per SIMD with two blocks per CU), as on the im2col-order kernel; the four-wave form (64 x 64 per wave, register
-    // epilogue) measured the same 690 TFLOP/s and is not instantiated
-    (snprintf(g_last_conv_kernel, sizeof g_last_conv_kernel, "conv_fprop_cells_kernel<%s, 8>", tname<T>()), note_kernel(g_last_conv_kernel));
-    hipLaunchKernelGGL((conv_fprop_cells_kernel<T, 8>), dim3(a.nblk_m * nbn_valid), dim3(512), pipe > epi ? pipe : epi, st, a);
-    SA_CHECK_LAUNCH();
-    return 0;
-}
-
-template <typename T>
 static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
     const int cv = a.g.cout_valid;
     if (a.ep.out_pre || a.ep.out_lp) {
@@ -1494,10 +1304,6 @@ static int dispatch_fprop(const FpropArgs& a, hipStream_t st) {
     if (!multi && halo_eligible(a, (int)sizeof(T))) return launch_fprop_halo<T, false>(a, st);
     if constexpr (sizeof(T) == 2) {
         if (cells256_eligible(a, 2, std::is_same<T, f16_t>::value)) return launch_fprop_cells256<T>(a, st);
-        if (cells_eligible(a, 2)) return multi ? SA_EUNSUPPORTED : launch_fprop_cells<T>(a, st);      // (the opt-in 128-voxel cell kernel: one class per launch)
-        if (multi && dense_gemm_eligible(a, 2)) return SA_EUNSUPPORTED;
-        // dense layers (one tap, identity row map): opt-in (SA_DBG_DENSE_RING) four-wave ring mainloop of dense.hip
-        if (dense_gemm_eligible(a, 2)) return launch_dense_gemm(a, std::is_same<T, f16_t>::value ? SA_F16 : SA_BF16, st);
     }
     // (measured and removed: a 3-stage ring with 8 waves and counted vmcnt = the 2-stage loop; an 8-wave ping-pong with staggered
     // barriers and s_setprio = -7 %: the L2 -> LDS operand stream bounds this loop, not the barrier structure.  DESIGN.md section 4.1)

@@ -40,10 +40,8 @@ static uint32_t flags_from_env() {
     if (on("SA_DETERMINISTIC")) f |= SA_DBG_DETERMINISTIC;
     if (on("SA_NO_KGROUPS")) f |= SA_DBG_NO_KGROUPS;
     if (on("SA_FAVOR_SEQ_ALWAYS")) f |= SA_DBG_FAVOR_SEQ_ALWAYS;
-    if (on("SA_CELLS")) f |= SA_DBG_CELLS;
     if (on("SA_NO_CELLS256")) f |= SA_DBG_NO_CELLS256;
     if (on("SA_NO_CLASS_LAUNCH")) f |= SA_DBG_NO_CLASS_LAUNCH;
-    if (on("SA_DENSE_RING")) f |= SA_DBG_DENSE_RING;
     if (on("SA_SCAN_VALU")) f |= SA_DBG_SCAN_VALU;
     if (num("SA_LOCAL_ATTN_EXACT", 0) == 1) f |= SA_DBG_LOCAL_ATTN_EXACT;
     f |= ((uint32_t)num("SA_SCAN_EXACT", 0) & 7u) << SA_DBG_SCAN_EXACT_SHIFT;

@@ -14,7 +14,7 @@ import contextlib
 import os
 
 LIB_FLAGS = dict(no_halo=1 << 0, no_halo256=1 << 1, no_halo256_fuse=1 << 2, no_dma=1 << 3, no_small_tiles=1 << 4, no_fused_db=1 << 5,
-                 no_wgrad_halo9=1 << 6, im2col_direct=1 << 7, scan_valu=1 << 8, local_attn_exact=1 << 9, halo256_4w=1 << 13, dense_narrow=1 << 15, deterministic=1 << 16, no_kgroups=1 << 17, favor_seq_always=1 << 18, cells=1 << 19, dense_ring=1 << 20, no_cells256=1 << 21, no_class_launch=1 << 22)
+                 no_wgrad_halo9=1 << 6, im2col_direct=1 << 7, scan_valu=1 << 8, local_attn_exact=1 << 9, halo256_4w=1 << 13, dense_narrow=1 << 15, deterministic=1 << 16, no_kgroups=1 << 17, favor_seq_always=1 << 18, no_cells256=1 << 21, no_class_launch=1 << 22)
 SCAN_EXACT_SHIFT = 10   # scan_exact=0..7
 
 _HOST_ENV = dict(no_fused_res="SA_NO_FUSED_RES", no_fused_1x1_bwd="SA_NO_FUSED_1X1_BWD", no_conv1_gemm="SA_NO_CONV1_GEMM",

@@ -13,6 +13,7 @@ and running-state scans, fp32 rotary + banded local attention.  See oracle/perfo
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import math
 import os
@@ -294,8 +295,16 @@ def _favor_bracket_end(e0, key, flops):
 class _SideWgrad:
     """Weight gradients on a second HIP stream.  They are leaves of the backward pass: nothing on the main chain reads a dW before the optimizer, and the dense
     data-gradient launches they sit between run one block per CU (§4.4 (iii)) -- the weight-gradient blocks of the other queue share those CUs.  Every launch is
-    ordered behind an event of the main stream (its operands are complete), its operands are handed to the side stream with record_stream (the allocator must not
-    recycle them while the side launch still reads), and the main stream joins once at the end of the backward pass."""
+    ordered behind an event of the main stream (its operands are complete) and the main stream joins once at the end of the backward pass.
+
+    Operand lifetime (round 6): the operands of the last ``LAG`` side launches are kept alive HERE, and before the launch that pushes one out of that window
+    the main stream waits for its completion event -- so an operand returns to the main stream's allocator pool only behind a stream-ordered wait, and the next
+    main-stream kernel that is handed the same block cannot overtake the side launch still reading it.  Rounds 3-5 used ``Tensor.record_stream`` instead: the
+    caching allocator then parks every freed operand until an event recorded AT FREE TIME on the side stream has completed, and with the host a whole iteration
+    ahead of the device no block ever became reusable -- the pool of the adversarial iteration grew to 113 GB for 29 GB of live tensors, with GB-sized
+    ``hipMalloc``s inside the first dozen iterations (the 1 431 ms "adversarial" record of round 5: one warm-up + three timed iterations, all of them allocating)."""
+
+    LAG = int(os.environ.get("SA_SIDE_WGRAD_LAG", "3"))
 
     def __init__(self, dev):
         self.main = torch.cuda.current_stream(dev)
@@ -303,19 +312,25 @@ class _SideWgrad:
         if key not in _SIDE_STREAMS:
             _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
         self.side = _SIDE_STREAMS[key]
+        self.inflight = collections.deque()
 
     def run(self, fn, *operands):
         ev = torch.cuda.Event()
         ev.record(self.main)
         self.side.wait_event(ev)
-        for t in operands:
-            if t is not None:
-                t.record_stream(self.side)
         with torch.cuda.stream(self.side):
-            fn()
+            fn()                                  # (workspaces allocated in here come from the side stream's own pool: stream-ordered reuse)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        self.inflight.append((done, operands))
+        while len(self.inflight) > self.LAG:
+            old, ops = self.inflight.popleft()
+            self.main.wait_event(old)
+            del ops
 
     def join(self):
         self.main.wait_stream(self.side)
+        self.inflight.clear()
 
 
 class _GradCtx:

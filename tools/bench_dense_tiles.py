@@ -37,7 +37,7 @@ def main():
         ref = None
         cols = []
         for label, kw in (("2buf narrow", dict(no_small_tiles=False, no_kgroups=True)), ("2buf wide", dict(no_small_tiles=True, no_kgroups=True)),
-                          ("ring (opt-in)", dict(dense_ring=True)), ("product", dict())):
+                          ("product", dict())):
             with debug.override(**kw):
                 t = timeit(lambda: op.fprop(x, out_dtype=torch.float32))
                 y = op.fprop(x, out_dtype=torch.float32)
