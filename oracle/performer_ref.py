@@ -2,7 +2,7 @@
 
 PARITY UNPINNED.  The arithmetic of this path does not live in the reference tree: ``src/networks/transformers/
 performer.py:8-16,194-219`` delegates to the third-party ``performer-pytorch==1.0.11`` (docker/requirements.txt:10),
-which uses the un-pinned ``local-attention`` package and, on CUDA, ``fast_transformers.causal_product`` (docker/Dockerfile:32).
+which uses the un-pinned ``local-attention`` package and, on CUDA, ``fast_transformers.causal_product`` (docker/Dockerfile:20).
 None of them is installed or vendored here and the reference has no tests or golden vectors for this path, so this file
 restates the PUBLISHED algorithms as best known and is the build's frozen spec ("spec by restatement"):
 

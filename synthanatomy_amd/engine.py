@@ -297,12 +297,18 @@ class ConvOp:
             n = len(plans)
             geoms = (ConvGeom * n)(*[pl.geom for pl in plans])
             wpks = (ctypes.c_void_p * n)(*[pl.wpk.data_ptr() for pl in plans])
-            rc = []
-            _launch(None, sum(_geom_flops(pl.geom) for pl in plans),
-                    lambda: rc.append(lib.sa_conv_fprop_classes(geoms, n, did, _ffi.ptr(src), wpks, _ffi.ptr(dst), ctypes.byref(ep), st)))
-            if rc[0] != _ffi.SA_EUNSUPPORTED:
-                _ffi.check(rc[0], what + " (classes)")
-                return
+            if not getattr(plans[0], "no_classes", False):
+                # (a timer bracket is recorded only for a launch that happened: SA_EUNSUPPORTED launches nothing, and its bracket would credit the summed
+                #  FLOPs of all classes to whichever kernel ran before)
+                rc = []
+                pend = len(TIMER.pending) if TIMER is not None else 0
+                _launch(None, sum(_geom_flops(pl.geom) for pl in plans),
+                        lambda: rc.append(lib.sa_conv_fprop_classes(geoms, n, did, _ffi.ptr(src), wpks, _ffi.ptr(dst), ctypes.byref(ep), st)))
+                if rc[0] != _ffi.SA_EUNSUPPORTED:
+                    _ffi.check(rc[0], what + " (classes)")
+                    return
+                if TIMER is not None:
+                    del TIMER.pending[pend:]
         for pl in plans:
             _launch(None, _geom_flops(pl.geom),
                     lambda pl=pl: _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(src), _ffi.ptr(pl.wpk), _ffi.ptr(dst), ctypes.byref(ep), st), what))

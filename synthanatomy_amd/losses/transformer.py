@@ -61,7 +61,12 @@ class _WeightedCEFn(torch.autograd.Function):
         if d is not None:
             d.mul_(wr.view(B, N, 1))
         ctx.d = d
-        return (row_loss * wr).sum()
+        terms = (row_loss * wr).contiguous()
+        if debug.deterministic():     # fixed-order sum, like every other reduction of the deterministic mode
+            out = torch.empty((), dtype=torch.float32, device=rows.device)
+            _ffi.check(_ffi.lib().sa_sum_det(_ffi.ptr(terms), terms.numel(), _ffi.ptr(out), 0, _ffi.stream()), "sa_sum_det")
+            return out
+        return terms.sum()
 
     @staticmethod
     def backward(ctx, g):
@@ -75,13 +80,17 @@ class CELoss(torch.nn.Module):
         super().__init__()
         if reduction not in ["sum", "mean"]:
             raise ValueError("Reduction must be either 'sum' or 'mean'")
-        self._weight = weight
+        # a buffer like torch.nn.CrossEntropyLoss.weight: follows .to(device) and is moved once, not per step.  ("mean" with every target ignored divides by a
+        # zero weight sum and returns NaN, as torch does.)
+        self.register_buffer("weight", None if weight is None else torch.as_tensor(weight, dtype=torch.float32).clone())
         self.reduction = reduction
         self.summaries: Dict = {"scalar": {}}
 
     def forward(self, y_pred: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-        if self._weight is not None:
-            loss = _WeightedCEFn.apply(y_pred, y, self._weight, self.reduction == "mean")
+        if self.weight is not None:
+            if self.weight.device != y_pred.device:
+                self.weight = self.weight.to(y_pred.device)        # one copy, then resident
+            loss = _WeightedCEFn.apply(y_pred, y, self.weight, self.reduction == "mean")
         else:
             loss = _CEFn.apply(y_pred, y, self.reduction == "mean")
         self.summaries["scalar"]["Loss-CE-Prediction"] = loss.detach()

@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from ... import _ffi, debug
 from ..._ffi import ACT_NONE, ACT_RELU, MASK_NONE, MASK_POS
-from ...engine import ConvOp, PackSet, _launch, cast_pad, vec_of
+from ...engine import ConvOp, PackSet, _launch, _ru, cast_pad, vec_of
 from .vqvae import VQVAEBase
 
 
@@ -480,18 +480,21 @@ class _ResStage:
                                                                        ctypes.byref(ep), st), "sa_resblock_fprop"))
         return (_Act(y, ys) if self.mixed else y), h
 
-    def _dropout_mask(self, N, C, dev):
-        """nn.Dropout3d (baseline.py:155): whole channels of a sample are zeroed with probability p, the others scaled by 1 / (1 - p); [N, 1, 1, 1, C] fp32."""
+    def _dropout_mask(self, N, C, dev, stride=None):
+        """nn.Dropout3d (baseline.py:155): whole channels of a sample are zeroed with probability p, the others scaled by 1 / (1 - p); [N, 1, 1, 1, stride] fp32
+        (``stride`` = the channel stride of the hidden tensor: padding channels beyond C carry ones)."""
         p = self.mod.p_dropout
-        keep = torch.bernoulli(torch.full((N, 1, 1, 1, C), 1.0 - p, device=dev))
-        return keep / (1.0 - p)
+        keep = torch.bernoulli(torch.full((N, 1, 1, 1, C), 1.0 - p, device=dev)) / (1.0 - p)
+        if stride is not None and stride > C:
+            keep = torch.cat([keep, torch.ones((N, 1, 1, 1, stride - C), device=dev)], dim=-1)
+        return keep
 
     def _fwd_dropout(self, xf, xs, tape):
         """Training step with p_dropout > 0: relu(conv3(x)) -> channel mask -> conv1 + x -> relu as two launches with the mask (a broadcast multiply on the device)
         between them.  Saved for the backward pass: x, the MASKED hidden activation (the operand of the 1x1x1 weight gradient; its sign pattern is the ReLU mask
         of the surviving channels) and the mask."""
         N, C = xf.shape[0], self.c3.cout
-        m = self._dropout_mask(N, C, xf.device)
+        m = self._dropout_mask(N, C, xf.device, _ru(C, vec_of(self.dtype)))
         if self.mixed:
             hf, _, h = self.c3.fprop(xf, act=ACT_RELU, want_lp=True)
             hf = (hf * m).to(hf.dtype)
@@ -502,14 +505,15 @@ class _ResStage:
             h = self.c3.fprop(xf, act=ACT_RELU)
             h = (h * m).to(h.dtype)
             y = self.c1.fprop(h, act=ACT_RELU, addend=xf, add_before_act=True)
-        tape.append((xs, h, m))
+        if tape is not None:
+            tape.append((xs, h, m))
         return y
 
     def fwd(self, x, tape):
         self._sync()
         xf, xs = _fs(x)
         rec = tape is not None
-        if rec and self.mod.p_dropout > 0.0 and self.mod.training:
+        if self.mod.p_dropout > 0.0 and self.mod.training:      # nn.Dropout3d is active whenever the module trains, recorded or not (no_grad forward in train())
             return self._fwd_dropout(xf, xs, tape)
         if self._fused_ok(xf):
             y, h = self._fwd_fused(xf, rec)

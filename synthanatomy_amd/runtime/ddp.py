@@ -51,7 +51,13 @@ def init_distributed(backend: Optional[str] = None, timeout_s: Optional[float] =
     import datetime
     ipc_mode_default()
     if timeout_s is None:
-        timeout_s = float(os.environ.get("SA_DIST_TIMEOUT_S", DEFAULT_TIMEOUT_S))
+        raw = os.environ.get("SA_DIST_TIMEOUT_S")
+        try:
+            timeout_s = float(raw) if raw not in (None, "") else DEFAULT_TIMEOUT_S
+        except ValueError:
+            raise ValueError(f"SA_DIST_TIMEOUT_S={raw!r}: expected the collective timeout in seconds (a number > 0)") from None
+    if not timeout_s > 0:
+        raise ValueError(f"collective timeout must be > 0 seconds, got {timeout_s!r} (SA_DIST_TIMEOUT_S / init_distributed(timeout_s=...))")
     os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -61,6 +67,11 @@ def init_distributed(backend: Optional[str] = None, timeout_s: Optional[float] =
         backend = backend or "gloo"
     single = world == 1 and "RANK" in os.environ and "MASTER_PORT" in os.environ and debug.host("ddp_single_rank")   # one-GPU box: RCCL on a one-rank group
     if (world > 1 or single) and not dist.is_initialized():
+        if torch.cuda.is_available():
+            # load (or, on a cold node, build) the HIP library BEFORE the rendezvous: a rank that compiles for minutes behind init_process_group would run the
+            # others into the collective timeout
+            from .. import _ffi
+            _ffi.lib()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
