@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 3   /* 3 (round 5): sa_sample_step takes top_k.  2 (round 4): sa_local_attn_fwd/bwd + sa_epilogue grew trailing pointers in round 3, SA_F16 operand type, sa_mse partials; a caller built against 1 must not load this library */
+#define SA_ABI_VERSION 4   /* 4 (round 6): + sa_rotary_pairs, sa_subpixel_pool_fwd / _bwd (additions only; developer switches SA_DBG_CELLS / SA_DBG_DENSE_RING retired).  3 (round 5): sa_sample_step takes top_k.  2 (round 4): sa_local_attn_fwd/bwd + sa_epilogue grew trailing pointers in round 3, SA_F16 operand type, sa_mse partials; a caller built against 1 must not load this library */
 enum { SA_F32 = 0, SA_BF16 = 1, SA_F16 = 2 /* IEEE half: FORWARD operand / activation type only (the reference's AMP dtype, src/engines/trainer.py:161-163); see sa_conv_fprop */ };
 enum { SA_ACT_NONE = 0, SA_ACT_RELU = 1, SA_ACT_LRELU = 2, SA_ACT_GELU = 3 };
 enum { SA_MASK_NONE = 0, SA_MASK_POS = 1 /* out *= (mask > 0) */, SA_MASK_LRELU = 2 /* out *= mask>0 ? 1 : slope */,
@@ -195,6 +195,11 @@ int sa_vq_embed(const float *codebook, const int64_t *idx, int64_t M, int K, int
 /* ---- small fused elementwise / reduction kernels ---------------------------------------------------------------- */
 /* dst[i*dst_stride + c] = (c < src_c) ? src[i*src_c + c] : 0,  i < rows  (dtype conversion + channel padding) */
 int sa_cast_pad(const void *src, int src_dtype, int src_c, void *dst, int dst_dtype, int dst_stride, int64_t rows, void *stream);
+/* use_subpixel_conv=True (reference src/networks/vqvae/baseline.py:274-282: the last decoder layer is MONAI's SubpixelUpsample(3, n_channels // 2, 1, scale_factor=2,
+ * apply_pad_pool=True)): the tail behind its conv_block.  c [N, D, H, W, 8] fp32 (channel = (fd*2 + fh)*2 + fw) -> pixelshuffle -> ConstantPad3d((1, 0) x 3) ->
+ * AvgPool3d(2, stride 1) -> out [N, 2D, 2H, 2W] fp32; _bwd: the adjoint, g [N, 2D, 2H, 2W] fp32 -> dc [N, D, H, W, 8] in dc_dtype (SA_F32 / SA_BF16). */
+int sa_subpixel_pool_fwd(const float *c, float *out, int N, int D, int H, int W, void *stream);
+int sa_subpixel_pool_bwd(const float *g, void *dc, int dc_dtype, int N, int D, int H, int W, void *stream);
 /* MSELoss (losses/vqvae/vqvae.py:14-71): loss_sum[0] += sum (a-b)^2 ; grad = (a-b) * (2*gscale/n) if grad != NULL */
 int sa_mse(const float *a, const float *b, int64_t n, float *loss_sum, float *grad, float gscale, void *stream);
 /* Adam (torch.optim.Adam semantics, run_vqvae.py:82-86) over a flat fp32 parameter buffer; step >= 1 */
@@ -334,6 +339,12 @@ int sa_rotary(const float *x, int stride, int off, int L, int dh, const float *c
 /* the same rotation for `ngroups` operands in one launch (q and k of a layer): operand gi is read x_goff and written y_goff ELEMENTS behind operand 0 */
 int sa_rotary_groups(const float *x, int stride, int off, int L, int dh, const float *cosb, const float *sinb, float *y, int y_stride, int y_off,
                      int N, int64_t R, int transpose, int accumulate, int ngroups, int64_t x_goff, int64_t y_goff, void *y_lp, void *stream);
+/* rotary embedding of the GLOBAL heads -- the wrapper's rotary_position_emb=True (reference src/networks/transformers/performer.py:134-137,246: layer_pos_emb handed
+ * to every performer_pytorch SelfAttention, whose apply_rotary_pos_emb rotates q / k of the FAVOR+ heads): pairs of consecutive dimensions (2i, 2i + 1) of L head
+ * rows of width dh at column `off` of x [R, stride] are rotated by the angle of columns i (sine) and dh/2 + i (cosine) of row (r mod N) of `sincos` [N, dh];
+ * transpose=1 applies the adjoint; `ngroups` operands x_goff / y_goff ELEMENTS apart (q and k) in one launch; y may alias x. */
+int sa_rotary_pairs(const float *x, int stride, int off, int L, int dh, const float *sincos, float *y, int y_stride, int y_off, int N, int64_t R, int transpose,
+                    int ngroups, int64_t x_goff, int64_t y_goff, void *stream);
 /* "_lp" outputs (here and in sa_local_attn_* / sa_favor_fused_*): optional (NULL = none) bf16 mirror of an fp32 output matrix -- every element written
  * to the fp32 rows is also written, rounded to nearest even, at the SAME element offset (strides and offsets in elements) of the bf16 buffer.  It is the
  * operand the next dense layer consumes, so the stand-alone fp32 -> bf16 cast launch (and its read of the fp32 matrix) disappears. */

@@ -16,6 +16,11 @@ restates the PUBLISHED algorithms as best known and is the build's frozen spec (
                  multiple of the window, look_backward=1, look_forward=0, causal mask q_pos < k_pos, softmax over <= 2*window keys
 * FeedForward    Linear(dim, 4 dim) -> GELU(erf) -> Linear(4 dim, dim)
 * projection     gaussian_orthogonal_random_matrix(nb_rows = int(d ln d), d, scaling=0)
+* non-README options of the wrapper (round 6; performer.py:94-106,134-148,201,286-288): ``rotary_position_emb`` (performer_pytorch 1.0.11
+                 ``apply_rotary_pos_emb``: q, k of the GLOBAL heads rotated pairwise -- rotate_every_two -- with the sin | cos rows of
+                 FixedPositionalEmbedding(dim_head); the sinusoidal table of width dim is still added to x), ``axial_position_emb``
+                 (axial_positional_embedding: parameters weights_0 [1, s0, 1, dim], weights_1 [1, 1, s1, dim], summed and flattened),
+                 ``tie_embed`` (logits = x @ token_emb.weight^T), ``emb_dropout`` (nn.Dropout on the summed embeddings)
 
 Known ambiguities: the key-stabiliser scope and the local-attention relative-position variant.
 What IS pinned: ordering / batch preparation / sampling post-processing (tests/golden/{ordering,sample}.npz) and the
@@ -47,6 +52,11 @@ class PerformerConfig:
     nb_features: Optional[int] = None
     spatial_shape: tuple = (10, 14, 10)
     use_rezero: bool = True
+    # the non-README options of the wrapper (reference performer.py:94-106,134-148,201,286-288)
+    rotary_position_emb: bool = False       # sinusoidal pos_emb on x + rotate-every-two of q / k of the GLOBAL heads in every layer (performer_pytorch 1.0.11)
+    axial_position_emb: bool = False        # axial_positional_embedding.AxialPositionalEmbedding(dim, axial_position_shape), summed form
+    axial_position_shape: Optional[tuple] = None
+    tie_embed: bool = False                 # logits = x @ token_emb.weight^T, no to_out
 
     @property
     def m(self):
@@ -217,6 +227,30 @@ def local_attention_bucketed(q, k, v, window, rotary=True):
 
 
 # ------------------------------------------------------------------------------------------------ network
+def rotate_every_two(x):
+    """performer_pytorch 1.0.11: (x0, x1, x2, x3, ...) -> (-x1, x0, -x3, x2, ...)"""
+    x1, x2 = x[..., 0::2], x[..., 1::2]
+    return torch.stack((-x2, x1), dim=-1).reshape(x.shape)
+
+
+def apply_rotary_pos_emb(q, k, sinu_pos):
+    """performer_pytorch 1.0.11 ``apply_rotary_pos_emb``: sinu_pos [n, dim_head] = sin | cos halves of FixedPositionalEmbedding(dim_head); every frequency
+    serves a PAIR of consecutive dimensions."""
+    half = sinu_pos.shape[-1] // 2
+    sin, cos = sinu_pos[:, :half], sinu_pos[:, half:]
+    sin, cos = sin.repeat_interleave(2, dim=-1), cos.repeat_interleave(2, dim=-1)
+    return q * cos + rotate_every_two(q) * sin, k * cos + rotate_every_two(k) * sin
+
+
+def axial_position_table(st, shape):
+    """axial_positional_embedding.AxialPositionalEmbedding(dim, shape) in its summed form: position t of the flattened (s0, s1) grid gets
+    weights_0[t // s1] + weights_1[t % s1]."""
+    s0, s1 = shape
+    w0, w1 = st["pos_emb.weights_0"], st["pos_emb.weights_1"]
+    dim = w0.shape[-1]
+    return (w0.expand(1, s0, s1, dim) + w1.expand(1, s0, s1, dim)).reshape(s0 * s1, dim)
+
+
 def self_attention(st, p, cfg: PerformerConfig, x):
     b, n, _ = x.shape
     h, gh = cfg.heads, cfg.heads - cfg.local_attn_heads
@@ -227,8 +261,11 @@ def self_attention(st, p, cfg: PerformerConfig, x):
     outs = []
     if gh > 0:
         proj = st[p + ".fast_attention.projection_matrix"]
-        qp = softmax_kernel(q[:, :gh], proj, True)
-        kp = softmax_kernel(k[:, :gh], proj, False)
+        qg, kg = q[:, :gh], k[:, :gh]
+        if cfg.rotary_position_emb:      # SelfAttention.forward of performer_pytorch 1.0.11: only the global heads see pos_emb
+            qg, kg = apply_rotary_pos_emb(qg, kg, fixed_position_table(cfg.dim_head, cfg.max_seq_len)[:n])
+        qp = softmax_kernel(qg, proj, True)
+        kp = softmax_kernel(kg, proj, False)
         outs.append(causal_linear_attention(qp, kp, v[:, :gh]))
     if gh < h:
         outs.append(local_attention(q[:, gh:], k[:, gh:], v[:, gh:], cfg.local_window_size))
@@ -270,7 +307,7 @@ def fixed_position_table(dim, max_seq_len):
     return torch.cat((sin_inp.sin(), sin_inp.cos()), dim=-1)
 
 
-def embed(st, cfg: PerformerConfig, tokens, spatial_index_sequences, conditionings=None, conditioning_type="none", spatial_position_emb="absolute"):
+def embed(st, cfg: PerformerConfig, tokens, spatial_index_sequences, conditionings=None, conditioning_type="none", spatial_position_emb="absolute", emb_mask=None):
     """performer.py:241-266: token emb + zero-front-padded spatial embeddings (learned `absolute` tables indexed by coordinate, or `fixed`
     sinusoids) [+ conditioning: BOS replacement or prepending] + absolute positional embedding."""
     b, n = tokens.shape
@@ -287,17 +324,25 @@ def embed(st, cfg: PerformerConfig, tokens, spatial_index_sequences, conditionin
     elif conditionings and conditioning_type == "prepending":          # performer.py:262-264 (the last conditioning ends up first)
         for i, cond in enumerate(conditionings):
             x = torch.cat((F.embedding(cond, st[f"conditioning_emb.{i}.weight"]), x), dim=1)
-    pos = st["pos_emb.emb"] if "pos_emb.emb" in st else st["pos_emb.emb.weight"]      # the fixed sinusoidal buffer, or the learned table
+    if cfg.axial_position_emb:
+        shape = cfg.axial_position_shape or (math.ceil(cfg.max_seq_len / 64), 64)       # performer.py:141-144
+        pos = axial_position_table(st, shape)
+    else:
+        pos = st["pos_emb.emb"] if "pos_emb.emb" in st else st["pos_emb.emb.weight"]      # the fixed sinusoidal buffer, or the learned table
     x = x + pos[: x.shape[1]][None]
+    if emb_mask is not None:           # nn.Dropout(emb_dropout) in training (performer.py:201,270): the mask = keep / (1 - p), handed in by the test
+        x = x * emb_mask
     return x
 
 
-def forward(st, cfg: PerformerConfig, tokens, spatial_index_sequences, conditionings=None, conditioning_type="none", spatial_position_emb="absolute"):
-    x = embed(st, cfg, tokens, spatial_index_sequences, conditionings, conditioning_type, spatial_position_emb)
+def forward(st, cfg: PerformerConfig, tokens, spatial_index_sequences, conditionings=None, conditioning_type="none", spatial_position_emb="absolute", emb_mask=None):
+    x = embed(st, cfg, tokens, spatial_index_sequences, conditionings, conditioning_type, spatial_position_emb, emb_mask)
     x = layer_stack(st, cfg, x)
     x = F.layer_norm(x, (cfg.dim,), st["norm.weight"], st["norm.bias"])
     if conditionings and conditioning_type == "prepending":            # performer.py:279-281
         x = x[:, len(conditionings):, :]
+    if cfg.tie_embed:                                                  # performer.py:286-288
+        return x @ st["token_emb.weight"].t()
     return F.linear(x, st["to_out.weight"], st["to_out.bias"])
 
 

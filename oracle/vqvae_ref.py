@@ -47,6 +47,7 @@ class VQVAEConfig:
     commitment_cost: float = 0.25
     vq_decay: float = 0.5
     eps: float = 1e-5
+    use_subpixel_conv: bool = False     # baseline.py:274-282: the LAST up-sampling layer is MONAI's SubpixelUpsample(3, n_channels // 2, 1, scale_factor, apply_pad_pool=True)
 
     def enc_channels(self, level: int) -> Tuple[int, int]:
         cin = 1 if level == 0 else self.n_channels // 2
@@ -101,7 +102,12 @@ def init_state(cfg: VQVAEConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
         for r in range(cfg.n_res_layers):
             conv(f"decoder.0.{1 + 3 * i}.{r}.0", cin, cin, 3)
             conv(f"decoder.0.{1 + 3 * i}.{r}.3", cin, cin, 1)
-        convT(f"decoder.0.{2 + 3 * i}", cin, cout, cfg.upsample_parameters[i][0])
+        if cfg.use_subpixel_conv and i == cfg.n_levels - 1:
+            # MONAI SubpixelUpsample: `conv_block` = Conv3d(n_channels // 2 -> out_channels * scale^3, k 3, p 1); (its ICNR initialisation is not restated: parity
+            # tests load explicit weights)
+            conv(f"decoder.0.{2 + 3 * i}.conv_block", cout * cfg.upsample_parameters[i][1] ** 3, cfg.n_channels // 2, 3)
+        else:
+            convT(f"decoder.0.{2 + 3 * i}", cin, cout, cfg.upsample_parameters[i][0])
     return st
 
 
@@ -186,6 +192,24 @@ def embed(st, idx: torch.Tensor) -> torch.Tensor:
     return F.embedding(idx, st["quantizer.0.impl.weight"]).permute(0, 4, 1, 2, 3).contiguous()
 
 
+def pixelshuffle3d(x: torch.Tensor, factor: int) -> torch.Tensor:
+    """monai.networks.utils.pixelshuffle(x, 3, factor): channel c = o * factor^3 + (fd * factor + fh) * factor + fw of voxel (d, h, w) becomes channel o of
+    voxel (d * factor + fd, h * factor + fh, w * factor + fw).  (MONAI is absent offline: restated from the published source.)"""
+    b, c, d, h, w = x.shape
+    o = c // factor ** 3
+    x = x.reshape(b, o, factor, factor, factor, d, h, w)
+    x = x.permute(0, 1, 5, 2, 6, 3, 7, 4)
+    return x.reshape(b, o, d * factor, h * factor, w * factor)
+
+
+def subpixel_upsample(x, weight, bias, factor: int):
+    """monai.networks.blocks.SubpixelUpsample(dimensions=3, ..., apply_pad_pool=True): conv_block -> pixelshuffle -> ConstantPad3d((factor - 1, 0) * 3, 0) ->
+    AvgPool3d(kernel_size=factor, stride=1)."""
+    x = pixelshuffle3d(F.conv3d(x, weight, bias, padding=1), factor)
+    x = F.pad(x, (factor - 1, 0) * 3, value=0.0)
+    return F.avg_pool3d(x, kernel_size=factor, stride=1)
+
+
 def decode(st, cfg: VQVAEConfig, zq: torch.Tensor, round_dtype=None) -> torch.Tensor:
     """baseline.py:257-299 / :338-340."""
     x = _rd(zq, round_dtype)
@@ -197,7 +221,10 @@ def decode(st, cfg: VQVAEConfig, zq: torch.Tensor, round_dtype=None) -> torch.Te
             x = residual_layer(x, st[q + ".0.weight"], st[q + ".0.bias"], st[q + ".3.weight"], st[q + ".3.bias"], round_dtype)
         k, s, p, op, dil = cfg.upsample_parameters[i]
         q = f"decoder.0.{2 + 3 * i}"
-        x = F.conv_transpose3d(x, _rd(st[q + ".weight"], round_dtype), st[q + ".bias"], stride=s, padding=p, output_padding=op, dilation=dil)
+        if cfg.use_subpixel_conv and i == cfg.n_levels - 1:
+            x = subpixel_upsample(x, _rd(st[q + ".conv_block.weight"], round_dtype), st[q + ".conv_block.bias"], s)
+        else:
+            x = F.conv_transpose3d(x, _rd(st[q + ".weight"], round_dtype), st[q + ".bias"], stride=s, padding=p, output_padding=op, dilation=dil)
         if i != cfg.n_levels - 1:
             x = _rd(F.relu(x), round_dtype)
     return x

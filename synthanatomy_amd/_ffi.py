@@ -136,6 +136,9 @@ _SIGS = {
     "sa_favor_den": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "sa_favor_dden": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "sa_rotary": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
+    "sa_subpixel_pool_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "sa_subpixel_pool_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "sa_rotary_pairs": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_void_p]),
     "sa_rotary_groups": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_int, c_int64,
                                  c_int64, c_void_p, c_void_p]),
     "sa_local_attn_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
@@ -200,7 +203,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 3   # include/synthanatomy_hip.h: SA_ABI_VERSION
+ABI_VERSION = 4   # include/synthanatomy_hip.h: SA_ABI_VERSION
 SA_EINVAL, SA_EUNSUPPORTED, SA_ENOGPU = -1, -2, -3   # include/synthanatomy_hip.h
 
 

@@ -408,6 +408,75 @@ extern "C" int sa_cast_pad(const void* src, int src_dtype, int src_c, void* dst,
     return 0;
 }
 
+// ---- sub-pixel up-sampling tail (use_subpixel_conv=True, reference baseline.py:274-282: MONAI SubpixelUpsample(3, C, 1, scale_factor=2, apply_pad_pool=True)) ----
+// c [N, D, H, W, 8] fp32 = the conv_block output, channel f = (fd*2 + fh)*2 + fw.  pixelshuffle: S[2d+fd, 2h+fh, 2w+fw] = c[d, h, w, f]; ConstantPad3d((1, 0) x 3) +
+// AvgPool3d(2, stride 1): out[z, y, x] = 1/8 sum_{dz,dy,dx in {0,1}} S[z-1+dz, y-1+dy, x-1+dx] (zero outside).  HBM-bound gathers; the eight channels of a cell are
+// one 32-byte row, so the eight reads of an output voxel touch at most eight rows, all shared with its neighbours through L2.
+namespace sa {
+__global__ void subpixel_pool_fwd_kernel(const float* __restrict__ c, float* __restrict__ out, int N, int D, int H, int W) {
+    const int64_t D2 = 2 * D, H2 = 2 * H, W2 = 2 * W, total = (int64_t)N * D2 * H2 * W2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W2), y = (int)((i / W2) % H2), z = (int)((i / (W2 * H2)) % D2);
+        const int64_t n = i / (W2 * H2 * D2);
+        float acc = 0.f;
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int sz = z - 1 + dz, sy = y - 1 + dy, sx = x - 1 + dx;
+                    if (sz < 0 || sy < 0 || sx < 0) continue;
+                    acc += c[((((n * D + (sz >> 1)) * H + (sy >> 1)) * W + (sx >> 1)) << 3) + ((sz & 1) * 4 + (sy & 1) * 2 + (sx & 1))];
+                }
+        out[i] = acc * 0.125f;
+    }
+}
+// adjoint: dc[d, h, w, f] = 1/8 sum over the outputs o in {s, s + 1} per axis (o < 2 D, 2 H, 2 W) of g[o], s = (2d+fd, 2h+fh, 2w+fw); written in the operand type of
+// the conv_block weight / data gradient launches that read it
+__global__ void subpixel_pool_bwd_kernel(const float* __restrict__ g, void* __restrict__ dc, int dc_dtype, int N, int D, int H, int W) {
+    const int64_t D2 = 2 * D, H2 = 2 * H, W2 = 2 * W, total = (int64_t)N * D * H * W * 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i & 7);
+        const int64_t cell = i >> 3;
+        const int w = (int)(cell % W), h = (int)((cell / W) % H), d = (int)((cell / ((int64_t)W * H)) % D);
+        const int64_t n = cell / ((int64_t)W * H * D);
+        const int sz = 2 * d + (f >> 2), sy = 2 * h + ((f >> 1) & 1), sx = 2 * w + (f & 1);
+        float acc = 0.f;
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int oz = sz + dz, oy = sy + dy, ox = sx + dx;
+                    if (oz >= D2 || oy >= H2 || ox >= W2) continue;
+                    acc += g[((n * D2 + oz) * H2 + oy) * W2 + ox];
+                }
+        acc *= 0.125f;
+        if (dc_dtype == SA_F32) ((float*)dc)[i] = acc;
+        else ((bf16_t*)dc)[i] = f32_to_bf16(acc);
+    }
+}
+}  // namespace sa
+
+extern "C" int sa_subpixel_pool_fwd(const float* c, float* out, int N, int D, int H, int W, void* stream) {
+    using namespace sa;
+    if (!c || !out || N <= 0 || D <= 0 || H <= 0 || W <= 0) return SA_EINVAL;
+    SA_LAUNCH(subpixel_pool_fwd_kernel, dim3(grid_for((int64_t)N * D * H * W * 8, 256, 16384)), dim3(256), 0, (hipStream_t)stream, c, out, N, D, H, W);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sa_subpixel_pool_bwd(const float* g, void* dc, int dc_dtype, int N, int D, int H, int W, void* stream) {
+    using namespace sa;
+    if (!g || !dc || N <= 0 || D <= 0 || H <= 0 || W <= 0) return SA_EINVAL;
+    if (dc_dtype != SA_F32 && dc_dtype != SA_BF16) return SA_EUNSUPPORTED;
+    SA_LAUNCH(subpixel_pool_bwd_kernel, dim3(grid_for((int64_t)N * D * H * W * 8, 256, 16384)), dim3(256), 0, (hipStream_t)stream, g, dc, dc_dtype, N, D, H, W);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int sa_mse(const float* a, const float* b, int64_t n, float* loss_sum, float* grad, float gscale, void* stream) {
     using namespace sa;
     if (!a || !b || !loss_sum || n <= 0) return SA_EINVAL;

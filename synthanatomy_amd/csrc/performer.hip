@@ -2439,6 +2439,44 @@ extern "C" int sa_rotary_groups(const float* x, int stride, int off, int L, int 
     return 0;
 }
 
+// rotary embedding of the GLOBAL heads (the wrapper's rotary_position_emb=True; performer_pytorch 1.0.11 apply_rotary_pos_emb): the pair of consecutive
+// dimensions (2i, 2i + 1) of every head row is rotated by the angle whose sine / cosine sit in columns i / dh/2 + i of row n of the table [N, dh] (sin | cos
+// halves of FixedPositionalEmbedding(dim_head)).  transpose = 1: the adjoint (the rotation by the opposite angle).  Thread = two pairs (one 16-byte access);
+// in place (y == x) is fine: a thread reads its four values before it writes them.
+__global__ void rotary_pairs_kernel(const float* __restrict__ x, int stride, int off, int L, int dh, const float* __restrict__ sincos, float* __restrict__ y,
+                                    int y_stride, int y_off, int N, int64_t R, int transpose, int ngroups, int64_t x_goff, int64_t y_goff) {
+    const int q4 = dh / 4, half = dh / 2;
+    const int64_t per = R * L * q4, total = per * ngroups;
+    for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += (int64_t)gridDim.x * blockDim.x) {
+        const int gi = (int)(e0 / per);
+        const int64_t e = e0 - gi * per;
+        const int j = (int)(e % q4);
+        const int64_t rh = e / q4;
+        const int h = (int)(rh % L);
+        const int64_t r = rh / L;
+        const int n = (int)(r % N);
+        const float4 v = *(const float4*)(x + gi * x_goff + r * stride + off + h * dh + 4 * j);
+        const float2 sn = *(const float2*)(sincos + (int64_t)n * dh + 2 * j), cs = *(const float2*)(sincos + (int64_t)n * dh + half + 2 * j);
+        const float s0 = transpose ? -sn.x : sn.x, s1 = transpose ? -sn.y : sn.y;
+        float4 o;
+        o.x = v.x * cs.x - v.y * s0;      // x cos + rotate_every_two(x) sin: rotate_every_two(x)_{2i} = -x_{2i+1}, _{2i+1} = x_{2i}
+        o.y = v.y * cs.x + v.x * s0;
+        o.z = v.z * cs.y - v.w * s1;
+        o.w = v.w * cs.y + v.z * s1;
+        *(float4*)(y + gi * y_goff + r * y_stride + y_off + h * dh + 4 * j) = o;
+    }
+}
+
+extern "C" int sa_rotary_pairs(const float* x, int stride, int off, int L, int dh, const float* sincos, float* y, int y_stride, int y_off, int N, int64_t R,
+                               int transpose, int ngroups, int64_t x_goff, int64_t y_goff, void* stream) {
+    if (!x || !sincos || !y || L <= 0 || dh <= 0 || R <= 0 || N <= 0 || ngroups < 1) return SA_EINVAL;
+    if ((dh & 3) || ((stride | off | y_stride | y_off) & 3) || ((x_goff | y_goff) & 3)) return SA_EUNSUPPORTED;   // 16-byte accesses
+    SA_LAUNCH(rotary_pairs_kernel, dim3(grid1d(R * L * dh / 4 * ngroups)), dim3(256), 0, ST(stream), x, stride, off, L, dh, sincos, y, y_stride, y_off, N, R, transpose,
+              ngroups, x_goff, y_goff);
+    SA_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int sa_cross_entropy(const float* logits, const int64_t* target, int64_t R, int V, float* loss_sum, void* dlogits, int d_dtype, float gscale,
                                 void* stream) {
     if (!logits || !target || !loss_sum || R <= 0 || V <= 0) return SA_EINVAL;

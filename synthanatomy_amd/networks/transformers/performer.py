@@ -65,6 +65,20 @@ class FixedPositionalEmbedding(nn.Module):
         self.register_buffer("emb", torch.cat((sinusoid_inp.sin(), sinusoid_inp.cos()), dim=-1).contiguous())
 
 
+class AxialPositionalEmbedding(nn.Module):
+    """axial_positional_embedding.AxialPositionalEmbedding(dim, axial_shape) in its summed form (the wrapper's `axial_position_emb=True`, performer.py:141-145; the
+    package is un-pinned and absent offline -- restated): parameters ``weights_0`` [1, s0, 1, dim] and ``weights_1`` [1, 1, s1, dim], N(0, 1); position t of the
+    flattened (s0, s1) grid receives weights_0[t // s1] + weights_1[t % s1].  The embedding-sum kernel gathers the two tables with those two index rows."""
+
+    def __init__(self, dim, axial_shape):
+        super().__init__()
+        assert len(axial_shape) == 2, "axial_position_shape must have two axes (performer.py:142-144: (ceil(max_seq_len / 64), 64))"
+        self.dim, self.shape = dim, tuple(int(a) for a in axial_shape)
+        self.max_seq_len = self.shape[0] * self.shape[1]
+        self.weights_0 = nn.Parameter(torch.zeros(1, self.shape[0], 1, dim).normal_(0, 1))
+        self.weights_1 = nn.Parameter(torch.zeros(1, 1, self.shape[1], dim).normal_(0, 1))
+
+
 class AbsoluteSpatialPositionalEmbedding(nn.Module):  # performer.py:23-40
     def __init__(self, dim: int, spatial_indices_sequence: torch.Tensor):
         super().__init__()
@@ -406,6 +420,23 @@ class _LayerEngine:
         self._rot = None
         self._one = None
         self._ws = None
+        self.layer_pos = None      # rotary_position_emb=True: the wrapper's FixedPositionalEmbedding(dim_head) -- q / k of the GLOBAL heads are rotated pairwise
+
+    def _rotate_global(self, q, k, B, N, transpose):
+        """performer_pytorch 1.0.11 apply_rotary_pos_emb on the FAVOR+ heads (columns [0, G dh) of q and k), in place; transpose=1: the adjoint on dq / dk"""
+        if self.layer_pos is None or self.G == 0:
+            return
+        lib, st = _ffi.lib(), _ffi.stream()
+        tab = self.layer_pos.emb
+        assert N <= tab.shape[0] and tab.shape[1] == self.dh and tab.is_contiguous()
+        R, inner = B * N, self.H * self.dh
+        if k.data_ptr() - q.data_ptr() == inner * 4 and q.stride(0) == k.stride(0):   # column blocks of one matrix: one launch
+            _ck(lib.sa_rotary_pairs(_ffi.ptr(q), q.stride(0), 0, self.G, self.dh, _ffi.ptr(tab), _ffi.ptr(q), q.stride(0), 0, N, R, transpose, 2, inner, inner, st),
+                "sa_rotary_pairs(q|k)")
+        else:
+            for t in (q, k):
+                _ck(lib.sa_rotary_pairs(_ffi.ptr(t), t.stride(0), 0, self.G, self.dh, _ffi.ptr(tab), _ffi.ptr(t), t.stride(0), 0, N, R, transpose, 1, 0, 0, st),
+                    "sa_rotary_pairs")
 
     def invalidate(self):
         for op in self.ops.values():
@@ -520,6 +551,7 @@ class _LayerEngine:
             k = self.ops["to_k"].fprop(_as5(xaT), out_dtype=f32).view(R, inner)
             v = self.ops["to_v"].fprop(_as5(xaT), out_dtype=f32).view(R, inner)
         qs = q.stride(0)   # row stride of q / k / v (3 * inner when they are column blocks of one matrix)
+        self._rotate_global(q, k, B, N, 0)       # (rotary_position_emb=True only; the tape keeps the rotated rows -- what the FAVOR+ backward differentiates)
         attn = torch.empty(R, inner, dtype=f32, device=dev)
         # throughput mode: the attention kernels write the bf16 operand of to_out next to the fp32 rows (no cast launch); needs every head on a kernel that can
         attn_lp = (torch.empty(R, inner, dtype=T, device=dev)
@@ -843,7 +875,7 @@ class _LayerEngine:
             dq = torch.empty(R, inner, dtype=f32, device=dev)
             dk = torch.empty(R, inner, dtype=f32, device=dev)
             dv = torch.empty(R, inner, dtype=f32, device=dev)
-        if not fused_qkv or dqkv_lp is None:
+        if not fused_qkv or dqkv_lp is None or (self.layer_pos is not None and G > 0):    # (rotated global heads: dq / dk are rotated back below, then cast)
             dqkv_lp = dq_lp = dk_lp = dv_lp = None
         qs = dq.stride(0)   # == q.stride(0): the kernels below address v / dv (and dq / dk) with one row stride
         assert qs == q.stride(0) == v.stride(0)
@@ -950,6 +982,7 @@ class _LayerEngine:
             else:
                 _ck(lib.sa_rotary(_ffi.ptr(dqr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dq), qs, G * dh, N, R, 1, 0, st), "sa_rotary^T(q)")
                 _ck(lib.sa_rotary(_ffi.ptr(dkr), L * dh, 0, L, dh, _ffi.ptr(cosb), _ffi.ptr(sinb), _ffi.ptr(dk), qs, G * dh, N, R, 1, 0, st), "sa_rotary^T(k)")
+        self._rotate_global(dq, dk, B, N, 1)
         xaT = _as5(sv["xaT"])
         base = _as5(dx1) if self.rezero else None
         if fused_qkv:
@@ -1124,6 +1157,21 @@ class _LinearFn(torch.autograd.Function):
         return None, dx, dw, db
 
 
+class _TiedOut:
+    """`tie_embed=True`: the logits are x @ token_emb.weight^T (performer.py:288) -- the token table seen as a bias-free nn.Linear(dim, num_tokens)"""
+
+    def __init__(self, emb: nn.Embedding):
+        self._emb = emb
+        self.bias = None
+
+    @property
+    def weight(self):
+        return self._emb.weight
+
+    in_features = property(lambda self: self._emb.weight.shape[1])
+    out_features = property(lambda self: self._emb.weight.shape[0])
+
+
 # ------------------------------------------------------------------------------------------------ the plugin class
 class Performer(TransformerBase):
     """NOTE: all tensor logic assumes the ordering [Batch, Length, Channel] (as the reference)."""
@@ -1175,15 +1223,23 @@ class Performer(TransformerBase):
             f"rotary_position_emb, fixed_position_emb and axial_position_emb are exclusive, but received "
             f"{rotary_position_emb} {fixed_position_emb} and {axial_position_emb}."
         )
-        if rotary_position_emb or axial_position_emb or tie_embed or emb_dropout:
-            raise NotImplementedError("performer on MI355X implements the absolute (README configuration) and the fixed sinusoidal positional embedding; "
-                                      "rotary / axial position embeddings, tied embeddings and embedding dropout are not built")
         # accounting for the number of prepended conditionings (performer.py:119-125)
         self.max_seq_len = max_seq_len + (len(conditioning_num_tokens)
                                           if conditioning_num_tokens and conditioning_type == TransformerConditioningType.PREPENDING.value else 0)
         self.token_emb = nn.Embedding(num_tokens, dim)
-        # performer.py:138-147: the sinusoidal table (a buffer) or the learned one
-        self.pos_emb = FixedPositionalEmbedding(dim, self.max_seq_len) if fixed_position_emb else AbsolutePositionalEmbedding(dim, self.max_seq_len)
+        # performer.py:134-147: rotary = the sinusoidal table on x AND a dim_head-wide one handed to every attention layer (q / k of the global heads are rotated);
+        # fixed = the sinusoidal table (a buffer); axial = two learned axis tables; else the learned absolute table
+        self.layer_pos_emb = None
+        if rotary_position_emb:
+            self.pos_emb = FixedPositionalEmbedding(dim, self.max_seq_len)
+            self.layer_pos_emb = FixedPositionalEmbedding(dim_head, self.max_seq_len)
+        elif fixed_position_emb:
+            self.pos_emb = FixedPositionalEmbedding(dim, self.max_seq_len)
+        elif axial_position_emb:
+            axial_position_shape = axial_position_shape if axial_position_shape is not None else (math.ceil(self.max_seq_len / 64), 64)
+            self.pos_emb = AxialPositionalEmbedding(dim, axial_position_shape)
+        else:
+            self.pos_emb = AbsolutePositionalEmbedding(dim, self.max_seq_len)
         self.ordering = ordering
         self.spatial_position_emb = nn.ModuleList()
         if spatial_position_emb:
@@ -1204,11 +1260,23 @@ class Performer(TransformerBase):
                                        feature_redraw_interval, reversible, ff_chunks, generalized_attention, kernel_fn, use_scalenorm, use_rezero,
                                        ff_glu, ff_dropout, attn_dropout, cross_attend, no_projection, auto_check_redraw, qkv_bias, attn_out_bias)
         self.norm = nn.LayerNorm(dim)
-        self.to_out = nn.Linear(dim, num_tokens)
+        self.to_out = nn.Linear(dim, num_tokens) if not tie_embed else None       # performer.py:222, 286-288: tied = x @ token_emb.weight^T, no bias
         self.dim, self.compute_dtype = dim, compute_dtype
         self._chain = _StackChain(self.performer, dim, compute_dtype)
-        self._out_op = _lin(self.to_out, compute_dtype)
+        if self.layer_pos_emb is not None:
+            for l in self._chain.layers:
+                l.layer_pos = self.layer_pos_emb
+        self._out_op = _lin(self._out_mod(), compute_dtype)
         self._idx_cache = {}
+
+    def _out_mod(self):
+        """the vocabulary projection as a (weight, bias) holder: ``to_out``, or the token table itself when the embeddings are tied"""
+        if self.to_out is not None:
+            return self.to_out
+        tied = self.__dict__.get("_tied_out")
+        if tied is None:
+            tied = self.__dict__["_tied_out"] = _TiedOut(self.token_emb)
+        return tied
 
     def check_redraw_projections(self):
         self.performer.check_redraw_projections()
@@ -1255,7 +1323,9 @@ class Performer(TransformerBase):
         HIP graph per token."""
         bos = self.conditioning_type == TransformerConditioningType.BOSREPLACEMENT.value
         if stateful is None:     # O(N) decoding unless the conditioning lengthens the sequence (prepending: the reference-faithful loop)
-            stateful = conditioning is None or bos
+            stateful = (conditioning is None or bos) and self.layer_pos_emb is None
+        if stateful and self.layer_pos_emb is not None:
+            raise NotImplementedError("stateful (O(N)) sampling does not rotate the global heads' q / k (rotary_position_emb=True): use stateful=False")
         if not stateful:
             return super().sample(prefix, conditioning=conditioning, temperature=temperature, sample=sample, top_k=top_k)
         assert conditioning is None or bos, "stateful sampling takes BOS-replacement conditionings only (use stateful=False)"
@@ -1286,9 +1356,10 @@ class Performer(TransformerBase):
             tok_table = torch.cat((self.token_emb.weight.detach(), c.to(self.token_emb.weight.dtype)), dim=0).contiguous()
             seq[:, 0] = tok_table.shape[0] - B + torch.arange(B, device=dev)
             seq0 = seq.clone()
-        tables = [tok_table] + [(m.emb if isinstance(m, FixedSpatialPositionalEmbedding) else m.emb.weight) for m in self.spatial_position_emb] + [self._pos_table()]
-        idx = [tok] + sp + [pidx]
-        per_pos = [0] + [1] * len(sp) + [1]
+        ptabs, pidxs = self._pos_tables(pidx)
+        tables = [tok_table] + [(m.emb if isinstance(m, FixedSpatialPositionalEmbedding) else m.emb.weight) for m in self.spatial_position_emb] + ptabs
+        idx = [tok] + sp + pidxs
+        per_pos = [0] + [1] * len(sp) + [1] * len(ptabs)
         n = len(tables)
         tp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tables])
         ip = (ctypes.c_void_p * n)(*[i.data_ptr() for i in idx])
@@ -1302,7 +1373,7 @@ class Performer(TransformerBase):
         tok.copy_(seq0[:, 0])
 
         fused_tail = not debug.host("no_sample_step")     # one launch for the decision (incl. the top-k cut) + sequence update (sa_sample_step)
-        n_vocab = self.to_out.weight.shape[0]
+        n_vocab = self._out_mod().weight.shape[0]
         if top_k is not None and not 0 < int(top_k) <= n_vocab:   # what torch.topk of the reference (transformer.py:14) raises on
             raise RuntimeError(f"selected index k out of range (top_k = {top_k}, vocabulary {n_vocab})")
         # the uniforms of every step, drawn once (a torch.rand inside the captured step costs three launches per token: the generator's seed / offset fills + the draw)
@@ -1317,8 +1388,8 @@ class Performer(TransformerBase):
             for l, stt in zip(layers, states):
                 x = l.step(x, B, npos, pos, stt)
             h = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
-            logits = torch.empty(B, self.to_out.weight.shape[0], dtype=torch.float32, device=dev)
-            layers[0]._gemv(h, [self.to_out], logits)
+            logits = torch.empty(B, n_vocab, dtype=torch.float32, device=dev)
+            layers[0]._gemv(h, [self._out_mod()], logits)
             if fused_tail:
                 # temperature, softmax, the draw (inverse CDF against the pre-drawn uniforms -- torch.multinomial cannot be captured in a HIP graph) or arg-max,
                 # seq[:, pos + 1] (unless it belongs to the given prefix), the next step's token, pos += 1: one launch instead of ~20 small torch kernels
@@ -1383,6 +1454,20 @@ class Performer(TransformerBase):
     def _pos_table(self):
         return self.pos_emb.emb if isinstance(self.pos_emb, FixedPositionalEmbedding) else self.pos_emb.emb.weight
 
+    def _pos_tables(self, pos):
+        """(tables, index rows) of the positional term for the positions `pos`: one table, or the two axis tables of the axial embedding"""
+        if isinstance(self.pos_emb, AxialPositionalEmbedding):
+            s0, s1 = self.pos_emb.shape
+            assert int(pos.numel()) <= s0 * s1, f"sequence length {int(pos.numel())} exceeds the axial grid {s0} x {s1}"
+            return ([self.pos_emb.weights_0.view(s0, self.dim), self.pos_emb.weights_1.view(s1, self.dim)],
+                    [torch.div(pos, s1, rounding_mode="floor"), pos % s1])
+        return [self._pos_table()], [pos]
+
+    def _pos_rows(self, n, dev):
+        """the positional term of positions 0 .. n-1 as a dense [n, dim] tensor (autograd-visible): the conditioning paths add single rows of it"""
+        tabs, idx = self._pos_tables(torch.arange(n, device=dev, dtype=torch.int64))
+        return sum(t[i] for t, i in zip(tabs, idx))
+
     def _position_indices(self, n, dev):
         key = (n, str(dev))
         if key not in self._idx_cache:
@@ -1420,19 +1505,25 @@ class Performer(TransformerBase):
                 h = torch.cat((emb(conditionings[i].to(dev)), h), dim=1)
             nt = h.shape[1]
             assert nt <= self.max_seq_len, f"sequence length {nt} must be less than the max sequence length {self.max_seq_len}"
-            ptab = [self._pos_table()]
-            h = h + _EmbedFn.apply(ptab, [torch.arange(nt, device=dev, dtype=torch.int64)], [1], b, nt, *ptab)
+            ptab, pix = self._pos_tables(torch.arange(nt, device=dev, dtype=torch.int64))
+            h = h + _EmbedFn.apply(ptab, pix, [1] * len(ptab), b, nt, *ptab)
         else:
-            tables = [self.token_emb.weight] + sp_tables + [self._pos_table()]
-            idx = [tok] + sp + [pos]
-            per_pos = [0] + [1] * len(sp) + [1]
+            ptab, pix = self._pos_tables(pos)
+            tables = [self.token_emb.weight] + sp_tables + ptab
+            idx = [tok] + sp + pix
+            per_pos = [0] + [1] * len(sp) + [1] * len(ptab)
             h = _EmbedFn.apply(tables, idx, per_pos, b, n, *tables)
         if conditionings and self.conditioning_type == TransformerConditioningType.BOSREPLACEMENT.value:
             # performer.py:252-261: the BOS embedding (incl. its spatial terms) is REPLACED by the summed conditioning embeddings,
             # the absolute positional embedding is added afterwards
             c = sum(emb(conditionings[i].to(dev))[:, 0, :] for i, emb in enumerate(self.conditioning_emb))
-            first = c + self._pos_table()[0]
+            first = c + self._pos_rows(1, dev)[0]
             h = torch.cat((first[:, None, :], h[:, 1:, :]), dim=1)
+        if self.dropout.p > 0.0 and self.training:
+            # nn.Dropout(emb_dropout) on the summed embeddings (performer.py:201,270): elementwise keep / (1 - p) mask drawn on the device, a broadcast-free multiply
+            keep = torch.bernoulli(torch.full_like(h, 1.0 - self.dropout.p)) / (1.0 - self.dropout.p)
+            self._last_emb_mask = keep          # (tests replay it through the oracle)
+            h = h * keep
         if self.performer.auto_check_redraw:
             self.performer.proj_updater.redraw_projections()
         params = self._chain.params()
@@ -1443,4 +1534,5 @@ class Performer(TransformerBase):
             h = h[:, len(conditionings):, :]
         if return_encodings:
             return h
-        return _LinearFn.apply(self._out_op, h, self.to_out.weight, self.to_out.bias)
+        om = self._out_mod()
+        return _LinearFn.apply(self._out_op, h, om.weight, om.bias)

@@ -438,6 +438,67 @@ class _ConvT1Stage:
         return dx
 
 
+class SubpixelUpsample(nn.Module):
+    """Parameter holder with the state_dict keys of ``monai.networks.blocks.SubpixelUpsample(dimensions=3, in_channels, out_channels, scale_factor,
+    apply_pad_pool=True, bias=True)`` -- the last decoder layer with ``use_subpixel_conv=True`` (reference baseline.py:274-282): ``conv_block`` =
+    Conv3d(in_channels -> out_channels * scale_factor^3, k 3, p 1) with MONAI's ICNR initialisation (every group of scale_factor^3 output channels starts
+    from one Kaiming-normal kernel), then pixelshuffle -> ConstantPad3d((scale_factor - 1, 0) x 3) -> AvgPool3d(scale_factor, stride 1) (``pad_pool``,
+    no parameters).  MONAI is absent offline: restated from its published source (oracle/vqvae_ref.subpixel_upsample)."""
+
+    def __init__(self, dimensions: int, in_channels: int, out_channels: int, scale_factor: int = 2, apply_pad_pool: bool = True, bias: bool = True):
+        super().__init__()
+        if dimensions != 3 or scale_factor != 2 or not apply_pad_pool or out_channels != 1:
+            raise NotImplementedError("SubpixelUpsample on MI355X: the reference's use (3-D, scale factor 2, one output channel, pad + pool)")
+        self.dimensions, self.scale_factor = dimensions, scale_factor
+        self.conv_block = nn.Conv3d(in_channels, out_channels * scale_factor ** 3, kernel_size=3, stride=1, padding=1, bias=bias)
+        with torch.no_grad():      # monai.networks.utils.icnr_init
+            oc, ic = self.conv_block.weight.shape[:2]
+            sf = scale_factor ** 3
+            k = nn.init.kaiming_normal_(torch.zeros(oc // sf, ic, 3, 3, 3)).transpose(0, 1)
+            k = k.reshape(oc // sf, ic, -1).repeat(1, 1, sf)
+            self.conv_block.weight.copy_(k.reshape(ic, oc, 3, 3, 3).transpose(0, 1))
+        self.pad_pool = nn.Sequential(nn.ConstantPad3d((scale_factor - 1, 0) * 3, 0.0), nn.AvgPool3d(kernel_size=scale_factor, stride=1))
+
+
+class _SubpixelStage:
+    """conv_block on the implicit-GEMM kernels (eight output channels, fp32 out) + one gather launch for pixelshuffle / pad / pool (csrc/elementwise.hip:
+    sa_subpixel_pool_fwd); backward: the gather's adjoint, then the conv_block's weight and data gradient launches."""
+
+    def __init__(self, mod: SubpixelUpsample, in_act, dtype):
+        conv = mod.conv_block
+        self.mod, self.conv, self.in_act, self.dtype = mod, conv, in_act, dtype
+        self.op = ConvOp("conv", conv.in_channels, conv.out_channels, 3, 1, 1, conv.weight, conv.bias, dtype)
+
+    def params(self):
+        return [self.conv.weight, self.conv.bias]
+
+    def _sync(self):
+        self.op.weight, self.op.bias = self.conv.weight, self.conv.bias
+
+    def fwd(self, x, tape):
+        self._sync()
+        N, D, H, W, _ = x.shape
+        c = self.op.fprop(x, act=ACT_NONE, out_dtype=torch.float32, out_channels_stride=8)
+        out = torch.empty((N, 2 * D, 2 * H, 2 * W, 1), dtype=torch.float32, device=x.device)
+        _ffi.check(_ffi.lib().sa_subpixel_pool_fwd(_ffi.ptr(c), _ffi.ptr(out), N, D, H, W, _ffi.stream()), "sa_subpixel_pool_fwd")
+        if tape is not None:
+            tape.append((x,))
+        return out
+
+    def bwd(self, G, saved, grads, wgrad_only=False):
+        (x,) = saved
+        self._sync()
+        N, D, H, W, _ = x.shape
+        G = G.float().contiguous()
+        dc = torch.empty((N, D, H, W, 8), dtype=self.dtype, device=x.device)
+        _ffi.check(_ffi.lib().sa_subpixel_pool_bwd(_ffi.ptr(G), _ffi.ptr(dc), _ffi.dtype_id(self.dtype), N, D, H, W, _ffi.stream()), "sa_subpixel_pool_bwd")
+        grads.wgrad(self.op, x, dc, grads.buf(self.conv.weight), grads.buf(self.conv.bias))
+        grads.done(self.conv.weight, self.conv.bias)
+        if wgrad_only:
+            return None
+        return self.op.dgrad(dc, (D, H, W), mask=x if self.in_act else None, mask_mode=MASK_POS)
+
+
 class _ResStage:
     def __init__(self, mod: ResidualLayer, in_act, dtype, fwd_dtype=None):
         c3, c1 = mod[0], mod[3]
@@ -643,7 +704,7 @@ class _Chain:
             raise RuntimeError("last_stage_wgrad needs a recorded forward whose backward has not run yet")
         st = self.stages[-1]
         gc = _GradCtx(None)
-        if isinstance(st, (_ConvStage, _ConvT1Stage)):
+        if isinstance(st, (_ConvStage, _ConvT1Stage, _SubpixelStage)):
             st.bwd(G, self.last_tape[-1], gc, wgrad_only=True)   # no data gradient: the caller only wants d loss / d W_last
         else:
             st.bwd(G, self.last_tape[-1], gc)
@@ -712,8 +773,10 @@ class BaselineVQVAE(VQVAEBase, nn.Module):
             f"downsample_parameters, upsample_parameters must have the same number of elements as n_levels. "
             f"But got {len(downsample_parameters)} and {len(upsample_parameters)}, instead of {n_levels}."
         )
-        if use_subpixel_conv:
-            raise NotImplementedError("use_subpixel_conv=True needs MONAI's SubpixelUpsample; the MI355X build implements the README setting (False)")
+        if use_subpixel_conv and (n_levels < 2 or n_channels // 2 % 8):
+            # (baseline.py:274-282 builds SubpixelUpsample(in_channels=n_channels // 2): with one level the residual stack in front of it is n_channels wide and
+            #  the reference itself fails in the first forward)
+            raise NotImplementedError("use_subpixel_conv=True needs n_levels >= 2 and n_channels // 2 a multiple of 8")
         for dp in downsample_parameters:
             if dp[3] != 1:
                 raise NotImplementedError("dilation != 1")
@@ -771,7 +834,10 @@ class BaselineVQVAE(VQVAEBase, nn.Module):
             width = self._level_width(lvl, decoder=True)
             last = lvl == self.n_levels - 1
             seq.append(self._res_stack(width))
-            seq.append(nn.ConvTranspose3d(width, 1 if last else self.n_channels // 2, kernel_size=k, stride=s, padding=p, output_padding=op, dilation=dil))
+            if last and self.use_subpixel_conv:
+                seq.append(SubpixelUpsample(dimensions=3, in_channels=self.n_channels // 2, out_channels=1, scale_factor=s, apply_pad_pool=True, bias=True))
+            else:
+                seq.append(nn.ConvTranspose3d(width, 1 if last else self.n_channels // 2, kernel_size=k, stride=s, padding=p, output_padding=op, dilation=dil))
             if not last:
                 seq.append(nn.ReLU())
         return nn.ModuleList([nn.Sequential(*seq)])
@@ -801,7 +867,9 @@ class BaselineVQVAE(VQVAEBase, nn.Module):
             res, up = mods[i], mods[i + 1]
             for j, r in enumerate(res):
                 stages.append(_ResStage(r, in_act=not (lvl == 0 and j == 0), dtype=dt))
-            if last and _ConvT1Stage.applicable(up):
+            if isinstance(up, SubpixelUpsample):
+                stages.append(_SubpixelStage(up, in_act=True, dtype=dt))
+            elif last and _ConvT1Stage.applicable(up):
                 stages.append(_ConvT1Stage(up, in_act=True, dtype=dt))
             else:
                 stages.append(_ConvStage(up, "convT", ACT_NONE if last else ACT_RELU, in_act=True, dtype=dt, out_f32=last))
@@ -866,6 +934,8 @@ class BaselineVQVAE(VQVAEBase, nn.Module):
         return [self.quantizer[0].get_perplexity()]
 
     def get_last_layer(self) -> nn.parameter.Parameter:
+        if self.use_subpixel_conv:     # (baseline.py:322 would pick the parameter-free AvgPool3d of pad_pool and raise: the conv_block is the last layer with weights)
+            return list(self.decoder[0])[-1].conv_block.weight
         return list(self.decoder.modules())[-1].weight
 
     def last_layer_grad(self, d_recon: torch.Tensor) -> torch.Tensor:

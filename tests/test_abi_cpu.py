@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for s in hdr:
         assert hasattr(lib, s), f"{s} declared in the header but not exported"
     assert sorted(_ffi.declared_symbols()) == hdr, "ctypes signatures out of sync with include/synthanatomy_hip.h"
-    assert lib.sa_abi_version() == 3 == _ffi.ABI_VERSION
+    assert lib.sa_abi_version() == 4 == _ffi.ABI_VERSION
 
 
 def test_ctypes_struct_layout_matches_header():

@@ -254,7 +254,7 @@ def test_residual_layer_with_dropout_matches_torch(dtype):
     st = _ResStage(mod, in_act=True, dtype=dtype)
     masks = []
 
-    def fixed_mask(N, Cc, dev):
+    def fixed_mask(N, Cc, dev, stride=None):
         g = torch.Generator().manual_seed(100 + len(masks))
         m = (torch.bernoulli(torch.full((N, 1, 1, 1, Cc), 1.0 - p), generator=g) / (1.0 - p)).to(dev)
         masks.append(m)
