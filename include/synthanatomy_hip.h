@@ -414,7 +414,10 @@ int sa_convt1_im2col(const float *g, int dtype, void *gc, float *db, int N, int 
  * q / k / v / dq / dk / dv: fp32 rows of `stride` floats whose first G*64 columns are the global heads; ps = projection matrix [m][64] with the
  * data normaliser folded in; tiles = 5 * 16 KiB from sa_favor_fused_proj_tiles(ps); offq / offk [B*N*G] floats, amq [B*N*G] int32 and gmax_ws (8 bytes)
  * from sa_favor_fused_prepass; state buffers of sa_favor_fused_state_bytes bytes; dden_ws B*N*G floats, tsum_ws B*G*ceil(N/64) floats.
- * No fp32 atomics: results are run-to-run deterministic.  m <= 272, head width 64. */
+ * No fp32 atomics: results are run-to-run deterministic.  m <= 272, head width 64.
+ * Round 6: sa_favor_fused_proj_tiles also records (in the last 16 bytes of `tiles`, never an operand row) whether every lo half of the split matrix is zero, i.e.
+ * whether ps is bf16-representable -- what the Python layer hands over in throughput mode (a bf16 copy of the folded fp32 matrix, like every dense weight of
+ * that mode).  The kernels then skip the lo * hi products and the lo half of every projection-slab transfer: exact zeros, bit-identical results. */
 int64_t sa_favor_fused_state_bytes(int B, int N, int G, int m);
 int sa_favor_fused_proj_tiles(const float *ps, int m, void *tiles, void *stream);
 int sa_favor_fused_prepass(const float *q, const float *k, int stride, int G, const void *tiles, float *offq, int32_t *amq, float *offk, void *gmax_ws,

@@ -7,6 +7,7 @@
 // it; the weights (16 KiB) are register-resident MFMA operands, outputs leave through the quarter transpose as 32-byte pieces.
 // HBM traffic = the output (forward) / the gradient (backward) once; the volume itself is 4 bytes per voxel and is re-read from L2.
 #include "sa_common.h"
+#define SA_LROFF_NO_HALF_SWAP   // this file's tiles are private to it and read with ds_read_b128 / transposing reads only: the round-5 form of lroff() (one VALU op less per address)
 #include "split_bf16.h"
 
 namespace sa {

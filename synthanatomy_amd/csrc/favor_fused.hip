@@ -40,6 +40,14 @@ __device__ unsigned long long g_ftime[24];
 #endif
 constexpr int FT_BYTES = 64 * 128;   // one [64 rows][64 bf16] tile
 constexpr int FSLAB = 64;
+// The last 16 bytes of the 80 KiB projection-tile buffer (row 63 of the fifth slab's lo tile = projection row 319: never an operand row, LDF <= 272) carry a
+// flag word written by favor_proj_tiles_kernel: 0 = every lo half-word of the matrix is zero, i.e. the operand is bf16-representable (what the throughput mode's
+// layer hands over: its projection operand is a bf16 copy of the folded fp32 matrix, like every dense weight of that mode).  The chunk kernels then skip the
+// P_lo * x_hi products, the lo fragment reads and the lo half of every slab transfer -- exact zeros, so the results do not change by a bit (round 6).
+constexpr int PT_FLAG_OFF = 5 * 2 * FT_BYTES - 16;
+__device__ __forceinline__ bool ptiles_lo_zero(const unsigned char* ptiles) {
+    return __builtin_amdgcn_readfirstlane(*(const uint32_t*)(ptiles + PT_FLAG_OFF)) == 0u;
+}
 #ifndef FUSED_WPS
 #define FUSED_WPS 2   // waves per SIMD the chunk kernels are compiled for (measured: 3 forces ~100 spilled VGPRs and is 20 % slower end to end)
 #endif
@@ -104,11 +112,11 @@ __device__ __forceinline__ void load_x_operand(XOperand& xo, const FeatSrc& f, c
 __device__ __forceinline__ int slab_frags(const FusedArgs& s, int slab0) { return min(4, (s.LDF - slab0 + 15) >> 4); }
 
 __device__ __forceinline__ void feat_slab(float4_t (&F)[4], const unsigned char* sPh, const unsigned char* sPl, const XOperand& xo, bool valid, int slab0,
-                                          const FusedArgs& s, int fr, int g4) {
+                                          const FusedArgs& s, int fr, int g4, bool plo0 = false) {
     const int nf = slab_frags(s, slab0);
 #pragma unroll
     for (int f = 0; f < 4; ++f) F[f] = (float4_t){0.f, 0.f, 0.f, 0.f};
-    tile_rows_gemm(F, sPh, sPl, xo.h, xo.l, fr, g4, nf);
+    tile_rows_gemm(F, sPh, sPl, xo.h, xo.l, fr, g4, nf, plo0);
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
         if (f >= nf) break;
@@ -123,7 +131,7 @@ __device__ __forceinline__ void feat_slab(float4_t (&F)[4], const unsigned char*
 
 // two feature maps of the same positions from ONE walk over the projection fragments (half the ds_read_b128 traffic of two feat_slab calls)
 __device__ __forceinline__ void feat_slab2(float4_t (&F0)[4], float4_t (&F1)[4], const unsigned char* sPh, const unsigned char* sPl, const XOperand& x0, const XOperand& x1,
-                                           bool valid, int slab0, const FusedArgs& s, int fr, int g4) {
+                                           bool valid, int slab0, const FusedArgs& s, int fr, int g4, bool plo0 = false) {
     const int nf = slab_frags(s, slab0);
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -134,7 +142,7 @@ __device__ __forceinline__ void feat_slab2(float4_t (&F0)[4], float4_t (&F1)[4],
     auto frag = [&](const int f, const int ks, short8_t& ah, short8_t& al) __attribute__((always_inline)) {
         const uint32_t o = lroff(f * 16 + fr, ks * 32 + g4 * 8);
         ah = *(const short8_t*)(sPh + o);
-        al = *(const short8_t*)(sPl + o);
+        if (!plo0) al = *(const short8_t*)(sPl + o);
     };
     if (nf == 4) {
 #pragma unroll
@@ -147,10 +155,12 @@ __device__ __forceinline__ void feat_slab2(float4_t (&F0)[4], float4_t (&F1)[4],
                 F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], x0.l[ks], F0[f], 0, 0, 0);
                 F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], x1.l[ks], F1[f], 0, 0, 0);
             }
+            if (!plo0) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], x0.h[ks], F0[f], 0, 0, 0);
-                F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], x1.h[ks], F1[f], 0, 0, 0);
+                for (int f = 0; f < 4; ++f) {
+                    F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], x0.h[ks], F0[f], 0, 0, 0);
+                    F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], x1.h[ks], F1[f], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
@@ -168,8 +178,10 @@ __device__ __forceinline__ void feat_slab2(float4_t (&F0)[4], float4_t (&F1)[4],
                 frag(f, ks, ah, al);
                 F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, x0.l[ks], F0[f], 0, 0, 0);
                 F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, x1.l[ks], F1[f], 0, 0, 0);
-                F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, x0.h[ks], F0[f], 0, 0, 0);
-                F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, x1.h[ks], F1[f], 0, 0, 0);
+                if (!plo0) {
+                    F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, x0.h[ks], F0[f], 0, 0, 0);
+                    F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, x1.h[ks], F1[f], 0, 0, 0);
+                }
                 F0[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, x0.h[ks], F0[f], 0, 0, 0);
                 F1[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, x1.h[ks], F1[f], 0, 0, 0);
             }
@@ -219,11 +231,12 @@ __device__ __forceinline__ void pslab_store(unsigned char* sP, const PSlabRegs& 
 // the same 16 KiB straight into LDS (LDS-DMA, sixteen 1 KiB pieces: wave w takes pieces w, w + 4, ...), issued from inline assembly: invisible to the
 // compiler's waitcnt pass (which answers a builtin LDS-DMA with s_waitcnt vmcnt(0) in front of the next LDS read) -- the caller waits (pslab_dma_wait) and
 // synchronises before the slab is read.  No staging registers.
-__device__ __forceinline__ void pslab_dma(unsigned char* sP, const unsigned char* ptiles, int slab, int wave, int lane) {
+__device__ __forceinline__ void pslab_dma(unsigned char* sP, const unsigned char* ptiles, int slab, int wave, int lane, bool plo0 = false) {
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(ptiles + (size_t)slab * (2 * FT_BYTES)), 0, 2 * FT_BYTES, 0x00020000);
     const uint32_t l0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)sP;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+        if (t >= 2 && plo0) break;      // pieces 8 .. 15 are the lo tile: not read when the operand is bf16-representable
         const uint32_t piece = (uint32_t)(wave + 4 * t);
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                      : : "s"(l0 + piece * 1024u), "v"(piece * 1024u + (uint32_t)lane * 16u), "s"(rp) : "memory", "m0");
@@ -282,7 +295,8 @@ __global__ __launch_bounds__(256) void favor_proj_tiles_kernel(const float* __re
         split_pair(v.z, v.w, h.y, l.y);
         const uint32_t o = lroff(rho, c4 * 4);
         *(uint2*)(hi + o) = h;
-        *(uint2*)(lo + o) = l;
+        if (!(sl == 4 && o >= (uint32_t)(FT_BYTES - 16))) *(uint2*)(lo + o) = l;      // (the flag's sixteen bytes: zeroed by the launcher, see PT_FLAG_OFF)
+        if ((l.x | l.y) & 0x7fff7fffu) atomicOr((unsigned int*)(tiles + PT_FLAG_OFF), 1u);
     }
 }
 
@@ -308,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs
                                                                            // for the block maximum made it 81 952 B = ONE block per CU and two rounds of the "persistent" grid)
     const int nfr = a.LDF >> 4;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), qi = lane & 15, g = lane >> 4;
+    const bool plo0 = ptiles_lo_zero(a.ptiles);
     {
         const u32x4* src = (const u32x4*)a.ptiles;
         u32x4 v[20];
@@ -343,9 +358,9 @@ __global__ __launch_bounds__(256, 2) void favor_prepass_kernel(const PrepassArgs
             const unsigned char* sPh = smem + (f >> 2) * (2 * FT_BYTES);
             const unsigned char* sPl = sPh + FT_BYTES;
             const uint32_t o = lroff((f & 3) * 16 + qi, ks * 32 + g * 8);
-            const short8_t ah = *(const short8_t*)(sPh + o), al = *(const short8_t*)(sPl + o);
+            const short8_t ah = *(const short8_t*)(sPh + o);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[ks], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[ks], c, 0, 0, 0);
+            if (!plo0) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const short8_t*)(sPl + o), xh[ks], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[ks], c, 0, 0, 0);
         };
         auto take = [&](int f, const float4_t& c) __attribute__((always_inline)) {
@@ -430,7 +445,8 @@ __device__ __forceinline__ void favor_fstate_body(const FusedArgs& s, const int 
     const int ri = f_row(s, p);
     XOperand xa;
     load_x_operand(xa, s.fa, s, b, g, ri, g4, kmax);
-    pslab_dma(sP[0], s.ptiles, 0, w, lane);      // projection slabs: global -> LDS without staging registers (see pslab_dma)
+    const bool plo0 = ptiles_lo_zero(s.ptiles);
+    pslab_dma(sP[0], s.ptiles, 0, w, lane, plo0);      // projection slabs: global -> LDS without staging registers (see pslab_dma)
     f_stage_values(sBh, sBl, s.b, s.b_stride, s.b_scale, s, b, g, chunk, tid);
     if (tid < 64) {
         const int pj = chunk * 64 + tid;
@@ -463,10 +479,10 @@ __device__ __forceinline__ void favor_fstate_body(const FusedArgs& s, const int 
         const int slab0 = sl * FSLAB;
         const unsigned char* sPc = sP[sl & 1];
         float4_t F[4];
-        feat_slab(F, sPc, sPc + FT_BYTES, xa, valid, slab0, s, fr, g4);
+        feat_slab(F, sPc, sPc + FT_BYTES, xa, valid, slab0, s, fr, g4, plo0);
         // (the barrier at the end of the previous trip: its feature tile has been consumed, the other projection buffer has no readers left)
         feat_to_tile(sAh, sAl, F, w, fr, g4);
-        if (sl + 1 < nslab) pslab_dma(sP[(sl + 1) & 1], s.ptiles, sl + 1, w, lane);
+        if (sl + 1 < nslab) pslab_dma(sP[(sl + 1) & 1], s.ptiles, sl + 1, w, lane, plo0);
         __syncthreads();
         float4_t acc[4];
 #pragma unroll
@@ -548,6 +564,7 @@ __device__ __forceinline__ void favor_fstate_seq_body(const FusedArgs& s, const 
     const __amdgpu_buffer_rsrc_t rex = f_rsrc((s.zmode == 2 ? s.ex_scale : s.b) + (int64_t)b * s.N * s.G, (int64_t)s.N * s.G * 4);
     FSeqStep nxt;
     fseq_load(nxt, s, b, g, 0, tid, w, fr, g4, kmax, rx, ro, rv, rsc, rex);
+    const bool plo0 = ptiles_lo_zero(s.ptiles);
     {
         PSlabRegs pre;
         pslab_load(pre, s.ptiles, sl, tid);
@@ -600,7 +617,7 @@ __device__ __forceinline__ void favor_fstate_seq_body(const FusedArgs& s, const 
         if (tid < 64) sW[tid] = cur.wv;
         const bool valid = c * 64 + w * 16 + fr < s.N;
         float4_t F[4];
-        feat_slab(F, sPh, sPl, xa, valid, slab0, s, fr, g4);
+        feat_slab(F, sPh, sPl, xa, valid, slab0, s, fr, g4, plo0);
         feat_to_tile(sAh, sAl, F, w, fr, g4);
         __syncthreads();
         short8_t bh[2], bl[2], wh[2], wl[2];
@@ -669,7 +686,8 @@ __device__ __forceinline__ void favor_fout_a_body(const FusedArgs& s, const int 
     load_x_operand(xa, s.fa, s, b, g, ri, g4, kmax);
     load_x_operand(xc, s.fx, s, b, g, ri, g4, kmax);
     u32x4 pt[4], pz[4];
-    pslab_dma(sP[0], s.ptiles, 0, w, lane);      // projection slabs: global -> LDS without staging registers (see pslab_dma)
+    const bool plo0 = ptiles_lo_zero(s.ptiles);
+    pslab_dma(sP[0], s.ptiles, 0, w, lane, plo0);      // projection slabs: global -> LDS without staging registers (see pslab_dma)
     tslab_load(pt, rt, 0, tid);
 #pragma unroll
     for (int q = 0; q < 4; ++q) pz[q] = f_ld4(rz, (uint32_t)(q * 16 + g4 * 4) * 4u);
@@ -699,7 +717,7 @@ __device__ __forceinline__ void favor_fout_a_body(const FusedArgs& s, const int 
             for (int q = 0; q < 4; ++q) pz[q] = f_ld4(rz, (uint32_t)(slab0 + FSLAB + q * 16 + g4 * 4) * 4u);
         }
         float4_t Fa[4], F[4];
-        feat_slab2(Fa, F, sPc, sPc + FT_BYTES, xa, xc, vi, slab0, s, fr, g4);
+        feat_slab2(Fa, F, sPc, sPc + FT_BYTES, xa, xc, vi, slab0, s, fr, g4, plo0);
         // (the barrier at the end of the previous trip: its GEMMs are done with the feature tile and with the other slab buffers)
         feat_to_tile(sAh, sAl, Fa, w, fr, g4);
 #pragma unroll
@@ -710,7 +728,7 @@ __device__ __forceinline__ void favor_fout_a_body(const FusedArgs& s, const int 
         acc_to_operand(Ch, Cl, F);
         if (sl + 1 < nslab) {      // next slab's operands into the other buffers while this slab's GEMMs run
             tile_stage(sT[(sl + 1) & 1], sT[(sl + 1) & 1] + FT_BYTES, pt, tid);
-            pslab_dma(sP[(sl + 1) & 1], s.ptiles, sl + 1, w, lane);
+            pslab_dma(sP[(sl + 1) & 1], s.ptiles, sl + 1, w, lane, plo0);
         }
         __syncthreads();
         const int nks = (min(64, s.LDF - slab0) + 31) >> 5;
@@ -793,7 +811,8 @@ __device__ __forceinline__ void favor_fout_b_body(const FusedArgs& s, const int 
     load_x_operand(xa, s.fa, s, b, g, ri, g4, kmax);
     load_x_operand(xx, s.fx, s, b, g, ri, g4, kmax);
     u32x4 pt[4];
-    pslab_dma(sP[0], s.ptiles, 0, w, lane);      // projection slabs go global -> LDS without staging registers (sP is not aliased by the prologue's tiles)
+    const bool plo0 = ptiles_lo_zero(s.ptiles);
+    pslab_dma(sP[0], s.ptiles, 0, w, lane, plo0);      // projection slabs go global -> LDS without staging registers (sP is not aliased by the prologue's tiles)
     tslab_load(pt, rt, 0, tid);
     f_stage_values(sBh, sBl, s.b, s.b_stride, s.b_scale, s, b, g, chunk, tid);
     short8_t Ch[2], Cl[2];   // c_i (times c_scale) as B operand, natural order d = ks*32 + g4*8 + e
@@ -853,13 +872,13 @@ __device__ __forceinline__ void favor_fout_b_body(const FusedArgs& s, const int 
 #pragma unroll
         for (int q = 0; q < 4; ++q) zc[q] = f_ld4(rz, (uint32_t)(slab0 + q * 16 + g4 * 4) * 4u);
         float4_t F[4], Fx[4];
-        feat_slab2(F, Fx, sPc, sPc + FT_BYTES, xa, xx, vi, slab0, s, fr, g4);
+        feat_slab2(F, Fx, sPc, sPc + FT_BYTES, xa, xx, vi, slab0, s, fr, g4, plo0);
         FT_T(ft1);
         // (no barrier here: the one at the end of the previous trip already says that its GEMMs are done with the feature tile and with the other slab buffers)
         feat_to_tile(sAh, sAl, F, w, fr, g4);
         if (sl + 1 < nslab) {      // next slab's operands into the other buffers while this slab's GEMMs run
             tile_stage(sT[(sl + 1) & 1], sT[(sl + 1) & 1] + FT_BYTES, pt, tid);
-            pslab_dma(sP[(sl + 1) & 1], s.ptiles, sl + 1, w, lane);
+            pslab_dma(sP[(sl + 1) & 1], s.ptiles, sl + 1, w, lane, plo0);
         }
         FT_T(ft2);
         __syncthreads();
@@ -889,7 +908,7 @@ __device__ __forceinline__ void favor_fout_b_body(const FusedArgs& s, const int 
         short8_t Dh[2], Dl[2];
         acc_to_operand(Dh, Dl, acc);
         FT_T(ft5);
-        tile_cols_gemm(dxa, sPc, sPc + FT_BYTES, Dh, Dl, lane, (min(64, s.LDF - slab0) + 31) >> 5);   // dx^T[d][i] += sum_m P[m][d] v[m][i]
+        tile_cols_gemm(dxa, sPc, sPc + FT_BYTES, Dh, Dl, lane, (min(64, s.LDF - slab0) + 31) >> 5, 4, plo0);   // dx^T[d][i] += sum_m P[m][d] v[m][i]
 #ifdef SA_TIMING_FAVOR
         asm volatile("s_nop 0" ::"v"(dxa[0][0]), "v"(dxa[1][0]), "v"(dxa[2][0]), "v"(dxa[3][0]));
 #endif
@@ -1105,6 +1124,8 @@ extern "C" int64_t sa_favor_fused_state_bytes(int B, int N, int G, int m) {
 
 extern "C" int sa_favor_fused_proj_tiles(const float* ps, int m, void* tiles, void* stream) {
     if (!ps || !tiles || m <= 0 || m > 272) return SA_EINVAL;
+    (void)hipMemsetAsync((unsigned char*)tiles + PT_FLAG_OFF, 0, 16, (hipStream_t)stream);   // "every lo half-word is zero" until a block finds one that is not
+    SA_CHECK_LAUNCH();
     SA_LAUNCH(favor_proj_tiles_kernel, dim3(5), dim3(256), 0, (hipStream_t)stream, ps, m, (unsigned char*)tiles);
     SA_CHECK_LAUNCH();
     return 0;

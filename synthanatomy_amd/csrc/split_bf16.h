@@ -38,8 +38,17 @@ __device__ __forceinline__ void split8(const float (&x)[8], short8_t& hi, short8
 }
 
 // byte offset of column c (bf16 index, multiple of 4) of row m in a [rows][64] bf16 tile with 128-byte rows; 32-byte chunks are
-// XOR-swizzled with the row so that both the row-major ds_read_b128 fragments and the transposing reads are bank-conflict free
+// XOR-swizzled with the row so that both the row-major ds_read_b128 fragments and the transposing reads are bank-conflict free.
+// Round 6: rows m and m + 8 also swap the two 16-byte halves of a chunk.  Row parity x the chunk swizzle give eight distinct 32-byte bank groups to eight
+// consecutive rows, but the 8-byte reads of tile_rows_gemm_perm put SIXTEEN rows x 16 bytes into one half-wave pass -- rows m and m + 8 met on the same
+// sixteen bytes (2-way conflict: 56 % of scan A's LDS cycles, profiles/r04_performer_pmc_lds.txt); with the half swap they use the two halves of the group.
+#ifndef SA_LROFF_NO_HALF_SWAP
+__device__ __forceinline__ uint32_t lroff(uint32_t m, uint32_t c) {
+    return m * 128u + (((((c >> 4) ^ ((m >> 1) & 3u)) << 5) | ((c & 15u) << 1)) ^ ((m & 8u) << 1));
+}
+#else
 __device__ __forceinline__ uint32_t lroff(uint32_t m, uint32_t c) { return m * 128u + ((((c >> 4) ^ ((m >> 1) & 3u)) << 5) | ((c & 15u) << 1)); }
+#endif
 
 // ds_read_b64_tr_b16: per 16-lane group a [4 rows][16 columns] bf16 block -> lane s holds column s of the 4 rows.  Lane (group gq, s)
 // addresses row 4*gq + (s >> 2), columns 4*(s & 3)..+3 of the block; two reads 16 rows apart make one MFMA operand whose reduction index
@@ -68,22 +77,24 @@ __device__ __forceinline__ void acc_to_operand(short8_t (&hi)[2], short8_t (&lo)
 
 // acc[f] += rows (f*16 + lane&15) of the tile . B operand; reduction over the 64 tile columns in natural order: B operand word e of lane
 // (n, g) is column ks*32 + g*8 + e.  Fragments via ds_read_b128.
+// a_lo_zero (block-uniform): the tile's lo half is known to hold zeros (a bf16-representable operand: the throughput mode's projection matrix) -- its fragment
+// reads and the lo*hi products are skipped; adding their exact zeros would not change a bit of the result.
 __device__ __forceinline__ void tile_rows_gemm(float4_t (&acc)[4], const unsigned char* tHi, const unsigned char* tLo, const short8_t (&bh)[2],
-                                               const short8_t (&bl)[2], int i16, int g, int nf = 4) {
+                                               const short8_t (&bl)[2], int i16, int g, int nf = 4, bool a_lo_zero = false) {
     if (nf == 4) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             short8_t ah[4], al[4];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const uint32_t o = lroff(f * 16 + i16, ks * 32 + g * 8);
-                ah[f] = *(const short8_t*)(tHi + o);
-                al[f] = *(const short8_t*)(tLo + o);
-            }
+            for (int f = 0; f < 4; ++f) ah[f] = *(const short8_t*)(tHi + lroff(f * 16 + i16, ks * 32 + g * 8));
 #pragma unroll
             for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bl[ks], acc[f], 0, 0, 0);
+            if (!a_lo_zero) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], bh[ks], acc[f], 0, 0, 0);
+                for (int f = 0; f < 4; ++f) al[f] = *(const short8_t*)(tLo + lroff(f * 16 + i16, ks * 32 + g * 8));
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], bh[ks], acc[f], 0, 0, 0);
+            }
 #pragma unroll
             for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bh[ks], acc[f], 0, 0, 0);
         }
@@ -96,9 +107,9 @@ __device__ __forceinline__ void tile_rows_gemm(float4_t (&acc)[4], const unsigne
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const uint32_t o = lroff(f * 16 + i16, ks * 32 + g * 8);
-            const short8_t ah = *(const short8_t*)(tHi + o), al = *(const short8_t*)(tLo + o);
+            const short8_t ah = *(const short8_t*)(tHi + o);
             acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ks], acc[f], 0, 0, 0);
-            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ks], acc[f], 0, 0, 0);
+            if (!a_lo_zero) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const short8_t*)(tLo + o), bh[ks], acc[f], 0, 0, 0);
             acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ks], acc[f], 0, 0, 0);
         }
     }
@@ -129,7 +140,7 @@ __device__ __forceinline__ void tile_rows_gemm_perm(float4_t (&acc)[4], const un
 
 // acc[f] += tile^T (tile columns f*16 + lane&15) . B operand; reduction over the 64 tile ROWS in accumulator-row order (transposing reads)
 __device__ __forceinline__ void tile_cols_gemm(float4_t (&acc)[4], const unsigned char* tHi, const unsigned char* tLo, const short8_t (&bh)[2],
-                                               const short8_t (&bl)[2], int lane, int nks = 2, int nf = 4) {
+                                               const short8_t (&bl)[2], int lane, int nks = 2, int nf = 4, bool a_lo_zero = false) {
     const uint32_t trow = (uint32_t)(lane >> 4) * 4u + ((uint32_t)(lane & 15) >> 2), tcol = (uint32_t)(lane & 3) * 4u;
     if (nf == 4) {
 #pragma unroll
@@ -140,12 +151,18 @@ __device__ __forceinline__ void tile_cols_gemm(float4_t (&acc)[4], const unsigne
             for (int f = 0; f < 4; ++f) {
                 const uint32_t o0 = lroff(ks * 32 + trow, f * 16 + tcol), o1 = lroff(ks * 32 + 16 + trow, f * 16 + tcol);
                 ah[f] = __builtin_shufflevector(lds_tr16_b64(tHi + o0), lds_tr16_b64(tHi + o1), 0, 1, 2, 3, 4, 5, 6, 7);
-                al[f] = __builtin_shufflevector(lds_tr16_b64(tLo + o0), lds_tr16_b64(tLo + o1), 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
             for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bl[ks], acc[f], 0, 0, 0);
+            if (!a_lo_zero) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], bh[ks], acc[f], 0, 0, 0);
+                for (int f = 0; f < 4; ++f) {
+                    const uint32_t o0 = lroff(ks * 32 + trow, f * 16 + tcol), o1 = lroff(ks * 32 + 16 + trow, f * 16 + tcol);
+                    al[f] = __builtin_shufflevector(lds_tr16_b64(tLo + o0), lds_tr16_b64(tLo + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[f], bh[ks], acc[f], 0, 0, 0);
+            }
 #pragma unroll
             for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[f], bh[ks], acc[f], 0, 0, 0);
         }
@@ -160,9 +177,11 @@ __device__ __forceinline__ void tile_cols_gemm(float4_t (&acc)[4], const unsigne
             if (ks >= nks) break;
             const uint32_t o0 = lroff(ks * 32 + trow, f * 16 + tcol), o1 = lroff(ks * 32 + 16 + trow, f * 16 + tcol);
             const short8_t ah = __builtin_shufflevector(lds_tr16_b64(tHi + o0), lds_tr16_b64(tHi + o1), 0, 1, 2, 3, 4, 5, 6, 7);
-            const short8_t al = __builtin_shufflevector(lds_tr16_b64(tLo + o0), lds_tr16_b64(tLo + o1), 0, 1, 2, 3, 4, 5, 6, 7);
             acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ks], acc[f], 0, 0, 0);
-            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ks], acc[f], 0, 0, 0);
+            if (!a_lo_zero) {
+                const short8_t al = __builtin_shufflevector(lds_tr16_b64(tLo + o0), lds_tr16_b64(tLo + o1), 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ks], acc[f], 0, 0, 0);
+            }
             acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ks], acc[f], 0, 0, 0);
         }
     }

@@ -25,6 +25,7 @@ _HOST_ENV = dict(no_fused_res="SA_NO_FUSED_RES", no_fused_1x1_bwd="SA_NO_FUSED_1
                  no_sample_step="SA_NO_SAMPLE_STEP",     # stateful sampler: the decision + sequence update as torch ops instead of sa_sample_step (A/B, equality test)
                  opt_in_backward="SA_OPT_IN_BACKWARD",   # CLIs: FusedAdam(in_backward=reducer) -- per-bucket optimizer slices + re-packs behind the gradients (measured slower on one GPU)
                  share_device="SA_SHARE_DEVICE",         # test aid: every rank on cuda:0 over gloo (RCCL refuses two ranks per device) -- the N > 1 code path of the CLIs on a one-GPU box
+                 no_proj_bf16="SA_NO_PROJ_BF16",         # Performer throughput mode: keep the fp32 FAVOR+ projection operand (default: its bf16 copy -> lo(P) = 0, two products instead of three)
                  keep_ipc_mode="SA_KEEP_IPC_MODE")       # do NOT default HSA_ENABLE_IPC_MODE_LEGACY=0 (runtime/ddp.ipc_mode_default; hosts whose driver wants legacy IPC)
 _host = {k: os.environ.get(v) is not None for k, v in _HOST_ENV.items()}
 

@@ -476,10 +476,15 @@ class _LayerEngine:
 
     def _proj_op(self):
         pm = self.sa.fast_attention.projection_matrix
-        ver = (pm.data_ptr(), pm._version, getattr(pm, "_sa_epoch", 0))
+        ver = (pm.data_ptr(), pm._version, getattr(pm, "_sa_epoch", 0), debug.host("no_proj_bf16"))
         if self._pop is None or self._pop[0] != ver:
             c = self.dh ** -0.25
             ps = (pm.detach() * c).contiguous()  # data_normalizer folded into the operand
+            if self.dtype == torch.bfloat16 and not debug.host("no_proj_bf16"):
+                # throughput mode: the projection OPERAND is a bf16 copy of the folded matrix, as every dense weight of this mode is (fp32 master in the buffer
+                # `projection_matrix`, bf16 operand in the launches) -- the split-bf16 kernels then see lo(P) = 0 and run two products instead of three per
+                # feature-map / adjoint GEMM and move half the projection bytes (csrc/favor_fused.hip: PT_FLAG_OFF).  SA_NO_PROJ_BF16=1 keeps the fp32 operand.
+                ps = ps.to(torch.bfloat16).float().contiguous()
             op = ConvOp("conv", self.dh, self.m, 1, 1, 0, ps, None, torch.float32)
             self._pop = (ver, op, ps)
         return self._pop[1]

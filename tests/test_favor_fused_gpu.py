@@ -29,7 +29,7 @@ def _reference(q, k, v, proj, dattn):
     return out.detach(), q.grad, k.grad, v.grad
 
 
-def _fused(q, k, v, proj, dattn, local_cols=64):
+def _fused(q, k, v, proj, dattn, local_cols=64, ps=None, force_flag=None):
     """The C ABI on head blocks of wider rows (as q | k | v sit in the fused qkv matrix): returns out, dq, dk, dv [B, G, N, 64]."""
     from synthanatomy_amd import _ffi
     lib, st = _ffi.lib(), _ffi.stream()
@@ -43,9 +43,12 @@ def _fused(q, k, v, proj, dattn, local_cols=64):
     qkv[:, :G * dh], qkv[:, inner:inner + G * dh], qkv[:, 2 * inner:2 * inner + G * dh] = pack(q), pack(k), pack(v)
     qkv = qkv.cuda()
     qd, kd, vd = qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:]
-    ps = (proj * dh ** -0.25).contiguous().cuda()
+    ps = ((proj * dh ** -0.25) if ps is None else ps).contiguous().cuda()
     tiles = torch.empty(5 * 16384, dtype=torch.uint8, device="cuda")
     _ffi.check(lib.sa_favor_fused_proj_tiles(_ffi.ptr(ps), m, _ffi.ptr(tiles), st))
+    flag = int(tiles[-16:].view(torch.int32)[0])      # 0: every lo half of the split matrix is zero (csrc/favor_fused.hip: PT_FLAG_OFF)
+    if force_flag is not None:
+        tiles[-16:].view(torch.int32)[0] = force_flag
     offq = torch.empty(R * G, device="cuda")
     offk = torch.empty(R * G, device="cuda")
     amq = torch.empty(R * G, dtype=torch.int32, device="cuda")
@@ -76,7 +79,7 @@ def _fused(q, k, v, proj, dattn, local_cols=64):
     assert torch.equal(attn_lp, attn.to(torch.bfloat16)) and torch.equal(dqkv_lp, dqkv.to(torch.bfloat16))
     assert float((attn[:, G * dh:] - 7.0).abs().max()) == 0.0 and float((dqkv[:, G * dh:inner] - 3.0).abs().max()) == 0.0   # only the global-head columns are written
     un = lambda t: t[:, :G * dh].reshape(B, N, G, dh).permute(0, 2, 1, 3).cpu()
-    return un(attn), un(dq), un(dk), un(dv), dict(offq=offq, offk=offk, amq=amq, gws=gws, ps=ps)
+    return un(attn), un(dq), un(dk), un(dv), dict(offq=offq, offk=offk, amq=amq, gws=gws, ps=ps, flag=flag)
 
 
 @pytest.mark.parametrize("seq_states", [False, True])
@@ -107,6 +110,31 @@ def test_fused_favor_matches_fp64_reference(B, G, N, m, seq_states):
     print(f"[fused favor B{B} G{G} N{N} m{m}] max-rel {errs}  fro {fro}")
     assert errs["out"] < 1e-4 and errs["dv"] < 2e-4, errs
     assert fro["dq"] < 2e-3 and fro["dk"] < 2e-3 and errs["dq"] < 1e-2 and errs["dk"] < 1e-2, (errs, fro)
+
+
+@pytest.mark.parametrize("seq_states", [False, True])
+@pytest.mark.parametrize("B,G,N,m", [(2, 2, 150, 266), (1, 8, 1400, 266), (1, 2, 77, 120)])
+def test_bf16_representable_projection_takes_the_two_product_path_bit_identically(B, G, N, m, seq_states):
+    """Round 6: a projection operand whose lo halves are all zero (the throughput mode's bf16 copy of the folded matrix) is recognised by sa_favor_fused_proj_tiles
+    (flag word 0) and every kernel skips the P_lo * x_hi products and the lo half of the slab transfers.  Forcing the flag to 1 runs the three-product path on the
+    SAME tiles: every output must agree bit for bit (the skipped terms are exact zeros); an fp32 matrix keeps the flag at 1."""
+    from synthanatomy_amd import debug
+    g = torch.Generator().manual_seed(N + m + 1)
+    q, k, v = (torch.randn(B, G, N, 64, generator=g) for _ in range(3))
+    dattn = torch.randn(B, G, N, 64, generator=g)
+    proj = P.gaussian_orthogonal_random_matrix(m, 64, g)
+    ps16 = (proj * 64 ** -0.25).to(torch.bfloat16).float()
+    with debug.override(favor_seq_always=seq_states):
+        two = _fused(q, k, v, proj, dattn, ps=ps16)
+        three = _fused(q, k, v, proj, dattn, ps=ps16, force_flag=1)
+        full = _fused(q, k, v, proj, dattn)
+    assert two[4]["flag"] == 0 and full[4]["flag"] == 1
+    for a, b, what in zip(two[:4], three[:4], ("out", "dq", "dk", "dv")):
+        assert torch.equal(a, b), what
+    for key in ("offq", "offk", "amq", "gws"):
+        assert torch.equal(two[4][key], three[4][key]), key
+    # and the rounded operand stays within bf16 rounding of the fp32 one (what the throughput mode trades: 2^-9 relative on P)
+    assert _fro(two[0], full[0]) < 2e-2 and _fro(two[3], full[3]) < 2e-2
 
 
 def test_fused_favor_is_deterministic_and_ignores_the_future():

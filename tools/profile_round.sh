@@ -15,7 +15,7 @@ vqvae)
   python tools/rocpd_tools.py stats "$(db $OUT/kt)" --by-grid > $OUT/vqvae_train_b8_kernel_stats_by_grid.txt 2>&1
   timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pf -o pf -- $VQ > $OUT/pf.log 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pw -o pw -- $VQ > $OUT/pw.log 2>&1
-  python tools/rocpd_tools.py traffic "$(db $OUT/pf)" "$(db $OUT/pw)" $OUT/pmc_traffic.json "round 5: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (--kernel-trace only) of: $VQ; hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB * 1024 (gfx950 correction of MI355X_MICROARCH.md)" --by-grid > $OUT/vqvae_pmc_hbm.txt 2>&1
+  python tools/rocpd_tools.py traffic "$(db $OUT/pf)" "$(db $OUT/pw)" $OUT/pmc_traffic.json "round 6: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (--kernel-trace only) of: $VQ; hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB * 1024 (gfx950 correction of MI355X_MICROARCH.md)" --by-grid > $OUT/vqvae_pmc_hbm.txt 2>&1
   timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/sq -o sq -- $VQ > $OUT/sq.log 2>&1
   python tools/rocpd_tools.py pmc "$(db $OUT/sq)" --by-grid > $OUT/vqvae_pmc_sq.txt 2>&1
   timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace -d $OUT/lds -o lds -- $VQ > $OUT/lds.log 2>&1
@@ -31,7 +31,7 @@ performer)
   python tools/rocpd_tools.py pmc "$(db $OUT/plds)" > $OUT/performer_pmc_lds.txt 2>&1
   timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/ppf -o ppf -- $PF > $OUT/ppf.log 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/ppw -o ppw -- $PF > $OUT/ppw.log 2>&1
-  python tools/rocpd_tools.py traffic "$(db $OUT/ppf)" "$(db $OUT/ppw)" $OUT/pmc_traffic_performer.json "round 5: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (--kernel-trace only) of: $PF; hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB * 1024 (gfx950 correction of MI355X_MICROARCH.md)" --sources=performer > $OUT/performer_pmc_hbm.txt 2>&1
+  python tools/rocpd_tools.py traffic "$(db $OUT/ppf)" "$(db $OUT/ppw)" $OUT/pmc_traffic_performer.json "round 6: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes (--kernel-trace only) of: $PF; hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB * 1024 (gfx950 correction of MI355X_MICROARCH.md)" --sources=performer > $OUT/performer_pmc_hbm.txt 2>&1
   timeout 300 rocprofv3 --kernel-trace -d $OUT/dense -o dense -- python tools/bench_dense_tiles.py > $OUT/dense.log 2>&1
   python tools/rocpd_tools.py stats "$(db $OUT/dense)" --by-grid > $OUT/dense_layers_by_grid.txt 2>&1
   ;;
