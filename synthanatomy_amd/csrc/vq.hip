@@ -22,6 +22,11 @@ __global__ void vq_wnorm_kernel(const float* __restrict__ cb, int K, int D, floa
     wn[k] = s;
 }
 
+// Round 6: the codebook walk is a per-wave software pipeline.  Every wave owns the 16-code tiles wave, wave + 4, ... and a PRIVATE LDS tile, so the loop needs no
+// block barrier at all (rounds 1-5 ran two __syncthreads and one exposed L2 round trip per tile: 32 trips x ~3.5 us = 110 us per block, 326 us per launch for
+// 1.5 GFLOP); the rows of the next TWO tiles are requested into registers (NV float4 per lane and tile) while the current tile multiplies.  The arithmetic -- one
+// exact-f32 MFMA chain in k order per (row, code), the expanded distance, the first-index tie-break -- is unchanged: indices stay bit-identical.
+template <int NV>
 __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict__ rows, const float* __restrict__ cb, int64_t M, int K, int D,
                                                         int64_t* __restrict__ idx_out, float* __restrict__ zq_st, bf16_t* __restrict__ zq_lp,
                                                         float* __restrict__ counts, float* __restrict__ dw, float* __restrict__ sqerr,
@@ -62,19 +67,49 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
     float* myW = sW + wave * 16 * LD;
     const int ntiles = (K + 15) >> 4;
     const int iters = (ntiles + 3) >> 2;
-    for (int it = 0; it < iters; ++it) {
-        const int tile = it * 4 + wave;
-        const int c0 = tile * 16;
-        if (tile < ntiles) {
-            for (int e = lane; e < 16 * D4; e += 64) {
-                const int r = e / D4, c4 = e - r * D4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c0 + r < K) v = *(const float4*)(cb + (int64_t)(c0 + r) * D + c4 * 4);
-                *(float4*)(myW + r * LD + c4 * 4) = v;
-            }
+    // this lane's pieces of a tile: float4 e = lane + 64 u of the [16][D4] tile (row e / D4, columns 4 (e % D4) ..)
+    int pr[NV], pc[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int e = lane + 64 * u;
+        pr[u] = e < 16 * D4 ? e / D4 : -1;
+        pc[u] = e < 16 * D4 ? (e - (e / D4) * D4) * 4 : 0;
+    }
+    auto request = [&](int it, float4 (&v)[NV], float (&wn4)[4]) __attribute__((always_inline)) {
+        const int c0 = (it * 4 + wave) * 16;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pr[u] >= 0 && c0 + pr[u] < K) v[u] = *(const float4*)(cb + (int64_t)(c0 + pr[u]) * D + pc[u]);
         }
-        __syncthreads();
-        if (tile < ntiles) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wn4[r] = (c0 + fq * 4 + r < K) ? wnorm[c0 + fq * 4 + r] : 0.f;
+    };
+    auto park = [&](const float4 (&v)[NV]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u)
+            if (pr[u] >= 0) *(float4*)(myW + pr[u] * LD + pc[u]) = v[u];
+    };
+    float4 va[NV], vb[NV];
+    float wna[4], wnb[4];
+    request(0, va, wna);
+    if (iters > 1) request(1, vb, wnb);
+    for (int it = 0; it < iters; ++it) {
+        // (LDS operations of one wave execute in order: the tile of trip it - 1 has been read before these stores land; no other wave touches myW)
+        float wnc[4];
+        if (it & 1) {
+            park(vb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wnc[r] = wnb[r];
+            if (it + 2 < iters) request(it + 2, vb, wnb);
+        } else {
+            park(va);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wnc[r] = wna[r];
+            if (it + 2 < iters) request(it + 2, va, wna);
+        }
+        const int c0 = (it * 4 + wave) * 16;
+        if (c0 < K) {
             float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f};
             for (int kk = 0; kk < D4; ++kk) {
                 const float a = myW[frow * LD + kk * 4 + fq];
@@ -85,7 +120,7 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
             for (int r = 0; r < 4; ++r) {
                 const int code = c0 + fq * 4 + r;
                 if (code < K) {
-                    const float d = __fadd_rn(__fsub_rn(xx, __fmul_rn(2.f, acc[r])), wnorm[code]);
+                    const float d = __fadd_rn(__fsub_rn(xx, __fmul_rn(2.f, acc[r])), wnc[r]);
                     const float nd = -d;
                     if (nd > best) {
                         best = nd;
@@ -94,7 +129,6 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
                 }
             }
         }
-        __syncthreads();
     }
     // reduce over the 4 lane groups that share a row
 #pragma unroll
@@ -124,11 +158,23 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
             }
         }
         if (bi < 0 || bi >= K) bi = 0;  // all-NaN row: torch.max would return the NaN's position; keep in range
-        sfin[tid] = bi;
-        if (m0 + tid < M) {
-            idx_out[m0 + tid] = bi;
-            unsafeAtomicAdd(counts + bi, 1.f);
+        sfin[tid] = (m0 + tid < M) ? bi : -1;
+        if (m0 + tid < M) idx_out[m0 + tid] = bi;
+    }
+    __syncthreads();
+    // EMA statistics: the rows of this block that chose the same code are summed HERE and leave as one atomic per (code, dimension) from the first of them (round 6:
+    // with a collapsed codebook -- a handful of codes in use, what synthetic volumes train to -- every row of every block added to the same few cache lines, and
+    // 11 200 x 32 same-line atomics were ~250 of the launch's 300 us)
+    if (tid < 16 && sfin[tid] >= 0) {
+        const int bi = sfin[tid];
+        bool lead = true;
+        for (int r2 = 0; r2 < tid; ++r2) lead = lead && sfin[r2] != bi;
+        if (lead) {
+            float c = 1.f;
+            for (int r2 = tid + 1; r2 < 16; ++r2) c += sfin[r2] == bi ? 1.f : 0.f;
+            unsafeAtomicAdd(counts + bi, c);
         }
+        sbidx[tid] = lead ? 1 : 0;      // (the wave minima are consumed: their slots carry the leader flags)
     }
     __syncthreads();
     float err = 0.f;
@@ -143,7 +189,12 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
             zq_st[o] = __fadd_rn(dqx, x);
             if (zq_lp) zq_lp[o] = f32_to_bf16(__fadd_rn(dqx, x));
             err += dqx * dqx;
-            unsafeAtomicAdd(dw + (int64_t)bi * D + j, x);
+            if (sbidx[r]) {
+                float acc = x;
+                for (int r2 = r + 1; r2 < 16; ++r2)
+                    if (sfin[r2] == bi) acc += sX[r2 * LD + j];
+                unsafeAtomicAdd(dw + (int64_t)bi * D + j, acc);
+            }
         }
     }
     err = wave_sum(err);
@@ -237,8 +288,15 @@ extern "C" int sa_vq_assign(const float* rows, const float* codebook, int64_t M,
     const size_t lds = (size_t)(5 * 16 * (D + 4) + 16 + 64 + 64 + 16 + 4) * 4;
     if (lds > 160 * 1024) return SA_EUNSUPPORTED;
     const unsigned nblk = (unsigned)((M + 15) / 16);
-    SA_LAUNCH(vq_assign_kernel, dim3(nblk), dim3(256), lds, st, rows, codebook, M, K, D, idx, zq_st, (bf16_t*)zq_lp, counts, dw, sqerr,
-                       wnorm);
+    // NV = float4 pieces of a [16 codes][D] tile per lane (two tiles ahead in registers): D <= 16 / 32 / 64 / 128 / 256 / 496
+#define SA_VQ_LAUNCH(NV) SA_LAUNCH(vq_assign_kernel<NV>, dim3(nblk), dim3(256), lds, st, rows, codebook, M, K, D, idx, zq_st, (bf16_t*)zq_lp, counts, dw, sqerr, wnorm)
+    if (D <= 16) SA_VQ_LAUNCH(1);
+    else if (D <= 32) SA_VQ_LAUNCH(2);
+    else if (D <= 64) SA_VQ_LAUNCH(4);
+    else if (D <= 128) SA_VQ_LAUNCH(8);
+    else if (D <= 256) SA_VQ_LAUNCH(16);
+    else SA_VQ_LAUNCH(32);      // (D <= 496: wider rows do not fit the 160 KiB of LDS, checked above)
+#undef SA_VQ_LAUNCH
     SA_CHECK_LAUNCH();
     return 0;
 }
