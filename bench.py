@@ -273,11 +273,17 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
             stats = timer.collect()
             engine.TIMER = None
         single = {k: v for k, v in stats.items() if "+" not in k and v[1] > 0} or stats
-        name, (n, flops, ms, _nb) = max(single.items(), key=lambda kv: kv[1][2])
+        name, dom = max(single.items(), key=lambda kv: kv[1][2])
+        n, flops, ms, ab = dom[0], dom[1], dom[2], dom[4]
         ach = flops / (ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if dt == torch.bfloat16 else PEAK_F32_TFLOPS
         traffic = _pmc_lookup(name, PMC_FILE_PERFORMER, PERFORMER_KERNEL_SOURCES) if (B == 6 and dt == torch.bfloat16) else None
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                # the dense launches sit below the MFMA / HBM ridge on their OWN bytes (bf16 operands in, fp32 residual stream + bf16 copies out): the HBM fraction of the
+                # same launches, from their operand bytes (input, packed weights, every output / addend once), next to the MFMA fraction
+                "algorithmic_bytes_per_launch": round(ab / n) if n else None,
+                "achieved_gbs": round(ab / (ms * 1e-3) / 1e9, 1) if ms > 0 else None, "frac_hbm": round(ab / (ms * 1e-3) / 1e9 / 8000.0, 4) if ms > 0 else None,
+                "traffic_over_algorithmic": round(traffic / (ab / n), 3) if (traffic and ab) else None,
                 "traffic_source": _pmc_source(PMC_FILE_PERFORMER), "kernel": name,
                 "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                 "note": "one-stream pass (weight gradients not overlapped) of 2 steps; dense layers (nn.Linear) on the im2col-order MFMA kernel; brackets with '+' "
@@ -319,8 +325,8 @@ def bench_performer(args, rank, world, dev, shape=None, batch=None):
     return res
 
 
-PMC_FILE = "r05_pmc_traffic.json"   # profiles/: HBM bytes per launch from the committed PMC passes (its `_provenance` names the command and commit)
-PMC_FILE_PERFORMER = "r05_pmc_traffic_performer.json"
+PMC_FILE = "r06_pmc_traffic.json"   # profiles/: HBM bytes per launch from the committed PMC passes (its `_provenance` names the command and commit)
+PMC_FILE_PERFORMER = "r06_pmc_traffic_performer.json"
 
 
 VQVAE_KERNEL_SOURCES = ("conv1.hip", "conv_fprop.hip", "conv_fprop_f16.hip", "conv_fprop_kernels.h", "conv_fprop_common.h", "conv_wgrad.hip", "convt1.hip",
@@ -848,11 +854,12 @@ def main():
         # its avg_launch_us has to be comparable with rocprofv3's per-kernel average
         single = {k: v for k, v in stats.items() if "+" not in k} or stats
         dom = max(single.items(), key=lambda kv: kv[1][2])
-        name, (n, flops, ms, _nb) = dom
+        name, (n, flops, ms, _nb, ab) = dom
         ach = flops / (ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": _pmc_traffic(name, args), "traffic_source": _pmc_source(),
+                "algorithmic_bytes_per_launch": round(ab / n) if n else None,      # operand bytes of the same launches (input, weights, every output / addend / mask once)
                 "kernel": name, "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                 "how": f"separate pass of {args.roofline_steps} steps after the timed region, HIP events around every launch on the launch stream",
                 "kernels": {k: {"launches": v[0], "ms": round(v[2], 3), "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2) if v[2] > 0 else None}

@@ -26,26 +26,31 @@ class KernelTimer:
     FLOPs and -- after ``collect()`` -- device time."""
 
     def __init__(self):
-        self.pending = []   # (key, flops, ev0, ev1, bytes)
-        self.stats = {}     # key -> [launches, flops, ms, algorithmic bytes]
+        self.pending = []   # (key, flops, ev0, ev1, bytes[, operand bytes])
+        self.stats = {}     # key -> [launches, flops, ms, algorithmic bytes of the launches reported against HBM, operand bytes of the MFMA launches]
 
-    def wrap(self, key, flops, fn, nbytes=0.0):
+    def wrap(self, key, flops, fn, nbytes=0.0, abytes=0.0):
+        """nbytes: algorithmic bytes of a launch that is REPORTED against the HBM roof (one-channel layers, fused 1x1x1 backward: bench.py's roofline_hbm picks among
+        the keys that carry them); abytes: operand bytes of an MFMA launch (input once, packed weights once, every output / addend / mask once) -- what its PMC
+        traffic is compared with and what `frac_hbm` of the Performer's dense layers is computed from."""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
         if key is None or key == "+wgrad_reduce_kernel":  # convolution launches: the dispatcher says which instance it picked
             key = _ffi.lib().sa_last_conv_kernel().decode() + (key or "")
-        self.pending.append((key, flops, e0, e1, nbytes))
+        self.pending.append((key, flops, e0, e1, nbytes, abytes))
 
     def collect(self):
         torch.cuda.synchronize()
-        for key, flops, e0, e1, nbytes in self.pending:
-            st = self.stats.setdefault(key, [0, 0.0, 0.0, 0.0])
+        for ent in self.pending:
+            key, flops, e0, e1, nbytes = ent[:5]
+            st = self.stats.setdefault(key, [0, 0.0, 0.0, 0.0, 0.0])
             st[0] += 1
             st[1] += flops
             st[2] += e0.elapsed_time(e1)
             st[3] += nbytes
+            st[4] += ent[5] if len(ent) > 5 else 0.0
         self.pending = []
         return self.stats
 
@@ -58,11 +63,15 @@ def _geom_flops(g) -> float:
     return 2.0 * m * (g.KT[0] * g.KT[1] * g.KT[2]) * g.cin_valid * g.cout_valid
 
 
-def _launch(key, flops, fn, nbytes=0.0):
+def _launch(key, flops, fn, nbytes=0.0, abytes=0.0):
     if TIMER is not None:
-        TIMER.wrap(key, flops, fn, nbytes)
+        TIMER.wrap(key, flops, fn, nbytes, abytes)
     else:
         fn()
+
+
+def _tbytes(*ts) -> float:
+    return float(sum(t.numel() * t.element_size() for t in ts if t is not None))
 
 
 def _ru(x: int, m: int) -> int:
@@ -284,12 +293,12 @@ class ConvOp:
         lp = torch.empty((N, *od, cout_s), dtype=torch.bfloat16, device=x.device) if want_lp else None
         ep = self._epilogue(self._bias_padded() if use_bias else None, addend, mask, alpha, act, mask_mode, add_before_act, out_dtype, slope, pre, lp)
         lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.fwd_dtype)
-        self._run_plans(plans["fwd"], did, x, out, ep, "sa_conv_fprop")
+        self._run_plans(plans["fwd"], did, x, out, ep, "sa_conv_fprop", _tbytes(addend, mask, pre, lp))
         if want_pre or want_lp:
             return out, pre, lp
         return out
 
-    def _run_plans(self, plans, did, src, dst, ep, what):
+    def _run_plans(self, plans, did, src, dst, ep, what, extra_bytes=0.0):
         """One launch per geometry -- or ONE launch for the eight output-parity classes of a stride-2 layer (sa_conv_fprop_classes: geometries that differ
         only in their offsets, each with its packed operand); the library answers SA_EUNSUPPORTED when the kernel it would pick does not take classes."""
         lib, st = _ffi.lib(), _ffi.stream()
@@ -303,15 +312,17 @@ class ConvOp:
                 rc = []
                 pend = len(TIMER.pending) if TIMER is not None else 0
                 _launch(None, sum(_geom_flops(pl.geom) for pl in plans),
-                        lambda: rc.append(lib.sa_conv_fprop_classes(geoms, n, did, _ffi.ptr(src), wpks, _ffi.ptr(dst), ctypes.byref(ep), st)))
+                        lambda: rc.append(lib.sa_conv_fprop_classes(geoms, n, did, _ffi.ptr(src), wpks, _ffi.ptr(dst), ctypes.byref(ep), st)),
+                        abytes=_tbytes(src, dst, *[pl.wpk for pl in plans]) + extra_bytes)
                 if rc[0] != _ffi.SA_EUNSUPPORTED:
                     _ffi.check(rc[0], what + " (classes)")
                     return
                 if TIMER is not None:
                     del TIMER.pending[pend:]
-        for pl in plans:
+        for pl in plans:     # (operand bytes: input and output once per LAYER, shared between the launches of its classes)
             _launch(None, _geom_flops(pl.geom),
-                    lambda pl=pl: _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(src), _ffi.ptr(pl.wpk), _ffi.ptr(dst), ctypes.byref(ep), st), what))
+                    lambda pl=pl: _ffi.check(lib.sa_conv_fprop(ctypes.byref(pl.geom), did, _ffi.ptr(src), _ffi.ptr(pl.wpk), _ffi.ptr(dst), ctypes.byref(ep), st), what),
+                    abytes=(_tbytes(src, dst) + extra_bytes) / len(plans) + _tbytes(pl.wpk))
 
     def dgrad(self, g: torch.Tensor, idims: Tuple[int, int, int], *, addend=None, mask=None, mask_mode=MASK_NONE, out_dtype=None, slope=0.2,
               fwd_out_stride=None) -> torch.Tensor:
@@ -330,7 +341,7 @@ class ConvOp:
             dx.zero_()
         ep = self._epilogue(None, addend, mask, None, ACT_NONE, mask_mode, False, out_dtype, slope)
         lib, st, did = _ffi.lib(), _ffi.stream(), _ffi.dtype_id(self.dtype)
-        self._run_plans(plans["dgrad"], did, g, dx, ep, "sa_conv_fprop(dgrad)")
+        self._run_plans(plans["dgrad"], did, g, dx, ep, "sa_conv_fprop(dgrad)", _tbytes(addend, mask))
         return dx
 
     def wgrad(self, x: torch.Tensor, g: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor] = None, fwd_out_stride=None):

@@ -538,7 +538,8 @@ class _ResStage:
         engine._launch(None, engine._geom_flops(p3["fwd"][0].geom) + engine._geom_flops(p1["fwd"][0].geom),
                        lambda: _ffi.check(_ffi.lib().sa_resblock_fprop(ctypes.byref(p3["fwd"][0].geom), _ffi.dtype_id(fdt), _ffi.ptr(x),
                                                                        _ffi.ptr(p3["fwd"][0].wpk), _ffi.ptr(b1), _ffi.ptr(p1["fwd"][0].wpk), _ffi.ptr(h), _ffi.ptr(y),
-                                                                       ctypes.byref(ep), st), "sa_resblock_fprop"))
+                                                                       ctypes.byref(ep), st), "sa_resblock_fprop"),
+                       abytes=engine._tbytes(x, y, h, ys, p3["fwd"][0].wpk, p1["fwd"][0].wpk))     # x in (operand and addend: once), both weight operands, every output
         return (_Act(y, ys) if self.mixed else y), h
 
     def _dropout_mask(self, N, C, dev, stride=None):
