@@ -19,12 +19,12 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 4   /* 4 (round 6): + sa_rotary_pairs, sa_subpixel_pool_fwd / _bwd (additions only; developer switches SA_DBG_CELLS / SA_DBG_DENSE_RING retired).  3 (round 5): sa_sample_step takes top_k.  2 (round 4): sa_local_attn_fwd/bwd + sa_epilogue grew trailing pointers in round 3, SA_F16 operand type, sa_mse partials; a caller built against 1 must not load this library */
+#define SA_ABI_VERSION 4   /* 4 (round 6): + sa_rotary_pairs, sa_subpixel_pool_fwd / _bwd, sa_comm_* (additions only; developer switches SA_DBG_CELLS / SA_DBG_DENSE_RING retired).  3 (round 5): sa_sample_step takes top_k.  2 (round 4): sa_local_attn_fwd/bwd + sa_epilogue grew trailing pointers in round 3, SA_F16 operand type, sa_mse partials; a caller built against 1 must not load this library */
 enum { SA_F32 = 0, SA_BF16 = 1, SA_F16 = 2 /* IEEE half: FORWARD operand / activation type only (the reference's AMP dtype, src/engines/trainer.py:161-163); see sa_conv_fprop */ };
 enum { SA_ACT_NONE = 0, SA_ACT_RELU = 1, SA_ACT_LRELU = 2, SA_ACT_GELU = 3 };
 enum { SA_MASK_NONE = 0, SA_MASK_POS = 1 /* out *= (mask > 0) */, SA_MASK_LRELU = 2 /* out *= mask>0 ? 1 : slope */,
        SA_MASK_GELU = 3 /* out *= gelu'(mask) */ };
-enum { SA_EINVAL = -1, SA_EUNSUPPORTED = -2, SA_ENOGPU = -3 };
+enum { SA_EINVAL = -1, SA_EUNSUPPORTED = -2, SA_ENOGPU = -3, SA_ECOMM = -4 /* an RCCL call failed: sa_comm_last_error() */ };
 #define SA_MAX_TAPS 64
 
 /* Geometry of one implicit-GEMM convolution-like gather.  The GEMM M index enumerates a logical grid
@@ -465,6 +465,25 @@ int sa_mse_det(const float *a, const float *b, int64_t n, float *loss_sum, float
 int sa_dot_det(const float *a, const void *b, int b_dtype, int64_t n, float *out, int accumulate, float *ws, void *stream);
 int sa_cross_entropy_rows(const float *logits, const int64_t *target, int64_t R, int V, float *row_loss, void *dlogits, int d_dtype, float gscale, void *stream);
 int sa_layernorm_dwprod(const float *dy, const float *x, const float *stats, float *prod, int64_t R, int C, void *stream);
+
+/* ---- collectives of the data-parallel path for a host without torch.distributed (csrc/comm.hip): RCCL behind the C ABI ----------------------------------
+ * One communicator per process (one process per GPU).  Replaces DistributedDataParallel's gradient all-reduce (reference run_vqvae.py:71-77,
+ * run_transformer.py:95-103; here per flat 32 MiB bucket, or reduce-scatter + all-gather) and dist.all_reduce(encodings_sum) / dist.all_reduce(dw) of the EMA
+ * quantizer (src/networks/vqvae/baseline.py:70-72; here ONE call on the packed [K + K D] statistics buffer that sa_vq_assign fills and sa_vq_ema_update reads).
+ * RCCL is resolved with dlopen at the first call (librccl.so.1, or SA_RCCL_LIB): the library has no link-time dependency on it, and SA_EUNSUPPORTED says it was
+ * not found.  Every call enqueues on the caller's stream and returns.  The Python host of this repository keeps using torch.distributed (backend nccl = RCCL);
+ * these entry points are for a non-torch host.  id: 128 bytes from sa_comm_unique_id on rank 0, handed to the other ranks by the host
+ * (file, socket, environment).  dtype: SA_F32 / SA_BF16 / SA_F16. */
+typedef struct sa_comm sa_comm;
+int sa_comm_unique_id(void *id_out_128_bytes);
+int sa_comm_init(sa_comm **comm, const void *id_128_bytes, int rank, int world);
+int sa_comm_destroy(sa_comm *comm);
+int sa_comm_rank(const sa_comm *comm);
+int sa_comm_world(const sa_comm *comm);
+int sa_comm_all_reduce_sum(sa_comm *comm, void *buf, int64_t n, int dtype, void *stream);                                       /* in place */
+int sa_comm_reduce_scatter_sum(sa_comm *comm, const void *send, void *recv, int64_t n_per_rank, int dtype, void *stream);      /* send: world * n_per_rank */
+int sa_comm_all_gather(sa_comm *comm, const void *send, void *recv, int64_t n_per_rank, int dtype, void *stream);              /* recv: world * n_per_rank */
+const char *sa_comm_last_error(void);   /* text of the calling thread's last failed sa_comm_* call */
 
 #ifdef __cplusplus
 }

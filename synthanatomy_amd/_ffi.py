@@ -136,6 +136,15 @@ _SIGS = {
     "sa_favor_den": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "sa_favor_dden": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "sa_rotary": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
+    "sa_comm_unique_id": (c_int, [c_void_p]),
+    "sa_comm_init": (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    "sa_comm_destroy": (c_int, [c_void_p]),
+    "sa_comm_rank": (c_int, [c_void_p]),
+    "sa_comm_world": (c_int, [c_void_p]),
+    "sa_comm_all_reduce_sum": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "sa_comm_reduce_scatter_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "sa_comm_all_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "sa_comm_last_error": (c_char_p, []),
     "sa_subpixel_pool_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sa_subpixel_pool_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "sa_rotary_pairs": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_void_p]),
