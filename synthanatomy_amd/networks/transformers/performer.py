@@ -318,7 +318,10 @@ class _SideWgrad:
     ahead of the device no block ever became reusable -- the pool of the adversarial iteration grew to 113 GB for 29 GB of live tensors, with GB-sized
     ``hipMalloc``s inside the first dozen iterations (the 1 431 ms "adversarial" record of round 5: one warm-up + three timed iterations, all of them allocating)."""
 
-    LAG = int(os.environ.get("SA_SIDE_WGRAD_LAG", "3"))
+    try:
+        LAG = max(1, int(os.environ.get("SA_SIDE_WGRAD_LAG", "3")))
+    except ValueError:
+        raise ValueError(f"SA_SIDE_WGRAD_LAG={os.environ.get('SA_SIDE_WGRAD_LAG')!r}: expected the number of side-stream launches whose operands stay alive (an integer >= 1)") from None
 
     def __init__(self, dev):
         self.main = torch.cuda.current_stream(dev)
