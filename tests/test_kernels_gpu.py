@@ -352,7 +352,8 @@ def test_vq_against_reference_golden():
         cb, N, avg = r["cb"], r["N"], r["avg"]
 
 
-@pytest.mark.parametrize("M,K,D", [(1, 16, 4), (17, 40, 8), (1400, 2048, 32), (333, 256, 256), (11200, 2048, 32)])
+@pytest.mark.parametrize("M,K,D", [(1, 16, 4), (17, 40, 8), (1400, 2048, 32), (333, 256, 256), (11200, 2048, 32),
+                                   (100, 72, 64), (50, 48, 128), (40, 33, 320)])     # (round 6: every register-prefetch width of vq_assign_kernel<NV>: 1, 1, 2, 16, 2, 4, 8, 32)
 def test_vq_against_c_oracle(M, K, D):
     from test_oracle_vs_golden import c_vq_assign
     torch.manual_seed(M + K)
@@ -369,6 +370,24 @@ def test_vq_against_c_oracle(M, K, D):
         np.testing.assert_allclose(r["counts"].numpy(), counts)
         np.testing.assert_allclose(r["dw"].numpy(), dw, rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(r["sq"].item(), se, rtol=1e-4)
+
+
+def test_vq_statistics_of_a_collapsed_codebook():
+    """Round 6: rows of a block that choose the same code are summed in the block and leave as ONE atomic per (code, dimension).  A codebook with three codes in use
+    (what synthetic volumes train to) puts whole blocks on one code; ragged last block; counts / dw / commitment error against the C oracle."""
+    from test_oracle_vs_golden import c_vq_assign
+    torch.manual_seed(7)
+    M, K, D = 2003, 256, 32
+    cb = torch.randn(K, D) * 10.0
+    centers = cb[torch.tensor([5, 77, 200])]
+    x = centers[torch.randint(0, 3, (M,))] + 0.01 * torch.randn(M, D)
+    x[:64] = centers[0] + 0.01 * torch.randn(64, D)          # four whole blocks on one code
+    r = _vq_run(x, cb)
+    idx, counts, dw, se, _gap = c_vq_assign(x.numpy(), cb.numpy())
+    assert np.array_equal(r["idx"].numpy(), idx) and set(np.unique(idx)) == {5, 77, 200}
+    np.testing.assert_allclose(r["counts"].numpy(), counts)
+    np.testing.assert_allclose(r["dw"].numpy(), dw, rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(r["sq"].item(), se, rtol=1e-4)
 
 
 def test_vq_misc_kernels():
