@@ -124,3 +124,43 @@ def test_rotary_global_heads_on_the_fused_bf16_path_and_sampling_falls_back_to_t
         net32.sample(torch.zeros(1, 1, dtype=torch.long), stateful=True)
     seq = net32.sample(torch.zeros(1, 1, dtype=torch.long, device="cuda"), sample=False)
     assert seq.numel() == 24          # sequence_to_grid: the 2 x 3 x 4 latent grid of one sample
+
+
+def test_rotary_pairs_kernel_against_the_oracle_and_its_adjoint():
+    """sa_rotary_pairs alone: head blocks inside wider rows (as q | k sit in the q|k|v matrix), two operands in one launch, in place; the transpose flag is the adjoint
+    (<R x, y> = <x, R^T y>) and undoes the rotation (R^T R = I)."""
+    from synthanatomy_amd import _ffi
+    lib, st = _ffi.lib(), _ffi.stream()
+    B, N, G, dh, extra = 2, 37, 3, 64, 64
+    inner = G * dh + extra
+    stride = 3 * inner
+    R = B * N
+    g = torch.Generator().manual_seed(2)
+    qkv = torch.randn(R, stride, generator=g)
+    tab = P.fixed_position_table(dh, 50)
+    d = qkv.clone().cuda()
+    tabd = tab.cuda().contiguous()
+    _ffi.check(lib.sa_rotary_pairs(_ffi.ptr(d), stride, 0, G, dh, _ffi.ptr(tabd), _ffi.ptr(d), stride, 0, N, R, 0, 2, inner, inner, st), "sa_rotary_pairs")
+    torch.cuda.synchronize()
+    un = lambda t, o: t[:, o:o + G * dh].reshape(B, N, G, dh).permute(0, 2, 1, 3)
+    qr, kr = P.apply_rotary_pos_emb(un(qkv, 0), un(qkv, inner), tab[:N])
+    assert torch.allclose(un(d.cpu(), 0), qr, atol=1e-6) and torch.allclose(un(d.cpu(), inner), kr, atol=1e-6)
+    keep = qkv.clone()
+    keep[:, :G * dh] = 0
+    keep[:, inner:inner + G * dh] = 0
+    got = d.cpu().clone()
+    got[:, :G * dh] = 0
+    got[:, inner:inner + G * dh] = 0
+    assert torch.equal(got, keep)                     # nothing outside the global-head columns of q and k is touched
+    y = torch.randn(R, stride, generator=g).cuda()
+    yt = y.clone()
+    _ffi.check(lib.sa_rotary_pairs(_ffi.ptr(yt), stride, 0, G, dh, _ffi.ptr(tabd), _ffi.ptr(yt), stride, 0, N, R, 1, 2, inner, inner, st), "sa_rotary_pairs^T")
+    cols = torch.cat((torch.arange(G * dh), inner + torch.arange(G * dh))).cuda()
+    lhs = (d[:, cols].double() * y[:, cols].double()).sum()
+    rhs = (qkv.cuda()[:, cols].double() * yt[:, cols].double()).sum()
+    assert abs(float(lhs - rhs)) < 1e-6 * abs(float(lhs)) + 1e-6
+    back = d.clone()
+    _ffi.check(lib.sa_rotary_pairs(_ffi.ptr(back), stride, 0, G, dh, _ffi.ptr(tabd), _ffi.ptr(back), stride, 0, N, R, 1, 2, inner, inner, st), "sa_rotary_pairs^T")
+    torch.cuda.synchronize()
+    assert torch.allclose(back.cpu(), qkv, atol=1e-5)
+    assert lib.sa_rotary_pairs(_ffi.ptr(d), stride + 1, 0, G, dh, _ffi.ptr(tabd), _ffi.ptr(d), stride, 0, N, R, 0, 1, 0, 0, st) == _ffi.SA_EUNSUPPORTED
